@@ -1,0 +1,102 @@
+"""ctypes binding of csrc/libcovo_hip.so (C ABI: include/covo_hip.h).
+
+Fails loudly: a missing library is an ImportError-class failure at first use, never a silent
+fallback to another backend.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libcovo_hip.so")
+_lib = None
+
+COVO_H = 32
+COVO_DU = 4
+COVO_NA = COVO_H * COVO_DU
+COVO_STATE_FLOATS = 32
+COVO_PARTIAL_FLOATS = 132
+COVO_POS_STATS_DOUBLES = COVO_H * 6
+ABI_VERSION = 1
+
+
+class CovoError(RuntimeError):
+    pass
+
+
+class EnvParamsC(C.Structure):
+    """struct covo_env_params (include/covo_hip.h)."""
+    _fields_ = [
+        ("max_thrust", C.c_float), ("max_torque", C.c_float * 3), ("max_omega", C.c_float * 3),
+        ("dt", C.c_float), ("g", C.c_float), ("m", C.c_float), ("action_scale", C.c_float),
+        ("alpha_bodyrate", C.c_float), ("max_steps_in_episode", C.c_int32), ("pos_limit", C.c_float),
+    ]
+
+
+class ConfigC(C.Structure):
+    """struct covo_config (include/covo_hip.h)."""
+    _fields_ = [("n_local", C.c_int32), ("H", C.c_int32), ("du", C.c_int32), ("lam", C.c_float),
+                ("discount", C.c_float), ("flags", C.c_int32)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "covo_last_error": (C.c_char_p, []),
+    "covo_abi_version": (C.c_int, []),
+    "covo_create": (C.c_int, [C.POINTER(ConfigC), C.POINTER(_P)]),
+    "covo_destroy": (C.c_int, [_P]),
+    "covo_randn": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    "covo_noise_gemm": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
+    "covo_noise_blockdiag": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
+    "covo_rollout_cost": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P,
+                                    C.c_int32, _P, _P, _P, _P]),
+    "covo_softmax_reduce": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
+    "covo_softmax_update": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_float, _P, _P]),
+    "covo_merge": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P]),
+    "covo_shift_mean": (C.c_int, [_P, _P, _P, _P]),
+    "covo_hessian": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, C.c_int32, _P, _P]),
+    "covo_sigma": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),
+    "covo_cholesky": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def load_library():
+    """Load libcovo_hip.so and declare every prototype of include/covo_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise CovoError(
+            f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C covo_mpc_amd/csrc`).  covo_mpc_amd has no CPU/torch fallback.")
+    lib = C.CDLL(_SO)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch, surfaced as is
+        fn.restype = res
+        fn.argtypes = args
+    if lib.covo_abi_version() != ABI_VERSION:
+        raise CovoError(f"libcovo_hip.so ABI {lib.covo_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load_library().covo_last_error()
+        raise CovoError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

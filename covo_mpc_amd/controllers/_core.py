@@ -1,0 +1,161 @@
+"""Shared device-side machinery of the sampling controllers (MPPI / CoVO).
+
+Owns the libcovo_hip handle and the HBM buffers of one control step and issues the kernels of
+include/covo_hip.h on torch's current stream.  When a torch.distributed process group with more
+than one rank is given, the sample axis N is sharded: rank g owns global sample ids
+[g*N/G, (g+1)*N/G), epsilon is keyed by global id, every rank reduces its shard to one
+online-softmax record and ONE all-gather (RCCL over xGMI when the backend is nccl) exchanges the
+records; all ranks then merge identically.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .._lib import COVO_H, COVO_NA, COVO_PARTIAL_FLOATS, COVO_POS_STATS_DOUBLES, check, ptr
+
+
+def shard_range(N: int, rank: int, world: int):
+    """Global sample ids owned by `rank`: [offset, offset + n_local)."""
+    if N % world != 0:
+        raise ValueError(f"N={N} must be divisible by the number of ranks {world}")
+    n_local = N // world
+    return rank * n_local, n_local
+
+
+def exchange_records(record, gathered_flat, process_group=None):
+    """THE one collective of a sample-sharded control step: all-gather the per-rank online-softmax
+    records (RCCL over xGMI under the nccl backend; gloo in the CPU tests).  `gathered_flat` is a flat
+    (world * len(record)) tensor; returns it viewed as (world, len(record))."""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(gathered_flat, record, group=process_group)
+    return gathered_flat.view(-1, record.numel())
+
+
+class SamplingCore:
+    def __init__(self, N: int, H: int, lam: float, discount: float, device=None, process_group=None,
+                 compute_info: bool = True):
+        import torch
+        if H != COVO_H:
+            raise NotImplementedError(f"the fused kernels are built for H={COVO_H}, got H={H}")
+        if not torch.cuda.is_available():
+            raise _lib.CovoError("covo_mpc_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.torch = torch
+        self.lib = _lib.load_library()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.N, self.H, self.lam, self.discount = int(N), int(H), float(lam), float(discount)
+        self.compute_info = compute_info
+        self.pg = process_group
+        self.world, self.rank = 1, 0
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        self.offset, self.n_local = shard_range(self.N, self.rank, self.world)
+        cfg = _lib.ConfigC(self.n_local, self.H, 4, self.lam, self.discount, 0)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.covo_create(C.byref(cfg), C.byref(h)), "covo_create")
+        self.h = h
+        f32 = dict(dtype=torch.float32, device=self.device)
+        n = self.n_local
+        self.eps = torch.empty((n, COVO_NA), **f32)
+        self.a = torch.empty((COVO_H, n, 4), **f32)
+        self.cost = torch.empty((n,), **f32)
+        self.blockmin = torch.empty(((n + 255) // 256,), **f32)
+        self.stats = torch.zeros((COVO_POS_STATS_DOUBLES,), dtype=torch.float64, device=self.device)
+        self.partial = torch.zeros((COVO_PARTIAL_FLOATS,), **f32)
+        self.gathered = torch.zeros((self.world * COVO_PARTIAL_FLOATS,), **f32) if self.world > 1 else None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.covo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- individual kernels -------------------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def shift_mean(self, a_mean):
+        out = self.torch.empty_like(a_mean)
+        check(self.lib.covo_shift_mean(self.h, ptr(a_mean), ptr(out), self.stream()), "covo_shift_mean")
+        return out
+
+    def randn(self, key):
+        check(self.lib.covo_randn(self.h, int(key[0]), int(key[1]), self.offset, self.n_local, COVO_NA, ptr(self.eps),
+                                  self.stream()), "covo_randn")
+        return self.eps
+
+    def noise_gemm(self, L, mu, eps=None):
+        eps = self.eps if eps is None else eps
+        check(self.lib.covo_noise_gemm(self.h, ptr(L), ptr(mu), ptr(eps), self.n_local, ptr(self.a), self.stream()),
+              "covo_noise_gemm")
+        return self.a
+
+    def noise_blockdiag(self, Ls, mu, eps=None):
+        eps = self.eps if eps is None else eps
+        check(self.lib.covo_noise_blockdiag(self.h, ptr(Ls), ptr(mu), ptr(eps), self.n_local, ptr(self.a),
+                                            self.stream()), "covo_noise_blockdiag")
+        return self.a
+
+    def cholesky(self, A, n, batch):
+        out = self.torch.empty_like(A)
+        check(self.lib.covo_cholesky(self.h, ptr(A), n, batch, ptr(out), self.stream()), "covo_cholesky")
+        return out
+
+    def rollout(self, dstate, params_c, f_shared, want_stats):
+        fs = (C.c_float * 3)(*[float(x) for x in f_shared])
+        check(self.lib.covo_rollout_cost(self.h, ptr(dstate.packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj),
+                                         dstate.T, C.byref(params_c), fs, ptr(self.a), self.n_local, ptr(self.cost),
+                                         ptr(self.blockmin), ptr(self.stats) if want_stats else None, self.stream()),
+              "covo_rollout_cost")
+        return self.cost
+
+    def hessian(self, packed, dstate, params_c, a_mean, batch=1):
+        R = self.torch.empty((batch, COVO_NA, COVO_NA), dtype=self.torch.float64, device=self.device)
+        check(self.lib.covo_hessian(self.h, ptr(packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj), dstate.T,
+                                    C.byref(params_c), ptr(a_mean), batch, ptr(R), self.stream()), "covo_hessian")
+        return R
+
+    def sigma(self, R, sample_sigma, batch=1):
+        f32 = dict(dtype=self.torch.float32, device=self.device)
+        Sigma = self.torch.empty((batch, COVO_NA, COVO_NA), **f32)
+        L = self.torch.empty((batch, COVO_NA, COVO_NA), **f32)
+        check(self.lib.covo_sigma(self.h, ptr(R), batch, float(sample_sigma), ptr(Sigma), ptr(L), self.stream()),
+              "covo_sigma")
+        return Sigma, L
+
+    def update(self, a_mean_shifted, gamma_mean):
+        """softmax weights + weighted mean (+ the one collective when sharded) -> new mean (H,4)."""
+        out = self.torch.empty_like(a_mean_shifted)
+        if self.world == 1:
+            check(self.lib.covo_softmax_update(self.h, ptr(self.cost), ptr(self.a), self.n_local, ptr(self.blockmin),
+                                               ptr(a_mean_shifted), float(gamma_mean), ptr(out), self.stream()),
+                  "covo_softmax_update")
+            return out
+        check(self.lib.covo_softmax_reduce(self.h, ptr(self.cost), ptr(self.a), self.n_local, ptr(self.blockmin),
+                                           ptr(self.partial), self.stream()), "covo_softmax_reduce")
+        exchange_records(self.partial, self.gathered, self.pg)  # the ONE collective per step
+        check(self.lib.covo_merge(self.h, ptr(self.gathered), self.world, ptr(a_mean_shifted), float(gamma_mean),
+                                  ptr(out), self.stream()), "covo_merge")
+        return out
+
+    def info(self, dstate):
+        """{"pos_mean","pos_std"} (H,3) from the per-step sums (controllers/covo.py:281)."""
+        torch = self.torch
+        stats = self.stats
+        if self.world > 1:
+            import torch.distributed as dist
+            stats = stats.clone()
+            dist.all_reduce(stats, group=self.pg)
+        s = stats.view(COVO_H, 6)
+        n = float(self.N)
+        m1 = s[:, :3] / n
+        var = torch.clamp(s[:, 3:] / n - m1 * m1, min=0.0)
+        p0 = dstate.packed[0:3].to(torch.float64)
+        return {"pos_mean": (p0[None, :] + m1).to(torch.float32), "pos_std": torch.sqrt(var).to(torch.float32)}

@@ -1,0 +1,16 @@
+"""Controller protocol: quadjax/controllers/base.py:5-19 (same names, arguments and defaults)."""
+
+
+class BaseController:
+    def __init__(self, env, control_params) -> None:
+        self.env = env
+        self.init_control_params = control_params
+
+    def update_params(self, env_params, control_params):
+        return control_params
+
+    def reset(self, env_state=None, env_params=None, control_params=None, key=None):
+        return self.init_control_params
+
+    def __call__(self, obs, state, env_params, rng_act, control_params, env_info=None):
+        raise NotImplementedError

@@ -1,0 +1,134 @@
+"""CoVO-MPC controller behind quadjax's call signature: quadjax/controllers/covo.py:13-283.
+
+Differs from MPPI only in how the sampling covariance is chosen (covo.py:205-208): `online`
+takes the exact Hessian of the rollout cost at the shifted mean (hyper-dual HIP kernel),
+maps its spectrum to the optimal Sigma (Jacobi eigendecomposition kernel) and factors it;
+`offline` looks Sigma up in a per-episode table built at reset() along a PID-tracked nominal
+trajectory (covo.py:44-112).
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass
+from typing import Any, Optional
+
+import numpy as np
+
+from .._lib import COVO_NA
+from ..dynamics.dataclass import as_device_state
+from .base import BaseController
+from .pid import PIDController, PIDParams
+from ._core import SamplingCore
+
+
+@dataclass(frozen=True)
+class CoVOParams:
+    """covo.py:13-22.  a_mean (H,4), a_cov (128,128), a_cov_offline (T,128,128): torch fp32 on the GPU.
+    a_chol_offline caches the table's Cholesky factors (the reference re-factors every step inside
+    multivariate_normal, covo.py:216; the result is identical)."""
+    gamma_mean: float
+    gamma_sigma: float
+    discount: float
+    sample_sigma: float
+    a_mean: Any
+    a_cov: Any
+    a_cov_offline: Any
+    a_chol_offline: Optional[Any] = None
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+class CoVOController(BaseController):
+    def __init__(self, env, control_params, N: int, H: int, lam: float, mode: str = "online", *, device=None,
+                 process_group=None, compute_info: bool = True) -> None:
+        super().__init__(env, control_params)
+        self.N, self.H, self.lam = N, H, lam
+        self.action_dim = self.env.action_dim
+        if mode not in ("online", "offline"):
+            raise NotImplementedError(mode)  # covo.py:113-114
+        if mode == "offline":
+            assert env.action_dim == 4, "only support 4D action space Quadrotor environment for now"  # covo.py:45-47
+            self.expansion_control_params = PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0)  # covo.py:48-53
+            self.expansion_controller = PIDController(env, control_params=control_params)
+            self.reset = self.reset_a_cov_offline  # covo.py:112
+        self.mode = mode
+        self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
+                                 compute_info=compute_info)
+
+    # ---- Sigma selection (covo.py:36-41 / 107-108) ----------------------------------------------
+    def get_hessian(self, env_state, env_params, control_params, a_mean, rng_act=None):
+        """covo.py:134-185 -> (128,128) fp64 tensor."""
+        dstate = as_device_state(env_state, self.core.device)
+        return self.core.hessian(dstate.packed, dstate, env_params.to_c(), a_mean.reshape(-1))[0]
+
+    def optimize_sigma(self, R, control_params):
+        """covo.py:116-132 -> (Sigma, chol(Sigma)) fp32."""
+        Sigma, L = self.core.sigma(R.reshape(1, COVO_NA, COVO_NA), control_params.sample_sigma)
+        return Sigma[0], L[0]
+
+    # ---- covo-offline reset (covo.py:58-104) --------------------------------------------------------
+    def reset_a_cov_offline(self, env_state, env_params, control_params, key):
+        from .. import random as crandom
+        torch = self.core.torch
+        env = self.env
+        T = env.default_params.max_steps_in_episode
+        packed = np.zeros((T, 32), dtype=np.float32)
+        a_means = np.zeros((T, COVO_NA), dtype=np.float32)
+        s = env_state
+        for t in range(T):  # get_single_a_cov_offline, covo.py:72-90
+            # nominal mean: H deterministic PID steps (covo.py:58-76)
+            sr, kr = s, key
+            for k in range(self.H):
+                rng_act, kr = crandom.split(kr)
+                action, _, _ = self.expansion_controller(None, sr, env_params, rng_act, self.expansion_control_params)
+                rng_step, kr = crandom.split(kr)
+                _, sr, _, _, _ = env.step_env(rng_step, sr, action, env_params, deterministic=True, need_info=False)
+                a_means[t, 4 * k:4 * k + 4] = action
+            packed[t] = s.pack()
+            # advance the real state one PID step, deterministic=False (covo.py:80-90)
+            rng_step, key = crandom.split(key)
+            action, _, _ = self.expansion_controller(None, s, env_params, rng_step, self.expansion_control_params)
+            rng_step, key = crandom.split(key)
+            _, s, _, _, _ = env.step_env(rng_step, s, action, env_params, need_info=False)
+        dstate = as_device_state(env_state, self.core.device)
+        packed_d = torch.from_numpy(packed).to(self.core.device)
+        a_means_d = torch.from_numpy(a_means).to(self.core.device)
+        R = self.core.hessian(packed_d, dstate, env_params.to_c(), a_means_d, batch=T)
+        Sigma, L = self.core.sigma(R, control_params.sample_sigma, batch=T)
+        return control_params.replace(a_cov_offline=Sigma, a_chol_offline=L)
+
+    # ---- one MPC control step (covo.py:187-283) -----------------------------------------------------
+    def __call__(self, obs, env_state, env_params, rng_act, control_params: CoVOParams, info):
+        from .. import random as crandom
+        core = self.core
+        dstate = as_device_state(info["noisy_state"], core.device)  # covo.py:198
+        params_c = env_params.to_c()
+        a_mean = core.shift_mean(control_params.a_mean.reshape(-1))  # covo.py:201-203
+        control_params = control_params.replace(a_mean=a_mean.view(self.H, 4))
+        # optimal Sigma (covo.py:205-208)
+        if self.mode == "online":
+            R = core.hessian(dstate.packed, dstate, params_c, a_mean)
+            Sigma, L = core.sigma(R, control_params.sample_sigma)
+            a_cov, L = Sigma[0], L[0]
+        else:
+            if control_params.a_chol_offline is None:
+                raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
+            t_idx = dstate.packed[25:26].view(core.torch.int32).long()  # env_state.time, stays on the device
+            t_idx = t_idx.clamp(0, control_params.a_cov_offline.shape[0] - 1)  # JAX gather clamps
+            a_cov = control_params.a_cov_offline.index_select(0, t_idx)[0]
+            L = control_params.a_chol_offline.index_select(0, t_idx)[0]
+        control_params = control_params.replace(a_cov=a_cov)
+        # sampling (covo.py:212-224)
+        rng_act, act_key = crandom.split(rng_act)
+        core.randn(act_key)
+        core.noise_gemm(L, a_mean)
+        # rollout, deterministic=True -> no disturbance draw (covo.py:225-263)
+        rng_act, step_key = crandom.split(rng_act)
+        core.rollout(dstate, params_c, (0.0, 0.0, 0.0), core.compute_info)
+        # weights + update (covo.py:266-278)
+        a_mean_new = core.update(a_mean, control_params.gamma_mean).view(self.H, 4)
+        control_params = control_params.replace(a_mean=a_mean_new)
+        u = a_mean_new[0]
+        out_info = core.info(dstate) if core.compute_info else {}
+        return u, control_params, out_info

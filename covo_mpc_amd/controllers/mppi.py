@@ -1,0 +1,65 @@
+"""MPPI controller behind quadjax's call signature: quadjax/controllers/mppi.py:11-134.
+
+Same constructor / __call__ arguments and return triple; the body is the HIP pipeline
+(noise -> fused rollout -> two-stage softmax reduction) instead of jit-compiled JAX.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass
+from typing import Any
+
+from ..dynamics.dataclass import as_device_state
+from .base import BaseController
+from ._core import SamplingCore
+
+
+@dataclass(frozen=True)
+class MPPIParams:
+    """mppi.py:11-19.  a_mean (H,4), a_cov (H,4,4): torch fp32 tensors on the GPU."""
+    gamma_mean: float
+    gamma_sigma: float
+    discount: float
+    sample_sigma: float
+    a_mean: Any
+    a_cov: Any
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+class MPPIController(BaseController):
+    def __init__(self, env, control_params, N: int, H: int, lam: float, *, device=None, process_group=None,
+                 compute_info: bool = True) -> None:
+        super().__init__(env, control_params)
+        self.N, self.H, self.lam = N, H, lam
+        self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
+                                 compute_info=compute_info)
+
+    def __call__(self, obs, env_state, env_params, rng_act, control_params: MPPIParams, info):
+        from .. import random as crandom
+        core = self.core
+        torch = core.torch
+        if control_params.gamma_sigma != 0.0:
+            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0, mppi.py:119-125) is not built; "
+                                      "quadjax's own factory fixes gamma_sigma = 0 (envs/quadrotor.py:715)")
+        dstate = as_device_state(info["noisy_state"], core.device)  # mppi.py:40
+        # shift operator (mppi.py:43-49)
+        a_mean = core.shift_mean(control_params.a_mean.reshape(-1)).view(self.H, 4)
+        a_cov = torch.cat([control_params.a_cov[1:], control_params.a_cov[-1:]], dim=0).contiguous()
+        control_params = control_params.replace(a_mean=a_mean, a_cov=a_cov)
+        # sampling (mppi.py:53-66)
+        rng_act, act_key = crandom.split(rng_act)
+        core.randn(act_key)
+        Ls = core.cholesky(a_cov, 4, self.H)
+        core.noise_blockdiag(Ls, a_mean)
+        # rollout (mppi.py:69-106): deterministic=False -> the shared step_key's disturbance draw
+        rng_act, step_key = crandom.split(rng_act)
+        f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)
+        core.rollout(dstate, env_params.to_c(), f_shared, core.compute_info)
+        # weights + update (mppi.py:109-125; gamma_sigma = 0 leaves a_cov as shifted)
+        a_mean_new = core.update(a_mean.reshape(-1), control_params.gamma_mean).view(self.H, 4)
+        control_params = control_params.replace(a_mean=a_mean_new)
+        u = a_mean_new[0]  # mppi.py:129
+        out_info = core.info(dstate) if core.compute_info else {}
+        return u, control_params, out_info

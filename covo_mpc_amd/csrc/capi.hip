@@ -1,0 +1,152 @@
+// capi.hip -- the extern "C" surface declared in include/covo_hip.h.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "covo_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void covo_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define REQUIRE(cond, ...)            \
+    do {                              \
+        if (!(cond)) {                \
+            covo_set_error(__VA_ARGS__); \
+            return COVO_E_BADARG;     \
+        }                             \
+    } while (0)
+
+extern "C" {
+
+const char *covo_last_error(void) { return g_err; }
+int covo_abi_version(void) { return COVO_ABI_VERSION; }
+
+int covo_create(const covo_config *cfg, covo_handle_t *out)
+{
+    REQUIRE(cfg && out, "covo_create: null argument");
+    REQUIRE(cfg->H == COVO_H && cfg->du == COVO_DU, "covo_create: H=%d du=%d unsupported (kernels are built for H=%d du=%d)",
+            cfg->H, cfg->du, COVO_H, COVO_DU);
+    REQUIRE(cfg->n_local > 0, "covo_create: n_local=%d", cfg->n_local);
+    REQUIRE(cfg->lam > 0.0f, "covo_create: lam=%g", (double)cfg->lam);
+    covo_ctx *h = new covo_ctx();
+    h->cfg = *cfg;
+    COVO_CHECK_HIP(hipGetDevice(&h->device));
+    h->max_red_blocks = 256;
+    const int nb = (cfg->n_local + 255) / 256;
+    COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)nb * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)nb * COVO_H * 6 * sizeof(float)));
+    *out = h;
+    return 0;
+}
+
+int covo_destroy(covo_handle_t h)
+{
+    if (!h) return COVO_E_NOHANDLE;
+    (void)hipFree(h->ws_partials);
+    (void)hipFree(h->ws_blockmin);
+    (void)hipFree(h->ws_stats);
+    delete h;
+    return 0;
+}
+
+int covo_randn(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t sample_offset, int32_t n_samples, int32_t n_cols,
+               float *eps_out, void *stream)
+{
+    REQUIRE(h, "covo_randn: null handle");
+    REQUIRE(eps_out && n_samples > 0 && n_cols > 0, "covo_randn: bad argument");
+    return launch_randn(key0, key1, sample_offset, n_samples, n_cols, eps_out, (hipStream_t)stream);
+}
+
+int covo_noise_gemm(covo_handle_t h, const float *L, const float *mu, const float *eps, int32_t N, float *a_out,
+                    void *stream)
+{
+    REQUIRE(h, "covo_noise_gemm: null handle");
+    REQUIRE(L && mu && eps && a_out && N > 0, "covo_noise_gemm: bad argument");
+    return launch_noise_gemm(L, mu, eps, N, a_out, (hipStream_t)stream);
+}
+
+int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, const float *eps, int32_t N, float *a_out,
+                         void *stream)
+{
+    REQUIRE(h, "covo_noise_blockdiag: null handle");
+    REQUIRE(Ls && mu && eps && a_out && N > 0, "covo_noise_blockdiag: bad argument");
+    return launch_noise_blockdiag(Ls, mu, eps, N, a_out, (hipStream_t)stream);
+}
+
+int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                      const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
+                      float *cost_out, float *blockmin, double *pos_stats, void *stream)
+{
+    REQUIRE(h, "covo_rollout_cost: null handle");
+    REQUIRE(state && pos_traj && vel_traj && params && a && cost_out && T > 0, "covo_rollout_cost: bad argument");
+    REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_rollout_cost: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount, cost_out,
+                          blockmin, pos_stats, h->ws_stats, (hipStream_t)stream);
+}
+
+int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+                        float *partial_out, void *stream)
+{
+    REQUIRE(h, "covo_softmax_reduce: null handle");
+    REQUIRE(cost && a && partial_out, "covo_softmax_reduce: bad argument");
+    REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_reduce: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    return launch_softmax_reduce(h, cost, a, N, blockmin, (N + 255) / 256, partial_out, nullptr, 1.0f, nullptr,
+                                 (hipStream_t)stream);
+}
+
+int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+                        const float *a_mean_old, float gamma_mean, float *a_mean_out, void *stream)
+{
+    REQUIRE(h, "covo_softmax_update: null handle");
+    REQUIRE(cost && a && a_mean_old && a_mean_out, "covo_softmax_update: bad argument");
+    REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_update: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    return launch_softmax_reduce(h, cost, a, N, blockmin, (N + 255) / 256, nullptr, a_mean_old, gamma_mean, a_mean_out,
+                                 (hipStream_t)stream);
+}
+
+int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a_mean_old, float gamma_mean,
+               float *a_mean_out, void *stream)
+{
+    REQUIRE(h, "covo_merge: null handle");
+    REQUIRE(partials && a_mean_old && a_mean_out && G > 0, "covo_merge: bad argument");
+    return launch_merge(partials, G, h->cfg.lam, a_mean_old, gamma_mean, a_mean_out, (hipStream_t)stream);
+}
+
+int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, void *stream)
+{
+    REQUIRE(h, "covo_shift_mean: null handle");
+    REQUIRE(a_mean_in && a_mean_out && a_mean_in != a_mean_out, "covo_shift_mean: bad argument (in must differ from out)");
+    return launch_shift_mean(a_mean_in, a_mean_out, (hipStream_t)stream);
+}
+
+int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                 const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream)
+{
+    REQUIRE(h, "covo_hessian: null handle");
+    REQUIRE(state && pos_traj && vel_traj && params && a_mean && R_out && T > 0 && batch > 0, "covo_hessian: bad argument");
+    return launch_hessian(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, (hipStream_t)stream);
+}
+
+int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out, float *L_out,
+               void *stream)
+{
+    REQUIRE(h, "covo_sigma: null handle");
+    REQUIRE(R && L_out && batch > 0 && sample_sigma > 0.0f, "covo_sigma: bad argument");
+    return launch_sigma(R, batch, sample_sigma, Sigma_out, L_out, (hipStream_t)stream);
+}
+
+int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, float *L_out, void *stream)
+{
+    REQUIRE(h, "covo_cholesky: null handle");
+    REQUIRE(A && L_out && batch > 0, "covo_cholesky: bad argument");
+    return launch_cholesky(A, n, batch, L_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// covo_common.hpp -- internal declarations shared by the gfx950 kernels and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/covo_hip.h"
+#include "quad_model.hpp"
+
+#define COVO_WAVE 64
+
+// state buffer offsets (include/covo_hip.h "Data layouts")
+enum { ST_POS = 0, ST_VEL = 3, ST_QUAT = 6, ST_OMEGA = 10, ST_FDIST = 13, ST_POSTAR = 16, ST_VELTAR = 19, ST_ACCTAR = 22, ST_TIME = 25 };
+
+struct covo_ctx {
+    covo_config cfg;
+    int device;
+    // workspace (device)
+    float *ws_partials;   // [max_blocks][COVO_PARTIAL_FLOATS] stage-1 records of the softmax reduce
+    float *ws_blockmin;   // [ceil(n_local/256)] per-block cost minima when the caller passes none
+    float *ws_stats;      // [ceil(n_local/256)][H*6] per-block position statistics
+    int max_red_blocks;
+};
+
+void covo_set_error(const char *fmt, ...);
+
+#define COVO_CHECK_HIP(expr)                                                         \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            covo_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (int)_e;                                                          \
+        }                                                                            \
+    } while (0)
+
+template <class U>
+__host__ __device__ inline qm::Consts<U> make_consts(const covo_env_params &p)
+{
+    qm::Consts<U> c;
+    // fp32 products first: the model constants are fp32 quantities (JAX default dtype)
+    c.thrust_half = (U)(0.5f * p.max_thrust * p.action_scale);
+    for (int i = 0; i < 3; ++i) c.komega[i] = (U)(p.max_omega[i] * p.action_scale);
+    c.dt = (U)p.dt;
+    c.half_dt = (U)(0.5f * p.dt);
+    c.neg_g = (U)(-p.g);
+    c.inv_m = (U)(1.0f / p.m);
+    c.alpha = (U)p.alpha_bodyrate;
+    c.one_m_alpha = (U)(1.0f - p.alpha_bodyrate);
+    c.pos_limit = (U)p.pos_limit;
+    return c;
+}
+
+// ---- wave-level reductions over 64 lanes (DPP-lowered by the compiler from __shfl_xor)
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// launch entry points implemented in the .hip files (host functions)
+int launch_randn(uint32_t k0, uint32_t k1, int64_t off, int n_samples, int n_cols, float *out, hipStream_t s);
+int launch_noise_gemm(const float *L, const float *mu, const float *eps, int N, float *a, hipStream_t s);
+int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, int N, float *a, hipStream_t s);
+int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
+                   const float *f_shared, const float *a, int N, float discount, float *cost, float *blockmin,
+                   double *pos_stats, float *stats_ws, hipStream_t s);
+// a_mean_out != null: finish on this GPU (normalise + blend); else write the merged record to partial_out
+int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
+                          float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,
+                          hipStream_t s);
+int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
+                 hipStream_t s);
+int launch_shift_mean(const float *in, float *out, hipStream_t s);
+int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
+                   const float *a_mean, int batch, double *R, hipStream_t s);
+int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, hipStream_t s);
+int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);

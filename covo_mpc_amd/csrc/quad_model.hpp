@@ -1,0 +1,209 @@
+// quad_model.hpp -- one-step quadrotor model shared by the fp32 rollout kernel and the
+// fp64 hyper-dual Hessian kernel (gfx950 device code).
+//
+// Restates, in closed form, what XLA lowers from (paths relative to /root/reference/quadjax):
+//   envs/quadrotor.py:215-263   step_env / raw_step (clip, thrust & body-rate maps)
+//   dynamics/free.py:74-155     quad_dynamics_bodyrate + free_dynamics_3d_bodyrate
+//   dynamics/geom.py:41-77      L(q), H, qtoQ   (only Q[:,2] and 0.5 L(q) H w are needed)
+//   dynamics/utils.py:266-294   log_pos_fn, tracking_penyaw_reward_fn
+//   envs/quadrotor.py:479-490   is_terminal (rollover check disabled by main(), :779)
+//
+// The scalar type S is `float` (rollout: hardware v_rsq/v_sqrt/v_log/v_rcp, 1 ulp each) or
+// HyperDual (Hessian: value + two first-order parts + one mixed second-order part, fp64).
+// U is the type of wave-uniform quantities (float / double).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace qm {
+
+// ---------------------------------------------------------------- float primitives
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float log_(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
+__device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ float sat01_(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+__device__ __forceinline__ float clip11_(float x) { return __builtin_amdgcn_fmed3f(x, -1.0f, 1.0f); }
+__device__ __forceinline__ float value_(float x) { return x; }
+
+// |atan2(y, x)|: odd minimax polynomial of atan on [0,1] (max abs error 1.2e-7) + octant fix-up.
+__device__ __forceinline__ float atan2abs_(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = t * t;
+    float r = 0.00282363896f;
+    r = __builtin_fmaf(r, s, -0.0159569028f);
+    r = __builtin_fmaf(r, s, 0.0425049886f);
+    r = __builtin_fmaf(r, s, -0.0748900920f);
+    r = __builtin_fmaf(r, s, 0.106347933f);
+    r = __builtin_fmaf(r, s, -0.142027363f);
+    r = __builtin_fmaf(r, s, 0.199926957f);
+    r = __builtin_fmaf(r, s, -0.333331018f);
+    r = r * s;
+    r = __builtin_fmaf(r, t, t);
+    r = (mx == 0.0f) ? 0.0f : r;              // atan2(0,0) = 0
+    r = (ay > ax) ? (1.57079637f - r) : r;
+    r = (x < 0.0f) ? (3.14159274f - r) : r;
+    return r;
+}
+
+// ---------------------------------------------------------------- double primitives (primal prefix of the Hessian)
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double log_(double x) { return log(x); }
+__device__ __forceinline__ double abs_(double x) { return fabs(x); }
+__device__ __forceinline__ double sat01_(double x) { return fmin(fmax(x, 0.0), 1.0); }
+__device__ __forceinline__ double clip11_(double x) { return fmin(fmax(x, -1.0), 1.0); }
+__device__ __forceinline__ double value_(double x) { return x; }
+__device__ __forceinline__ double atan2abs_(double y, double x) { return fabs(atan2(y, x)); }
+
+// ---------------------------------------------------------------- hyper-dual fp64
+// x = v + a e1 + b e2 + ab e1 e2  (e1^2 = e2^2 = 0).  g(x) = g(v) + g'(v)(a e1 + b e2)
+//   + (g'(v) ab + g''(v) a b) e1 e2  -- forward-over-forward AD of jax.jacfwd(jax.jacfwd(.)).
+struct HD {
+    double v, a, b, ab;
+};
+__device__ __forceinline__ HD hd(double v) { return HD{v, 0.0, 0.0, 0.0}; }
+__device__ __forceinline__ HD operator+(HD x, HD y) { return HD{x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; }
+__device__ __forceinline__ HD operator-(HD x, HD y) { return HD{x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; }
+__device__ __forceinline__ HD operator-(HD x) { return HD{-x.v, -x.a, -x.b, -x.ab}; }
+__device__ __forceinline__ HD operator+(HD x, double c) { return HD{x.v + c, x.a, x.b, x.ab}; }
+__device__ __forceinline__ HD operator+(double c, HD x) { return HD{x.v + c, x.a, x.b, x.ab}; }
+__device__ __forceinline__ HD operator-(HD x, double c) { return HD{x.v - c, x.a, x.b, x.ab}; }
+__device__ __forceinline__ HD operator-(double c, HD x) { return HD{c - x.v, -x.a, -x.b, -x.ab}; }
+__device__ __forceinline__ HD operator*(HD x, double c) { return HD{x.v * c, x.a * c, x.b * c, x.ab * c}; }
+__device__ __forceinline__ HD operator*(double c, HD x) { return HD{x.v * c, x.a * c, x.b * c, x.ab * c}; }
+__device__ __forceinline__ HD operator*(HD x, HD y)
+{
+    return HD{x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b,
+              x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab};
+}
+// unary chain rule with f = g(v), d1 = g'(v), d2 = g''(v)
+__device__ __forceinline__ HD chain_(HD x, double f, double d1, double d2)
+{
+    return HD{f, d1 * x.a, d1 * x.b, d1 * x.ab + d2 * x.a * x.b};
+}
+__device__ __forceinline__ HD sqrt_(HD x)
+{
+    const double s = sqrt(x.v);
+    const double d1 = 0.5 / s;  // inf at 0 => NaN tangents, as jnp.linalg.norm's JVP at 0
+    return chain_(x, s, d1, -0.5 * d1 / x.v);
+}
+__device__ __forceinline__ HD rsqrt_(HD x)
+{
+    const double r = 1.0 / sqrt(x.v);
+    const double d1 = -0.5 * r / x.v;
+    return chain_(x, r, d1, -1.5 * d1 / x.v);
+}
+__device__ __forceinline__ HD log_(HD x)
+{
+    const double r = 1.0 / x.v;
+    return chain_(x, log(x.v), r, -r * r);
+}
+// lax.abs JVP: g * sign(x), sign(0) = 0
+__device__ __forceinline__ HD abs_(HD x)
+{
+    const double sg = (x.v > 0.0) ? 1.0 : ((x.v < 0.0) ? -1.0 : 0.0);
+    return HD{fabs(x.v), sg * x.a, sg * x.b, sg * x.ab};
+}
+// jnp.clip = minimum(maximum(x, lo), hi); lax.max/min JVPs split a tie 0.5/0.5 (_balanced_eq)
+__device__ __forceinline__ HD clip_(HD x, double lo, double hi)
+{
+    double g = 1.0;
+    double v = x.v;
+    if (v < lo) { v = lo; g = 0.0; } else if (v == lo) { g = 0.5; }
+    if (v > hi) { v = hi; g = 0.0; } else if (v == hi) { g *= 0.5; }
+    return HD{v, g * x.a, g * x.b, g * x.ab};
+}
+__device__ __forceinline__ HD sat01_(HD x) { return clip_(x, 0.0, 1.0); }
+__device__ __forceinline__ HD clip11_(HD x) { return clip_(x, -1.0, 1.0); }
+__device__ __forceinline__ double value_(HD x) { return x.v; }
+// |atan2(y, x)| = abs_(atan2(y, x))
+__device__ __forceinline__ HD atan2abs_(HD y, HD x)
+{
+    const double den = x.v * x.v + y.v * y.v;
+    const double f = atan2(y.v, x.v);
+    const double fy = x.v / den, fx = -y.v / den;  // d/dy, d/dx
+    const double fyy = -2.0 * x.v * y.v / (den * den);
+    const double fxx = -fyy;
+    const double fxy = (y.v * y.v - x.v * x.v) / (den * den);
+    HD r;
+    r.v = f;
+    r.a = fy * y.a + fx * x.a;
+    r.b = fy * y.b + fx * x.b;
+    r.ab = fy * y.ab + fx * x.ab + fyy * y.a * y.b + fxx * x.a * x.b + fxy * (y.a * x.b + x.a * y.b);
+    return abs_(r);
+}
+
+// ---------------------------------------------------------------- model
+template <class S>
+struct State {
+    S px, py, pz, vx, vy, vz, qx, qy, qz, qw, ox, oy, oz;
+};
+
+// wave-uniform constants derived once from covo_env_params
+template <class U>
+struct Consts {
+    U thrust_half;  // 0.5 * max_thrust * action_scale :  u0 = (a0 + 1) * thrust_half
+    U komega[3];    // max_omega * action_scale        :  omega_tar = a[1:] * komega
+    U dt, half_dt, neg_g, inv_m, alpha, one_m_alpha, pos_limit;
+};
+
+// dynamics/utils.py:285-294 on the PRE-step state (envs/quadrotor.py:243)
+template <class S, class U>
+__device__ __forceinline__ S reward(const State<S> &s, U tx, U ty, U tz, U tvx, U tvy, U tvz)
+{
+    const S dx = tx - s.px, dy = ty - s.py, dz = tz - s.pz;
+    const S ex = tvx - s.vx, ey = tvy - s.vy, ez = tvz - s.vz;
+    const S err_pos = sqrt_(dx * dx + dy * dy + dz * dz);
+    const S err_vel = sqrt_(ex * ex + ey * ey + ez * ez);
+    const S yaw = atan2abs_(U(2) * (s.qw * s.qz + s.qx * s.qy), U(1) - U(2) * (s.qy * s.qy + s.qz * s.qz));
+    const S l = log_(err_pos + U(1));
+    const S lp = err_pos * U(0.4) + sat01_(l * U(4)) * U(0.4) + sat01_(l * U(8)) * U(0.2) +
+                 sat01_(l * U(16)) * U(0.1) + sat01_(l * U(32)) * U(0.1);
+    return U(1.3) - err_vel * U(0.05) - lp - yaw * U(0.2);
+}
+
+// envs/quadrotor.py:250-263 + dynamics/free.py:114-155 (+74-112).  a* are already clipped.
+// (fx,fy,fz) = f_disturb acting during THIS step (free.py:91,98).
+template <class S, class U>
+__device__ __forceinline__ void dyn_step(State<S> &s, S a0, S a1, S a2, S a3, const Consts<U> &c, U fx, U fy, U fz)
+{
+    const S thrust = (a0 + U(1)) * c.thrust_half;  // quadrotor.py:259, free.py:82
+    const S wtx = a1 * c.komega[0], wty = a2 * c.komega[1], wtz = a3 * c.komega[2];  // quadrotor.py:260, free.py:122,82
+    // q = x[3:7] / norm (free.py:88)
+    const S rn = rsqrt_(s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw);
+    const S x = s.qx * rn, y = s.qy * rn, z = s.qz * rn, w = s.qw * rn;
+    // Q @ [0,0,T]: third column of qtoQ(q) (geom.py:68-77)
+    const S Qz0 = U(2) * (x * z + y * w), Qz1 = U(2) * (y * z - x * w), Qz2 = w * w - x * x - y * y + z * z;
+    // v_dot = [0,0,-g] + 1/m (Q [0,0,T] + f)   (free.py:97-99)
+    const S vdx = (Qz0 * thrust + fx) * c.inv_m;
+    const S vdy = (Qz1 * thrust + fy) * c.inv_m;
+    const S vdz = (Qz2 * thrust + fz) * c.inv_m + c.neg_g;
+    // q_dot = 0.5 L(q) H omega = 0.5 [w om + v x om, -v.om]   (free.py:96)
+    const S qdx = w * s.ox + (y * s.oz - z * s.oy);
+    const S qdy = w * s.oy + (z * s.ox - x * s.oz);
+    const S qdz = w * s.oz + (x * s.oy - y * s.ox);
+    const S qdw = -(x * s.ox + y * s.oy + z * s.oz);
+    // explicit Euler with OLD derivatives (free.py:102-107)
+    s.px = s.px + s.vx * c.dt;
+    s.py = s.py + s.vy * c.dt;
+    s.pz = s.pz + s.vz * c.dt;
+    s.vx = s.vx + vdx * c.dt;
+    s.vy = s.vy + vdy * c.dt;
+    s.vz = s.vz + vdz * c.dt;
+    const S nx = x + qdx * c.half_dt, ny = y + qdy * c.half_dt, nz = z + qdz * c.half_dt, nw = w + qdw * c.half_dt;
+    s.ox = s.ox * c.alpha + wtx * c.one_m_alpha;
+    s.oy = s.oy * c.alpha + wty * c.one_m_alpha;
+    s.oz = s.oz * c.alpha + wtz * c.one_m_alpha;
+    // re-normalise (free.py:139)
+    const S rn2 = rsqrt_(nx * nx + ny * ny + nz * nz + nw * nw);
+    s.qx = nx * rn2;
+    s.qy = ny * rn2;
+    s.qz = nz * rn2;
+    s.qw = nw * rn2;
+}
+
+}  // namespace qm

@@ -1,0 +1,284 @@
+// sigma.hip -- CoVO's optimal sampling covariance and its Cholesky factor (gfx950, fp64, one
+// workgroup per matrix; `batch` matrices per launch).
+//
+// Replaces quadjax/controllers/covo.py:116-132 (optimize_sigma: symmetrise, jnp.linalg.eigh,
+// spectrum shift to min 1e-2, Sigma = U diag(exp(log_s)) U^T with det Sigma = sigma^(2n),
+// symmetrise) and the Cholesky factorisation jax.random.multivariate_normal applies to a_cov
+// (covo.py:216-218; mppi.py:59 for the 4x4 blocks).
+//
+// Eigendecomposition: one-sided (Hestenes) cyclic Jacobi on G = A + shift*I, where `shift` is a
+// Gershgorin bound (+1) that makes G symmetric positive definite with eigenvalues >= 1.  Right
+// rotations orthogonalise the columns of G; at convergence G = V diag(lam'), so
+//     lam_k = |g_k| - shift,     v_k = g_k / |g_k|,
+// and only ONE n x n fp64 matrix (132 KiB of the CU's 160 KiB LDS, column-major, padded) is ever
+// stored -- no separate eigenvector matrix.  Sigma = sum_k f(lam_k) v_k v_k^T = H H^T with
+// h_k = g_k sqrt(f_k)/|g_k|.  Round-robin (circle) ordering: 64 disjoint column pairs per round,
+// one 16-lane group per pair, 127 rounds per sweep, sweeps until no rotation exceeds 1e-14.
+// Sigma is rounded to fp32 (the reference's a_cov dtype) before its Cholesky factor is taken in
+// fp64 and rounded to fp32.  Latency-bound section of covo-online (report us).
+#include "covo_common.hpp"
+
+constexpr int SG_N = COVO_NA;          // 128
+constexpr int SG_LD = SG_N + 1;        // padded column stride (doubles)
+constexpr int SG_THREADS = 1024;
+constexpr int SG_MAX_SWEEPS = 16;
+constexpr double SG_TOL = 1e-14;
+
+__device__ __forceinline__ double group16_sum(double v)
+{
+    // lanes of a pair group are 16 consecutive lanes; xor-butterfly stays inside the group
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// In-LDS lower Cholesky of the n x n SPD matrix stored column-major with stride ld in A
+// (right-looking; entries above the diagonal are left untouched).  All threads of the block call.
+__device__ void cholesky_lds(double *A, int n, int ld, int tid, int nthreads)
+{
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        const double djj = sqrt(A[j * ld + j]);
+        const double inv = 1.0 / djj;
+        __syncthreads();
+        // scale column j
+        for (int i = j + tid; i < n; i += nthreads) A[j * ld + i] = (i == j) ? djj : A[j * ld + i] * inv;
+        __syncthreads();
+        // trailing update: A[i][c] -= L[i][j] L[c][j] for j < c <= i
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += nthreads) {
+            const int c = j + 1 + e / m, i = j + 1 + e % m;
+            if (i >= c) A[c * ld + i] -= A[j * ld + i] * A[j * ld + c];
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SG_THREADS) void sigma_kernel(const double *__restrict__ Rin, float sample_sigma,
+                                                           float *__restrict__ Sigma_out, float *__restrict__ L_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *G = sm;                        // [SG_N][SG_LD] column-major
+    double *vec = sm + SG_N * SG_LD;       // [SG_N] scratch (norms / eigenvalues / scales)
+    double *red = vec + SG_N;              // [32] reduction scratch
+    int *flag = reinterpret_cast<int *>(red + 32);
+
+    const int tid = threadIdx.x;
+    const double *__restrict__ R = Rin + (size_t)blockIdx.x * SG_N * SG_N;
+
+    // ---- G = (R + R^T)/2, Gershgorin bound
+    for (int e = tid; e < SG_N * SG_N; e += SG_THREADS) {
+        const int c = e / SG_N, r = e % SG_N;
+        G[c * SG_LD + r] = 0.5 * (R[(size_t)r * SG_N + c] + R[(size_t)c * SG_N + r]);  // covo.py:117
+    }
+    __syncthreads();
+    if (tid < SG_N) {
+        double s = 0.0;
+        for (int r = 0; r < SG_N; ++r) s += fabs(G[tid * SG_LD + r]);
+        vec[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mx = 0.0;
+        for (int i = 0; i < SG_N; ++i) mx = fmax(mx, vec[i]);
+        red[0] = mx + 1.0;
+    }
+    __syncthreads();
+    const double shift = red[0];
+    if (tid < SG_N) G[tid * SG_LD + tid] += shift;
+    __syncthreads();
+
+    // ---- one-sided cyclic Jacobi
+    const int slot = tid >> 4, r16 = tid & 15;
+    for (int sweep = 0; sweep < SG_MAX_SWEEPS; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        bool rotated = false;
+        for (int round = 0; round < SG_N - 1; ++round) {
+            int p, q;
+            if (slot == 0) {
+                p = round;
+                q = SG_N - 1;
+            } else {
+                p = (round + slot) % (SG_N - 1);
+                q = (round - slot + (SG_N - 1)) % (SG_N - 1);
+            }
+            double *gp = G + p * SG_LD, *gq = G + q * SG_LD;
+            double cp[8], cq[8];
+            double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cp[i] = gp[r16 + 16 * i];
+                cq[i] = gq[r16 + 16 * i];
+                al = fma(cp[i], cp[i], al);
+                be = fma(cq[i], cq[i], be);
+                ga = fma(cp[i], cq[i], ga);
+            }
+            al = group16_sum(al);
+            be = group16_sum(be);
+            ga = group16_sum(ga);
+            if (fabs(ga) > SG_TOL * sqrt(al * be)) {   // uniform within the 16-lane group
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    gp[r16 + 16 * i] = c * cp[i] - s * cq[i];
+                    gq[r16 + 16 * i] = s * cp[i] + c * cq[i];
+                }
+            }
+            __syncthreads();
+        }
+        if (rotated) *flag = 1;
+        __syncthreads();
+        const int any = *flag;
+        __syncthreads();
+        if (!any) break;
+    }
+
+    // ---- eigenvalues (covo.py:118-122) and the spectrum map (covo.py:124-128)
+    if (tid < SG_N) {
+        double s = 0.0;
+        for (int r = 0; r < SG_N; ++r) s = fma(G[tid * SG_LD + r], G[tid * SG_LD + r], s);
+        vec[tid] = sqrt(s);  // lam'_k = |g_k|
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mn = vec[0] - shift;
+        for (int i = 1; i < SG_N; ++i) mn = fmin(mn, vec[i] - shift);
+        red[1] = mn;
+    }
+    __syncthreads();
+    const double min_eign = red[1];
+    double log_o = 0.0;
+    if (tid < SG_N) {
+        const double o = (vec[tid] - shift) + (-min_eign + 1e-2);  // eigns + offset
+        log_o = log(o);
+    }
+    __syncthreads();
+    // sum of log_o over the 128 eigenvalues (two waves)
+    {
+        double v = (tid < SG_N) ? log_o : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (tid < SG_N && (tid & 63) == 0) red[4 + (tid >> 6)] = v;
+    }
+    __syncthreads();
+    if (tid < SG_N) {
+        const double sum_log_o = red[4] + red[5];
+        const double n = (double)SG_N;
+        const double log_det_a_cov = n * (log((double)sample_sigma) * 2.0);
+        const double log_const = (log_det_a_cov * 2.0 + sum_log_o) / n;
+        const double log_s = 0.5 * log_const - 0.5 * log_o;
+        const double f = exp(log_s);
+        // h_k = g_k * sqrt(f_k) / |g_k|
+        const double sc = sqrt(f) / vec[tid];
+        vec[tid] = sc;
+    }
+    __syncthreads();
+    for (int e = tid; e < SG_N * SG_N; e += SG_THREADS) {
+        const int c = e / SG_N, r = e % SG_N;
+        G[c * SG_LD + r] *= vec[c];
+    }
+    __syncthreads();
+
+    // ---- Sigma = H H^T (covo.py:130-132; H H^T is symmetric by construction): 4x4 tile per thread
+    double acc[4][4];
+    const int bi = (tid >> 5) * 4, bj = (tid & 31) * 4;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+    for (int k = 0; k < SG_N; ++k) {
+        double hi[4], hj[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            hi[x] = G[k * SG_LD + bi + x];
+            hj[x] = G[k * SG_LD + bj + x];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[x][y] = fma(hi[x], hj[y], acc[x][y]);
+    }
+    __syncthreads();
+    // round to fp32 (a_cov dtype), publish, and keep the fp32-rounded values for the factorisation
+    float *So = Sigma_out ? Sigma_out + (size_t)blockIdx.x * SG_N * SG_N : nullptr;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const float v = (float)acc[x][y];
+            if (So) So[(size_t)(bi + x) * SG_N + bj + y] = v;
+            G[(bj + y) * SG_LD + bi + x] = (double)v;  // column-major: G[col][row]
+        }
+    __syncthreads();
+    // exact symmetry of the fp32 image: (a + a^T)/2 with a already symmetric to rounding
+    for (int e = tid; e < SG_N * SG_N; e += SG_THREADS) {
+        const int c = e / SG_N, r = e % SG_N;
+        if (r > c) {
+            const double v = 0.5 * (G[c * SG_LD + r] + G[r * SG_LD + c]);
+            G[c * SG_LD + r] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- lower Cholesky factor (covo.py:216 via multivariate_normal)
+    cholesky_lds(G, SG_N, SG_LD, tid, SG_THREADS);
+    float *Lo = L_out + (size_t)blockIdx.x * SG_N * SG_N;
+    for (int e = tid; e < SG_N * SG_N; e += SG_THREADS) {
+        const int r = e / SG_N, c = e % SG_N;
+        Lo[e] = (c <= r) ? (float)G[c * SG_LD + r] : 0.0f;
+    }
+}
+
+// Batched lower Cholesky of fp32 SPD matrices (n <= 128), fp64 internally, one workgroup each.
+__global__ __launch_bounds__(256) void cholesky_kernel(const float *__restrict__ Ain, int n, float *__restrict__ Lout)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int ld = n + 1;
+    const float *A = Ain + (size_t)blockIdx.x * n * n;
+    float *L = Lout + (size_t)blockIdx.x * n * n;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        const int r = e / n, c = e % n;
+        if (r >= c) sm[c * ld + r] = 0.5 * ((double)A[(size_t)r * n + c] + (double)A[(size_t)c * n + r]);
+    }
+    cholesky_lds(sm, n, ld, threadIdx.x, blockDim.x);
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        const int r = e / n, c = e % n;
+        L[e] = (c <= r) ? (float)sm[c * ld + r] : 0.0f;
+    }
+}
+
+int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, hipStream_t s)
+{
+    const size_t lds = (size_t)(SG_N * SG_LD + SG_N + 32 + 2) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sigma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sigma_kernel, dim3(batch), dim3(SG_THREADS), lds, s, R, sample_sigma, Sigma, L);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s)
+{
+    if (n < 1 || n > 128) {
+        covo_set_error("covo_cholesky: n=%d out of range [1,128]", n);
+        return COVO_E_BADARG;
+    }
+    const size_t lds = (size_t)n * (n + 1) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cholesky_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cholesky_kernel, dim3(batch), dim3(n <= 8 ? 64 : 256), lds, s, A, n, L);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

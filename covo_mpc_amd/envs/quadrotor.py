@@ -1,0 +1,333 @@
+"""Quadrotor environment plumbing + experiment drivers: quadjax/envs/quadrotor.py.
+
+Host-side (numpy fp32) mirror of `Quad3D` (quadrotor.py:23-503) -- same constructor, attributes,
+`step_env` / `raw_step` / `reset_env` / `get_info` / `get_obs*` / `is_terminal` -- plus
+`get_controller` (:670-752), `eval_env` (:506-591), `Args` (:755-766) and `main` (:769-803).
+No kernels live here: one state per control step is serial scalar math; the
+N x H rollouts the controllers need run in csrc/rollout.hip.  The controllers receive
+`info["noisy_state"]` exactly like the reference's (covo.py:198).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+import time as time_module
+from dataclasses import dataclass as pydataclass
+from functools import partial
+
+import numpy as np
+
+from .. import controllers
+from .. import random as crandom
+from ..dynamics import utils
+from ..dynamics.dataclass import Action3D, EnvParams3D, EnvState3D
+from ..dynamics.free import get_quadrotor_1st_order_dyn
+from .base import BaseEnvironment
+
+f32 = np.float32
+
+
+class Quad3D(BaseEnvironment):
+    def __init__(self, task: str = "tracking", obs_type: str = "quad", enable_randomizer: bool = True,
+                 lower_controller: str = "base", disturb_type: str = "periodic",
+                 disable_rollover_terminate: bool = False, generate_noisy_state: bool = False, device=None):
+        super().__init__()
+        self.task = task
+        self.disable_rollover_terminate = disable_rollover_terminate
+        self.generate_noisy_state = generate_noisy_state
+        self.disturb_type = disturb_type
+        self.device = device
+        dp = self.default_params
+        gens = {  # quadrotor.py:49-84
+            "tracking": (utils.generate_lissa_traj, utils.tracking_penyaw_reward_fn),
+            "tracking_slow": (utils.generate_lissa_traj_slow, utils.tracking_realworld_reward_fn),
+            "tracking_zigzag": (utils.generate_zigzag_traj, utils.tracking_penyaw_reward_fn),
+            "hovering": (utils.generate_fixed_traj, utils.tracking_penyaw_reward_fn),
+        }
+        if task not in gens:
+            raise NotImplementedError(task)
+        gen, self.reward_fn = gens[task]
+        self.generate_traj = partial(gen, dp.max_steps_in_episode, dp.dt)
+        self.get_init_state = self.get_zero_state
+        self.step_fn, self.dynamics_fn = get_quadrotor_1st_order_dyn(disturb_type=disturb_type)  # :87-89
+        self.get_err_pos = lambda state: np.linalg.norm(state.pos_tar - state.pos)
+        self.get_err_vel = lambda state: np.linalg.norm(state.vel_tar - state.vel)
+        if lower_controller != "base":  # the L1 lower controllers live on the reference's `rl` branch only
+            raise NotImplementedError(lower_controller)
+        self.default_control_params = 0.0
+        self.control_fn = lambda obs, state, env_params, rng_act, input_action: (input_action, None, state)
+        self.sim_dt = dp.dt
+        self.substeps = 1
+        self.enable_randomizer = enable_randomizer
+        if enable_randomizer and "params" not in obs_type:
+            print("Warning: enable domain randomziation without params in obs_type")
+        if obs_type == "quad_params":
+            self.get_obs = self.get_obs_quad_params
+            self.obs_dim = 39 + dp.traj_obs_len * 6
+        elif obs_type == "quad":
+            self.get_obs = self.get_obs_quadonly
+            self.obs_dim = 19 + dp.traj_obs_len * 6
+        else:
+            raise NotImplementedError(obs_type)
+        self.equib = np.array([0.0] * 6 + [1.0] + [0.0] * 9, dtype=f32)
+        self.action_dim = 4
+        self.adapt_obs_dim = 22 * dp.adapt_horizon
+        self.param_obs_dim = 20
+
+    @property
+    def default_params(self) -> EnvParams3D:
+        return EnvParams3D()
+
+    # ---- domain randomisation (quadrotor.py:132-171) ------------------------------------------------
+    def sample_params(self, key) -> EnvParams3D:
+        p = self.default_params
+        if self.enable_randomizer:
+            param_key = crandom.split(key)[0]
+            r = crandom.uniform(param_key, (17,), -1.0, 1.0)
+            I_diag = p.I_diag_mean + r[1:4] * p.I_diag_std
+            return EnvParams3D(m=float(p.m_mean + r[0] * p.m_std), I=np.diag(I_diag).astype(f32),
+                               action_scale=float(p.action_scale_mean + r[4] * p.action_scale_std),
+                               alpha_bodyrate=float(p.alpha_bodyrate_mean + r[5] * p.alpha_bodyrate_std),
+                               disturb_params=(r[6:12] * p.disturb_scale).astype(f32))
+        return EnvParams3D(disturb_params=crandom.uniform(key, (6,), -1.0, 1.0))
+
+    # ---- key methods ----------------------------------------------------------------------------------
+    def step_env(self, key, state: EnvState3D, action, params: EnvParams3D, deterministic: bool = False,
+                 need_info: bool = True):
+        """quadrotor.py:215-248: reward/done of the PRE-step state, one raw_step."""
+        action = np.clip(np.asarray(action, dtype=f32), -1.0, 1.0)
+        params = params.replace(dyn_noise_scale=params.dyn_noise_scale * (1.0 - float(deterministic)))  # :234-235
+        sub_action, _, state = self.control_fn(None, state, params, key, action)
+        next_state = self.raw_step(key, state, sub_action, params)
+        reward = self.reward_fn(state, params)
+        done = bool(self.is_terminal(state, params))
+        if not need_info:
+            return None, next_state, reward, done, None
+        info_key, key = crandom.split(key)
+        info = self.get_info(info_key, state, next_state, params)
+        return self.get_obs(next_state, params), next_state, reward, done, info
+
+    def raw_step(self, key, state, sub_action, params):
+        """quadrotor.py:250-263."""
+        sub_action = np.clip(np.asarray(sub_action, dtype=f32), -1.0, 1.0)
+        thrust = (sub_action[0] + f32(1.0)) / f32(2.0) * f32(params.max_thrust)
+        torque = sub_action[1:] * params.max_torque
+        key, step_key = crandom.split(key)
+        return self.step_fn(params, state, Action3D(thrust=thrust, torque=torque.astype(f32)), step_key, self.sim_dt)
+
+    def rollout_disturbance(self, step_key, params, deterministic: bool):
+        """The single f_disturb vector every sample/step of a controller rollout receives: all N x H
+        step_env calls share `step_key` (covo.py:225,231 / mppi.py:69,74), so free.py:147's draw is one
+        vector.  Key derivation follows step_env -> raw_step -> step_fn (quadrotor.py:262, free.py:136,144)."""
+        if self.disturb_type == "none":
+            return np.zeros(3, dtype=f32)
+        if self.disturb_type == "gaussian":
+            scale = params.dyn_noise_scale * (1.0 - float(deterministic))
+            _, k = crandom.split(step_key)      # raw_step: key, step_key = split(key)
+            k, _ = crandom.split(k)             # step_fn:  key, key_dyn = split(key)
+            disturb_key, _ = crandom.split(k)   #           disturb_key, key = split(key)
+            return (f32(scale) * crandom.normal(disturb_key, (3,))).astype(f32)
+        raise NotImplementedError(f"disturb_type={self.disturb_type!r} inside the fused rollout "
+                                  "(state/time-dependent models are outside the kernel's first scope)")
+
+    def get_zero_state(self, key, params) -> EnvState3D:
+        """quadrotor.py:265-312."""
+        traj_key, disturb_key, key = crandom.split(key, 3)
+        pos_traj, vel_traj, acc_traj = self.generate_traj(traj_key)
+        z3 = np.zeros(3, dtype=f32)
+        hist = self.default_params.adapt_horizon + 2
+        traj_dev = None
+        if self.device is not None:
+            import torch
+            traj_dev = (torch.from_numpy(pos_traj).to(self.device), torch.from_numpy(vel_traj).to(self.device))
+        return EnvState3D(
+            pos=z3.copy(), vel=z3.copy(), omega=z3.copy(), omega_tar=z3.copy(), quat=np.array([0, 0, 0, 1], dtype=f32),
+            pos_tar=pos_traj[0], vel_tar=vel_traj[0], acc_tar=acc_traj[0],
+            pos_traj=pos_traj, vel_traj=vel_traj, acc_traj=acc_traj, last_thrust=0.0, last_torque=z3.copy(), time=0,
+            f_disturb=crandom.uniform(disturb_key, (3,), -params.disturb_scale, params.disturb_scale),
+            vel_hist=np.zeros((hist, 3), f32), omega_hist=np.zeros((hist, 3), f32), action_hist=np.zeros((hist, 4), f32),
+            control_params=self.default_control_params, traj_dev=traj_dev)
+
+    def get_info(self, rng, state, next_state, params) -> dict:
+        """quadrotor.py:314-361."""
+        if self.generate_noisy_state:
+            rng_pos, rng_vel, rng_quat, rng_omega, rng = crandom.split(rng, 5)
+            s = f32(self.default_params.obs_noise_scale)
+            noisy_state = next_state.replace(
+                pos=(next_state.pos + crandom.normal(rng_pos, (3,)) * s * f32(0.25)).astype(f32),
+                vel=(next_state.vel + crandom.normal(rng_vel, (3,)) * s * f32(0.5)).astype(f32),
+                quat=(next_state.quat + crandom.normal(rng_quat, (4,)) * s * f32(0.02)).astype(f32),
+                omega=(next_state.omega + crandom.normal(rng_omega, (3,)) * s * f32(0.5)).astype(f32))
+        else:
+            noisy_state = None
+        return {"discount": 1.0, "err_pos": self.get_err_pos(state), "err_vel": self.get_err_vel(state),
+                "obs_param": self.get_obs_paramsonly(state, params), "noisy_state": noisy_state}
+
+    def reset_env(self, key, params):
+        """quadrotor.py:363-370 (note the (obs, info, state) order)."""
+        state = self.get_init_state(key, params)
+        info_key, key = crandom.split(key)
+        info = self.get_info(info_key, state, state, params)
+        return self.get_obs(state, params), info, state
+
+    def get_obs_quadonly(self, state, params):
+        """quadrotor.py:372-394."""
+        dp = self.default_params
+        idx = np.clip(state.time + 1 + np.arange(dp.traj_obs_len) * dp.traj_obs_gap, 0, state.pos_traj.shape[0] - 1)
+        return np.concatenate([state.pos, state.vel / 3.0, state.quat, state.omega / 5.0, state.pos_tar,
+                               state.vel_tar / 3.0, state.pos_traj[idx].flatten(),
+                               state.vel_traj[idx].flatten() / 3.0]).astype(f32)
+
+    def get_obs_paramsonly(self, state, params):
+        """quadrotor.py:425-452."""
+        return np.concatenate([
+            (np.diag(params.I) - params.I_diag_mean) / params.I_diag_std, state.f_disturb / params.disturb_scale,
+            (params.hook_offset - params.hook_offset_mean) / params.hook_offset_std, params.disturb_params,
+            [(params.m - params.m_mean) / params.m_std,
+             (params.action_scale - params.action_scale_mean) / params.action_scale_std,
+             (params.alpha_bodyrate - params.alpha_bodyrate_mean) / params.alpha_bodyrate_std]]).astype(f32)
+
+    def get_obs_quad_params(self, state, params):
+        """quadrotor.py:465-470."""
+        return np.concatenate([self.get_obs_quadonly(state, params), self.get_obs_paramsonly(state, params)])
+
+    def is_terminal(self, state, params) -> bool:
+        """quadrotor.py:479-490."""
+        done = (state.time >= params.max_steps_in_episode) or bool(np.any(np.abs(state.pos) > 3.0))
+        if not self.disable_rollover_terminate:
+            done = done or (state.quat[3] < np.cos(np.pi / 4.0)) or bool(np.any(np.abs(state.omega) > 100.0))
+        return done
+
+
+def eval_env(env: Quad3D, controller, total_steps=30000, filename="", num_trajs=4, seed=1, save=True, verbose=True):
+    """quadrotor.py:506-591: `num_trajs` reset keys x (episodes) x max_steps_in_episode steps; reports the
+    mean/std over episodes of the mean position error."""
+    rng = crandom.PRNGKey(seed)
+    T = env.default_params.max_steps_in_episode
+
+    def run_one_ep(rng_reset, rng):
+        env_params = env.default_params  # :543 (default params even under DR)
+        obs, info, env_state = env.reset(rng_reset, env_params)
+        rng_control, rng = crandom.split(rng)
+        control_params = controller.reset(env_state, env_params, controller.init_control_params, rng_control)
+        errs = []
+        for _ in range(T):  # run_one_step, :520-538
+            rng, rng_act, rng_step, rng_control = crandom.split(rng, 4)
+            action, control_params, control_info = controller(obs, env_state, env_params, rng_act, control_params, info)
+            if hasattr(action, "detach"):
+                action = action.detach().cpu().numpy()
+            obs, env_state, reward, done, info = env.step(rng_step, env_state, action, env_params)
+            rng, rng_control = crandom.split(rng)
+            errs.append(info["err_pos"])
+        return rng, np.asarray(errs)
+
+    t0 = time_module.time()
+    num_eps = int(total_steps // T)
+    err_pos_ep = []
+    rng, rng_reset_meta = crandom.split(rng)
+    for i, rng_reset in enumerate(crandom.split(rng_reset_meta, num_trajs)):
+        if verbose:
+            print(f"[DEBUG] test traj {i+1}")
+        for _ in range(max(num_eps // num_trajs, 1)):
+            rng, err_pos = run_one_ep(rng_reset, rng)
+            err_pos_ep.append(err_pos.mean())
+    err_pos_ep = np.asarray(err_pos_ep)
+    pos_mean, pos_std = err_pos_ep.mean(), err_pos_ep.std()
+    if verbose:
+        print(f"env running time: {time_module.time()-t0:.2f}s")
+        print(f"err_pos mean: {pos_mean:.3f}, std: {pos_std:.3f}")
+        print(f"${pos_mean*100:.2f} \\pm {pos_std*100:.2f}$")
+    if save:
+        from .. import get_package_path
+        save_path = f"{get_package_path()}/../results"
+        os.makedirs(save_path, exist_ok=True)
+        with open(f"{save_path}/eval_err_pos_{filename}.pkl", "wb") as f:
+            pickle.dump(np.array(err_pos_ep), f)
+    return err_pos_ep
+
+
+def get_controller(env, controller_name, controller_params=None, debug=False, device=None, process_group=None,
+                   compute_info=True):
+    """quadrotor.py:670-752."""
+    import torch
+
+    def parse_sample_params(param_text):
+        if not param_text:
+            return 8192, 32, 0.01, 0.5
+        parts = param_text.split("_")
+        return int(parts[0][1:]), int(parts[1][1:]), float(parts[2][3:]), 0.5
+
+    device = device if device is not None else (env.device if env.device is not None else "cuda")
+
+    def get_sample_mean(H):
+        dp = env.default_params
+        th = (dp.m * dp.g / dp.max_thrust) * 2.0 - 1.0
+        return torch.tensor([th, 0.0, 0.0, 0.0], dtype=torch.float32, device=device).repeat(H, 1)
+
+    if controller_name == "pid":
+        control_params = controllers.PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0)
+        return controllers.PIDController(env, control_params=control_params), control_params
+    if controller_name == "random":
+        return controllers.RandomController(env, None), None
+    if controller_name == "mppi":
+        N, H, lam, sigma = parse_sample_params(controller_params)
+        a_cov = (torch.eye(env.action_dim, dtype=torch.float32, device=device) * sigma ** 2).repeat(H, 1, 1)
+        control_params = controllers.MPPIParams(gamma_mean=1.0, gamma_sigma=0.0, discount=1.0, sample_sigma=sigma,
+                                                a_mean=get_sample_mean(H), a_cov=a_cov)
+        return controllers.MPPIController(env=env, control_params=control_params, N=N, H=H, lam=lam, device=device,
+                                          process_group=process_group, compute_info=compute_info), control_params
+    if "covo" in controller_name:
+        N, H, lam, sigma = parse_sample_params(controller_params)
+        mode = "offline" if "offline" in controller_name else "online"
+        if "online" not in controller_name and "offline" not in controller_name:
+            print("[DEBUG] unset mode, CoVO mode set to online")
+        control_params = controllers.CoVOParams(
+            gamma_mean=1.0, gamma_sigma=0.0, discount=1.0, sample_sigma=sigma, a_mean=get_sample_mean(H),
+            a_cov=torch.eye(H * env.action_dim, dtype=torch.float32, device=device) * sigma ** 2,
+            a_cov_offline=torch.zeros((H, env.action_dim, env.action_dim), dtype=torch.float32, device=device))
+        return controllers.CoVOController(env=env, control_params=control_params, N=N, H=H, lam=lam, mode=mode,
+                                          device=device, process_group=process_group,
+                                          compute_info=compute_info), control_params
+    raise NotImplementedError(controller_name)
+
+
+@pydataclass
+class Args:
+    """quadrotor.py:755-766."""
+    task: str = "tracking"
+    controller: str = "lqr"
+    controller_params: str = ""
+    obs_type: str = "quad"
+    debug: bool = False
+    mode: str = "render"
+    lower_controller: str = "base"
+    noDR: bool = False
+    disturb_type: str = "gaussian"
+    name: str = ""
+
+
+def main(args: Args):
+    """quadrotor.py:769-803 (eval mode; `render` needs matplotlib/meshcat post-processing, out of scope)."""
+    env = Quad3D(task=args.task, obs_type=args.obs_type, lower_controller=args.lower_controller,
+                 enable_randomizer=not args.noDR, disturb_type=args.disturb_type, disable_rollover_terminate=True,
+                 generate_noisy_state=True, device="cuda")
+    print("starting test...")
+    controller, control_params = get_controller(env, args.controller, args.controller_params)
+    if args.mode == "eval":
+        return eval_env(env, controller=controller, total_steps=300 * 4 * 10, filename=args.name)
+    raise NotImplementedError(args.mode)
+
+
+def _cli():
+    ap = argparse.ArgumentParser(description="quadjax-compatible driver (same flag names as quadrotor.py:755-766)")
+    for f, default in Args().__dict__.items():
+        if isinstance(default, bool):
+            ap.add_argument(f"--{f}", action="store_true")
+        else:
+            ap.add_argument(f"--{f}", type=type(default), default=default)
+    main(Args(**vars(ap.parse_args())))
+
+
+if __name__ == "__main__":
+    _cli()

@@ -1,0 +1,172 @@
+/* covo_hip.h -- C ABI of libcovo_hip.so: the MI355X (gfx950) sampling-MPC inner loop.
+ *
+ * The reference (LeCAR-Lab/CoVO-MPC, package quadjax) has NO plugin/FFI boundary for
+ * this path: it is pure Python-on-JAX and the boundary is the Python controller
+ * protocol quadjax/controllers/base.py:5-19.  This header is therefore the
+ * build-defined C ABI that covo_mpc_amd's Python controllers (the mirror of
+ * quadjax.controllers) bind with ctypes; each entry point cites the reference
+ * lines whose XLA-lowered ops it replaces.  INTEGRATION.md shows the ctypes stub
+ * a quadjax maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", every function returns int: 0 = ok, otherwise a COVO_E_* code
+ *     (negative) or a hipError_t (positive); covo_last_error() gives the text.
+ *   - All tensor arguments are CALLER-OWNED DEVICE pointers (torch data_ptr()),
+ *     fp32, contiguous, unless marked [host].  The library owns only the opaque
+ *     handle and a small device workspace allocated in covo_create().
+ *   - Every launch goes to the caller's hipStream_t (passed as void*); there are
+ *     no hidden synchronisations or allocations on these paths (graph-capturable).
+ *   - A handle is single-threaded and bound to the device current at creation.
+ *
+ * Data layouts in HBM
+ *   state    float[COVO_STATE_FLOATS]: the (noisy) env state the controller plans
+ *            from (quadjax/controllers/covo.py:198), packed as
+ *            pos[0:3] vel[3:6] quat_xyzw[6:10] omega[10:13] f_disturb[13:16]
+ *            pos_tar[16:19] vel_tar[19:22] acc_tar[22:25] time(int32 bits)[25]
+ *   traj     pos_traj / vel_traj: float[T][3] reference trajectory (EnvState3D)
+ *   eps      float[N][n]      standard-normal draws, sample-major, n = H*du = 128
+ *   a        float[H][N][4]   clipped sampled actions in "stripe" order: one
+ *            float4 (thrust, wx, wy, wz) per (step, sample); a wave of the rollout
+ *            kernel reads one contiguous 1 KiB stripe per step.
+ *   cost     float[N]
+ *   partial  float[COVO_PARTIAL_FLOATS] = {m, s, v[128], pad}: online-softmax
+ *            record of one shard (m = min cost, s = sum w, v = sum w*a)
+ */
+#ifndef COVO_HIP_H
+#define COVO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COVO_ABI_VERSION 1
+
+#define COVO_H 32            /* horizon (compile-time in the fused kernels)          */
+#define COVO_DU 4            /* action dim, quadjax/envs/quadrotor.py:198            */
+#define COVO_NA (COVO_H * COVO_DU) /* n = 128 flattened actions, index 4*t + d        */
+#define COVO_STATE_FLOATS 32
+#define COVO_PARTIAL_FLOATS 132
+#define COVO_POS_STATS_DOUBLES (COVO_H * 6) /* per step: sum(pos-c)[3], sum((pos-c)^2)[3] */
+
+#define COVO_E_BADARG (-1)
+#define COVO_E_NOHANDLE (-2)
+#define COVO_E_UNSUPPORTED (-3)
+
+typedef struct covo_ctx *covo_handle_t;
+
+/* Rollout-relevant subset of EnvParams3D (quadjax/dynamics/dataclass.py:40-100). [host] */
+typedef struct covo_env_params {
+    float max_thrust;       /* .8   */
+    float max_torque[3];    /* 9e-3, 9e-3, 2e-3 (cancels: quadrotor.py:260 * free.py:122) */
+    float max_omega[3];     /* 10, 10, 3 */
+    float dt;               /* .02  */
+    float g;                /* 9.81 */
+    float m;                /* .027 */
+    float action_scale;     /* 1    */
+    float alpha_bodyrate;   /* .5   */
+    int32_t max_steps_in_episode; /* 300 */
+    float pos_limit;        /* 3.0, quadrotor.py:484 */
+} covo_env_params;
+
+typedef struct covo_config {
+    int32_t n_local;        /* samples handled by this handle (this rank's shard)  */
+    int32_t H;              /* must equal COVO_H                                   */
+    int32_t du;             /* must equal COVO_DU                                  */
+    float lam;              /* temperature lambda, controllers/covo.py:266         */
+    float discount;         /* controllers/covo.py:258                             */
+    int32_t flags;          /* reserved, 0                                         */
+} covo_config;
+
+const char *covo_last_error(void);
+int covo_abi_version(void);
+
+/* Replaces nothing in the reference: lifetime of the opaque handle + workspace. */
+int covo_create(const covo_config *cfg, covo_handle_t *out);
+int covo_destroy(covo_handle_t h);
+
+/* Counter-based N(0,1) fill (Philox4x32-10 + Box-Muller) keyed by
+ * (key0, key1, global sample id, column): results do not depend on how samples are
+ * sharded.  Stands in for jax.random.split + normal inside
+ * jax.random.multivariate_normal (controllers/covo.py:212-220, mppi.py:53-65);
+ * jax's threefry bitstream is unpinned/unavailable, so the stream is build-defined.
+ * eps_out: float[n_samples][n_cols], rows = global ids sample_offset .. +n_samples. */
+int covo_randn(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t sample_offset, int32_t n_samples,
+               int32_t n_cols, float *eps_out, void *stream);
+
+/* a = clip(mu + L eps, -1, 1): jax.random.multivariate_normal's `mean + factor @ eps`
+ * followed by jnp.clip (controllers/covo.py:215-224).  fp32 MFMA GEMM
+ * (v_mfma_f32_32x32x2_f32; each dot product is an ascending-k fmaf chain, bit-exact).
+ * L: float[128][128] row-major lower-triangular Cholesky factor of a_cov (entries
+ * above the diagonal are ignored); mu: float[128]; eps: float[N][128]; a_out: float[H][N][4]. */
+int covo_noise_gemm(covo_handle_t h, const float *L, const float *mu, const float *eps, int32_t N, float *a_out,
+                    void *stream);
+
+/* MPPI's per-step sampling (controllers/mppi.py:53-66): a[t] = clip(mu[t] + Ls[t] eps[t]).
+ * Ls: float[H][4][4] lower factors; eps: float[N][H][4]; a_out: float[H][N][4]. */
+int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, const float *eps, int32_t N,
+                         float *a_out, void *stream);
+
+/* The fused N x H rollout: lax.scan(H) of vmap(N) Quad3D.step_env + done-freeze +
+ * discounted cost (controllers/covo.py:227-263, mppi.py:71-106; envs/quadrotor.py:215-263,
+ * 479-490; dynamics/free.py:74-155; dynamics/utils.py:266-294).  Per-sample state lives in
+ * registers; only cost[N] (+ one min per 256-sample block) is written.
+ * f_disturb_shared [host float[3]]: the single disturbance vector every sample receives
+ *   for rollout steps >= 1 from the shared step_key (0 for CoVO's deterministic=True).
+ * pos_stats (nullable): double[COVO_H*6] accumulators, zeroed by the call, receiving
+ *   per-step sum(pos - pos0) and sum((pos - pos0)^2) over samples of the post-step
+ *   positions (controllers/covo.py:234-237,281); pos0 = state pos.
+ * blockmin (nullable): float[ceil(N/256)] per-block minimum of cost. */
+int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                      const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
+                      float *cost_out, float *blockmin, double *pos_stats, void *stream);
+
+/* softmax weights + weighted sum as ONE online-softmax record of this shard
+ * (controllers/covo.py:266-272 before normalisation): two-stage wavefront reduction.
+ * blockmin (nullable): the per-256-sample minima covo_rollout_cost left for exactly this
+ *   cost/N (saves one pass over cost); recomputed internally when null.
+ * partial_out: float[COVO_PARTIAL_FLOATS]. */
+int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+                        float *partial_out, void *stream);
+
+/* Single-shard finish: covo_softmax_reduce + covo_merge(G=1) without materialising the record:
+ * a_mean_out = gamma_mean * sum_n w_n a_n + (1-gamma_mean) * a_mean_old (covo.py:266-275). */
+int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+                        const float *a_mean_old, float gamma_mean, float *a_mean_out, void *stream);
+
+/* Merge G shard records (this GPU's, or the all-gathered records of all ranks), normalise,
+ * blend with the old mean (controllers/covo.py:270-275):
+ *   a_mean_out = gamma_mean * (sum_g v_g e^{-(m_g-m)/lam}) / (sum_g s_g e^{-(m_g-m)/lam})
+ *              + (1-gamma_mean) * a_mean_old.         a_mean_*: float[128] (index 4t+d). */
+int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a_mean_old, float gamma_mean,
+               float *a_mean_out, void *stream);
+
+/* a_mean <- [a_mean[1:], a_mean[-1]] (controllers/covo.py:201-203).  in != out. */
+int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, void *stream);
+
+/* Exact Hessian of the CoVO objective -(sum_k r(s_k) + r(s_0)) w.r.t. the flattened mean
+ * actions: jax.jacfwd(jax.jacfwd(get_cumulated_cost)) of controllers/covo.py:134-185
+ * (deterministic, no discount, no done-freeze).  Hyper-dual fp64 rollout, one lane per
+ * unordered pair.  R_out: double[batch][128][128]; state/a_mean are strided by
+ * COVO_STATE_FLOATS / 128 per batch entry; traj is shared. */
+int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                 const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream);
+
+/* CoVO's optimal covariance (controllers/covo.py:116-132): symmetrise, eigendecompose
+ * (cyclic Jacobi, fp64, one workgroup per matrix), shift the spectrum so its minimum is
+ * 1e-2, Sigma = U diag(exp(log_s)) U^T with det Sigma = sigma^(2n), symmetrise -- followed by
+ * the lower Cholesky factor jax.random.multivariate_normal takes of it (covo.py:216-218).
+ * R: double[batch][128][128]; Sigma_out: float[batch][128][128] (nullable);
+ * L_out: float[batch][128][128] lower-triangular. */
+int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out,
+               float *L_out, void *stream);
+
+/* Lower Cholesky factors of `batch` symmetric PD n x n fp32 matrices (n <= 128), the
+ * factorisation inside jax.random.multivariate_normal (covo.py:216, mppi.py:59). */
+int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, float *L_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVO_HIP_H */

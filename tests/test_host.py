@@ -1,0 +1,101 @@
+"""CPU: host-side logic -- sharding, PRNG keys, env plumbing, PID, and the world_size-2 exchange."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from covo_mpc_amd import random as cr
+from covo_mpc_amd.controllers._core import shard_range
+from covo_mpc_amd.envs import Quad3D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range():
+    assert shard_range(65536, 3, 8) == (3 * 8192, 8192)
+    assert [shard_range(64, r, 4)[0] for r in range(4)] == [0, 16, 32, 48]
+    with pytest.raises(ValueError):
+        shard_range(100, 0, 8)
+
+
+def test_prng_split_is_deterministic_and_distinct():
+    k = cr.PRNGKey(1)
+    a, b = cr.split(k)
+    assert not np.array_equal(a, b) and np.array_equal(cr.split(k)[0], a)
+    z = cr.normal(a, (20000,))
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+    u = cr.uniform(b, (20000,), -0.2, 0.2)
+    assert u.min() >= -0.2 and u.max() <= 0.2 and abs(u.mean()) < 0.01
+    # the host philox equals the oracle's philox (and hence the device kernel's)
+    from oracle import rng_np
+    r = cr._philox([1, 2], [3, 4], [5, 6], [7, 8], 9, 10)
+    r2 = rng_np.philox4x32_10([1, 2], [3, 4], [5, 6], [7, 8], 9, 10)
+    assert all(np.array_equal(x, y) for x, y in zip(r, r2))
+
+
+def test_env_plumbing_matches_oracle_step():
+    """Quad3D.step_env (host plumbing) against the oracle's literal restatement on the same inputs."""
+    from oracle import ref_np as R
+    env = Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="none",
+                 disable_rollover_terminate=True, generate_noisy_state=True)
+    p = env.default_params
+    obs, info, st = env.reset(cr.PRNGKey(5), p)
+    assert obs.shape == (env.obs_dim,) == (49,) and st.pos_traj.shape == (320, 3) and st.time == 0
+    assert np.all(np.abs(st.f_disturb) <= 0.2) and info["noisy_state"] is not None
+    so = R.State(pos=st.pos.astype(np.float64), vel=st.vel.astype(np.float64), quat=st.quat.astype(np.float64),
+                 omega=st.omega.astype(np.float64), f_disturb=st.f_disturb.astype(np.float64),
+                 pos_tar=st.pos_tar.astype(np.float64), vel_tar=st.vel_tar.astype(np.float64), acc_tar=np.zeros(3),
+                 time=0, pos_traj=st.pos_traj.astype(np.float64), vel_traj=st.vel_traj.astype(np.float64),
+                 acc_traj=st.acc_traj.astype(np.float64))
+    key = cr.PRNGKey(6)
+    for i in range(5):
+        a = np.array([0.1 * i - 0.3, 0.2, -0.1, 0.05 * i], dtype=np.float32)
+        key, k = cr.split(key)
+        _, st, r, d, info = env.step_env(k, st, a, p)
+        so, ro, do = R.step_env(so, a.astype(np.float64), R.Params(), np.zeros(3))
+        assert abs(r - ro) < 1e-5 and d == bool(do)
+        assert np.abs(st.pos - so.pos).max() < 1e-6 and np.abs(st.quat - so.quat).max() < 1e-6
+        assert np.abs(st.vel - so.vel).max() < 1e-5 and np.abs(st.omega - so.omega).max() < 1e-5
+        assert np.array_equal(st.pos_tar, st.pos_traj[st.time])
+    packed = info["noisy_state"].pack()
+    assert packed.shape == (32,) and packed[25:26].view(np.int32)[0] == st.time
+
+
+def test_pid_tracks_hover_and_get_controller_errors():
+    import covo_mpc_amd as cm
+    env = Quad3D(task="hovering", enable_randomizer=False, disturb_type="none", disable_rollover_terminate=True)
+    pid = cm.controllers.PIDController(env, cm.controllers.PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0))
+    obs, info, st = env.reset(cr.PRNGKey(2), env.default_params)
+    cp, key = pid.init_control_params, cr.PRNGKey(3)
+    for _ in range(150):
+        a, cp, _ = pid(obs, st, env.default_params, key, cp)
+        key, k = cr.split(key)
+        obs, st, r, d, info = env.step(k, st, a, env.default_params)
+    assert info["err_pos"] < 0.2 and not d
+    with pytest.raises(NotImplementedError):
+        Quad3D(task="hover")  # README's name is not a valid task (quadrotor.py:83-84)
+    with pytest.raises(NotImplementedError):
+        cm.envs.get_controller(env, "lqr")
+
+
+def test_zigzag_generator_shape_and_speed():
+    from covo_mpc_amd.dynamics import utils
+    pos, vel, acc = utils.generate_zigzag_traj(300, 0.02, cr.PRNGKey(11))
+    assert pos.shape == vel.shape == acc.shape == (320, 3) and np.all(pos[0] == 0) and np.all(acc == 0)
+    seg_len = np.linalg.norm(pos[40] - pos[0])
+    assert 0.99 <= seg_len <= 1.51
+    assert np.allclose(np.linalg.norm(vel[0]), seg_len / 41 / 0.02, rtol=1e-5)  # divides by point_per_seg + 1
+
+
+def test_world_size_2_gloo_exchange():
+    """Two CPU processes (gloo): each reduces its shard (oracle arithmetic) to one record, ONE all-gather
+    exchanges the records, both merge -> identical to the unsharded update."""
+    script = os.path.join(ROOT, "tests", "_dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", script],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DIST_OK" in r.stdout

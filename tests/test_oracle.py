@@ -1,0 +1,149 @@
+"""CPU tests of the oracle (test infrastructure) against the hand-derived known answers and the
+committed golden vectors.  PARITY UNPINNED: no reference-produced fixture exists."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import ref_np as R
+from oracle import rng_np
+from tests.conftest import make_problem
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+
+
+def _rest_state(dtype):
+    z = np.zeros((320, 3))
+    return R.zero_state(z, z, z, [0, 0, 0], dtype=dtype), R.Params()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 2e-6)])
+def test_kat_hover_freefall_thrust_bodyrate_reward(dtype, tol):
+    s, p = _rest_state(dtype)
+    a = R.hover_action(p, 32, dtype)
+    assert np.allclose(a[0], KAT["hover_action"], atol=1e-6)
+    cost, rew, poses = R.rollout(s, p, a[None], 1.0, np.zeros(3, dtype=dtype))
+    assert abs(cost[0] - KAT["kat1_hover_cost"]) < 50 * tol * 41.6
+    assert np.allclose(rew, KAT["kat1_reward"], atol=10 * tol)
+    z3 = np.zeros(3, dtype=dtype)
+    down = np.array([-1, 0, 0, 0], dtype=dtype)
+    s1, _, _ = R.step_env(s, down, p, z3)
+    s2, _, _ = R.step_env(s1, down, p, z3)
+    k = KAT["kat2_freefall"]
+    assert abs(s1.vel[2] - k["v_z_1"]) < tol and abs(s1.pos[2] - k["p_z_1"]) < tol
+    assert abs(s2.vel[2] - k["v_z_2"]) < tol and abs(s2.pos[2] - k["p_z_2"]) < tol
+    s1, _, _ = R.step_env(s, np.array([1, 0, 0, 0], dtype=dtype), p, z3)
+    assert abs(s1.vel[2] - KAT["kat3_full_thrust_v_z"]) < tol
+    ar = a[0].copy()
+    ar[1] = 1
+    s1, _, _ = R.step_env(s, ar, p, z3)
+    s2, _, _ = R.step_env(s1, ar, p, z3)
+    k = KAT["kat4_bodyrate"]
+    assert abs(s1.omega[0] - k["omega_x_1"]) < 10 * tol and abs(s2.omega[0] - k["omega_x_2"]) < 10 * tol
+    assert np.allclose(s1.quat, k["quat_1"], atol=tol) and np.allclose(s2.quat, k["quat_2"], atol=tol)
+    assert abs(R.tracking_penyaw_reward_fn(s.replace(pos_tar=np.array([1, 0, 0], dtype=dtype))) - KAT["kat5_reward_err1"]) < tol
+    assert abs(R.log_pos_fn(dtype(1.0)) - KAT["kat5_log_pos_1"]) < tol
+    sq = s.replace(quat=np.array([0, 0, np.sin(np.pi / 4), np.cos(np.pi / 4)], dtype=dtype))
+    assert abs(R.tracking_penyaw_reward_fn(sq) - KAT["kat5_reward_yaw90"]) < tol
+
+
+def test_kat_softmax_and_sigma():
+    lam = 0.01
+    cost = np.array([1.0, 1.0 + lam * np.log(2)])
+    a = np.zeros((2, 32, 4))
+    a[0] += 1
+    a_new, w = R.softmax_update(cost, a, lam, 1.0, np.zeros((32, 4)))
+    assert np.allclose(w, KAT["kat6_softmax"], atol=1e-12) and np.allclose(a_new, 2 / 3)
+    assert np.abs(R.optimize_sigma(np.eye(128) * 3.0, 0.5, 32, 4) - 0.25 * np.eye(128)).max() < 1e-14
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(128, 128))
+    Rm = A + A.T
+    S = R.optimize_sigma(Rm, 0.5, 32, 4)
+    B = Rm + (0.01 - np.linalg.eigvalsh(Rm).min()) * np.eye(128)
+    M = S @ S @ B
+    assert np.abs(M - np.eye(128) * M[0, 0]).max() < 1e-9 and np.abs(S - S.T).max() == 0
+    assert abs(np.linalg.slogdet(S)[1] - KAT["kat7_logdet_sigma"]) < 1e-8
+
+
+def test_kat_done_freeze_and_horizon_past_episode_end():
+    # KAT 9: |pos_x| > 3 at step k: r_k is live, later rewards repeat it
+    s, p, rng = make_problem(seed=3, time=10)
+    s = s.replace(pos=s.pos + np.array([2.95, 0, 0]), vel=s.vel + np.array([4.0, 0, 0]))
+    a = np.tile(R.hover_action(p, 32, np.float64)[None], (2, 1, 1))
+    cost, rew, poses = R.rollout(s, p, a, 1.0, np.zeros(3))
+    kx = int(np.argmax(np.abs(np.concatenate([s.pos[None, :1], poses[:, 0, :1]]))[:, 0] > 3))
+    assert 0 < kx < 31 and np.all(rew[0, kx:] == rew[0, kx]) and rew[0, kx - 1] != rew[0, kx]
+    # KAT 10: t0 + k >= 300 -> done; targets clamp at the last row
+    s, p, rng = make_problem(seed=4, time=290)
+    cost, rew, poses = R.rollout(s, p, a, 1.0, np.zeros(3))
+    assert np.all(rew[0, 10:] == rew[0, 10]) and rew[0, 9] != rew[0, 10]
+    s2 = s.replace(time=330)  # beyond the 320-row zigzag table
+    nxt, _, _ = R.step_env(s2, a[0, 0], p, np.zeros(3))
+    assert np.array_equal(nxt.pos_tar, s.pos_traj[-1])
+
+
+def test_philox_known_answers():
+    for v in KAT["philox4x32_10"]:
+        out = rng_np.philox4x32_10(*v["ctr"], *v["key"])
+        assert [hex(int(x)) for x in out] == v["out"]
+    z = rng_np.randn(7, 9, 0, 2048, 128)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    # global-id keyed: a shard's rows equal the corresponding rows of the full draw
+    assert np.array_equal(rng_np.randn(7, 9, 1024, 256, 128), z[1024:1280])
+
+
+def test_c_oracle_matches_literal_numpy_and_golden():
+    g = np.load(os.path.join(HERE, "golden", "rollout_small.npz"))
+    p = R.Params()
+    for name in ("mid", "late", "start"):
+        st = g[f"{name}_state"]
+        z = np.zeros((1, 3))
+        s = R.State(pos=st[0:3], vel=st[3:6], quat=st[6:10], omega=st[10:13], f_disturb=st[13:16], pos_tar=st[16:19],
+                    vel_tar=st[19:22], acc_tar=np.zeros(3), time=int(g[f"{name}_time"]), pos_traj=g[f"{name}_pos_traj"],
+                    vel_traj=g[f"{name}_vel_traj"], acc_traj=np.zeros_like(g[f"{name}_pos_traj"]))
+        a, fs, disc = g[f"{name}_a"], g[f"{name}_f_shared"], float(g[f"{name}_discount"])
+        c64, r64, p64 = CO.rollout(s, p, a, disc, fs, dtype=np.float64, want_rewards=True, want_poses=True)
+        assert np.abs(c64 - g[f"{name}_cost"]).max() < 1e-11
+        assert np.abs(r64 - g[f"{name}_rewards"]).max() < 1e-12 and np.abs(p64 - g[f"{name}_poses"]).max() < 1e-12
+        c32 = CO.rollout(s.astype(np.float32), p, a.astype(np.float32), disc, fs, dtype=np.float32)
+        assert np.abs((c32 - c64) / np.maximum(np.abs(c64), 1)).max() < 1e-5
+    assert np.any(g["start_rewards"][:, -1] == g["start_rewards"][:, -2])  # the freeze case is exercised
+
+
+def test_c_noise_gemm_and_softmax_partial():
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(128, 128))
+    L = np.linalg.cholesky(A @ A.T / 128 + 0.1 * np.eye(128)).astype(np.float32)
+    mu = rng.normal(size=128).astype(np.float32) * 0.3
+    eps = rng.normal(size=(200, 128)).astype(np.float32)
+    a = CO.noise_gemm(L, mu, eps)
+    ref = np.clip(mu[None].astype(np.float64) + eps.astype(np.float64) @ L.astype(np.float64).T, -1, 1)
+    assert np.abs(a - ref).max() < 2e-5
+    cost = rng.normal(size=200).astype(np.float64) * 0.05
+    m, s, v = CO.softmax_partial(cost, a.astype(np.float64), 0.01, dtype=np.float64)
+    m2, s2, v2 = R.softmax_partial(cost, a.astype(np.float64), 0.01)
+    assert m == m2 and abs(s - s2) < 1e-12 * s2 and np.abs(v - v2).max() < 1e-12
+    # shard invariance of the record merge
+    am = np.zeros((32, 4))
+    full = R.merge_partials([m2], [s2], [v2], 0.01, 1.0, am)
+    for G in (2, 4, 8):
+        recs = [R.softmax_partial(cost[i::G], a[i::G].astype(np.float64), 0.01) for i in range(G)]
+        sh = R.merge_partials([r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], 0.01, 1.0, am)
+        assert np.abs(sh - full).max() < 1e-12
+    ref_mean, _ = R.softmax_update(cost, a.reshape(200, 32, 4).astype(np.float64), 0.01, 1.0, am)
+    assert np.abs(full - ref_mean).max() < 1e-12
+
+
+def test_hessian_ad_oracle_structure():
+    """KAT 8: symmetric, exact zeros for the last action, agrees with finite differences."""
+    from oracle import ref_torch as RT
+    s, p, rng = make_problem(seed=0, time=37)
+    H = 4  # short horizon keeps this CPU test to seconds; the GPU suite checks H=32
+    a = (R.hover_action(p, H, np.float64) + 0.1 * rng.normal(size=(H, 4))).reshape(-1)
+    Rm = RT.hessian(s, p, a, H)
+    assert np.abs(Rm - Rm.T).max() < 1e-12 and np.abs(Rm[-4:]).max() == 0.0
+    Rfd = R.hessian_fd(s, p, a, H, h=1e-4)
+    assert np.abs(Rfd - Rm).max() < 1e-5 * max(1.0, np.abs(Rm).max())
