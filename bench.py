@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- MPC control-steps/s of the MI355X-native sampling-MPC inner loop.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one controller __call__ (quadjax/controllers/covo.py:187-283) on one synthetic noisy
+state of a tracking_zigzag episode, teacher-forced (states resident in HBM before the timed region,
+a_mean carried from step to step).  Workload (BASELINE.json north_star / configs[3]):
+covo-online, tracking_zigzag, N = 65536 samples x H = 32, lambda = 0.01, sigma = 0.5; with G > 1 ranks
+the sample axis is sharded (N/G per GPU, "strong" scaling: total work fixed) and ONE all-gather of the
+132-float online-softmax records crosses xGMI per step.
+
+Rank 0 prints ONE JSON line with `roofline` (the fused rollout kernel, HBM bound, 516 B/sample
+algorithmic, duration measured with events on the launch stream inside the timed region) and, at
+N=1, `cpu_baseline` (the plain-C oracle port of the same sampling step on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ROLLOUT_BYTES_PER_SAMPLE = 516  # 32 x 16 B action read + 4 B cost write
+
+
+def make_states(env, params, n_states, seed):
+    """Synthetic teacher-forced inputs: noisy states of a PID-tracked tracking_zigzag episode
+    (host plumbing, outside the timed region)."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    obs, info, state = env.reset(cr.PRNGKey(seed), params)
+    pid = cm.controllers.PIDController(env, cm.controllers.PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0))
+    cp, key = pid.init_control_params, cr.PRNGKey(seed + 1)
+    packed, states = [], []
+    for _ in range(n_states):
+        packed.append(info["noisy_state"].pack())
+        states.append(info["noisy_state"])
+        a, cp, _ = pid(obs, state, params, key, cp)
+        key, k = cr.split(key)
+        obs, state, reward, done, info = env.step_env(k, state, a, params)
+    return state, np.stack(packed), states
+
+
+def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
+    """The oracle's C port of the sampling step (noise GEMM -> rollout -> softmax update, fp32, OpenMP
+    over samples) + LAPACK eigh/cholesky for Sigma, timed on this box's host cores."""
+    from oracle import c_oracle as CO
+    from oracle import ref_np as R
+    cores = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    ns = states[40]
+    so = R.State(pos=ns.pos, vel=ns.vel, quat=ns.quat, omega=ns.omega, f_disturb=ns.f_disturb, pos_tar=ns.pos_tar,
+                 vel_tar=ns.vel_tar, acc_tar=ns.acc_tar, time=ns.time, pos_traj=ns.pos_traj, vel_traj=ns.vel_traj,
+                 acc_traj=ns.acc_traj).astype(np.float32)
+    p = R.Params()
+    rng = np.random.default_rng(0)
+    eps = rng.standard_normal((N, H * 4), dtype=np.float32)
+    A = rng.standard_normal((128, 128))
+    Rm = 0.05 * (A + A.T)
+    a_mean = R.hover_action(p, H, np.float32)
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        Sigma = R.optimize_sigma(Rm, 0.5, H, 4)                      # covo.py:116-132 (LAPACK)
+        L = np.linalg.cholesky(Sigma).astype(np.float32)             # covo.py:216
+        a_new, cost, _ = CO.sampling_step(so, p, L, a_mean, eps, lam)  # covo.py:212-278
+        n_done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n_done >= 200:
+            break
+    return {"value": n_done / el, "unit": "control-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} full-size control steps (N={N}, H={H}) of the C oracle port: fp32 noise GEMM + rollout + "
+                      f"softmax update with OpenMP over samples, + fp64 LAPACK eigh/cholesky for Sigma; the Hessian "
+                      f"(jacfwd^2, covo.py:134-185) is NOT included in the CPU figure; {el:.1f} s of CPU work"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--controller", default="covo-online", choices=["covo-online", "covo-offline", "mppi"])
+    ap.add_argument("--N", type=int, default=65536, help="global number of samples")
+    ap.add_argument("--lam", type=float, default=0.01)
+    ap.add_argument("--info", action="store_true", help="also compute pos_mean/pos_std (covo.py:281); XLA drops "
+                    "them as dead code in the reference's eval loop (quadrotor.py:523-538)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    pg = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+        pg = dist.group.WORLD
+
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    from covo_mpc_amd.dynamics.dataclass import DeviceState
+
+    H = 32
+    env = cm.envs.Quad3D(task="tracking_zigzag", obs_type="quad", enable_randomizer=False, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=device)
+    params = env.default_params
+    controller, cp = cm.envs.get_controller(env, args.controller, f"N{args.N}_H{H}_lam{args.lam}", device=device,
+                                            process_group=pg, compute_info=args.info)
+    n_states = params.max_steps_in_episode
+    state0, packed, host_states = make_states(env, params, n_states, seed=1)
+    obs0, info0, s_reset = env.reset(cr.PRNGKey(1), params)
+    cp = controller.reset(s_reset, params, controller.init_control_params, cr.PRNGKey(7))  # offline: Sigma table
+    packed_d = torch.from_numpy(packed).to(device)
+    dref = s_reset.to_device(device)
+    dstates = [DeviceState(packed=packed_d[i], pos_traj=dref.pos_traj, vel_traj=dref.vel_traj) for i in range(n_states)]
+    core = controller.core
+
+    def step(i, key, cp):
+        key, k_act = cr.split(key)
+        u, cp, _ = controller(None, None, params, k_act, cp, {"noisy_state": dstates[i % n_states]})
+        return key, cp
+
+    key = cr.PRNGKey(1)  # mirrors eval_env's PRNGKey(1) (quadrotor.py:517)
+    for i in range(args.warmup):
+        key, cp = step(i, key, cp)
+    torch.cuda.synchronize()
+
+    # events around the rollout launch, on the stream it is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    orig_rollout = core.rollout
+
+    def timed_rollout(*a, **kw):
+        e0, e1 = ev[timed_rollout.i]
+        e0.record()
+        r = orig_rollout(*a, **kw)
+        e1.record()
+        timed_rollout.i += 1
+        return r
+    timed_rollout.i = 0
+    core.rollout = timed_rollout
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        key, cp = step(args.warmup + i, key, cp)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    core.rollout = orig_rollout
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(cp.a_mean).all(), "non-finite a_mean after the timed region"
+
+    rollout_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # same kernel, launched back-to-back (no host gaps between launches): per-launch duration
+    reps = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pc = params.to_c()
+    e0.record()
+    for _ in range(reps):
+        orig_rollout(dstates[40], pc, (0.0, 0.0, 0.0), args.info)
+    e1.record()
+    torch.cuda.synchronize()
+    rollout_b2b_ms = e0.elapsed_time(e1) / reps
+
+    if rank == 0:
+        n_local = core.n_local
+        alg_bytes = n_local * ROLLOUT_BYTES_PER_SAMPLE
+        achieved = alg_bytes / (rollout_b2b_ms * 1e-3) / 1e9
+        out = {
+            "metric": "mpc_control_steps_per_sec", "value": args.steps / elapsed, "unit": "control-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.controller} tracking_zigzag N={args.N} H={H} lam={args.lam} sigma=0.5 "
+                                   f"(teacher-forced noisy states of one 300-step episode; samples sharded {world}x"
+                                   f"{n_local}, one 132-float all-gather per step)",
+                       "controller": args.controller, "N_global": args.N, "N_local": n_local, "H": H,
+                       "pos_stats_info": bool(args.info)},
+            "roofline": {"bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_us_back_to_back": 1e3 * rollout_b2b_ms,
+                         "launch_us_in_step_events": 1e3 * rollout_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host_states, params, args.N, H, args.lam, args.cpu_budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

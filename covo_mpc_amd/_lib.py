@@ -75,6 +75,10 @@ def load_library():
         raise CovoError(
             f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C covo_mpc_amd/csrc`).  covo_mpc_amd has no CPU/torch fallback.")
+    # torch bundles its own ROCm runtime (libamdhip64): load it FIRST so this library binds to the
+    # runtime instance that owns torch's device context and streams (two runtimes in one process do
+    # not see each other's devices).
+    import torch  # noqa: F401
     lib = C.CDLL(_SO)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, surfaced as is

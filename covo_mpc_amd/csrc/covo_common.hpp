@@ -35,16 +35,17 @@ template <class U>
 __host__ __device__ inline qm::Consts<U> make_consts(const covo_env_params &p)
 {
     qm::Consts<U> c;
-    // fp32 products first: the model constants are fp32 quantities (JAX default dtype)
-    c.thrust_half = (U)(0.5f * p.max_thrust * p.action_scale);
-    for (int i = 0; i < 3; ++i) c.komega[i] = (U)(p.max_omega[i] * p.action_scale);
-    c.dt = (U)p.dt;
-    c.half_dt = (U)(0.5f * p.dt);
-    c.neg_g = (U)(-p.g);
-    c.inv_m = (U)(1.0f / p.m);
-    c.alpha = (U)p.alpha_bodyrate;
-    c.one_m_alpha = (U)(1.0f - p.alpha_bodyrate);
-    c.pos_limit = (U)p.pos_limit;
+    // the model constants are the fp32 parameter values (JAX default dtype); derived constants are
+    // formed in the working precision U from them (U = float reproduces the reference's fp32 products)
+    c.thrust_half = U(0.5) * U(p.max_thrust) * U(p.action_scale);
+    for (int i = 0; i < 3; ++i) c.komega[i] = U(p.max_omega[i]) * U(p.action_scale);
+    c.dt = U(p.dt);
+    c.half_dt = U(0.5) * U(p.dt);
+    c.neg_g = -U(p.g);
+    c.inv_m = U(1) / U(p.m);
+    c.alpha = U(p.alpha_bodyrate);
+    c.one_m_alpha = U(1) - U(p.alpha_bodyrate);
+    c.pos_limit = U(p.pos_limit);
     return c;
 }
 

@@ -28,6 +28,16 @@ def _philox(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
+def _philox_scalar(c0, c1, c2, c3, k0, k1):
+    """Same function on Python ints (key splitting sits on the per-control-step host path)."""
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = (p1 >> 32) ^ c1 ^ k0, p1 & 0xFFFFFFFF, (p0 >> 32) ^ c3 ^ k1, p0 & 0xFFFFFFFF
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
 def PRNGKey(seed: int) -> np.ndarray:
     """jax.random.PRNGKey(seed) analogue: (hi, lo) words of the seed."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -36,9 +46,12 @@ def PRNGKey(seed: int) -> np.ndarray:
 
 def split(key, num: int = 2) -> np.ndarray:
     """jax.random.split analogue: (num, 2) child keys."""
+    k0, k1 = int(key[0]), int(key[1])
+    if num <= 16:
+        return np.array([_philox_scalar(i, 0, 0, 0x5EED, k0, k1)[:2] for i in range(num)], dtype=np.uint32)
     i = np.arange(num, dtype=np.uint32)
     z = np.zeros(num, dtype=np.uint32)
-    r0, r1, _, _ = _philox(i, z, z, z + np.uint32(0x5EED), key[0], key[1])
+    r0, r1, _, _ = _philox(i, z, z, z + np.uint32(0x5EED), k0, k1)
     return np.stack([r0, r1], axis=-1)
 
 

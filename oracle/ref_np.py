@@ -57,6 +57,18 @@ class Params:
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)
 
+    def fp32(self):
+        """Every real parameter rounded to float32 -- the reference's parameters ARE fp32 numbers (JAX
+        default dtype), so fp64 yardstick runs must start from the same rounded constants."""
+        kw = {}
+        for f in dataclasses.fields(self):
+            v = getattr(self, f.name)
+            if isinstance(v, float):
+                kw[f.name] = float(np.float32(v))
+            elif isinstance(v, tuple):
+                kw[f.name] = tuple(float(np.float32(x)) for x in v)
+        return dataclasses.replace(self, **kw)
+
 
 @dataclass
 class State:

@@ -17,7 +17,7 @@ def make_problem(seed=0, time=37, dtype=np.float64, task="zigzag"):
     """A deterministic mid-episode tracking state + default params (oracle types)."""
     from oracle import ref_np as R
     rng = np.random.default_rng(seed)
-    p = R.Params()
+    p = R.Params().fp32()
     if task == "zigzag":
         pos, vel, acc = R.generate_zigzag_traj(300, p.dt, rng)
     elif task == "lissa":

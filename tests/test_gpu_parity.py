@@ -1,0 +1,341 @@
+"""GPU parity tests (-m gpu): every HIP kernel, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Tolerances (north_star: 1e-5 relative fp32):
+  noise GEMM / block-diag   bit-exact vs the oracle's ascending-k fmaf chain
+  rollout cost              <= 1e-5 relative (vs fp64 oracle; measured ~2e-6)
+  softmax update            <= 1e-5 absolute on a_mean in [-1,1]
+  Hessian                   <= 1e-9 absolute vs the fp64 AD oracle
+  Sigma / chol(Sigma)       <= 1e-6 relative Frobenius vs fp64 LAPACK
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("needs the MI355X", allow_module_level=True)
+
+from covo_mpc_amd import _lib  # noqa: E402
+from covo_mpc_amd.controllers._core import SamplingCore  # noqa: E402
+from covo_mpc_amd.dynamics.dataclass import DeviceState, EnvParams3D  # noqa: E402
+from oracle import c_oracle as CO  # noqa: E402
+from oracle import ref_np as R  # noqa: E402
+from oracle import rng_np  # noqa: E402
+from tests.conftest import make_problem  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = "cuda:0"
+
+
+def dev_state(s) -> DeviceState:
+    x = np.zeros(32, dtype=np.float32)
+    x[0:3], x[3:6], x[6:10], x[10:13], x[13:16] = s.pos, s.vel, s.quat, s.omega, s.f_disturb
+    x[16:19], x[19:22], x[22:25] = s.pos_tar, s.vel_tar, s.acc_tar
+    x[25:26] = np.asarray([s.time], dtype=np.int32).view(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    return DeviceState(packed=t(x), pos_traj=t(s.pos_traj), vel_traj=t(s.vel_traj))
+
+
+def to_stripes(a_nh4):
+    """(N,H,4) -> device stripe layout (H,N,4)."""
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(a_nh4, (1, 0, 2)), dtype=np.float32)).to(DEV)
+
+
+def sample_actions(p, rng, N, H=32, sigma=0.5):
+    a = np.clip(R.hover_action(p, H, np.float64)[None] + sigma * rng.normal(size=(N, H, 4)), -1, 1)
+    return a.astype(np.float32)
+
+
+def rel_err(x, ref):
+    return np.abs(x - ref) / np.maximum(np.abs(ref), 1.0)
+
+
+# ------------------------------------------------------------------------------------------ RNG
+def test_randn_matches_philox_oracle_and_is_shard_invariant():
+    core = SamplingCore(4096, 32, 0.01, 1.0, device=DEV)
+    z = core.randn((123, 456)).cpu().numpy()
+    ref = rng_np.randn(123, 456, 0, 4096, 128)
+    assert np.abs(z - ref).max() < 5e-6          # integer stream identical; libm-level float differences
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+    core.offset = 1 << 33                          # ids beyond 32 bits exercise the high counter word
+    z2 = core.randn((123, 456)).cpu().numpy()[:64]
+    assert np.abs(z2 - rng_np.randn(123, 456, 1 << 33, 64, 128)).max() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------ noise
+@pytest.mark.parametrize("N", [32, 1000, 8192])
+def test_noise_gemm_bit_exact(N):
+    rng = np.random.default_rng(N)
+    A = rng.normal(size=(128, 128))
+    L = np.linalg.cholesky(A @ A.T / 128 + 0.05 * np.eye(128)).astype(np.float32)
+    Lfull = L + np.triu(rng.normal(size=(128, 128)).astype(np.float32), 1)  # garbage above the diagonal is ignored
+    mu = (0.3 * rng.normal(size=128)).astype(np.float32)
+    eps = rng.normal(size=(N, 128)).astype(np.float32)
+    core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
+    a = core.noise_gemm(torch.from_numpy(Lfull).to(DEV), torch.from_numpy(mu).to(DEV), torch.from_numpy(eps).to(DEV))
+    got = a.permute(1, 0, 2).reshape(N, 128).cpu().numpy()
+    ref = CO.noise_gemm(L, mu, eps)
+    assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
+    assert (np.abs(got) == 1.0).mean() > 0.001  # the clip is exercised
+
+
+def test_noise_blockdiag_bit_exact_and_cholesky4():
+    rng = np.random.default_rng(5)
+    N, H = 777, 32
+    cov = np.stack([(lambda B: B @ B.T + 0.1 * np.eye(4))(rng.normal(size=(4, 4))) for _ in range(H)]).astype(np.float32)
+    core = SamplingCore(N, H, 0.01, 1.0, device=DEV)
+    Ls = core.cholesky(torch.from_numpy(cov).to(DEV), 4, H)
+    Ls_ref = np.stack([np.linalg.cholesky(c.astype(np.float64)) for c in cov])
+    assert np.abs(Ls.cpu().numpy() - Ls_ref).max() < 1e-6
+    mu = (0.3 * rng.normal(size=(H, 4))).astype(np.float32)
+    eps = rng.normal(size=(N, H, 4)).astype(np.float32)
+    a = core.noise_blockdiag(Ls, torch.from_numpy(mu).to(DEV), torch.from_numpy(eps).to(DEV))
+    ref = CO.noise_blockdiag(Ls.cpu().numpy(), mu, eps)
+    assert np.array_equal(a.permute(1, 0, 2).cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------------------------ rollout
+def _run_rollout(core, s, p, a_nh4, f_shared, want_stats=False):
+    core.a.copy_(to_stripes(a_nh4))
+    cost = core.rollout(dev_state(s), EnvParams3D().to_c(), f_shared, want_stats).cpu().numpy()
+    return cost
+
+
+def test_rollout_golden_fixtures():
+    g = np.load(os.path.join(HERE, "golden", "rollout_small.npz"))
+    for name in ("mid", "late", "start"):
+        st = g[f"{name}_state"]
+        s = R.State(pos=st[0:3], vel=st[3:6], quat=st[6:10], omega=st[10:13], f_disturb=st[13:16], pos_tar=st[16:19],
+                    vel_tar=st[19:22], acc_tar=np.zeros(3), time=int(g[f"{name}_time"]), pos_traj=g[f"{name}_pos_traj"],
+                    vel_traj=g[f"{name}_vel_traj"], acc_traj=np.zeros_like(g[f"{name}_pos_traj"]))
+        core = SamplingCore(64, 32, 0.01, float(g[f"{name}_discount"]), device=DEV)
+        cost = _run_rollout(core, s, R.Params().fp32(), g[f"{name}_a"], g[f"{name}_f_shared"])
+        assert rel_err(cost, g[f"{name}_cost"]).max() < 1e-5, name
+
+
+@pytest.mark.parametrize("time,seed,N", [(37, 0, 4096), (285, 1, 1000), (0, 2, 300), (330, 3, 257)])
+def test_rollout_vs_fp64_oracle(time, seed, N):
+    s, p, rng = make_problem(seed=seed, time=time)
+    a = sample_actions(p, rng, N)
+    fs = np.array([0.01, -0.02, 0.03], dtype=np.float32)
+    core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
+    cost = _run_rollout(core, s, p, a, fs, want_stats=True)
+    ref, rew, poses = CO.rollout(s, p, a.astype(np.float64), 1.0, fs.astype(np.float64), dtype=np.float64,
+                                 want_rewards=True, want_poses=True)
+    assert rel_err(cost, ref).max() < 1e-5
+    # block minima and position statistics (covo.py:281)
+    bm = core.blockmin.cpu().numpy()
+    assert np.array_equal(bm, np.array([cost[i:i + 256].min() for i in range(0, N, 256)], dtype=np.float32))
+    info = core.info(dev_state(s))
+    pm, ps = R.pos_stats(poses)
+    assert np.abs(info["pos_mean"].cpu().numpy() - pm).max() < 2e-5
+    assert np.abs(info["pos_std"].cpu().numpy() - ps).max() < 2e-5
+
+
+def test_rollout_freeze_and_box_exit():
+    s, p, rng = make_problem(seed=7, time=10)
+    s = s.replace(pos=s.pos + np.array([2.9, 0, 0]), vel=s.vel + np.array([3.0, 0, 0]))
+    a = sample_actions(p, rng, 512)
+    core = SamplingCore(512, 32, 0.01, 0.95, device=DEV)
+    cost = _run_rollout(core, s, p, a, np.zeros(3))
+    ref, rew = CO.rollout(s, p, a.astype(np.float64), 0.95, np.zeros(3), dtype=np.float64, want_rewards=True)
+    assert np.any(rew[:, -1] == rew[:, -2])  # frozen rewards present
+    assert rel_err(cost, ref).max() < 1e-5
+
+
+def test_rollout_full_size_properties():
+    """N = 65536 (BASELINE full size): duplicate / permutation invariance and a sub-sampled oracle check."""
+    N = 65536
+    s, p, rng = make_problem(seed=11, time=120)
+    base = sample_actions(p, rng, N // 2)
+    a = np.concatenate([base, base[::-1]], axis=0)  # second half = mirrored copy of the first
+    core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
+    cost = _run_rollout(core, s, p, a, np.zeros(3))
+    assert np.array_equal(cost[:N // 2], cost[N // 2:][::-1])  # same sample -> same bits wherever it sits
+    idx = rng.choice(N, 2048, replace=False)
+    ref = CO.rollout(s, p, a[idx].astype(np.float64), 1.0, np.zeros(3), dtype=np.float64)
+    assert rel_err(cost[idx], ref).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ reduce
+@pytest.mark.parametrize("lam,N", [(0.01, 8192), (1.0, 3000), (100.0, 512)])
+def test_softmax_update_vs_oracle(lam, N):
+    rng = np.random.default_rng(int(lam * 100) + N)
+    a = np.clip(0.6 * rng.normal(size=(N, 32, 4)), -1, 1).astype(np.float32)
+    cost = (5.0 + rng.normal(size=N) * (3.0 if lam < 1 else 1.0)).astype(np.float32)
+    cost[rng.integers(N)] = cost.min() - 0.003  # a clear winner plus close runners-up
+    a_mean_old = (0.1 * rng.normal(size=(32, 4))).astype(np.float32)
+    core = SamplingCore(N, 32, lam, 1.0, device=DEV)
+    core.a.copy_(to_stripes(a))
+    core.cost.copy_(torch.from_numpy(cost))
+    core.blockmin.copy_(torch.from_numpy(np.array([cost[i:i + 256].min() for i in range(0, N, 256)], dtype=np.float32)))
+    for gamma in (1.0, 0.7):
+        out = core.update(torch.from_numpy(a_mean_old.reshape(-1)).to(DEV), gamma).cpu().numpy().reshape(32, 4)
+        ref, w = R.softmax_update(cost.astype(np.float64), a.astype(np.float64), lam, gamma, a_mean_old.astype(np.float64))
+        assert np.abs(out - ref).max() < 1e-5, (lam, gamma, np.abs(out - ref).max())
+    # record path + blockmin recomputed internally (blockmin = NULL) + merge of G shard records
+    lib = core.lib
+    rec = torch.zeros(132, device=DEV)
+    _lib.check(lib.covo_softmax_reduce(core.h, _lib.ptr(core.cost), _lib.ptr(core.a), N, None, _lib.ptr(rec), core.stream()))
+    m, s_, v = R.softmax_partial(cost.astype(np.float64), a.reshape(N, 128).astype(np.float64), lam)
+    r = rec.cpu().numpy()
+    assert r[0] == np.float32(m) and abs(r[1] - s_) < 1e-5 * s_ and np.abs(r[2:130] - v).max() < 1e-5 * max(1.0, s_)
+
+
+def test_merge_shard_invariance_on_device():
+    """G in {1,2,4,8} logical shards reduced separately then merged == unsharded."""
+    N, lam = 8192, 0.05
+    rng = np.random.default_rng(3)
+    a = np.clip(0.6 * rng.normal(size=(N, 32, 4)), -1, 1).astype(np.float32)
+    cost = (5.0 + 0.2 * rng.normal(size=N)).astype(np.float32)
+    am = (0.1 * rng.normal(size=128)).astype(np.float32)
+    ref, _ = R.softmax_update(cost.astype(np.float64), a.astype(np.float64), lam, 1.0, am.reshape(32, 4).astype(np.float64))
+    outs = []
+    for G in (1, 2, 4, 8):
+        n = N // G
+        core = SamplingCore(n, 32, lam, 1.0, device=DEV)
+        recs = torch.zeros((G, 132), device=DEV)
+        for g in range(G):
+            core.a.copy_(to_stripes(a[g * n:(g + 1) * n]))
+            core.cost.copy_(torch.from_numpy(cost[g * n:(g + 1) * n]))
+            _lib.check(core.lib.covo_softmax_reduce(core.h, _lib.ptr(core.cost), _lib.ptr(core.a), n, None,
+                                                    _lib.ptr(recs[g]), core.stream()))
+        out = torch.empty(128, device=DEV)
+        _lib.check(core.lib.covo_merge(core.h, _lib.ptr(recs), G, _lib.ptr(torch.from_numpy(am).to(DEV)), 1.0,
+                                       _lib.ptr(out), core.stream()))
+        outs.append(out.cpu().numpy())
+        assert np.abs(outs[-1].reshape(32, 4) - ref).max() < 1e-5, G
+    assert max(np.abs(o - outs[0]).max() for o in outs) < 2e-6
+
+
+def test_shift_mean():
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    x = torch.arange(128, dtype=torch.float32, device=DEV)
+    y = core.shift_mean(x).cpu().numpy().reshape(32, 4)
+    assert np.array_equal(y, R.shift_mean(np.arange(128, dtype=np.float32).reshape(32, 4)))
+
+
+# ------------------------------------------------------------------------------------------ Sigma path
+def test_hessian_vs_ad_oracle():
+    from oracle import ref_torch as RT
+    s, p, rng = make_problem(seed=0, time=37)
+    a = (R.hover_action(p, 32, np.float64) + 0.1 * rng.normal(size=(32, 4))).astype(np.float32)
+    a[3, 1] = 1.0    # exact clip tie: jnp.clip's JVP passes 0.5 per clip, two clips on the path
+    a[5, 2] = -1.0
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    ds = dev_state(s)
+    Rm = core.hessian(ds.packed, ds, EnvParams3D().to_c(), torch.from_numpy(a.reshape(-1)).to(DEV))[0].cpu().numpy()
+    ref = RT.hessian(s, p, a.reshape(-1).astype(np.float64), 32)
+    assert np.abs(Rm - Rm.T).max() == 0.0 and np.abs(Rm[124:]).max() == 0.0  # KAT 8
+    assert np.abs(Rm - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), np.abs(Rm - ref).max()
+    assert np.abs(ref[13]).max() > 0 and np.abs(Rm[13] - ref[13]).max() < 1e-9  # the tie rows are live
+
+
+def test_sigma_and_cholesky_vs_lapack():
+    s, p, rng = make_problem(seed=0, time=37)
+    mats = []
+    A = rng.normal(size=(128, 128))
+    mats.append(0.05 * (A + A.T))                     # generic indefinite
+    B = 0.05 * (A + A.T)
+    B[124:, :] = 0
+    B[:, 124:] = 0
+    mats.append(B)                                    # exact 4-dim null space like a real CoVO Hessian
+    mats.append(np.eye(128) * 3.0)                    # KAT 7: R = c I -> Sigma = sigma^2 I
+    Rb = np.stack(mats)
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    Sigma, L = core.sigma(torch.from_numpy(Rb).to(DEV), 0.5, batch=3)
+    Sigma, L = Sigma.cpu().numpy(), L.cpu().numpy()
+    for i, Rm in enumerate(mats):
+        ref = R.optimize_sigma(Rm, 0.5, 32, 4)
+        assert np.linalg.norm(Sigma[i] - ref) / np.linalg.norm(ref) < 1e-6, i
+        assert np.array_equal(Sigma[i], Sigma[i].T)
+        Lref = np.linalg.cholesky(Sigma[i].astype(np.float64))
+        assert np.linalg.norm(L[i] - Lref) / np.linalg.norm(Lref) < 1e-6 and np.all(np.triu(L[i], 1) == 0)
+    assert np.abs(Sigma[2] - 0.25 * np.eye(128)).max() < 1e-7
+    # standalone batched Cholesky at n = 128
+    L2 = core.cholesky(torch.from_numpy(Sigma).to(DEV), 128, 3).cpu().numpy()
+    assert np.abs(L2 - L).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ controllers
+def _oracle_state_from(ns):
+    return R.State(pos=ns.pos, vel=ns.vel, quat=ns.quat, omega=ns.omega, f_disturb=ns.f_disturb, pos_tar=ns.pos_tar,
+                   vel_tar=ns.vel_tar, acc_tar=ns.acc_tar, time=ns.time, pos_traj=ns.pos_traj, vel_traj=ns.vel_traj,
+                   acc_traj=ns.acc_traj).astype(np.float64)
+
+
+@pytest.mark.parametrize("name,task,N", [("mppi", "hovering", 1024), ("covo-online", "tracking_zigzag", 2048),
+                                         ("covo-offline", "tracking_zigzag", 2048)])
+def test_controller_step_teacher_forced(name, task, N):
+    """BASELINE configs 1-3 (reduced N): per control step, same epsilon -> cost, Sigma and a_mean parity."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    controller, cp = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
+    params = env.default_params
+    obs, info, state = env.reset(cr.PRNGKey(1), params)
+    cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(2))
+    key = cr.PRNGKey(3)
+    core = controller.core
+    for step in range(4):
+        key, k_act, k_step = cr.split(key, 3)
+        ns = info["noisy_state"]
+        a_mean_shift = R.shift_mean(cp.a_mean.cpu().numpy().astype(np.float64))
+        u, cp_new, cinfo = controller(obs, state, params, k_act, cp, info)
+        so = _oracle_state_from(ns)
+        eps = core.eps.cpu().numpy()
+        a_dev = core.a.permute(1, 0, 2).contiguous().cpu().numpy()
+        if name == "mppi":
+            a_ref, _ = R.sample_actions_blockdiag(a_mean_shift.astype(np.float32), np.tile(np.eye(4, dtype=np.float32) * 0.25, (32, 1, 1)),
+                                                  eps.reshape(N, 32, 4))
+            _, k2 = cr.split(k_act)
+            _, step_key = cr.split(cr.split(k_act)[0])
+            fs = env.rollout_disturbance(step_key, params, deterministic=False)
+            assert np.abs(fs).max() > 0
+        else:
+            Sigma = cp_new.a_cov.cpu().numpy().astype(np.float64)
+            if name == "covo-online":
+                from oracle import ref_torch as RT
+                if step == 3:  # one AD Hessian (9 s on the host) is enough
+                    Rm = RT.hessian(so, R.Params().fp32(), a_mean_shift.reshape(-1), 32)
+                    Sref = R.optimize_sigma(Rm, 0.5, 32, 4)
+                    assert np.linalg.norm(Sigma - Sref) / np.linalg.norm(Sref) < 2e-5
+            a_ref, _ = R.sample_actions_full(a_mean_shift.astype(np.float32), Sigma.astype(np.float32), eps)
+            fs = np.zeros(3, dtype=np.float32)
+        assert np.abs(a_dev - a_ref).max() < 2e-6
+        cost_ref = CO.rollout(so, R.Params().fp32(), a_dev.astype(np.float64), 1.0, fs.astype(np.float64), dtype=np.float64)
+        assert rel_err(core.cost.cpu().numpy(), cost_ref).max() < 1e-5
+        a_new_ref, w = R.softmax_update(cost_ref, a_dev.astype(np.float64), 0.01, 1.0, a_mean_shift)
+        gap = np.diff(np.sort(cost_ref)[:2])[0]
+        err = np.abs(cp_new.a_mean.cpu().numpy() - a_new_ref).max()
+        assert err < 1e-4 or gap < 1e-3, (step, err, gap)
+        assert np.array_equal(u.cpu().numpy(), cp_new.a_mean[0].cpu().numpy())
+        assert cinfo["pos_mean"].shape == (32, 3) and cinfo["pos_std"].shape == (32, 3)
+        cp = cp_new
+        obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+
+
+def test_closed_loop_tracking_sanity():
+    """Free-running covo-offline on tracking_zigzag: tracking error stays at the few-cm level after the
+    start-up transient."""
+    import covo_mpc_amd as cm
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    controller, _ = cm.envs.get_controller(env, "mppi", "N4096_H32_lam0.01", device=DEV, compute_info=False)
+    err = cm.envs.eval_env(env, controller, total_steps=300, num_trajs=1, save=False, verbose=False)
+    assert err[0] < 0.15, err
+
+
+def test_errors_are_reported_through_the_abi():
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    with pytest.raises(_lib.CovoError):
+        _lib.check(core.lib.covo_shift_mean(core.h, _lib.ptr(core.cost), _lib.ptr(core.cost), core.stream()), "shift")
+    with pytest.raises(NotImplementedError):
+        SamplingCore(256, 16, 0.01, 1.0, device=DEV)
+    cfg = _lib.ConfigC(0, 32, 4, 0.01, 1.0, 0)
+    h = C.c_void_p()
+    assert core.lib.covo_create(C.byref(cfg), C.byref(h)) == -1 and b"n_local" in core.lib.covo_last_error()
