@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libcovo_hip.so")
+_SO = os.environ.get("COVO_HIP_LIB") or os.path.join(_HERE, "csrc", "libcovo_hip.so")  # COVO_HIP_LIB: A/B builds
 _lib = None
 
 COVO_H = 32
@@ -19,6 +19,7 @@ COVO_STATE_FLOATS = 32
 COVO_PARTIAL_FLOATS = 132
 COVO_POS_STATS_DOUBLES = COVO_H * 6
 ABI_VERSION = 1
+COVO_FLAG_ACTIONS_CLIPPED = 1
 
 
 class CovoError(RuntimeError):

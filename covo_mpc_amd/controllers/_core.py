@@ -36,7 +36,7 @@ def exchange_records(record, gathered_flat, process_group=None):
 
 class SamplingCore:
     def __init__(self, N: int, H: int, lam: float, discount: float, device=None, process_group=None,
-                 compute_info: bool = True):
+                 compute_info: bool = True, trust_clipped: bool = False):
         import torch
         if H != COVO_H:
             raise NotImplementedError(f"the fused kernels are built for H={COVO_H}, got H={H}")
@@ -54,7 +54,8 @@ class SamplingCore:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.offset, self.n_local = shard_range(self.N, self.rank, self.world)
-        cfg = _lib.ConfigC(self.n_local, self.H, 4, self.lam, self.discount, 0)
+        # the action stripes this core rolls out always come from covo_noise_* (already clipped)
+        cfg = _lib.ConfigC(self.n_local, self.H, 4, self.lam, self.discount, _lib.COVO_FLAG_ACTIONS_CLIPPED if trust_clipped else 0)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.covo_create(C.byref(cfg), C.byref(h)), "covo_create")
@@ -64,7 +65,7 @@ class SamplingCore:
         self.eps = torch.empty((n, COVO_NA), **f32)
         self.a = torch.empty((COVO_H, n, 4), **f32)
         self.cost = torch.empty((n,), **f32)
-        self.blockmin = torch.empty(((n + 255) // 256,), **f32)
+        self.blockmin = torch.empty(((n + 63) // 64,), **f32)  # per-64-sample cost minima
         self.stats = torch.zeros((COVO_POS_STATS_DOUBLES,), dtype=torch.float64, device=self.device)
         self.partial = torch.zeros((COVO_PARTIAL_FLOATS,), **f32)
         self.gathered = torch.zeros((self.world * COVO_PARTIAL_FLOATS,), **f32) if self.world > 1 else None

@@ -54,7 +54,7 @@ class CoVOController(BaseController):
             self.reset = self.reset_a_cov_offline  # covo.py:112
         self.mode = mode
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
-                                 compute_info=compute_info)
+                                 compute_info=compute_info, trust_clipped=True)
 
     # ---- Sigma selection (covo.py:36-41 / 107-108) ----------------------------------------------
     def get_hessian(self, env_state, env_params, control_params, a_mean, rng_act=None):

@@ -34,7 +34,7 @@ class MPPIController(BaseController):
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
-                                 compute_info=compute_info)
+                                 compute_info=compute_info, trust_clipped=True)
 
     def __call__(self, obs, env_state, env_params, rng_act, control_params: MPPIParams, info):
         from .. import random as crandom

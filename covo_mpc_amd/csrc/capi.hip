@@ -38,9 +38,9 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     h->cfg = *cfg;
     COVO_CHECK_HIP(hipGetDevice(&h->device));
     h->max_red_blocks = 256;
-    const int nb = (cfg->n_local + 255) / 256;
+    const int nb = (cfg->n_local + 255) / 256, ng = (cfg->n_local + 63) / 64;
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
-    COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)nb * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)nb * COVO_H * 6 * sizeof(float)));
     *out = h;
     return 0;
@@ -82,32 +82,33 @@ int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, cons
 
 int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
                       const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
-                      float *cost_out, float *blockmin, double *pos_stats, void *stream)
+                      float *cost_out, float *groupmin, double *pos_stats, void *stream)
 {
     REQUIRE(h, "covo_rollout_cost: null handle");
     REQUIRE(state && pos_traj && vel_traj && params && a && cost_out && T > 0, "covo_rollout_cost: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_rollout_cost: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
-    return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount, cost_out,
-                          blockmin, pos_stats, h->ws_stats, (hipStream_t)stream);
+    return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount,
+                          (h->cfg.flags & COVO_FLAG_ACTIONS_CLIPPED) != 0, cost_out, groupmin, pos_stats, h->ws_stats,
+                          (hipStream_t)stream);
 }
 
-int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
                         float *partial_out, void *stream)
 {
     REQUIRE(h, "covo_softmax_reduce: null handle");
     REQUIRE(cost && a && partial_out, "covo_softmax_reduce: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_reduce: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
-    return launch_softmax_reduce(h, cost, a, N, blockmin, (N + 255) / 256, partial_out, nullptr, 1.0f, nullptr,
+    return launch_softmax_reduce(h, cost, a, N, groupmin, (N + 63) / 64, partial_out, nullptr, 1.0f, nullptr,
                                  (hipStream_t)stream);
 }
 
-int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
                         const float *a_mean_old, float gamma_mean, float *a_mean_out, void *stream)
 {
     REQUIRE(h, "covo_softmax_update: null handle");
     REQUIRE(cost && a && a_mean_old && a_mean_out, "covo_softmax_update: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_update: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
-    return launch_softmax_reduce(h, cost, a, N, blockmin, (N + 255) / 256, nullptr, a_mean_old, gamma_mean, a_mean_out,
+    return launch_softmax_reduce(h, cost, a, N, groupmin, (N + 63) / 64, nullptr, a_mean_old, gamma_mean, a_mean_out,
                                  (hipStream_t)stream);
 }
 

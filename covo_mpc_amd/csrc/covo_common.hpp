@@ -15,7 +15,7 @@ struct covo_ctx {
     int device;
     // workspace (device)
     float *ws_partials;   // [max_blocks][COVO_PARTIAL_FLOATS] stage-1 records of the softmax reduce
-    float *ws_blockmin;   // [ceil(n_local/256)] per-block cost minima when the caller passes none
+    float *ws_blockmin;   // [ceil(n_local/64)] per-wave cost minima when the caller passes none
     float *ws_stats;      // [ceil(n_local/256)][H*6] per-block position statistics
     int max_red_blocks;
 };
@@ -68,8 +68,8 @@ int launch_randn(uint32_t k0, uint32_t k1, int64_t off, int n_samples, int n_col
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, int N, float *a, hipStream_t s);
 int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, int N, float *a, hipStream_t s);
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                   const float *f_shared, const float *a, int N, float discount, float *cost, float *blockmin,
-                   double *pos_stats, float *stats_ws, hipStream_t s);
+                   const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
+                   float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s);
 // a_mean_out != null: finish on this GPU (normalise + blend); else write the merged record to partial_out
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,

@@ -3,8 +3,8 @@
 // Replaces quadjax/controllers/covo.py:266-278 (mppi.py:109-129):
 //     w = exp(-(cost - min cost)/lam) / sum ;  a_mean' = gamma * sum_n w_n a_n + (1-gamma) a_mean
 //
-// Stage 1 (softmax_partial_kernel): every workgroup first reduces the per-block cost minima left
-//   by the rollout kernel (<= 4 KiB, L2-resident) to the exact global minimum m, so weights are
+// Stage 1 (softmax_partial_kernel): every workgroup first reduces the per-wave (64-sample) cost minima left
+//   by the rollout kernel (4 KiB at N = 65536, L2-resident) to the exact global minimum m, so weights are
 //   formed exactly like the reference's `cost - jnp.min(cost)`.  A wave then walks 64-sample
 //   groups: one coalesced cost load, w = exp((m-c)/lam); 8-sample sub-groups whose weights are
 //   all exactly 0 (the overwhelming majority at lam = 0.01: exp underflows once c-m > 1.04) are
@@ -23,14 +23,11 @@
 constexpr int RD_BLOCK = 256;
 constexpr int RD_WAVES = RD_BLOCK / 64;
 
-__global__ __launch_bounds__(256) void blockmin_kernel(const float *__restrict__ cost, int N, float *__restrict__ bm)
+__global__ __launch_bounds__(256) void groupmin_kernel(const float *__restrict__ cost, int N, float *__restrict__ gm)
 {
-    __shared__ float red[4];
     const int n = blockIdx.x * 256 + threadIdx.x;
     const float wm = wave_min(n < N ? cost[n] : __builtin_inff());
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wm;
-    __syncthreads();
-    if (threadIdx.x == 0) bm[blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    if ((threadIdx.x & 63) == 0 && (n >> 6) < (N + 63) / 64) gm[n >> 6] = wm;
 }
 
 __global__ __launch_bounds__(RD_BLOCK) void softmax_partial_kernel(const float *__restrict__ cost,
@@ -182,8 +179,8 @@ int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N,
 {
     const float inv_lam = 1.0f / h->cfg.lam;
     if (blockmin == nullptr) {
-        n_blockmin = (N + 255) / 256;
-        hipLaunchKernelGGL(blockmin_kernel, dim3(n_blockmin), dim3(256), 0, s, cost, N, h->ws_blockmin);
+        n_blockmin = (N + 63) / 64;
+        hipLaunchKernelGGL(groupmin_kernel, dim3((N + 255) / 256), dim3(256), 0, s, cost, N, h->ws_blockmin);
         blockmin = h->ws_blockmin;
     }
     const int ngroups = (N + 63) / 64;

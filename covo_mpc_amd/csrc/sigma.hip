@@ -10,19 +10,19 @@
 // Gershgorin bound (+1) that makes G symmetric positive definite with eigenvalues >= 1.  Right
 // rotations orthogonalise the columns of G; at convergence G = V diag(lam'), so
 //     lam_k = |g_k| - shift,     v_k = g_k / |g_k|,
-// and only ONE n x n fp64 matrix (132 KiB of the CU's 160 KiB LDS, column-major, padded) is ever
+// and only ONE n x n fp64 matrix (128 KiB of the CU's 160 KiB LDS, column-major) is ever
 // stored -- no separate eigenvector matrix.  Sigma = sum_k f(lam_k) v_k v_k^T = H H^T with
 // h_k = g_k sqrt(f_k)/|g_k|.  Round-robin (circle) ordering: 64 disjoint column pairs per round,
-// one 16-lane group per pair, 127 rounds per sweep, sweeps until no rotation exceeds 1e-14.
+// one 16-lane group per pair, 127 rounds per sweep, sweeps until no pair exceeds 1e-12 relative.
 // Sigma is rounded to fp32 (the reference's a_cov dtype) before its Cholesky factor is taken in
 // fp64 and rounded to fp32.  Latency-bound section of covo-online (report us).
 #include "covo_common.hpp"
 
 constexpr int SG_N = COVO_NA;          // 128
-constexpr int SG_LD = SG_N + 1;        // padded column stride (doubles)
+constexpr int SG_LD = SG_N;            // column stride (doubles); bank spreading is done by chunk rotation
 constexpr int SG_THREADS = 1024;
 constexpr int SG_MAX_SWEEPS = 16;
-constexpr double SG_TOL = 1e-14;
+constexpr double SG_TOL = 1e-12;   // |g_p.g_q| <= tol |g_p||g_q| for every pair of a whole sweep
 
 __device__ __forceinline__ double group16_sum(double v)
 {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_kernel(const double *__restr
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *G = sm;                        // [SG_N][SG_LD] column-major
-    double *vec = sm + SG_N * SG_LD;       // [SG_N] scratch (norms / eigenvalues / scales)
+    double *vec = sm + SG_N * SG_LD;       // [SG_N] squared column norms / eigenvalues / scales
     double *red = vec + SG_N;              // [32] reduction scratch
     int *flag = reinterpret_cast<int *>(red + 32);
 
@@ -88,9 +88,19 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_kernel(const double *__restr
     if (tid < SG_N) G[tid * SG_LD + tid] += shift;
     __syncthreads();
 
-    // ---- one-sided cyclic Jacobi
+    // ---- one-sided cyclic Jacobi.  16 lanes per column pair, lane r16 owns rows {r16 + 16 i}; the
+    // chunk order is rotated by the pair's slot so the two pairs of a half-wave hit opposite LDS
+    // bank halves.  Squared column norms are carried in vec[] and refreshed once per sweep; only the
+    // cross product gamma needs a reduction.  The rotation angle is seeded in fp32 (hardware rcp /
+    // sqrt / rsq) and (c, s) are polished in fp64 so that c^2 + s^2 = 1 to rounding: an inexact
+    // ANGLE only costs convergence speed, never orthogonality.
     const int slot = tid >> 4, r16 = tid & 15;
     for (int sweep = 0; sweep < SG_MAX_SWEEPS; ++sweep) {
+        if (tid < SG_N) {
+            double s = 0.0;
+            for (int r = 0; r < SG_N; ++r) s = fma(G[tid * SG_LD + r], G[tid * SG_LD + r], s);
+            vec[tid] = s;
+        }
         if (tid == 0) *flag = 0;
         __syncthreads();
         bool rotated = false;
@@ -103,29 +113,39 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_kernel(const double *__restr
                 p = (round + slot) % (SG_N - 1);
                 q = (round - slot + (SG_N - 1)) % (SG_N - 1);
             }
-            double *gp = G + p * SG_LD, *gq = G + q * SG_LD;
+            double *gp = G + p * SG_LD + r16, *gq = G + q * SG_LD + r16;
             double cp[8], cq[8];
-            double al = 0.0, be = 0.0, ga = 0.0;
+            double ga = 0.0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                cp[i] = gp[r16 + 16 * i];
-                cq[i] = gq[r16 + 16 * i];
-                al = fma(cp[i], cp[i], al);
-                be = fma(cq[i], cq[i], be);
+                const int ch = ((i + slot) & 7) * 16;
+                cp[i] = gp[ch];
+                cq[i] = gq[ch];
                 ga = fma(cp[i], cq[i], ga);
             }
-            al = group16_sum(al);
-            be = group16_sum(be);
+            const double al = vec[p], be = vec[q];
             ga = group16_sum(ga);
-            if (fabs(ga) > SG_TOL * sqrt(al * be)) {   // uniform within the 16-lane group
+            if (ga * ga > (SG_TOL * SG_TOL) * al * be) {   // uniform within the 16-lane group
                 rotated = true;
-                const double zeta = (be - al) / (2.0 * ga);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                const float zeta = (float)(be - al) * __builtin_amdgcn_rcpf(2.0f * (float)ga);
+                const float tf = __builtin_copysignf(1.0f, zeta) *
+                                 __builtin_amdgcn_rcpf(__builtin_fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f)));
+                const double t = (double)tf;
+                const double u = fma(t, t, 1.0);
+                double c = (double)__builtin_amdgcn_rsqf((float)u);
+                c = c * fma(-0.5 * u, c * c, 1.5);
+                c = c * fma(-0.5 * u, c * c, 1.5);
+                const double s = c * t;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    gp[r16 + 16 * i] = c * cp[i] - s * cq[i];
-                    gq[r16 + 16 * i] = s * cp[i] + c * cq[i];
+                    const int ch = ((i + slot) & 7) * 16;
+                    gp[ch] = c * cp[i] - s * cq[i];
+                    gq[ch] = s * cp[i] + c * cq[i];
+                }
+                if (r16 == 0) {
+                    const double cc = c * c, ss = s * s, cs2 = 2.0 * c * s * ga;
+                    vec[p] = cc * al - cs2 + ss * be;
+                    vec[q] = ss * al + cs2 + cc * be;
                 }
             }
             __syncthreads();

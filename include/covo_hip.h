@@ -50,6 +50,9 @@ extern "C" {
 #define COVO_PARTIAL_FLOATS 132
 #define COVO_POS_STATS_DOUBLES (COVO_H * 6) /* per step: sum(pos-c)[3], sum((pos-c)^2)[3] */
 
+#define COVO_FLAG_ACTIONS_CLIPPED 1 /* covo_config.flags: every `a` handed to covo_rollout_cost is already
+                                       clipped to [-1,1] (true for covo_noise_* outputs): skip step_env's re-clip */
+
 #define COVO_E_BADARG (-1)
 #define COVO_E_NOHANDLE (-2)
 #define COVO_E_UNSUPPORTED (-3)
@@ -76,7 +79,7 @@ typedef struct covo_config {
     int32_t du;             /* must equal COVO_DU                                  */
     float lam;              /* temperature lambda, controllers/covo.py:266         */
     float discount;         /* controllers/covo.py:258                             */
-    int32_t flags;          /* reserved, 0                                         */
+    int32_t flags;          /* COVO_FLAG_* bits                                    */
 } covo_config;
 
 const char *covo_last_error(void);
@@ -111,28 +114,29 @@ int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, cons
 /* The fused N x H rollout: lax.scan(H) of vmap(N) Quad3D.step_env + done-freeze +
  * discounted cost (controllers/covo.py:227-263, mppi.py:71-106; envs/quadrotor.py:215-263,
  * 479-490; dynamics/free.py:74-155; dynamics/utils.py:266-294).  Per-sample state lives in
- * registers; only cost[N] (+ one min per 256-sample block) is written.
+ * registers; only cost[N] (+ one min per 64-sample wave) is written.  Actions are re-clipped like
+ * step_env does unless the handle was created with COVO_FLAG_ACTIONS_CLIPPED.
  * f_disturb_shared [host float[3]]: the single disturbance vector every sample receives
  *   for rollout steps >= 1 from the shared step_key (0 for CoVO's deterministic=True).
  * pos_stats (nullable): double[COVO_H*6] accumulators, zeroed by the call, receiving
  *   per-step sum(pos - pos0) and sum((pos - pos0)^2) over samples of the post-step
  *   positions (controllers/covo.py:234-237,281); pos0 = state pos.
- * blockmin (nullable): float[ceil(N/256)] per-block minimum of cost. */
+ * groupmin (nullable): float[ceil(N/64)] minimum of cost over each group of 64 consecutive samples. */
 int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
                       const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
-                      float *cost_out, float *blockmin, double *pos_stats, void *stream);
+                      float *cost_out, float *groupmin, double *pos_stats, void *stream);
 
 /* softmax weights + weighted sum as ONE online-softmax record of this shard
  * (controllers/covo.py:266-272 before normalisation): two-stage wavefront reduction.
- * blockmin (nullable): the per-256-sample minima covo_rollout_cost left for exactly this
+ * groupmin (nullable): the per-64-sample minima covo_rollout_cost left for exactly this
  *   cost/N (saves one pass over cost); recomputed internally when null.
  * partial_out: float[COVO_PARTIAL_FLOATS]. */
-int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
                         float *partial_out, void *stream);
 
 /* Single-shard finish: covo_softmax_reduce + covo_merge(G=1) without materialising the record:
  * a_mean_out = gamma_mean * sum_n w_n a_n + (1-gamma_mean) * a_mean_old (covo.py:266-275). */
-int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *blockmin,
+int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
                         const float *a_mean_old, float gamma_mean, float *a_mean_out, void *stream);
 
 /* Merge G shard records (this GPU's, or the all-gathered records of all ranks), normalise,

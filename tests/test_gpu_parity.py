@@ -128,7 +128,7 @@ def test_rollout_vs_fp64_oracle(time, seed, N):
     assert rel_err(cost, ref).max() < 1e-5
     # block minima and position statistics (covo.py:281)
     bm = core.blockmin.cpu().numpy()
-    assert np.array_equal(bm, np.array([cost[i:i + 256].min() for i in range(0, N, 256)], dtype=np.float32))
+    assert np.array_equal(bm, np.array([cost[i:i + 64].min() for i in range(0, N, 64)], dtype=np.float32))
     info = core.info(dev_state(s))
     pm, ps = R.pos_stats(poses)
     assert np.abs(info["pos_mean"].cpu().numpy() - pm).max() < 2e-5
@@ -171,7 +171,7 @@ def test_softmax_update_vs_oracle(lam, N):
     core = SamplingCore(N, 32, lam, 1.0, device=DEV)
     core.a.copy_(to_stripes(a))
     core.cost.copy_(torch.from_numpy(cost))
-    core.blockmin.copy_(torch.from_numpy(np.array([cost[i:i + 256].min() for i in range(0, N, 256)], dtype=np.float32)))
+    core.blockmin.copy_(torch.from_numpy(np.array([cost[i:i + 64].min() for i in range(0, N, 64)], dtype=np.float32)))
     for gamma in (1.0, 0.7):
         out = core.update(torch.from_numpy(a_mean_old.reshape(-1)).to(DEV), gamma).cpu().numpy().reshape(32, 4)
         ref, w = R.softmax_update(cost.astype(np.float64), a.astype(np.float64), lam, gamma, a_mean_old.astype(np.float64))
