@@ -62,7 +62,7 @@ class SamplingCore:
         self.h = h
         f32 = dict(dtype=torch.float32, device=self.device)
         n = self.n_local
-        self.eps = torch.empty((n, COVO_NA), **f32)
+        self._eps = None  # (n, 128) epsilon buffer, only materialised on request (parity tests)
         self.a = torch.empty((COVO_H, n, 4), **f32)
         self.cost = torch.empty((n,), **f32)
         self.blockmin = torch.empty(((n + 63) // 64,), **f32)  # per-64-sample cost minima
@@ -87,6 +87,12 @@ class SamplingCore:
         check(self.lib.covo_shift_mean(self.h, ptr(a_mean), ptr(out), self.stream()), "covo_shift_mean")
         return out
 
+    @property
+    def eps(self):
+        if self._eps is None:
+            self._eps = self.torch.empty((self.n_local, COVO_NA), dtype=self.torch.float32, device=self.device)
+        return self._eps
+
     def randn(self, key):
         check(self.lib.covo_randn(self.h, int(key[0]), int(key[1]), self.offset, self.n_local, COVO_NA, ptr(self.eps),
                                   self.stream()), "covo_randn")
@@ -96,6 +102,18 @@ class SamplingCore:
         eps = self.eps if eps is None else eps
         check(self.lib.covo_noise_gemm(self.h, ptr(L), ptr(mu), ptr(eps), self.n_local, ptr(self.a), self.stream()),
               "covo_noise_gemm")
+        return self.a
+
+    def noise_gemm_philox(self, L, mu, key):
+        """covo_randn + covo_noise_gemm in one kernel: epsilon is drawn in registers (same values)."""
+        check(self.lib.covo_noise_gemm_philox(self.h, ptr(L), ptr(mu), int(key[0]), int(key[1]), self.offset,
+                                              self.n_local, ptr(self.a), self.stream()), "covo_noise_gemm_philox")
+        return self.a
+
+    def noise_blockdiag_philox(self, Ls, mu, key):
+        check(self.lib.covo_noise_blockdiag_philox(self.h, ptr(Ls), ptr(mu), int(key[0]), int(key[1]), self.offset,
+                                                   self.n_local, ptr(self.a), self.stream()),
+              "covo_noise_blockdiag_philox")
         return self.a
 
     def noise_blockdiag(self, Ls, mu, eps=None):

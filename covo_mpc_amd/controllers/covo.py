@@ -44,6 +44,7 @@ class CoVOController(BaseController):
                  process_group=None, compute_info: bool = True) -> None:
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
+        self.materialize_eps = False
         self.action_dim = self.env.action_dim
         if mode not in ("online", "offline"):
             raise NotImplementedError(mode)  # covo.py:113-114
@@ -121,8 +122,11 @@ class CoVOController(BaseController):
         control_params = control_params.replace(a_cov=a_cov)
         # sampling (covo.py:212-224)
         rng_act, act_key = crandom.split(rng_act)
-        core.randn(act_key)
-        core.noise_gemm(L, a_mean)
+        if self.materialize_eps:  # parity/debug: epsilon written to HBM first (identical values)
+            core.randn(act_key)
+            core.noise_gemm(L, a_mean)
+        else:
+            core.noise_gemm_philox(L, a_mean, act_key)
         # rollout, deterministic=True -> no disturbance draw (covo.py:225-263)
         rng_act, step_key = crandom.split(rng_act)
         core.rollout(dstate, params_c, (0.0, 0.0, 0.0), core.compute_info)

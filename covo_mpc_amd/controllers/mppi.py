@@ -33,6 +33,7 @@ class MPPIController(BaseController):
                  compute_info: bool = True) -> None:
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
+        self.materialize_eps = False
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
 
@@ -50,9 +51,12 @@ class MPPIController(BaseController):
         control_params = control_params.replace(a_mean=a_mean, a_cov=a_cov)
         # sampling (mppi.py:53-66)
         rng_act, act_key = crandom.split(rng_act)
-        core.randn(act_key)
         Ls = core.cholesky(a_cov, 4, self.H)
-        core.noise_blockdiag(Ls, a_mean)
+        if self.materialize_eps:  # parity/debug: epsilon written to HBM first (identical values)
+            core.randn(act_key)
+            core.noise_blockdiag(Ls, a_mean)
+        else:
+            core.noise_blockdiag_philox(Ls, a_mean, act_key)
         # rollout (mppi.py:69-106): deterministic=False -> the shared step_key's disturbance draw
         rng_act, step_key = crandom.split(rng_act)
         f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)

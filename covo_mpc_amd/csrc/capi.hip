@@ -69,7 +69,15 @@ int covo_noise_gemm(covo_handle_t h, const float *L, const float *mu, const floa
 {
     REQUIRE(h, "covo_noise_gemm: null handle");
     REQUIRE(L && mu && eps && a_out && N > 0, "covo_noise_gemm: bad argument");
-    return launch_noise_gemm(L, mu, eps, N, a_out, (hipStream_t)stream);
+    return launch_noise_gemm(L, mu, eps, 0u, 0u, 0, N, a_out, (hipStream_t)stream);
+}
+
+int covo_noise_gemm_philox(covo_handle_t h, const float *L, const float *mu, uint32_t key0, uint32_t key1,
+                           int64_t sample_offset, int32_t N, float *a_out, void *stream)
+{
+    REQUIRE(h, "covo_noise_gemm_philox: null handle");
+    REQUIRE(L && mu && a_out && N > 0, "covo_noise_gemm_philox: bad argument");
+    return launch_noise_gemm(L, mu, nullptr, key0, key1, sample_offset, N, a_out, (hipStream_t)stream);
 }
 
 int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, const float *eps, int32_t N, float *a_out,
@@ -77,7 +85,15 @@ int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, cons
 {
     REQUIRE(h, "covo_noise_blockdiag: null handle");
     REQUIRE(Ls && mu && eps && a_out && N > 0, "covo_noise_blockdiag: bad argument");
-    return launch_noise_blockdiag(Ls, mu, eps, N, a_out, (hipStream_t)stream);
+    return launch_noise_blockdiag(Ls, mu, eps, 0u, 0u, 0, N, a_out, (hipStream_t)stream);
+}
+
+int covo_noise_blockdiag_philox(covo_handle_t h, const float *Ls, const float *mu, uint32_t key0, uint32_t key1,
+                                int64_t sample_offset, int32_t N, float *a_out, void *stream)
+{
+    REQUIRE(h, "covo_noise_blockdiag_philox: null handle");
+    REQUIRE(Ls && mu && a_out && N > 0, "covo_noise_blockdiag_philox: bad argument");
+    return launch_noise_blockdiag(Ls, mu, nullptr, key0, key1, sample_offset, N, a_out, (hipStream_t)stream);
 }
 
 int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,

@@ -65,8 +65,11 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // launch entry points implemented in the .hip files (host functions)
 int launch_randn(uint32_t k0, uint32_t k1, int64_t off, int n_samples, int n_cols, float *out, hipStream_t s);
-int launch_noise_gemm(const float *L, const float *mu, const float *eps, int N, float *a, hipStream_t s);
-int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, int N, float *a, hipStream_t s);
+// eps == null: epsilon is drawn in-kernel from (k0, k1, sample_offset + n) (rng_device.hpp)
+int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
+                      int N, float *a, hipStream_t s);
+int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
+                           int64_t sample_offset, int N, float *a, hipStream_t s);
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s);

@@ -10,8 +10,11 @@
 // Structure (one wave = one 32-sample column tile x all 128 rows; waves are independent):
 //   * L is lower-triangular: row tile rt (32 rows) only needs k < 32(rt+1) -> 160 of the 256
 //     MFMAs per tile are issued (0.625 of dense; skipped terms are exact zeros).
-//   * the 160 A-fragments of L live in VGPRs for the whole kernel (staged once per workgroup
-//     through a padded LDS image, conflict-free ds_read_b32) -- the main loop touches no LDS.
+//   * L is staged once per workgroup into a padded LDS image (66 KiB) and its A-fragments are read
+//     with conflict-free ds_read_b32 at the point of use; <= 256 registers per lane keep TWO waves
+//     resident per SIMD, which is what hides everything that is not an MFMA: a single wave issues
+//     one non-MFMA instruction per ~5 cycles in order, so at 1 wave/SIMD the epilogue, the swaps
+//     and the epsilon generation all serialise with the matrix pipe (measured: 77 -> see DESIGN.md).
 //   * B fragments come straight from global memory: lanes (j, kh) of a wave load float4 chunk
 //     2c+kh of sample row j (the lane pair consumes the whole 512-B row, full 128-B lines), and
 //     two v_permlane32_swap per chunk pair put elements {k, k+1} on lanes {j, j+32} as the
@@ -21,28 +24,60 @@
 //     layout a[H][N][4] the rollout kernel reads.
 // fp32 MFMA roofline: 2*128*128 flop per sample (dense-equivalent), 157.3 TFLOP/s peak.
 #include "covo_common.hpp"
+#include "rng_device.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NG_BLOCK = 256;
 constexpr int NG_LDA = COVO_NA + 1;  // padded leading dimension of the LDS image of L
 
-__device__ __forceinline__ constexpr int lf_off(int rt) { return 8 * rt * (rt + 1); }  // sum_{r<rt} 16(r+1)
 
 struct BGroup {
     float4 c[4];  // this lane's chunks (2*(4g+i) + kh) of its sample row, i = 0..3
 };
+struct BTile {
+    BGroup g[4];  // the lane's half of its 512-B sample row: 16 x float4 (64 VGPRs)
+};
 
-__device__ __forceinline__ BGroup load_group(const float4 *__restrict__ row, int g, int kh)
+__device__ __forceinline__ BTile load_tile(const float4 *__restrict__ row, int kh)
+{
+    BTile t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.g[g].c[i] = row[2 * (4 * g + i) + kh];
+    return t;
+}
+
+// the same 16 chunks drawn in place: chunk index = Philox counter word 0 (rng_device.hpp), so the
+// values equal randn_kernel's for the same (key, global sample id)
+__device__ __forceinline__ BTile gen_tile(uint64_t id, int kh, uint32_t k0, uint32_t k1)
+{
+    BTile t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.g[g].c[i] = rngd::normal4((uint32_t)(2 * (4 * g + i) + kh), id, k0, k1);
+    return t;
+}
+
+// One k-group (32 k's = 16 k-steps) of the tile.  A fragments A[i = lane&31][k = 2 ks + (lane>>5)] are
+// read from the padded LDS image of L right where they are used (conflict-free ds_read_b32; two
+// resident waves per SIMD hide their latency), so the kernel fits 2 waves/SIMD and one wave's
+// epilogue / epsilon generation overlaps the other's MFMAs.
+__device__ __forceinline__ BGroup gen_group(uint64_t id, int g, int kh, uint32_t k0, uint32_t k1)
 {
     BGroup b;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b.c[i] = row[2 * (4 * g + i) + kh];
+    for (int i = 0; i < 4; ++i) {
+        b.c[i] = rngd::normal4((uint32_t)(2 * (4 * g + i) + kh), id, k0, k1);
+        __builtin_amdgcn_sched_barrier(0);  // one Philox live at a time: keeps the kernel under 256 VGPRs
+    }
     return b;
 }
 
 template <int G>
-__device__ __forceinline__ void mfma_group(const float (&Lf)[160], BGroup b, f32x16 (&acc)[4])
+__device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup b, f32x16 (&acc)[4])
 {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -57,18 +92,19 @@ __device__ __forceinline__ void mfma_group(const float (&Lf)[160], BGroup b, f32
         const float bb[4] = {bk0, bk2, bk4, bk6};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int ks = 16 * G + 4 * i + q;  // k-step (k0 = 2 ks)
 #pragma unroll
             for (int rt = G; rt < 4; ++rt)
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Lf[lf_off(rt) + ks], bb[q], acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(La[32 * rt * NG_LDA + 2 * ks], bb[q], acc[rt], 0, 0, 0);
         }
     }
 }
 
-__global__ __launch_bounds__(NG_BLOCK) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
-                                                              const float *__restrict__ eps, int N, int ntiles,
+// PHILOX = false: epsilon is read from `eps`; true: drawn in registers from (k0, k1, sample_offset + n).
+template <bool PHILOX>
+__global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
+                                                              const float *__restrict__ eps, uint32_t k0, uint32_t k1,
+                                                              int64_t sample_offset, int N, int ntiles,
                                                               float4 *__restrict__ a_out)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -78,6 +114,27 @@ __global__ __launch_bounds__(NG_BLOCK) void noise_gemm_kernel(const float *__res
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kh = lane >> 5;
+
+    const int wave_global = blockIdx.x * (NG_BLOCK / 64) + wave;
+    const int wave_stride = gridDim.x * (NG_BLOCK / 64);
+    auto rowptr = [&](int t) {
+        int row = t * 32 + j;
+        row = row < N ? row : N - 1;
+        return reinterpret_cast<const float4 *>(eps + (size_t)row * COVO_NA);
+    };
+    int tile = wave_global;
+    // the first tile's epsilon rows are requested before anything else: their HBM latency hides
+    // behind the staging of L below
+    auto tile_of = [&](int t) {
+        if (PHILOX) {
+            int row = t * 32 + j;
+            row = row < N ? row : N - 1;
+            return gen_tile((uint64_t)(sample_offset + row), kh, k0, k1);
+        }
+        return load_tile(rowptr(t), kh);
+    };
+    BTile cur = tile_of(tile < ntiles ? tile : 0);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- stage L (masked to its lower triangle) and mu
     for (int idx = tid; idx < COVO_NA * COVO_NA / 4; idx += NG_BLOCK) {
@@ -92,29 +149,9 @@ __global__ __launch_bounds__(NG_BLOCK) void noise_gemm_kernel(const float *__res
     if (tid < COVO_NA) mus[tid] = mu[tid];
     __syncthreads();
 
-    // ---- A fragments: lane supplies A[i = lane&31][k = 2 ks + (lane>>5)] for each 32-row tile
-    float Lf[160];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < 16 * (rt + 1); ++ks)
-            Lf[lf_off(rt) + ks] = Ls[(32 * rt + j) * NG_LDA + 2 * ks + kh];
+    const float *__restrict__ La = Ls + j * NG_LDA + kh;  // this lane's row / k-parity of every A fragment
 
-    // this lane's mean entries: t = 8 rt + 2 g + kh
-    // (read from LDS in the epilogue; 2 distinct addresses per wave -> broadcast)
-
-    const int wave_global = blockIdx.x * (NG_BLOCK / 64) + wave;
-    const int wave_stride = gridDim.x * (NG_BLOCK / 64);
-
-    int tile = wave_global;
     if (tile >= ntiles) return;
-    auto rowptr = [&](int t) {
-        int row = t * 32 + j;
-        row = row < N ? row : N - 1;
-        return reinterpret_cast<const float4 *>(eps + (size_t)row * COVO_NA);
-    };
-    const float4 *row = rowptr(tile);
-    BGroup cur = load_group(row, 0, kh);
 
     for (; tile < ntiles; tile += wave_stride) {
         f32x16 acc[4];
@@ -124,20 +161,27 @@ __global__ __launch_bounds__(NG_BLOCK) void noise_gemm_kernel(const float *__res
             for (int e = 0; e < 16; ++e) acc[rt][e] = 0.0f;
 
         const int next_tile = tile + wave_stride;
-        const float4 *nrow = rowptr(next_tile < ntiles ? next_tile : tile);
-
-        BGroup nxt = load_group(row, 1, kh);
-        mfma_group<0>(Lf, cur, acc);
-        cur = nxt;
-        nxt = load_group(row, 2, kh);
-        mfma_group<1>(Lf, cur, acc);
-        cur = nxt;
-        nxt = load_group(row, 3, kh);
-        mfma_group<2>(Lf, cur, acc);
-        cur = nxt;
-        nxt = load_group(nrow, 0, kh);
-        mfma_group<3>(Lf, cur, acc);
-        cur = nxt;
+        BTile nxt;
+        uint64_t next_id = 0;
+        if (PHILOX) {
+            int row = (next_tile < ntiles ? next_tile : tile) * 32 + j;
+            row = row < N ? row : N - 1;
+            next_id = (uint64_t)(sample_offset + row);
+        } else {
+            // whole next tile in flight while this one is multiplied (10 240 MFMA cycles of cover)
+            nxt = load_tile(rowptr(next_tile < ntiles ? next_tile : tile), kh);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // PHILOX: each k-group of the next tile is drawn in place right behind the MFMAs that consumed
+        // the current one, i.e. in the shadow of the matrix pipe
+        mfma_group<0>(La, cur.g[0], acc);
+        if (PHILOX) cur.g[0] = gen_group(next_id, 0, kh, k0, k1);
+        mfma_group<1>(La, cur.g[1], acc);
+        if (PHILOX) cur.g[1] = gen_group(next_id, 1, kh, k0, k1);
+        mfma_group<2>(La, cur.g[2], acc);
+        if (PHILOX) cur.g[2] = gen_group(next_id, 2, kh, k0, k1);
+        mfma_group<3>(La, cur.g[3], acc);
+        if (PHILOX) cur.g[3] = gen_group(next_id, 3, kh, k0, k1);
 
         // ---- epilogue: + mu, clip, stripe-ordered float4 stores
         const int n = tile * 32 + j;
@@ -156,15 +200,16 @@ __global__ __launch_bounds__(NG_BLOCK) void noise_gemm_kernel(const float *__res
                     a_out[(size_t)t * N + n] = v;
                 }
         }
-        row = nrow;
+        if (!PHILOX) cur = nxt;
     }
 }
 
 // MPPI: a[t] = clip(mu[t] + Ls[t] eps[t]) with 4x4 lower factors; eps [N][H][4] -> a [H][N][4].
 // HBM-bound streaming kernel (1 KiB per sample); fmaf chains in ascending k like the oracle.
+template <bool PHILOX>
 __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__restrict__ Ls, const float *__restrict__ mu,
-                                                              const float4 *__restrict__ eps, int N,
-                                                              float4 *__restrict__ a_out)
+                                                              const float4 *__restrict__ eps, uint32_t k0, uint32_t k1,
+                                                              int64_t sample_offset, int N, float4 *__restrict__ a_out)
 {
     __shared__ float sL[COVO_H * 16];
     __shared__ float sm[COVO_NA];
@@ -178,7 +223,7 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
     if (gid >= total) return;
     const int t = (int)(gid % COVO_H);
     const size_t n = gid / COVO_H;
-    const float4 e = eps[gid];
+    const float4 e = PHILOX ? rngd::normal4((uint32_t)t, (uint64_t)(sample_offset + (int64_t)n), k0, k1) : eps[gid];
     const float ev[4] = {e.x, e.y, e.z, e.w};
     float o[4];
 #pragma unroll
@@ -191,31 +236,43 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
     a_out[(size_t)t * N + n] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-int launch_noise_gemm(const float *L, const float *mu, const float *eps, int N, float *a, hipStream_t s)
+int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
+                      int N, float *a, hipStream_t s)
 {
     const int ntiles = (N + 31) / 32;
     const int waves_per_block = NG_BLOCK / 64;
     int grid = (ntiles + waves_per_block - 1) / waves_per_block;
-    if (grid > 256) grid = 256;  // persistent: one workgroup per CU, waves stride over tiles
+    if (grid > 512) grid = 512;  // persistent: two workgroups per CU (2 waves/SIMD), waves stride over tiles
     const size_t lds = (size_t)(COVO_NA * NG_LDA + COVO_NA) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel),
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(noise_gemm_kernel, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, N, ntiles,
-                       reinterpret_cast<float4 *>(a));
+    if (eps != nullptr)
+        hipLaunchKernelGGL(noise_gemm_kernel<false>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
+                           ntiles, reinterpret_cast<float4 *>(a));
+    else
+        hipLaunchKernelGGL(noise_gemm_kernel<true>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, (const float *)nullptr, k0,
+                           k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a));
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, int N, float *a, hipStream_t s)
+int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
+                           int64_t sample_offset, int N, float *a, hipStream_t s)
 {
     const size_t total = (size_t)N * COVO_H;
     const int grid = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(noise_blockdiag_kernel, dim3(grid), dim3(256), 0, s, Ls, mu,
-                       reinterpret_cast<const float4 *>(eps), N, reinterpret_cast<float4 *>(a));
+    if (eps != nullptr)
+        hipLaunchKernelGGL(noise_blockdiag_kernel<false>, dim3(grid), dim3(256), 0, s, Ls, mu,
+                           reinterpret_cast<const float4 *>(eps), 0u, 0u, (int64_t)0, N, reinterpret_cast<float4 *>(a));
+    else
+        hipLaunchKernelGGL(noise_blockdiag_kernel<true>, dim3(grid), dim3(256), 0, s, Ls, mu, (const float4 *)nullptr, k0,
+                           k1, sample_offset, N, reinterpret_cast<float4 *>(a));
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -151,19 +151,37 @@ struct Consts {
     U dt, half_dt, neg_g, inv_m, alpha, one_m_alpha, pos_limit;
 };
 
-// dynamics/utils.py:285-294 on the PRE-step state (envs/quadrotor.py:243)
+// dynamics/utils.py:289-290: yaw = atan2(yn, yd) of the STORED quaternion
 template <class S, class U>
-__device__ __forceinline__ S reward(const State<S> &s, U tx, U ty, U tz, U tvx, U tvy, U tvz)
+__device__ __forceinline__ void yaw_terms(const State<S> &s, S &yn, S &yd)
 {
-    const S dx = tx - s.px, dy = ty - s.py, dz = tz - s.pz;
-    const S ex = tvx - s.vx, ey = tvy - s.vy, ez = tvz - s.vz;
+    yn = U(2) * (s.qw * s.qz + s.qx * s.qy);
+    yd = U(1) - U(2) * (s.qy * s.qy + s.qz * s.qz);
+}
+
+// dynamics/utils.py:285-294 from position, velocity and the yaw terms
+template <class S, class U>
+__device__ __forceinline__ S reward_parts(S px, S py, S pz, S vx, S vy, S vz, S yn, S yd, U tx, U ty, U tz, U tvx, U tvy,
+                                          U tvz)
+{
+    const S dx = tx - px, dy = ty - py, dz = tz - pz;
+    const S ex = tvx - vx, ey = tvy - vy, ez = tvz - vz;
     const S err_pos = sqrt_(dx * dx + dy * dy + dz * dz);
     const S err_vel = sqrt_(ex * ex + ey * ey + ez * ez);
-    const S yaw = atan2abs_(U(2) * (s.qw * s.qz + s.qx * s.qy), U(1) - U(2) * (s.qy * s.qy + s.qz * s.qz));
+    const S yaw = atan2abs_(yn, yd);
     const S l = log_(err_pos + U(1));
     const S lp = err_pos * U(0.4) + sat01_(l * U(4)) * U(0.4) + sat01_(l * U(8)) * U(0.2) +
                  sat01_(l * U(16)) * U(0.1) + sat01_(l * U(32)) * U(0.1);
     return U(1.3) - err_vel * U(0.05) - lp - yaw * U(0.2);
+}
+
+// dynamics/utils.py:285-294 on the PRE-step state (envs/quadrotor.py:243)
+template <class S, class U>
+__device__ __forceinline__ S reward(const State<S> &s, U tx, U ty, U tz, U tvx, U tvy, U tvz)
+{
+    S yn, yd;
+    yaw_terms<S, U>(s, yn, yd);
+    return reward_parts<S, U>(s.px, s.py, s.pz, s.vx, s.vy, s.vz, yn, yd, tx, ty, tz, tvx, tvy, tvz);
 }
 
 // envs/quadrotor.py:250-263 + dynamics/free.py:114-155 (+74-112).  a* are already clipped.

@@ -138,6 +138,127 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split variant for grids of <= 1 wave per SIMD (N <= 65 536 on one MI355X).  Measured on gfx950
+// (scripts/probe/issue_probe.hip): ONE wave issues at most one VALU instruction per ~5 cycles, the
+// SIMD sustains ~2.3 cycles/instruction only with >= 2 resident waves.  At N = 65 536 the plain
+// kernel is exactly one wave per SIMD, i.e. it runs at half the VALU rate.  Here every 64 samples
+// get a 2-wave workgroup: the DYNAMICS wave integrates the state and publishes what the reward needs
+// (pos, vel, yaw numerator/denominator = 2 x float4 per lane) into a 3-slot LDS ring; the REWARD
+// wave, one phase behind, turns them into reward / termination / frozen-reward / running cost.
+// One raw s_barrier per step (lgkmcnt only -- a __syncthreads() would also drain vmcnt and stall on
+// the whole prefetched action stream).  Same arithmetic as rollout_kernel (quad_model.hpp).
+constexpr int RS_RING = 3;
+constexpr int RS_PAIRS = 4;  // sample groups per workgroup: waves 0..3 integrate, waves 4..7 score -> with the
+                             // cyclic wave->SIMD placement every SIMD hosts one wave of each kind
+
+__device__ __forceinline__ void lds_phase_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool DISC1, bool CLIP>
+__global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel(const RolloutArgs A)
+{
+    __shared__ float4 ring_all[RS_PAIRS][RS_RING][2][COVO_WAVE];
+    const int lane = threadIdx.x & (COVO_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave & (RS_PAIRS - 1);
+    float4 (*ring_s)[2][COVO_WAVE] = ring_all[pair];
+    const float *__restrict__ st = A.state;
+    const int group = blockIdx.x * RS_PAIRS + pair;  // 64-sample group
+    const int n_raw = group * COVO_WAVE + lane;
+    const bool valid = n_raw < A.N;
+    const int n = valid ? n_raw : A.N - 1;
+
+    if (wave < RS_PAIRS) {
+        // ================= dynamics wave
+        const float4 *__restrict__ ap = A.a + n;
+        const size_t stride = (size_t)A.N;
+        float4 av[COVO_H];
+#pragma unroll
+        for (int i = 0; i < COVO_H - 1; ++i) av[i] = ap[(size_t)i * stride];  // a_{H-1} never reaches a reward
+        __builtin_amdgcn_sched_barrier(0);
+        qm::State<float> s;
+        s.px = st[ST_POS + 0]; s.py = st[ST_POS + 1]; s.pz = st[ST_POS + 2];
+        s.vx = st[ST_VEL + 0]; s.vy = st[ST_VEL + 1]; s.vz = st[ST_VEL + 2];
+        s.qx = st[ST_QUAT + 0]; s.qy = st[ST_QUAT + 1]; s.qz = st[ST_QUAT + 2]; s.qw = st[ST_QUAT + 3];
+        s.ox = st[ST_OMEGA + 0]; s.oy = st[ST_OMEGA + 1]; s.oz = st[ST_OMEGA + 2];
+        const float f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
+        const qm::Consts<float> c = A.c;
+#pragma unroll
+        for (int k = 0; k < COVO_H; ++k) {
+            float yn, yd;
+            qm::yaw_terms<float, float>(s, yn, yd);
+            ring_s[k % RS_RING][0][lane] = make_float4(s.px, s.py, s.pz, s.vx);
+            ring_s[k % RS_RING][1][lane] = make_float4(s.vy, s.vz, yn, yd);
+            lds_phase_barrier();  // B_k: state k is visible to the reward wave
+            if (k < COVO_H - 1) {
+                float4 a4 = av[k];
+                if (CLIP) { a4.x = qm::clip11_(a4.x); a4.y = qm::clip11_(a4.y); a4.z = qm::clip11_(a4.z); a4.w = qm::clip11_(a4.w); }
+                const float fx = (k == 0) ? f0x : A.f_shared[0];
+                const float fy = (k == 0) ? f0y : A.f_shared[1];
+                const float fz = (k == 0) ? f0z : A.f_shared[2];
+                qm::dyn_step<float, float>(s, a4.x, a4.y, a4.z, a4.w, c, fx, fy, fz);
+            }
+        }
+    } else {
+        // ================= reward wave
+        const int time0 = __float_as_int(st[ST_TIME]);
+        float wpx, wpy, wpz, wvx, wvy, wvz, wdisc = 1.0f;
+        {
+            const int k = lane & (COVO_H - 1);
+            int idx = time0 + k;
+            idx = idx < 0 ? 0 : (idx > A.T - 1 ? A.T - 1 : idx);
+            const bool own = (k == 0);
+            wpx = own ? st[ST_POSTAR + 0] : A.pos_traj[3 * idx + 0];
+            wpy = own ? st[ST_POSTAR + 1] : A.pos_traj[3 * idx + 1];
+            wpz = own ? st[ST_POSTAR + 2] : A.pos_traj[3 * idx + 2];
+            wvx = own ? st[ST_VELTAR + 0] : A.vel_traj[3 * idx + 0];
+            wvy = own ? st[ST_VELTAR + 1] : A.vel_traj[3 * idx + 1];
+            wvz = own ? st[ST_VELTAR + 2] : A.vel_traj[3 * idx + 2];
+            if (!DISC1) {
+                for (int i = 0; i < k; ++i) wdisc *= A.discount;
+            }
+        }
+        const int kdone = A.max_steps - time0;
+        const float pos_limit = A.c.pos_limit;
+        // the window loads above are ordinary VMEM loads: make sure they have landed before the first
+        // raw barrier sequence (which only waits on lgkmcnt)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float acc = 0.0f, r_before = 0.0f;
+        bool done_before = false;
+        lds_phase_barrier();  // B_0
+        float4 c0 = ring_s[0][0][lane], c1 = ring_s[0][1][lane];
+#pragma unroll
+        for (int k = 0; k < COVO_H; ++k) {
+            float4 n0 = c0, n1 = c1;
+            if (k + 1 < COVO_H) {
+                lds_phase_barrier();  // B_{k+1}
+                n0 = ring_s[(k + 1) % RS_RING][0][lane];
+                n1 = ring_s[(k + 1) % RS_RING][1][lane];
+            }
+            const float tx = lane_bcast(wpx, k), ty = lane_bcast(wpy, k), tz = lane_bcast(wpz, k);
+            const float tvx = lane_bcast(wvx, k), tvy = lane_bcast(wvy, k), tvz = lane_bcast(wvz, k);
+            float r = qm::reward_parts<float, float>(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, tx, ty, tz, tvx, tvy, tvz);
+            const float pmax = fmaxf(fmaxf(fabsf(c0.x), fabsf(c0.y)), fabsf(c0.z));
+            const bool done = (k >= kdone) | (pmax > pos_limit);
+            r = done_before ? r_before : r;  // covo.py:233
+            done_before = done_before | done;
+            r_before = r;
+            acc = DISC1 ? acc + r : fmaf(lane_bcast(wdisc, k), r, acc);
+            c0 = n0;
+            c1 = n1;
+        }
+        const float cost = -acc;
+        if (valid) A.cost[n] = cost;
+        if (A.groupmin != nullptr) {
+            const float wm = wave_min(valid ? cost : __builtin_inff());
+            if (lane == 0 && group * COVO_WAVE < A.N) A.groupmin[group] = wm;
+        }
+    }
+}
+
 // sums the per-block position statistics in fp64: out[k*6+i]
 __global__ __launch_bounds__(256) void pos_stats_finalize_kernel(const float *__restrict__ ws, int nblocks,
                                                                  double *__restrict__ out)
@@ -180,6 +301,15 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     const bool deep = grid <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
     const bool d1 = (discount == 1.0f);
     const bool stats = pos_stats != nullptr;
+    if (!stats && N <= 1024 * COVO_WAVE) {  // <= 1 wave per SIMD of samples: 2-wave workgroups (see rollout_split_kernel)
+        const int g2 = (N + RS_PAIRS * COVO_WAVE - 1) / (RS_PAIRS * COVO_WAVE);
+        if (d1) { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<true, false>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A);
+                  else hipLaunchKernelGGL((rollout_split_kernel<true, true>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A); }
+        else    { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<false, false>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A);
+                  else hipLaunchKernelGGL((rollout_split_kernel<false, true>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A); }
+        COVO_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define RO_DISPATCH(ST, D1, CL) launch_rollout_pf<ST, D1, CL>(A, grid, deep, s)
     if (stats) {
         if (d1) { if (trust_clipped) RO_DISPATCH(true, true, false); else RO_DISPATCH(true, true, true); }

@@ -106,10 +106,19 @@ int covo_randn(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t sample_off
 int covo_noise_gemm(covo_handle_t h, const float *L, const float *mu, const float *eps, int32_t N, float *a_out,
                     void *stream);
 
+/* Same, with epsilon drawn inside the kernel (never written to HBM): row n of the virtual eps matrix is
+ * the covo_randn row of global sample id sample_offset + n for the same key -- bit-identical to
+ * covo_randn followed by covo_noise_gemm. */
+int covo_noise_gemm_philox(covo_handle_t h, const float *L, const float *mu, uint32_t key0, uint32_t key1,
+                           int64_t sample_offset, int32_t N, float *a_out, void *stream);
+
 /* MPPI's per-step sampling (controllers/mppi.py:53-66): a[t] = clip(mu[t] + Ls[t] eps[t]).
  * Ls: float[H][4][4] lower factors; eps: float[N][H][4]; a_out: float[H][N][4]. */
 int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, const float *eps, int32_t N,
                          float *a_out, void *stream);
+
+int covo_noise_blockdiag_philox(covo_handle_t h, const float *Ls, const float *mu, uint32_t key0, uint32_t key1,
+                                int64_t sample_offset, int32_t N, float *a_out, void *stream);
 
 /* The fused N x H rollout: lax.scan(H) of vmap(N) Quad3D.step_env + done-freeze +
  * discounted cost (controllers/covo.py:227-263, mppi.py:71-106; envs/quadrotor.py:215-263,

@@ -53,6 +53,8 @@ def main():
         print(f"{N:>8} {'randn':<16} {t:9.2f}  {N*512/t/1e3:.0f} GB/s written")
         t = timeit(lambda: core.noise_gemm(L, am), args.reps)
         print(f"{N:>8} {'noise_gemm':<16} {t:9.2f}  {N*32768/t/1e6:.1f} TFLOP/s dense-equiv, {N*1024/t/1e3:.0f} GB/s")
+        t = timeit(lambda: core.noise_gemm_philox(L, am, (1, 2)), args.reps)
+        print(f"{N:>8} {'noise_gemm+rng':<16} {t:9.2f}  {N*32768/t/1e6:.1f} TFLOP/s dense-equiv (epsilon drawn in-kernel)")
         t = timeit(lambda: core.rollout(ds, pc, (0.0, 0.0, 0.0), False), args.reps)
         print(f"{N:>8} {'rollout':<16} {t:9.2f}  {N*516/t/1e3:.0f} GB/s = {N*516/t/1e3/8000*100:.1f}% of 8 TB/s")
         t = timeit(lambda: core.rollout(ds, pc, (0.0, 0.0, 0.0), True), args.reps)

@@ -58,11 +58,11 @@ def test_randn_matches_philox_oracle_and_is_shard_invariant():
     core = SamplingCore(4096, 32, 0.01, 1.0, device=DEV)
     z = core.randn((123, 456)).cpu().numpy()
     ref = rng_np.randn(123, 456, 0, 4096, 128)
-    assert np.abs(z - ref).max() < 5e-6          # integer stream identical; libm-level float differences
+    assert np.abs(z - ref).max() < 2e-5          # integer stream identical; hardware sin/cos/log vs libm
     assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
     core.offset = 1 << 33                          # ids beyond 32 bits exercise the high counter word
     z2 = core.randn((123, 456)).cpu().numpy()[:64]
-    assert np.abs(z2 - rng_np.randn(123, 456, 1 << 33, 64, 128)).max() < 5e-6
+    assert np.abs(z2 - rng_np.randn(123, 456, 1 << 33, 64, 128)).max() < 2e-5
 
 
 # ------------------------------------------------------------------------------------------ noise
@@ -80,6 +80,27 @@ def test_noise_gemm_bit_exact(N):
     ref = CO.noise_gemm(L, mu, eps)
     assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
     assert (np.abs(got) == 1.0).mean() > 0.001  # the clip is exercised
+
+
+def test_in_kernel_philox_equals_randn_then_gemm():
+    """The production path draws epsilon inside the noise kernels; it must equal covo_randn -> covo_noise_*
+    bit for bit, for any shard offset."""
+    rng = np.random.default_rng(9)
+    N = 4096 + 17
+    A = rng.normal(size=(128, 128))
+    L = torch.from_numpy(np.linalg.cholesky(A @ A.T / 128 + 0.05 * np.eye(128)).astype(np.float32)).to(DEV)
+    mu = torch.from_numpy((0.3 * rng.normal(size=128)).astype(np.float32)).to(DEV)
+    core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
+    for off in (0, 12345, 1 << 33):
+        core.offset = off
+        core.randn((77, 88))
+        ref = core.noise_gemm(L, mu).clone()
+        got = core.noise_gemm_philox(L, mu, (77, 88))
+        assert torch.equal(ref, got), off
+        Ls = torch.eye(4, device=DEV).repeat(32, 1, 1) * 0.5
+        ref = core.noise_blockdiag(Ls, mu).clone()
+        got = core.noise_blockdiag_philox(Ls, mu, (77, 88))
+        assert torch.equal(ref, got), off
 
 
 def test_noise_blockdiag_bit_exact_and_cholesky4():
@@ -158,6 +179,21 @@ def test_rollout_full_size_properties():
     idx = rng.choice(N, 2048, replace=False)
     ref = CO.rollout(s, p, a[idx].astype(np.float64), 1.0, np.zeros(3), dtype=np.float64)
     assert rel_err(cost[idx], ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("N", [70016, 600000])
+def test_rollout_plain_kernel_paths(N):
+    """N > 65 536 uses the one-wave-per-64-samples kernel (whole-horizon prefetch up to 2 waves/SIMD, 8-deep
+    ring beyond); N <= 65 536 without pos_stats uses the dynamics/reward split kernel (other tests)."""
+    s, p, rng = make_problem(seed=21, time=200)
+    a = sample_actions(p, rng, N)
+    core = SamplingCore(N, 32, 0.01, 0.99, device=DEV)
+    cost = _run_rollout(core, s, p, a, np.array([0.0, 0.01, -0.01]))
+    idx = rng.choice(N, 4096, replace=False)
+    ref = CO.rollout(s, p, a[idx].astype(np.float64), 0.99, np.array([0.0, 0.01, -0.01]), dtype=np.float64)
+    assert rel_err(cost[idx], ref).max() < 1e-5
+    gm = core.blockmin.cpu().numpy()
+    assert np.array_equal(gm, np.array([cost[i:i + 64].min() for i in range(0, N, 64)], dtype=np.float32))
 
 
 # ------------------------------------------------------------------------------------------ reduce
@@ -281,6 +317,7 @@ def test_controller_step_teacher_forced(name, task, N):
     cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(2))
     key = cr.PRNGKey(3)
     core = controller.core
+    controller.materialize_eps = True  # epsilon is an explicit input of the parity interface
     for step in range(4):
         key, k_act, k_step = cr.split(key, 3)
         ns = info["noisy_state"]
