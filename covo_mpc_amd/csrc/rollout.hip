@@ -139,18 +139,18 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split variant for grids of <= 1 wave per SIMD (N <= 65 536 on one MI355X).  Measured on gfx950
-// (scripts/probe/issue_probe.hip): ONE wave issues at most one VALU instruction per ~5 cycles, the
-// SIMD sustains ~2.3 cycles/instruction only with >= 2 resident waves.  At N = 65 536 the plain
-// kernel is exactly one wave per SIMD, i.e. it runs at half the VALU rate.  Here every 64 samples
-// get a 2-wave workgroup: the DYNAMICS wave integrates the state and publishes what the reward needs
+// Split variant for small grids (N <= 32 768 on one MI355X: the per-GPU shard of a sample-sharded
+// step).  Measured on gfx950 (scripts/probe/issue_probe.hip): ONE wave issues at most one VALU
+// instruction per ~5 cycles, so when there are fewer waves than SIMDs the kernel time is one wave's
+// instruction count x 5 cycles.  Here every 64 samples get a 2-wave workgroup, halving that count: the DYNAMICS wave integrates the state and publishes what the reward needs
 // (pos, vel, yaw numerator/denominator = 2 x float4 per lane) into a 3-slot LDS ring; the REWARD
 // wave, one phase behind, turns them into reward / termination / frozen-reward / running cost.
 // One raw s_barrier per step (lgkmcnt only -- a __syncthreads() would also drain vmcnt and stall on
 // the whole prefetched action stream).  Same arithmetic as rollout_kernel (quad_model.hpp).
 constexpr int RS_RING = 3;
-constexpr int RS_PAIRS = 4;  // sample groups per workgroup: waves 0..3 integrate, waves 4..7 score -> with the
-                             // cyclic wave->SIMD placement every SIMD hosts one wave of each kind
+constexpr int RS_PAIRS = 1;  // sample groups per workgroup (1: a dynamics wave + a reward wave).  Measured: the split
+                             // pays when each wave gets a SIMD to itself (7.6 vs 11.2 us at N = 8 192); packing both
+                             // kinds on one SIMD (RS_PAIRS = 4, N = 65 536) is no faster than the plain kernel.
 
 __device__ __forceinline__ void lds_phase_barrier()
 {
@@ -301,7 +301,7 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     const bool deep = grid <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
     const bool d1 = (discount == 1.0f);
     const bool stats = pos_stats != nullptr;
-    if (!stats && N <= 1024 * COVO_WAVE) {  // <= 1 wave per SIMD of samples: 2-wave workgroups (see rollout_split_kernel)
+    if (!stats && 2 * ((N + COVO_WAVE - 1) / COVO_WAVE) <= 1024) {  // both waves of every pair get their own SIMD
         const int g2 = (N + RS_PAIRS * COVO_WAVE - 1) / (RS_PAIRS * COVO_WAVE);
         if (d1) { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<true, false>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A);
                   else hipLaunchKernelGGL((rollout_split_kernel<true, true>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A); }
