@@ -141,12 +141,13 @@ class SamplingCore:
                                     C.byref(params_c), ptr(a_mean), batch, ptr(R), self.stream()), "covo_hessian")
         return R
 
-    def sigma(self, R, sample_sigma, batch=1):
+    def sigma(self, R, sample_sigma, batch=1, method="ns"):
+        """(Sigma, chol(Sigma)); method "ns" = eigh-free GEMM pipeline (default), "jacobi" = eigendecomposition."""
         f32 = dict(dtype=self.torch.float32, device=self.device)
         Sigma = self.torch.empty((batch, COVO_NA, COVO_NA), **f32)
         L = self.torch.empty((batch, COVO_NA, COVO_NA), **f32)
-        check(self.lib.covo_sigma(self.h, ptr(R), batch, float(sample_sigma), ptr(Sigma), ptr(L), self.stream()),
-              "covo_sigma")
+        fn = self.lib.covo_sigma if method == "ns" else self.lib.covo_sigma_jacobi
+        check(fn(self.h, ptr(R), batch, float(sample_sigma), ptr(Sigma), ptr(L), self.stream()), "covo_sigma")
         return Sigma, L
 
     def update(self, a_mean_shifted, gamma_mean):

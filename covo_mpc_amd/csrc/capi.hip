@@ -42,6 +42,8 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)nb * COVO_H * 6 * sizeof(float)));
+    h->ws_sigma_bytes = sigma_ns_workspace_bytes(1);
+    COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, h->ws_sigma_bytes));
     *out = h;
     return 0;
 }
@@ -52,6 +54,7 @@ int covo_destroy(covo_handle_t h)
     (void)hipFree(h->ws_partials);
     (void)hipFree(h->ws_blockmin);
     (void)hipFree(h->ws_stats);
+    (void)hipFree(h->ws_sigma);
     delete h;
     return 0;
 }
@@ -156,7 +159,41 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
 {
     REQUIRE(h, "covo_sigma: null handle");
     REQUIRE(R && L_out && batch > 0 && sample_sigma > 0.0f, "covo_sigma: bad argument");
-    return launch_sigma(R, batch, sample_sigma, Sigma_out, L_out, (hipStream_t)stream);
+    const size_t need = sigma_ns_workspace_bytes(batch);
+    if (need > h->ws_sigma_bytes) {  // only for batch sizes not seen before (never inside the steady-state step)
+        COVO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        (void)hipFree(h->ws_sigma);
+        h->ws_sigma = nullptr;
+        h->ws_sigma_bytes = 0;
+        COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, need));
+        h->ws_sigma_bytes = need;
+    }
+    return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream);
+}
+
+int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)
+{
+    REQUIRE(h && out, "covo_debug_sigma_workspace: bad argument");
+    REQUIRE((size_t)(offset_doubles + count) * sizeof(double) <= h->ws_sigma_bytes, "covo_debug_sigma_workspace: range");
+    COVO_CHECK_HIP(hipMemcpyAsync(out, (const double *)h->ws_sigma + offset_doubles, (size_t)count * sizeof(double),
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out, float *L_out,
+                      void *stream)
+{
+    REQUIRE(h, "covo_sigma_jacobi: null handle");
+    REQUIRE(R && L_out && batch > 0 && sample_sigma > 0.0f, "covo_sigma_jacobi: bad argument");
+    return launch_sigma(R, batch, sample_sigma, Sigma_out, L_out, nullptr, (hipStream_t)stream);
+}
+
+int covo_sigma_profile(covo_handle_t h, const double *R, float sample_sigma, float *Sigma_out, float *L_out,
+                       uint64_t *ticks_out, void *stream)
+{
+    REQUIRE(h, "covo_sigma_profile: null handle");
+    REQUIRE(R && L_out && ticks_out, "covo_sigma_profile: bad argument");
+    return launch_sigma(R, 1, sample_sigma, Sigma_out, L_out, (unsigned long long *)ticks_out, (hipStream_t)stream);
 }
 
 int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, float *L_out, void *stream)

@@ -17,6 +17,8 @@ struct covo_ctx {
     float *ws_partials;   // [max_blocks][COVO_PARTIAL_FLOATS] stage-1 records of the softmax reduce
     float *ws_blockmin;   // [ceil(n_local/64)] per-wave cost minima when the caller passes none
     float *ws_stats;      // [ceil(n_local/256)][H*6] per-block position statistics
+    void *ws_sigma;       // scratch of the eigh-free Sigma pipeline (grown on demand, outside graph capture)
+    size_t ws_sigma_bytes;
     int max_red_blocks;
 };
 
@@ -82,5 +84,9 @@ int launch_merge(const float *partials, int G, float lam, const float *a_mean_ol
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, hipStream_t s);
-int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, hipStream_t s);
+int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, unsigned long long *prof,
+                 hipStream_t s);
+size_t sigma_ns_workspace_bytes(int batch);
+int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
+                    hipStream_t s);
 int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);

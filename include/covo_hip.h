@@ -166,14 +166,34 @@ int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, 
 int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
                  const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream);
 
-/* CoVO's optimal covariance (controllers/covo.py:116-132): symmetrise, eigendecompose
- * (cyclic Jacobi, fp64, one workgroup per matrix), shift the spectrum so its minimum is
- * 1e-2, Sigma = U diag(exp(log_s)) U^T with det Sigma = sigma^(2n), symmetrise -- followed by
- * the lower Cholesky factor jax.random.multivariate_normal takes of it (covo.py:216-218).
+/* CoVO's optimal covariance (controllers/covo.py:116-132) and the lower Cholesky factor
+ * jax.random.multivariate_normal takes of it (covo.py:216-218).  The reference's
+ *   eigh -> shift spectrum to min 1e-2 -> U diag(exp(log_s)) U^T (det = sigma^(2n)) -> symmetrise
+ * is the matrix function Sigma = c (R + delta I)^(-1/2), delta = 1e-2 - lambda_min(R); it is evaluated
+ * WITHOUT an eigendecomposition (fp64 MFMA GEMM pipeline: repeated squaring + Rayleigh-Ritz for
+ * lambda_min, coupled Newton-Schulz for the inverse square root, Cholesky for log det; sigma_ns.hip)
+ * and agrees with LAPACK eigh to ~1e-15.  Sigma is rounded to fp32 (the reference's a_cov dtype)
+ * before its Cholesky factor is taken.  May (re)allocate scratch, with a stream sync, the first time a
+ * batch size is seen.
  * R: double[batch][128][128]; Sigma_out: float[batch][128][128] (nullable);
  * L_out: float[batch][128][128] lower-triangular. */
 int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out,
                float *L_out, void *stream);
+
+/* Same result by an explicit symmetric eigendecomposition (one-sided cyclic block Jacobi, fp64, one
+ * workgroup per matrix; sigma.hip).  Slower (latency of 10-12 sweeps); kept as an independent check. */
+int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out,
+                      float *L_out, void *stream);
+
+/* Debug aid: copy `count` doubles from offset `offset_doubles` of the Sigma pipeline's scratch (layout in
+ * sigma_ns.hip: 12 matrices [batch][128][128], then 64 scalars per matrix) to `out` (device). */
+int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
+
+/* Profiling aid: covo_sigma for ONE matrix that also stores shader-clock ticks (s_memtime) at the kernel's
+ * phase boundaries into ticks_out (device uint64[32]): [0] start, [1] loaded+shifted, [2+i] end of sweep i,
+ * [20] sweeps done, [21] spectrum map, [22] H H^T, [23] Cholesky, [24] number of sweeps. */
+int covo_sigma_profile(covo_handle_t h, const double *R, float sample_sigma, float *Sigma_out, float *L_out,
+                       uint64_t *ticks_out, void *stream);
 
 /* Lower Cholesky factors of `batch` symmetric PD n x n fp32 matrices (n <= 128), the
  * factorisation inside jax.random.multivariate_normal (covo.py:216, mppi.py:59). */

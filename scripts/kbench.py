@@ -65,7 +65,9 @@ def main():
             t = timeit(lambda: core.hessian(ds.packed, ds, pc, am), args.reps)
             print(f"{'-':>8} {'hessian':<16} {t:9.2f}")
             t = timeit(lambda: core.sigma(R, 0.5), max(args.reps // 5, 3))
-            print(f"{'-':>8} {'sigma(eigh+chol)':<16} {t:9.2f}")
+            print(f"{'-':>8} {'sigma (eigh-free)':<16} {t:9.2f}")
+            t = timeit(lambda: core.sigma(R, 0.5, method="jacobi"), max(args.reps // 5, 3))
+            print(f"{'-':>8} {'sigma (jacobi)':<16} {t:9.2f}")
             t = timeit(lambda: core.shift_mean(am), args.reps)
             print(f"{'-':>8} {'shift_mean':<16} {t:9.2f}")
         del core

@@ -270,7 +270,8 @@ def test_hessian_vs_ad_oracle():
     assert np.abs(ref[13]).max() > 0 and np.abs(Rm[13] - ref[13]).max() < 1e-9  # the tie rows are live
 
 
-def test_sigma_and_cholesky_vs_lapack():
+@pytest.mark.parametrize("method", ["ns", "jacobi"])
+def test_sigma_and_cholesky_vs_lapack(method):
     s, p, rng = make_problem(seed=0, time=37)
     mats = []
     A = rng.normal(size=(128, 128))
@@ -280,9 +281,14 @@ def test_sigma_and_cholesky_vs_lapack():
     B[:, 124:] = 0
     mats.append(B)                                    # exact 4-dim null space like a real CoVO Hessian
     mats.append(np.eye(128) * 3.0)                    # KAT 7: R = c I -> Sigma = sigma^2 I
+    C = 0.05 * (A + A.T)
+    w, U = np.linalg.eigh(C)
+    w[1] = w[0] + 1e-7                                # near-degenerate bottom pair: lambda_min must stay exact
+    w[-1] = w[0] + 40.0                               # wide spectrum: cond(R + delta I) = 4000
+    mats.append((U * w) @ U.T)
     Rb = np.stack(mats)
     core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
-    Sigma, L = core.sigma(torch.from_numpy(Rb).to(DEV), 0.5, batch=3)
+    Sigma, L = core.sigma(torch.from_numpy(Rb).to(DEV), 0.5, batch=len(mats), method=method)
     Sigma, L = Sigma.cpu().numpy(), L.cpu().numpy()
     for i, Rm in enumerate(mats):
         ref = R.optimize_sigma(Rm, 0.5, 32, 4)
@@ -292,7 +298,7 @@ def test_sigma_and_cholesky_vs_lapack():
         assert np.linalg.norm(L[i] - Lref) / np.linalg.norm(Lref) < 1e-6 and np.all(np.triu(L[i], 1) == 0)
     assert np.abs(Sigma[2] - 0.25 * np.eye(128)).max() < 1e-7
     # standalone batched Cholesky at n = 128
-    L2 = core.cholesky(torch.from_numpy(Sigma).to(DEV), 128, 3).cpu().numpy()
+    L2 = core.cholesky(torch.from_numpy(Sigma).to(DEV), 128, len(mats)).cpu().numpy()
     assert np.abs(L2 - L).max() < 1e-6
 
 
