@@ -4,10 +4,11 @@
 #include "wave_reduce.hpp"
 
 // in-LDS lower Cholesky of an n x n SPD matrix (n multiple of 8, n <= 128), column-major with stride ld.
-// Left-looking by panels of 8 columns: (1) every thread subtracts the contribution of the already
-// factored columns from its (row, panel column) entries; (2) wave 0 factors the panel in registers
-// (lane l owns rows l and l+64; pivots travel by v_readlane) -- two barriers per panel instead of three
-// per column.  1/sqrt(pivot) is seeded with v_rsq_f32 and polished in fp64.
+// Right-looking by panels of 8 columns: (1) wave 0 factors the panel in registers (lane l owns rows l and
+// l+64; pivots travel by v_readlane), (2) every wave applies the rank-8 update of the panel to its share of
+// the trailing columns (8 independent FMAs per entry -- short dependency chains; a left-looking variant
+// with one long LDS dot product per entry was latency-bound at 70 us).  Two barriers per panel.
+// 1/sqrt(pivot) is seeded with v_rsq_f32 and polished in fp64.
 __device__ __forceinline__ double rsqrt_f64(double x)
 {
     double y = (double)__builtin_amdgcn_rsqf((float)x);
@@ -17,23 +18,10 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 }
 __device__ void chol_lds_fast(double *A, int n, int ld, int tid, int nthreads)
 {
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    __syncthreads();
     for (int j0 = 0; j0 < n; j0 += 8) {
-        __syncthreads();
-        // (1) panel update: A[c][i] -= sum_{k<j0} L[k][i] L[k][c]   for c in the panel, rows i >= j0
-        if (j0 > 0) {
-            const int rows = n - j0;
-            for (int e = tid; e < rows * 8; e += nthreads) {
-                const int i = j0 + (e % rows), c = j0 + (e / rows);  // consecutive threads -> consecutive rows
-                if (i >= c) {
-                    double acc = A[c * ld + i];
-                    for (int k = 0; k < j0; ++k) acc = fma(-A[k * ld + i], A[k * ld + c], acc);
-                    A[c * ld + i] = acc;
-                }
-            }
-        }
-        __syncthreads();
-        // (2) factor the panel: wave 0, rows in registers
+        // (1) factor the panel: wave 0, rows in registers
         if (tid < 64) {
             double P[2][8];
             const int sj = j0 >> 6;  // slot (0: rows 0..63, 1: rows 64..127) holding the panel's diagonal rows
@@ -66,7 +54,19 @@ __device__ void chol_lds_fast(double *A, int n, int ld, int tid, int nthreads)
                 if (lane + 64 >= j0 + c && lane + 64 < n) A[(j0 + c) * ld + lane + 64] = P[1][c];
             }
         }
+        __syncthreads();
+        // (2) trailing update: A[c][i] -= sum_{k in panel} L[i][k] L[c][k]   for c >= j0+8, i >= c
+        for (int c = j0 + 8 + wave; c < n; c += nwaves) {
+            double lc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lc[k] = A[(j0 + k) * ld + c];
+            for (int i = c + lane; i < n; i += 64) {
+                double acc = A[c * ld + i];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = fma(-A[(j0 + k) * ld + i], lc[k], acc);
+                A[c * ld + i] = acc;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 }
-

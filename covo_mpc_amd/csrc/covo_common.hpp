@@ -19,6 +19,8 @@ struct covo_ctx {
     float *ws_stats;      // [ceil(n_local/256)][H*6] per-block position statistics
     void *ws_sigma;       // scratch of the eigh-free Sigma pipeline (grown on demand, outside graph capture)
     size_t ws_sigma_bytes;
+    hipStream_t side_stream;  // forked work inside one call (joined before the call's last kernel)
+    hipEvent_t ev_fork, ev_join;
     int max_red_blocks;
 };
 
@@ -88,5 +90,5 @@ int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, f
                  hipStream_t s);
 size_t sigma_ns_workspace_bytes(int batch);
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s);
+                    hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
 int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);

@@ -37,7 +37,7 @@ constexpr int RITZ = 4;            // Rayleigh-Ritz block: exact lambda_min for 
 
 // per-matrix scalar slots (doubles)
 enum { SC_NORMSQ = 0 /* ..NS_SQUARINGS */, SC_SHIFT = 24, SC_LMIN = 25, SC_DELTA = 26, SC_SCALE = 27, SC_LOGDET = 28,
-       SC_ZBUF = 29, SC_ITERS = 30, SC_ERR = 32 /* ..NS_ITERS */, SC_COUNT = 64 };
+       SC_ZBUF = 29, SC_ITERS = 30, SC_XBUF = 31, SC_SQ = 23, SC_ERR = 32 /* ..NS_ITERS */, SC_COUNT = 64 };
 static_assert(SC_ERR + NS_ITERS <= SC_COUNT && NS_SQUARINGS + 1 <= SC_SHIFT, "scalar slots");
 
 // ---- one wave = one 16x16 tile of C = At^T . B  (At, B row-major 128x128).
@@ -144,12 +144,21 @@ __global__ __launch_bounds__(512) void ns_prep_kernel(const double *__restrict__
 
 // ---- squaring: Xout = Xin^2 / |Xin|_F^2, accumulates |Xout|_F^2 into sc[SC_NORMSQ + step + 1]
 __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict__ Xin, double *__restrict__ Xout,
-                                                        double *__restrict__ sc, int step)
+                                                        double *__restrict__ sc, int step, int xbuf_out)
 {
     const int b = blockIdx.z, lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);  // lower tile 0..35
     const double *X = Xin + (size_t)b * SN * SN;
     double *O = Xout + (size_t)b * SN * SN;
     double *s = sc + (size_t)b * SC_COUNT;
+    // stationary: |X_k|_F^2 stopped moving (X is a projector onto the dominant eigenspace up to scale)
+    if (step >= 2 && fabs(s[SC_NORMSQ + step] - s[SC_NORMSQ + step - 1]) <= 1e-11 * s[SC_NORMSQ + step]) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) s[SC_NORMSQ + step + 1] = s[SC_NORMSQ + step];
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s[SC_XBUF] = (double)xbuf_out;
+        s[SC_SQ] = (double)(step + 1);
+    }
     int ti, tj;
     tri_tile(w, ti, tj);
     const f64x4 acc = tile_mm(X, X, ti, tj, lane);
@@ -169,8 +178,8 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
 
 // ---- Rayleigh-Ritz on the RITZ largest-diagonal columns of X: lambda_min(A); then B = A + delta I,
 // Y0 = B/s (s = Gershgorin bound of B), Z0 = I.
-__global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__ Aall, const double *__restrict__ Xall,
-                                                      double *__restrict__ Ball, double *__restrict__ Yall,
+__global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__ Aall, const double *__restrict__ X0all,
+                                                      const double *__restrict__ X1all, double *__restrict__ Ball, double *__restrict__ Yall,
                                                       double *__restrict__ Ytall, double *__restrict__ Zall,
                                                       double *__restrict__ Ztall, double *__restrict__ sc)
 {
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     __shared__ double red[512];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const double *A = Aall + (size_t)b * SN * SN;
-    const double *X = Xall + (size_t)b * SN * SN;
+    const double *X = ((sc[(size_t)b * SC_COUNT + SC_XBUF] != 0.0) ? X1all : X0all) + (size_t)b * SN * SN;
     double *B = Ball + (size_t)b * SN * SN, *Y = Yall + (size_t)b * SN * SN, *Z = Zall + (size_t)b * SN * SN;
     double *Yt = Ytall + (size_t)b * SN * SN, *Zt = Ztall + (size_t)b * SN * SN;
     double *s = sc + (size_t)b * SC_COUNT;
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (12 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s)
+                    hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
 {
     double *ws = reinterpret_cast<double *>(workspace);
     const size_t M = (size_t)batch * SN * SN;
@@ -443,17 +452,26 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     hipLaunchKernelGGL(ns_prep_kernel, dim3(batch), dim3(512), 0, s, R, A, X0, sc);
     double *xi = X0, *xo = X1;
     for (int i = 0; i < NS_SQUARINGS; ++i) {
-        hipLaunchKernelGGL(ns_square_kernel, dim3(NS_TILES / 4, 1, batch), dim3(256), 0, s, xi, xo, sc, i);
+        hipLaunchKernelGGL(ns_square_kernel, dim3(NS_TILES / 4, 1, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0);
         double *t = xi; xi = xo; xo = t;
     }
-    hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, xi, B, Y[0], Yt[0], Z[0], Zt[0], sc);
-    hipLaunchKernelGGL(ns_logdet_kernel, dim3(batch), dim3(512), lds, s, B, sc);
+    hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, B, Y[0], Yt[0], Z[0], Zt[0], sc);
+    // log det B only meets the main line again in the finalize kernel: run its Cholesky beside the
+    // Newton-Schulz launches on a forked stream (fork/join by events; also valid under stream capture)
+    const bool fork = side != nullptr;
+    if (fork) {
+        COVO_CHECK_HIP(hipEventRecord(ev_fork, s));
+        COVO_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    }
+    hipLaunchKernelGGL(ns_logdet_kernel, dim3(batch), dim3(512), lds, fork ? side : s, B, sc);
+    if (fork) COVO_CHECK_HIP(hipEventRecord(ev_join, side));
     for (int i = 0; i < NS_ITERS; ++i) {
         const int in = i & 1, out = in ^ 1;
         hipLaunchKernelGGL(ns_T_kernel, dim3(16, 1, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i);
         hipLaunchKernelGGL(ns_YZ_kernel, dim3(32, 1, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
                            Zt[out], sc, i, out);
     }
+    if (fork) COVO_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
     hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch), dim3(512), lds, s, Z[0], Z[1], sc, sample_sigma, Sigma, L);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
