@@ -129,7 +129,9 @@ def main():
     cp = controller.reset(s_reset, params, controller.init_control_params, cr.PRNGKey(7))  # offline: Sigma table
     packed_d = torch.from_numpy(packed).to(device)
     dref = s_reset.to_device(device)
-    dstates = [DeviceState(packed=packed_d[i], pos_traj=dref.pos_traj, vel_traj=dref.vel_traj) for i in range(n_states)]
+    dstates = [DeviceState(packed=packed_d[i], pos_traj=dref.pos_traj, vel_traj=dref.vel_traj, time=int(host_states[i].time))
+               for i in range(n_states)]
+    controller.alias_outputs = True  # returned tensors alias the controller's buffers: no per-step clones
     core = controller.core
 
     def step(i, key, cp):
@@ -142,20 +144,6 @@ def main():
         key, cp = step(i, key, cp)
     torch.cuda.synchronize()
 
-    # events around the rollout launch, on the stream it is launched on (torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    orig_rollout = core.rollout
-
-    def timed_rollout(*a, **kw):
-        e0, e1 = ev[timed_rollout.i]
-        e0.record()
-        r = orig_rollout(*a, **kw)
-        e1.record()
-        timed_rollout.i += 1
-        return r
-    timed_rollout.i = 0
-    core.rollout = timed_rollout
-
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -166,21 +154,25 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    core.rollout = orig_rollout
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(cp.a_mean).all(), "non-finite a_mean after the timed region"
 
-    rollout_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    # same kernel, launched back-to-back (no host gaps between launches): per-launch duration
+    # The rollout kernel of the timed steps runs inside the fused step (one hipGraph replay per step) and
+    # cannot be bracketed individually from the host.  Its launch duration is measured here, right after the
+    # timed region, with events on the launch stream over back-to-back launches of the SAME kernel on the
+    # SAME buffers (the action stripes the last step's GEMM left in HBM/L2); the rocprofv3 kernel-trace of
+    # this command (profiles/) gives the in-step average of the same kernel for cross-checking.
     reps = 50
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     pc = params.to_c()
+    for _ in range(3):
+        core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), args.info)
     e0.record()
     for _ in range(reps):
-        orig_rollout(dstates[40], pc, (0.0, 0.0, 0.0), args.info)
+        core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), args.info)
     e1.record()
     torch.cuda.synchronize()
     rollout_b2b_ms = e0.elapsed_time(e1) / reps
@@ -200,8 +192,7 @@ def main():
                        "pos_stats_info": bool(args.info)},
             "roofline": {"bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_us_back_to_back": 1e3 * rollout_b2b_ms,
-                         "launch_us_in_step_events": 1e3 * rollout_ms},
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_us": 1e3 * rollout_b2b_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_states, params, args.N, H, args.lam, args.cpu_budget)

@@ -42,6 +42,18 @@ class ConfigC(C.Structure):
 
 
 _P = C.c_void_p
+
+
+class StepArgsC(C.Structure):
+    """struct covo_step_args (include/covo_hip.h)."""
+    _fields_ = [("mode", C.c_int32), ("n_samples", C.c_int32), ("T", C.c_int32), ("n_table", C.c_int32),
+                ("state", _P), ("pos_traj", _P), ("vel_traj", _P), ("a_mean", _P), ("a_mean_shift", _P), ("a_cov", _P),
+                ("L_table", _P), ("a", _P), ("cost", _P), ("groupmin", _P), ("pos_stats", _P), ("partial_out", _P),
+                ("sample_offset", C.c_int64), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float)]
+
+
+MODE_MPPI, MODE_COVO_ONLINE, MODE_COVO_OFFLINE = 0, 1, 2
+COVO_FLAG_NO_GRAPH = 2
 _SIGS = {
     "covo_last_error": (C.c_char_p, []),
     "covo_abi_version": (C.c_int, []),
@@ -63,6 +75,8 @@ _SIGS = {
     "covo_debug_sigma_workspace": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "covo_sigma_jacobi": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "covo_sigma_profile": (C.c_int, [_P, _P, C.c_float, _P, _P, _P, _P]),
+    "covo_mpc_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_uint32, C.c_uint32,
+                                C.POINTER(C.c_float), _P]),
     "covo_cholesky": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)

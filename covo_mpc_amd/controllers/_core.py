@@ -63,6 +63,7 @@ class SamplingCore:
         f32 = dict(dtype=torch.float32, device=self.device)
         n = self.n_local
         self._eps = None  # (n, 128) epsilon buffer, only materialised on request (parity tests)
+        self._bufs = {}   # fixed-address buffers of the fused step
         self.a = torch.empty((COVO_H, n, 4), **f32)
         self.cost = torch.empty((n,), **f32)
         self.blockmin = torch.empty(((n + 63) // 64,), **f32)  # per-64-sample cost minima
@@ -149,6 +150,53 @@ class SamplingCore:
         fn = self.lib.covo_sigma if method == "ns" else self.lib.covo_sigma_jacobi
         check(fn(self.h, ptr(R), batch, float(sample_sigma), ptr(Sigma), ptr(L), self.stream()), "covo_sigma")
         return Sigma, L
+
+    # -- the whole step in one C call (hipGraph-replayed from its third invocation) ---------------
+    def _persistent(self, name, shape, dtype=None):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self.torch.zeros(shape, dtype=dtype or self.torch.float32, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    def step(self, mode, dstate, params_c, a_mean, key, *, a_cov=None, L_table=None, gamma_mean=1.0, sample_sigma=0.5,
+             f_shared=None, want_stats=False):
+        """covo_mpc_step: returns (a_mean_new, a_cov_out) as views of persistent buffers (clone to keep).
+        Inputs are copied into fixed-address buffers so the captured graph stays valid."""
+        torch = self.torch
+        state_buf = self._persistent("state", (_lib.COVO_STATE_FLOATS,))
+        state_buf.copy_(dstate.packed, non_blocking=True)
+        am = self._persistent("a_mean", (COVO_NA,))
+        if a_mean.data_ptr() != am.data_ptr():
+            am.copy_(a_mean.reshape(-1), non_blocking=True)
+        am_shift = self._persistent("a_mean_shift", (COVO_NA,))
+        args = _lib.StepArgsC()
+        args.mode, args.n_samples, args.T = mode, self.n_local, dstate.T
+        args.state, args.pos_traj, args.vel_traj = state_buf.data_ptr(), dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr()
+        args.a_mean, args.a_mean_shift = am.data_ptr(), am_shift.data_ptr()
+        cov_out = None
+        if mode == _lib.MODE_COVO_ONLINE:
+            cov_out = self._persistent("a_cov", (COVO_NA, COVO_NA))
+            args.a_cov = cov_out.data_ptr()
+        elif mode == _lib.MODE_MPPI:
+            cov_out = self._persistent("a_cov_mppi", (COVO_H, 4, 4))
+            if a_cov.data_ptr() != cov_out.data_ptr():
+                cov_out.copy_(a_cov, non_blocking=True)
+            args.a_cov = cov_out.data_ptr()
+        else:
+            args.L_table, args.n_table = L_table.data_ptr(), int(L_table.shape[0])
+        args.a, args.cost, args.groupmin = self.a.data_ptr(), self.cost.data_ptr(), self.blockmin.data_ptr()
+        args.pos_stats = self.stats.data_ptr() if want_stats else None
+        args.partial_out = self.partial.data_ptr() if self.world > 1 else None
+        args.sample_offset, args.gamma_mean, args.sample_sigma = self.offset, float(gamma_mean), float(sample_sigma)
+        fs = (C.c_float * 3)(*[float(x) for x in f_shared]) if f_shared is not None else None
+        check(self.lib.covo_mpc_step(self.h, C.byref(params_c), C.byref(args), int(key[0]), int(key[1]), fs, self.stream()),
+              "covo_mpc_step")
+        if self.world > 1:
+            exchange_records(self.partial, self.gathered, self.pg)  # the ONE collective per step
+            check(self.lib.covo_merge(self.h, ptr(self.gathered), self.world, ptr(am_shift), float(gamma_mean), ptr(am),
+                                      self.stream()), "covo_merge")
+        return am, cov_out
 
     def update(self, a_mean_shifted, gamma_mean):
         """softmax weights + weighted mean (+ the one collective when sharded) -> new mean (H,4)."""

@@ -44,7 +44,8 @@ class CoVOController(BaseController):
                  process_group=None, compute_info: bool = True) -> None:
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
-        self.materialize_eps = False
+        self.materialize_eps = False  # True: epsilon is written to HBM and the kernels are called one by one (parity)
+        self.alias_outputs = False    # True: returned a_mean / a_cov alias the controller's buffers (no clones)
         self.action_dim = self.env.action_dim
         if mode not in ("online", "offline"):
             raise NotImplementedError(mode)  # covo.py:113-114
@@ -102,37 +103,54 @@ class CoVOController(BaseController):
     # ---- one MPC control step (covo.py:187-283) -----------------------------------------------------
     def __call__(self, obs, env_state, env_params, rng_act, control_params: CoVOParams, info):
         from .. import random as crandom
+        from .. import _lib
         core = self.core
         dstate = as_device_state(info["noisy_state"], core.device)  # covo.py:198
         params_c = env_params.to_c()
+        if self.mode == "offline" and control_params.a_chol_offline is None:
+            raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
+        if not self.materialize_eps:
+            # ---- production path: the whole step is one C call / one hipGraph replay (csrc/step.hip)
+            rng_act, act_key = crandom.split(rng_act)   # covo.py:212
+            rng_act, step_key = crandom.split(rng_act)  # covo.py:225 (deterministic rollouts draw nothing from it)
+            mode = _lib.MODE_COVO_ONLINE if self.mode == "online" else _lib.MODE_COVO_OFFLINE
+            am, cov = core.step(mode, dstate, params_c, control_params.a_mean, act_key,
+                                L_table=control_params.a_chol_offline, gamma_mean=control_params.gamma_mean,
+                                sample_sigma=control_params.sample_sigma, want_stats=core.compute_info)
+            a_mean_new = am.view(self.H, 4)
+            if self.mode == "online":
+                a_cov = cov
+            elif dstate.time is not None:  # covo.py:107-108, JAX gather clamps
+                a_cov = control_params.a_cov_offline[min(max(dstate.time, 0), control_params.a_cov_offline.shape[0] - 1)]
+            else:
+                t_idx = dstate.packed[25:26].view(core.torch.int32).long().clamp(0, control_params.a_cov_offline.shape[0] - 1)
+                a_cov = control_params.a_cov_offline.index_select(0, t_idx)[0]
+            if not self.alias_outputs:
+                a_mean_new = a_mean_new.clone()
+                a_cov = a_cov.clone() if self.mode == "online" else a_cov
+            control_params = control_params.replace(a_mean=a_mean_new, a_cov=a_cov)
+            out_info = core.info(dstate) if core.compute_info else {}
+            return a_mean_new[0], control_params, out_info
+
+        # ---- kernel-by-kernel path with epsilon materialised in HBM (identical values; parity/debug)
         a_mean = core.shift_mean(control_params.a_mean.reshape(-1))  # covo.py:201-203
         control_params = control_params.replace(a_mean=a_mean.view(self.H, 4))
-        # optimal Sigma (covo.py:205-208)
-        if self.mode == "online":
+        if self.mode == "online":  # optimal Sigma (covo.py:205-208)
             R = core.hessian(dstate.packed, dstate, params_c, a_mean)
             Sigma, L = core.sigma(R, control_params.sample_sigma)
             a_cov, L = Sigma[0], L[0]
         else:
-            if control_params.a_chol_offline is None:
-                raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
             t_idx = dstate.packed[25:26].view(core.torch.int32).long()  # env_state.time, stays on the device
             t_idx = t_idx.clamp(0, control_params.a_cov_offline.shape[0] - 1)  # JAX gather clamps
             a_cov = control_params.a_cov_offline.index_select(0, t_idx)[0]
             L = control_params.a_chol_offline.index_select(0, t_idx)[0]
         control_params = control_params.replace(a_cov=a_cov)
-        # sampling (covo.py:212-224)
-        rng_act, act_key = crandom.split(rng_act)
-        if self.materialize_eps:  # parity/debug: epsilon written to HBM first (identical values)
-            core.randn(act_key)
-            core.noise_gemm(L, a_mean)
-        else:
-            core.noise_gemm_philox(L, a_mean, act_key)
-        # rollout, deterministic=True -> no disturbance draw (covo.py:225-263)
-        rng_act, step_key = crandom.split(rng_act)
+        rng_act, act_key = crandom.split(rng_act)  # covo.py:212-224
+        core.randn(act_key)
+        core.noise_gemm(L, a_mean)
+        rng_act, step_key = crandom.split(rng_act)  # covo.py:225-263: deterministic=True -> no disturbance draw
         core.rollout(dstate, params_c, (0.0, 0.0, 0.0), core.compute_info)
-        # weights + update (covo.py:266-278)
-        a_mean_new = core.update(a_mean, control_params.gamma_mean).view(self.H, 4)
+        a_mean_new = core.update(a_mean, control_params.gamma_mean).view(self.H, 4)  # covo.py:266-278
         control_params = control_params.replace(a_mean=a_mean_new)
-        u = a_mean_new[0]
         out_info = core.info(dstate) if core.compute_info else {}
-        return u, control_params, out_info
+        return a_mean_new[0], control_params, out_info

@@ -33,7 +33,8 @@ class MPPIController(BaseController):
                  compute_info: bool = True) -> None:
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
-        self.materialize_eps = False
+        self.materialize_eps = False  # True: epsilon is written to HBM and the kernels are called one by one (parity)
+        self.alias_outputs = False    # True: returned a_mean / a_cov alias the controller's buffers (no clones)
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
 
@@ -45,25 +46,34 @@ class MPPIController(BaseController):
             raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0, mppi.py:119-125) is not built; "
                                       "quadjax's own factory fixes gamma_sigma = 0 (envs/quadrotor.py:715)")
         dstate = as_device_state(info["noisy_state"], core.device)  # mppi.py:40
-        # shift operator (mppi.py:43-49)
-        a_mean = core.shift_mean(control_params.a_mean.reshape(-1)).view(self.H, 4)
+        if not self.materialize_eps:
+            # ---- production path: one C call / one hipGraph replay (csrc/step.hip)
+            from .. import _lib
+            rng_act, act_key = crandom.split(rng_act)   # mppi.py:53
+            rng_act, step_key = crandom.split(rng_act)  # mppi.py:69: deterministic=False -> shared disturbance draw
+            f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)
+            am, cov = core.step(_lib.MODE_MPPI, dstate, env_params.to_c(), control_params.a_mean, act_key,
+                                a_cov=control_params.a_cov, gamma_mean=control_params.gamma_mean,
+                                sample_sigma=control_params.sample_sigma, f_shared=f_shared, want_stats=core.compute_info)
+            a_mean_new = am.view(self.H, 4)
+            if not self.alias_outputs:
+                a_mean_new, cov = a_mean_new.clone(), cov.clone()
+            control_params = control_params.replace(a_mean=a_mean_new, a_cov=cov)
+            out_info = core.info(dstate) if core.compute_info else {}
+            return a_mean_new[0], control_params, out_info
+
+        # ---- kernel-by-kernel path with epsilon materialised in HBM (identical values; parity/debug)
+        a_mean = core.shift_mean(control_params.a_mean.reshape(-1)).view(self.H, 4)  # mppi.py:43-49
         a_cov = torch.cat([control_params.a_cov[1:], control_params.a_cov[-1:]], dim=0).contiguous()
         control_params = control_params.replace(a_mean=a_mean, a_cov=a_cov)
-        # sampling (mppi.py:53-66)
-        rng_act, act_key = crandom.split(rng_act)
+        rng_act, act_key = crandom.split(rng_act)  # mppi.py:53-66
         Ls = core.cholesky(a_cov, 4, self.H)
-        if self.materialize_eps:  # parity/debug: epsilon written to HBM first (identical values)
-            core.randn(act_key)
-            core.noise_blockdiag(Ls, a_mean)
-        else:
-            core.noise_blockdiag_philox(Ls, a_mean, act_key)
-        # rollout (mppi.py:69-106): deterministic=False -> the shared step_key's disturbance draw
-        rng_act, step_key = crandom.split(rng_act)
+        core.randn(act_key)
+        core.noise_blockdiag(Ls, a_mean)
+        rng_act, step_key = crandom.split(rng_act)  # mppi.py:69-106
         f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)
         core.rollout(dstate, env_params.to_c(), f_shared, core.compute_info)
-        # weights + update (mppi.py:109-125; gamma_sigma = 0 leaves a_cov as shifted)
-        a_mean_new = core.update(a_mean.reshape(-1), control_params.gamma_mean).view(self.H, 4)
+        a_mean_new = core.update(a_mean.reshape(-1), control_params.gamma_mean).view(self.H, 4)  # mppi.py:109-125
         control_params = control_params.replace(a_mean=a_mean_new)
-        u = a_mean_new[0]  # mppi.py:129
         out_info = core.info(dstate) if core.compute_info else {}
-        return u, control_params, out_info
+        return a_mean_new[0], control_params, out_info

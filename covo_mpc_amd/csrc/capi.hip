@@ -54,6 +54,7 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
 int covo_destroy(covo_handle_t h)
 {
     if (!h) return COVO_E_NOHANDLE;
+    step_state_destroy(h);
     (void)hipFree(h->ws_partials);
     (void)hipFree(h->ws_blockmin);
     (void)hipFree(h->ws_stats);
@@ -169,9 +170,6 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
     if (need > h->ws_sigma_bytes) {  // only for batch sizes not seen before (never inside the steady-state step)
         COVO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
         (void)hipFree(h->ws_sigma);
-    (void)hipEventDestroy(h->ev_fork);
-    (void)hipEventDestroy(h->ev_join);
-    (void)hipStreamDestroy(h->side_stream);
         h->ws_sigma = nullptr;
         h->ws_sigma_bytes = 0;
         COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, need));
@@ -206,6 +204,22 @@ int covo_sigma_profile(covo_handle_t h, const double *R, float sample_sigma, flo
     REQUIRE(h, "covo_sigma_profile: null handle");
     REQUIRE(R && L_out && ticks_out, "covo_sigma_profile: bad argument");
     return launch_sigma(R, 1, sample_sigma, Sigma_out, L_out, (unsigned long long *)ticks_out, (hipStream_t)stream);
+}
+
+int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, uint32_t key0, uint32_t key1,
+                  const float *f_disturb_shared, void *stream)
+{
+    REQUIRE(h, "covo_mpc_step: null handle");
+    REQUIRE(params && args, "covo_mpc_step: null argument");
+    REQUIRE(args->mode >= 0 && args->mode <= 2, "covo_mpc_step: mode=%d", args->mode);
+    REQUIRE(args->n_samples > 0 && args->n_samples <= h->cfg.n_local, "covo_mpc_step: n_samples=%d outside (0, %d]",
+            args->n_samples, h->cfg.n_local);
+    REQUIRE(args->state && args->pos_traj && args->vel_traj && args->a_mean && args->a && args->cost && args->groupmin &&
+                args->T > 0,
+            "covo_mpc_step: null buffer");
+    REQUIRE(args->mode != COVO_MODE_COVO_OFFLINE || (args->L_table && args->n_table > 0), "covo_mpc_step: offline needs L_table");
+    REQUIRE(args->mode != COVO_MODE_MPPI || args->a_cov, "covo_mpc_step: mppi needs a_cov");
+    return covo_step_impl(h, params, args, key0, key1, f_disturb_shared, (hipStream_t)stream);
 }
 
 int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, float *L_out, void *stream)

@@ -19,6 +19,7 @@ struct covo_ctx {
     float *ws_stats;      // [ceil(n_local/256)][H*6] per-block position statistics
     void *ws_sigma;       // scratch of the eigh-free Sigma pipeline (grown on demand, outside graph capture)
     size_t ws_sigma_bytes;
+    void *step;               // StepState (step.hip): fused-step scratch + graph cache
     hipStream_t side_stream;  // forked work inside one call (joined before the call's last kernel)
     hipEvent_t ev_fork, ev_join;
     int max_red_blocks;
@@ -71,12 +72,13 @@ __device__ __forceinline__ float wave_sum(float v)
 int launch_randn(uint32_t k0, uint32_t k1, int64_t off, int n_samples, int n_cols, float *out, hipStream_t s);
 // eps == null: epsilon is drawn in-kernel from (k0, k1, sample_offset + n) (rng_device.hpp)
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
-                      int N, float *a, hipStream_t s);
+                      int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr, const float *state_for_time = nullptr,
+                      int n_table = 0);
 int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
-                           int64_t sample_offset, int N, float *a, hipStream_t s);
+                           int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr);
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
-                   float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s);
+                   float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr);
 // a_mean_out != null: finish on this GPU (normalise + blend); else write the merged record to partial_out
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,
@@ -91,4 +93,7 @@ int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, f
 size_t sigma_ns_workspace_bytes(int batch);
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
                     hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
+void step_state_destroy(covo_ctx *h);
+int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, uint32_t key0, uint32_t key1,
+                   const float *f_shared, hipStream_t s);
 int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);

@@ -105,8 +105,18 @@ template <bool PHILOX>
 __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
                                                               const float *__restrict__ eps, uint32_t k0, uint32_t k1,
                                                               int64_t sample_offset, int N, int ntiles,
-                                                              float4 *__restrict__ a_out)
+                                                              float4 *__restrict__ a_out, const uint32_t *__restrict__ dyn,
+                                                              const float *__restrict__ state_for_time, int n_table)
 {
+    // dyn (nullable): {key0, key1} in device memory -- lets a captured graph see a fresh key every replay.
+    // state_for_time (nullable): L is a table [n_table][128][128]; use row state.time (covo.py:107-108, clamped
+    // like a JAX gather).
+    if (dyn != nullptr) { k0 = dyn[0]; k1 = dyn[1]; }
+    if (state_for_time != nullptr) {
+        int t = __float_as_int(state_for_time[ST_TIME]);
+        t = t < 0 ? 0 : (t > n_table - 1 ? n_table - 1 : t);
+        L += (size_t)t * COVO_NA * COVO_NA;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ls = smem;                       // [128][NG_LDA]
     float *mus = smem + COVO_NA * NG_LDA;   // [128]
@@ -209,8 +219,10 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
 template <bool PHILOX>
 __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__restrict__ Ls, const float *__restrict__ mu,
                                                               const float4 *__restrict__ eps, uint32_t k0, uint32_t k1,
-                                                              int64_t sample_offset, int N, float4 *__restrict__ a_out)
+                                                              int64_t sample_offset, int N, float4 *__restrict__ a_out,
+                                                              const uint32_t *__restrict__ dyn)
 {
+    if (dyn != nullptr) { k0 = dyn[0]; k1 = dyn[1]; }
     __shared__ float sL[COVO_H * 16];
     __shared__ float sm[COVO_NA];
     for (int i = threadIdx.x; i < COVO_H * 16; i += 256) sL[i] = Ls[i];
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
 }
 
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
-                      int N, float *a, hipStream_t s)
+                      int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table)
 {
     const int ntiles = (N + 31) / 32;
     const int waves_per_block = NG_BLOCK / 64;
@@ -254,25 +266,26 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
     }
     if (eps != nullptr)
         hipLaunchKernelGGL(noise_gemm_kernel<false>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
-                           ntiles, reinterpret_cast<float4 *>(a));
+                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table);
     else
         hipLaunchKernelGGL(noise_gemm_kernel<true>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, (const float *)nullptr, k0,
-                           k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a));
+                           k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn, state_for_time, n_table);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
-                           int64_t sample_offset, int N, float *a, hipStream_t s)
+                           int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn)
 {
     const size_t total = (size_t)N * COVO_H;
     const int grid = (int)((total + 255) / 256);
     if (eps != nullptr)
         hipLaunchKernelGGL(noise_blockdiag_kernel<false>, dim3(grid), dim3(256), 0, s, Ls, mu,
-                           reinterpret_cast<const float4 *>(eps), 0u, 0u, (int64_t)0, N, reinterpret_cast<float4 *>(a));
+                           reinterpret_cast<const float4 *>(eps), 0u, 0u, (int64_t)0, N, reinterpret_cast<float4 *>(a),
+                           (const uint32_t *)nullptr);
     else
         hipLaunchKernelGGL(noise_blockdiag_kernel<true>, dim3(grid), dim3(256), 0, s, Ls, mu, (const float4 *)nullptr, k0,
-                           k1, sample_offset, N, reinterpret_cast<float4 *>(a));
+                           k1, sample_offset, N, reinterpret_cast<float4 *>(a), dyn);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

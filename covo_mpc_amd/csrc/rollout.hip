@@ -25,6 +25,7 @@ struct RolloutArgs {
     int N, T, max_steps;
     float discount;
     float f_shared[3];
+    const float *f_shared_dev;  // nullable: {fx, fy, fz} in device memory (graph replays), overrides f_shared
     qm::Consts<float> c;
 };
 
@@ -42,8 +43,8 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // v_readlane_b3
 template <bool STATS, bool DISC1, bool CLIP, int PF>
 __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
 {
-    __shared__ float sacc[STATS ? COVO_H * 6 : 1];
-    const int tid = threadIdx.x, lane = tid & (COVO_WAVE - 1);
+    __shared__ float sacc[STATS ? (RO_BLOCK / COVO_WAVE) * COVO_H * 6 : 1];  // one slot per wave: no atomics, fixed order
+    const int tid = threadIdx.x, lane = tid & (COVO_WAVE - 1), wave = tid / COVO_WAVE;
     const float *__restrict__ st = A.state;
     const int time0 = __float_as_int(st[ST_TIME]);
 
@@ -78,10 +79,6 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
         }
     }
     const int kdone = A.max_steps - time0;  // steps k >= kdone see time >= max_steps (quadrotor.py:483)
-    if (STATS) {
-        for (int i = tid; i < COVO_H * 6; i += RO_BLOCK) sacc[i] = 0.0f;
-        __syncthreads();
-    }
 
     qm::State<float> s;
     s.px = st[ST_POS + 0]; s.py = st[ST_POS + 1]; s.pz = st[ST_POS + 2];
@@ -90,6 +87,9 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
     s.ox = st[ST_OMEGA + 0]; s.oy = st[ST_OMEGA + 1]; s.oz = st[ST_OMEGA + 2];
     const float p0x = s.px, p0y = s.py, p0z = s.pz;
     const float f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
+    const float fsx = A.f_shared_dev ? A.f_shared_dev[0] : A.f_shared[0];
+    const float fsy = A.f_shared_dev ? A.f_shared_dev[1] : A.f_shared[1];
+    const float fsz = A.f_shared_dev ? A.f_shared_dev[2] : A.f_shared[2];
     const qm::Consts<float> c = A.c;
 
     float acc = 0.0f, r_before = 0.0f;   // covo.py:246-247
@@ -111,17 +111,17 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
         float4 av = ring[k % PF];
         if (PF < COVO_H && k + PF < COVO_H) ring[k % PF] = ap[(size_t)(k + PF) * stride];
         if (CLIP) { av.x = qm::clip11_(av.x); av.y = qm::clip11_(av.y); av.z = qm::clip11_(av.z); av.w = qm::clip11_(av.w); }
-        const float fx = (k == 0) ? f0x : A.f_shared[0];
-        const float fy = (k == 0) ? f0y : A.f_shared[1];
-        const float fz = (k == 0) ? f0z : A.f_shared[2];
+        const float fx = (k == 0) ? f0x : fsx;
+        const float fy = (k == 0) ? f0y : fsy;
+        const float fz = (k == 0) ? f0z : fsz;
         qm::dyn_step<float, float>(s, av.x, av.y, av.z, av.w, c, fx, fy, fz);
         if (STATS) {  // covo.py:234-237: post-step positions, shifted by the initial position
             const float dx = valid ? s.px - p0x : 0.0f, dy = valid ? s.py - p0y : 0.0f, dz = valid ? s.pz - p0z : 0.0f;
             const float v0 = wave_sum(dx), v1 = wave_sum(dy), v2 = wave_sum(dz);
             const float v3 = wave_sum(dx * dx), v4 = wave_sum(dy * dy), v5 = wave_sum(dz * dz);
             if (lane == 0) {
-                atomicAdd(&sacc[k * 6 + 0], v0); atomicAdd(&sacc[k * 6 + 1], v1); atomicAdd(&sacc[k * 6 + 2], v2);
-                atomicAdd(&sacc[k * 6 + 3], v3); atomicAdd(&sacc[k * 6 + 4], v4); atomicAdd(&sacc[k * 6 + 5], v5);
+                float *sl = sacc + wave * (COVO_H * 6) + k * 6;
+                sl[0] = v0; sl[1] = v1; sl[2] = v2; sl[3] = v3; sl[4] = v4; sl[5] = v5;
             }
         }
     }
@@ -134,7 +134,9 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
     }
     if (STATS) {
         __syncthreads();
-        for (int i = tid; i < COVO_H * 6; i += RO_BLOCK) A.stats_ws[(size_t)blockIdx.x * (COVO_H * 6) + i] = sacc[i];
+        for (int i = tid; i < COVO_H * 6; i += RO_BLOCK)
+            A.stats_ws[(size_t)blockIdx.x * (COVO_H * 6) + i] =
+                (sacc[i] + sacc[COVO_H * 6 + i]) + (sacc[2 * COVO_H * 6 + i] + sacc[3 * COVO_H * 6 + i]);
     }
 }
 
@@ -185,6 +187,9 @@ __global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel
         s.qx = st[ST_QUAT + 0]; s.qy = st[ST_QUAT + 1]; s.qz = st[ST_QUAT + 2]; s.qw = st[ST_QUAT + 3];
         s.ox = st[ST_OMEGA + 0]; s.oy = st[ST_OMEGA + 1]; s.oz = st[ST_OMEGA + 2];
         const float f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
+        const float fsx = A.f_shared_dev ? A.f_shared_dev[0] : A.f_shared[0];
+        const float fsy = A.f_shared_dev ? A.f_shared_dev[1] : A.f_shared[1];
+        const float fsz = A.f_shared_dev ? A.f_shared_dev[2] : A.f_shared[2];
         const qm::Consts<float> c = A.c;
 #pragma unroll
         for (int k = 0; k < COVO_H; ++k) {
@@ -196,9 +201,9 @@ __global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel
             if (k < COVO_H - 1) {
                 float4 a4 = av[k];
                 if (CLIP) { a4.x = qm::clip11_(a4.x); a4.y = qm::clip11_(a4.y); a4.z = qm::clip11_(a4.z); a4.w = qm::clip11_(a4.w); }
-                const float fx = (k == 0) ? f0x : A.f_shared[0];
-                const float fy = (k == 0) ? f0y : A.f_shared[1];
-                const float fz = (k == 0) ? f0z : A.f_shared[2];
+                const float fx = (k == 0) ? f0x : fsx;
+                const float fy = (k == 0) ? f0y : fsy;
+                const float fz = (k == 0) ? f0z : fsz;
                 qm::dyn_step<float, float>(s, a4.x, a4.y, a4.z, a4.w, c, fx, fy, fz);
             }
         }
@@ -281,7 +286,7 @@ static void launch_rollout_pf(const RolloutArgs &A, int grid, bool deep, hipStre
 
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
-                   float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s)
+                   float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s, const float *f_shared_dev)
 {
     RolloutArgs A;
     A.state = state;
@@ -296,6 +301,7 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     A.max_steps = p.max_steps_in_episode;
     A.discount = discount;
     for (int i = 0; i < 3; ++i) A.f_shared[i] = f_shared ? f_shared[i] : 0.0f;
+    A.f_shared_dev = f_shared_dev;
     A.c = make_consts<float>(p);
     const int grid = (N + RO_BLOCK - 1) / RO_BLOCK;
     const bool deep = grid <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon

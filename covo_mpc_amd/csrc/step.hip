@@ -1,0 +1,172 @@
+// step.hip -- one C entry per MPC control step, replayed as a hipGraph.
+//
+// covo_mpc_step() enqueues everything quadjax's controller __call__ does between "shift the mean" and
+// "new mean" (controllers/covo.py:201-275, mppi.py:43-125) for this rank's shard of samples on ONE
+// stream, with no host work in between.  A control step is ~70 tiny launches for covo-online (the
+// eigh-free Sigma pipeline alone is ~60); issued one by one from the host they leave ~150 us of gaps.
+// The second call with the same buffers captures the sequence into a hipGraph, later calls replay it.
+// Quantities that change every step (Philox key, MPPI's shared disturbance draw) live in a 32-byte
+// device block refreshed by one async copy before each replay, so the captured kernel arguments stay valid.
+#include <cstring>
+#include "covo_common.hpp"
+
+__global__ void shift_cov_kernel(const float *__restrict__ in, float *__restrict__ out)
+{
+    const int i = threadIdx.x;  // 512 threads: (H, 4, 4); mppi.py:43-49
+    out[i] = (i < (COVO_H - 1) * 16) ? in[i + 16] : in[i];
+}
+__global__ void copy512_kernel(const float *__restrict__ in, float *__restrict__ out) { out[threadIdx.x] = in[threadIdx.x]; }
+
+struct StepKey {
+    covo_step_args args;
+    covo_env_params params;
+    hipStream_t stream;
+};
+
+struct StepState {
+    // device
+    uint32_t *dyn;        // {key0, key1, f_shared[3] as float bits, pad[3]}
+    float *a_mean_shift;  // [128]
+    double *R;            // [128][128]
+    float *Sigma, *L;     // [128][128]
+    float *cov_shift, *Ls;  // [H][4][4]
+    // host (pinned) staging ring for dyn
+    uint32_t *dyn_host;
+    int ring_pos;
+    // graph cache
+    bool have_key, have_graph;
+    StepKey key;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+constexpr int DYN_RING = 256;
+
+static int step_state_init(covo_ctx *h)
+{
+    StepState *st = new StepState();
+    std::memset(st, 0, sizeof(*st));
+    COVO_CHECK_HIP(hipMalloc(&st->dyn, 32));
+    COVO_CHECK_HIP(hipMalloc(&st->a_mean_shift, COVO_NA * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&st->R, (size_t)COVO_NA * COVO_NA * sizeof(double)));
+    COVO_CHECK_HIP(hipMalloc(&st->Sigma, (size_t)COVO_NA * COVO_NA * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&st->L, (size_t)COVO_NA * COVO_NA * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&st->cov_shift, COVO_H * 16 * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&st->Ls, COVO_H * 16 * sizeof(float)));
+    COVO_CHECK_HIP(hipHostMalloc((void **)&st->dyn_host, (size_t)DYN_RING * 32, hipHostMallocDefault));
+    h->step = st;
+    return 0;
+}
+
+void step_state_destroy(covo_ctx *h)
+{
+    StepState *st = reinterpret_cast<StepState *>(h->step);
+    if (!st) return;
+    if (st->have_graph) {
+        (void)hipGraphExecDestroy(st->exec);
+        (void)hipGraphDestroy(st->graph);
+    }
+    (void)hipFree(st->dyn);
+    (void)hipFree(st->a_mean_shift);
+    (void)hipFree(st->R);
+    (void)hipFree(st->Sigma);
+    (void)hipFree(st->L);
+    (void)hipFree(st->cov_shift);
+    (void)hipFree(st->Ls);
+    (void)hipHostFree(st->dyn_host);
+    delete st;
+    h->step = nullptr;
+}
+
+// the launch sequence of one step (everything reads per-step scalars from st->dyn)
+static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, const covo_step_args &a, hipStream_t s)
+{
+    const int N = a.n_samples;
+    const float *fdev = reinterpret_cast<const float *>(st->dyn + 2);
+    float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
+    int rc;
+    if ((rc = launch_shift_mean(a.a_mean, am_shift, s))) return rc;               // covo.py:201-203
+    if (a.mode == COVO_MODE_COVO_ONLINE) {
+        if ((rc = launch_hessian(a.state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, s))) return rc;  // :134-185
+        float *Sig = a.a_cov ? a.a_cov : st->Sigma;
+        if ((rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
+        if ((rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
+    } else if (a.mode == COVO_MODE_COVO_OFFLINE) {
+        if ((rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, a.state,
+                                    a.n_table)))
+            return rc;
+    } else {  // MPPI: shift a_cov, factor the 4x4 blocks, per-step draws (mppi.py:43-66)
+        hipLaunchKernelGGL(shift_cov_kernel, dim3(1), dim3(COVO_H * 16), 0, s, a.a_cov, st->cov_shift);
+        hipLaunchKernelGGL(copy512_kernel, dim3(1), dim3(COVO_H * 16), 0, s, st->cov_shift, a.a_cov);
+        if ((rc = launch_cholesky(st->cov_shift, 4, COVO_H, st->Ls, s))) return rc;
+        if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
+    }
+    const bool clipped = true;  // a comes straight from the noise kernels above
+    if ((rc = launch_rollout(a.state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
+                             a.groupmin, a.pos_stats, h->ws_stats, s, fdev)))
+        return rc;
+    // weights + update: finish locally, or leave this shard's record for the all-gather (covo.py:266-275)
+    if (a.partial_out != nullptr)
+        return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, a.partial_out, nullptr, 1.0f, nullptr, s);
+    return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, am_shift, a.gamma_mean,
+                                 a.a_mean, s);
+}
+
+int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, uint32_t key0, uint32_t key1,
+                   const float *f_shared, hipStream_t s)
+{
+    if (!h->step) {
+        int rc = step_state_init(h);
+        if (rc) return rc;
+    }
+    StepState *st = reinterpret_cast<StepState *>(h->step);
+    // per-step scalars -> device block (pinned ring slot so the async copy never races the next call's write)
+    uint32_t *slot = st->dyn_host + (size_t)st->ring_pos * 8;
+    st->ring_pos = (st->ring_pos + 1) % DYN_RING;
+    slot[0] = key0;
+    slot[1] = key1;
+    for (int i = 0; i < 3; ++i) {
+        const float f = f_shared ? f_shared[i] : 0.0f;
+        std::memcpy(&slot[2 + i], &f, 4);
+    }
+    COVO_CHECK_HIP(hipMemcpyAsync(st->dyn, slot, 32, hipMemcpyHostToDevice, s));
+
+    StepKey k;
+    std::memset(&k, 0, sizeof(k));
+    k.args = *args;
+    k.params = *params;
+    k.stream = s;
+    const bool same = st->have_key && std::memcmp(&k, &st->key, sizeof(k)) == 0;
+    if (same && st->have_graph) {
+        COVO_CHECK_HIP(hipGraphLaunch(st->exec, s));
+        return 0;
+    }
+    if (same && !st->have_graph && (h->cfg.flags & COVO_FLAG_NO_GRAPH) == 0) {
+        // second call with identical buffers: capture (all one-time attribute calls / allocations happened in
+        // the eager first call)
+        // capture on the library's own stream (the caller's may be the legacy default stream, which cannot
+        // capture); nothing executes during capture, the graph is then launched on the caller's stream
+        hipStream_t cs = h->side_stream;
+        COVO_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_step(h, st, *params, *args, cs);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc) return rc;
+        if (e != hipSuccess) {
+            covo_set_error("covo_mpc_step: stream capture failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        COVO_CHECK_HIP(hipGraphInstantiate(&st->exec, g, nullptr, nullptr, 0));
+        st->graph = g;
+        st->have_graph = true;
+        COVO_CHECK_HIP(hipGraphLaunch(st->exec, s));
+        return 0;
+    }
+    if (!same && st->have_graph) {  // buffers changed: drop the stale graph
+        (void)hipGraphExecDestroy(st->exec);
+        (void)hipGraphDestroy(st->graph);
+        st->have_graph = false;
+    }
+    st->key = k;
+    st->have_key = true;
+    return enqueue_step(h, st, *params, *args, s);
+}

@@ -93,6 +93,7 @@ class DeviceState:
     packed: Any
     pos_traj: Any
     vel_traj: Any
+    time: Optional[int] = None  # host copy of state.time when known (lets table look-ups be plain views)
 
     @property
     def T(self) -> int:
@@ -147,7 +148,7 @@ class EnvState3D:
             pt = torch.from_numpy(np.ascontiguousarray(self.pos_traj, dtype=np.float32)).to(device)
             vt = torch.from_numpy(np.ascontiguousarray(self.vel_traj, dtype=np.float32)).to(device)
         packed = torch.from_numpy(self.pack()).to(device, non_blocking=True)
-        return DeviceState(packed=packed, pos_traj=pt, vel_traj=vt)
+        return DeviceState(packed=packed, pos_traj=pt, vel_traj=vt, time=int(self.time))
 
 
 def as_device_state(state, device) -> DeviceState:

@@ -53,6 +53,12 @@ extern "C" {
 #define COVO_FLAG_ACTIONS_CLIPPED 1 /* covo_config.flags: every `a` handed to covo_rollout_cost is already
                                        clipped to [-1,1] (true for covo_noise_* outputs): skip step_env's re-clip */
 
+#define COVO_FLAG_NO_GRAPH 2         /* covo_config.flags: covo_mpc_step always launches eagerly (no hipGraph) */
+
+#define COVO_MODE_MPPI 0
+#define COVO_MODE_COVO_ONLINE 1
+#define COVO_MODE_COVO_OFFLINE 2
+
 #define COVO_E_BADARG (-1)
 #define COVO_E_NOHANDLE (-2)
 #define COVO_E_UNSUPPORTED (-3)
@@ -194,6 +200,39 @@ int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doub
  * [20] sweeps done, [21] spectrum map, [22] H H^T, [23] Cholesky, [24] number of sweeps. */
 int covo_sigma_profile(covo_handle_t h, const double *R, float sample_sigma, float *Sigma_out, float *L_out,
                        uint64_t *ticks_out, void *stream);
+
+/* Everything one controller __call__ does between "shift the mean" and "new mean", for this handle's shard
+ * of samples, in ONE call (controllers/covo.py:201-275, mppi.py:43-125):
+ *   shift mean -> [online: Hessian -> optimal Sigma -> Cholesky | offline: L_table[state.time] | mppi: shift
+ *   a_cov, factor the 4x4 blocks] -> in-kernel Philox draw + noise GEMM -> fused rollout -> softmax reduction
+ *   -> (partial_out == NULL) new mean written back to a_mean, or (partial_out != NULL) this shard's record.
+ * All pointers are device pointers that must stay valid and UNCHANGED from call to call for the sequence to be
+ * captured into a hipGraph (second identical call) and replayed (later calls); changing any of them or
+ * `params` falls back to eager launches and re-captures.  key0/key1 and f_disturb_shared may change freely. */
+typedef struct covo_step_args {
+    int32_t mode;            /* COVO_MODE_* */
+    int32_t n_samples;       /* <= n_local */
+    int32_t T;               /* rows of pos_traj / vel_traj */
+    int32_t n_table;         /* offline: rows of L_table */
+    const float *state;      /* float[32], the noisy state (controllers/covo.py:198) */
+    const float *pos_traj;
+    const float *vel_traj;
+    float *a_mean;           /* float[128] in/out */
+    float *a_mean_shift;     /* nullable: float[128] receives the shifted old mean (needed by covo_merge's blend) */
+    float *a_cov;            /* online: float[128][128] Sigma out (nullable); mppi: float[H][4][4] in/out (shifted) */
+    const float *L_table;    /* offline: float[n_table][128][128] lower Cholesky factors of a_cov_offline */
+    float *a;                /* work: float[H][n_samples][4] */
+    float *cost;             /* work: float[n_samples] */
+    float *groupmin;         /* work: float[ceil(n_samples/64)] */
+    double *pos_stats;       /* nullable, as in covo_rollout_cost */
+    float *partial_out;      /* nullable: float[132] record instead of finishing locally */
+    int64_t sample_offset;   /* global id of this shard's first sample */
+    float gamma_mean;
+    float sample_sigma;
+} covo_step_args;
+
+int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, uint32_t key0,
+                  uint32_t key1, const float *f_disturb_shared /* [host float[3]] or NULL */, void *stream);
 
 /* Lower Cholesky factors of `batch` symmetric PD n x n fp32 matrices (n <= 128), the
  * factorisation inside jax.random.multivariate_normal (covo.py:216, mppi.py:59). */

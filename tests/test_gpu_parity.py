@@ -362,6 +362,35 @@ def test_controller_step_teacher_forced(name, task, N):
         obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
 
 
+@pytest.mark.parametrize("name,task", [("mppi", "hovering"), ("covo-online", "tracking_zigzag"),
+                                       ("covo-offline", "tracking_zigzag")])
+def test_fused_step_equals_kernel_by_kernel(name, task):
+    """covo_mpc_step (one C call; eager, captured, then replayed as a hipGraph) must give bit-identical means
+    to the kernel-by-kernel path that materialises epsilon, step after step."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    N = 4096
+    ca, cpa = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
+    cb, cpb = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
+    cb.materialize_eps = True
+    params = env.default_params
+    obs, info, state = env.reset(cr.PRNGKey(4), params)
+    cpa = ca.reset(state, params, ca.init_control_params, cr.PRNGKey(5))
+    cpb = cb.reset(state, params, cb.init_control_params, cr.PRNGKey(5))
+    key = cr.PRNGKey(6)
+    for step in range(6):  # call 1 eager, call 2 captures, calls 3+ replay the graph
+        key, k_act, k_step = cr.split(key, 3)
+        ua, cpa, ia = ca(obs, state, params, k_act, cpa, info)
+        ub, cpb, ib = cb(obs, state, params, k_act, cpb, info)
+        assert torch.equal(cpa.a_mean, cpb.a_mean), (name, step, (cpa.a_mean - cpb.a_mean).abs().max())
+        assert torch.equal(ca.core.cost, cb.core.cost)
+        assert torch.allclose(cpa.a_cov, cpb.a_cov, rtol=0, atol=0)
+        assert torch.equal(ia["pos_mean"], ib["pos_mean"]) and torch.equal(ia["pos_std"], ib["pos_std"])
+        obs, state, reward, done, info = env.step(k_step, state, ua.cpu().numpy(), params)
+
+
 def test_closed_loop_tracking_sanity():
     """Free-running covo-offline on tracking_zigzag: tracking error stays at the few-cm level after the
     start-up transient."""
