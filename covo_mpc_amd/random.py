@@ -57,6 +57,12 @@ def split(key, num: int = 2) -> np.ndarray:
 
 def _bits(key, n: int) -> np.ndarray:
     m = (n + 3) // 4
+    if m <= 8:  # scalar path: per-control-step draws (3-vectors) sit on the host critical path
+        k0, k1 = int(key[0]), int(key[1])
+        out = []
+        for i in range(m):
+            out.extend(_philox_scalar(i, 0, 0, 0xB175, k0, k1))
+        return np.asarray(out[:n], dtype=np.uint32)
     i = np.arange(m, dtype=np.uint32)
     z = np.zeros(m, dtype=np.uint32)
     r = _philox(i, z, z, z + np.uint32(0xB175), key[0], key[1])
@@ -72,6 +78,15 @@ def uniform(key, shape=(), minval=0.0, maxval=1.0, dtype=np.float32) -> np.ndarr
 
 def normal(key, shape=(), dtype=np.float32) -> np.ndarray:
     n = int(np.prod(shape)) if shape != () else 1
+    if n <= 4 and shape != ():  # scalar path (same formula in Python floats): the MPPI disturbance 3-vector
+        import math
+        k0, k1 = int(key[0]), int(key[1])
+        b = []
+        for i in range((2 * n + 3) // 4):
+            b.extend(_philox_scalar(i, 0, 0, 0xB175, k0, k1))
+        z = [math.sqrt(-2.0 * math.log(((b[i] >> 8) + 0.5) / 16777216.0)) *
+             math.cos(2.0 * math.pi * (((b[n + i] >> 8) + 0.5) / 16777216.0)) for i in range(n)]
+        return np.asarray(z, dtype=dtype).reshape(shape)
     b = _bits(key, 2 * n)
     u1 = ((b[:n] >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0
     u2 = ((b[n:] >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0
