@@ -8,18 +8,29 @@
 //     log c = 2 log(sigma) + log det(R + delta I) / (2 n)        (so that det Sigma = sigma^(2n)).
 // A 128x128 eigensolver is a latency monster on a GPU (cyclic Jacobi on one CU: 10-12 sweeps on
 // CoVO Hessians, whose spectrum clusters near 0 -> ~2 ms; see sigma.hip, kept as covo_sigma_jacobi).
-// The same matrix is obtained here from three GEMM-shaped pieces, each a handful of 2-3 us launches of
-// 64 independent waves (v_mfma_f64_16x16x4_f64, one 16x16 tile per wave):
-//   1. lambda_min:  X <- X^2 / |X|_F^2  (NS_SQUARINGS times) on X0 = gershgorin*I - R drives X to the
+// The same matrix is obtained here from a chain of ~45 tiny DEPENDENT launches, each one 128^3 fp64 GEMM
+// (v_mfma_f64_16x16x4_f64).  What one link of such a chain costs was measured first
+// (scripts/probe/chain_probe.hip, profiles/r01_chain_probe.log): an empty graph node 1.6 us; one wave per
+// 16x16 tile with K = 128: 4.2 us; one 256-thread workgroup per tile with K split over its 4 waves:
+// 2.6 us; the same phases inside ONE persistent launch separated by a counter barrier: 6.1 us (spread
+// over the XCDs) / 22.8 us (confined to one XCD) -- so: separate launches, K-split tiles.
+//   1. lambda_min:  X <- X^2 / |X|_F^2  (NS_SQUARINGS times) on X0 = shift*I - R drives X to the
 //      dominant eigenspace; a Rayleigh-Ritz step on its RITZ largest-diagonal columns gives lambda_min
 //      (exact as soon as the eigenvector lies in the span -- robust to near-degenerate bottoms).
-//   2. (R + delta I)^(-1/2): coupled Newton-Schulz  T = (3I - ZY)/2, Y <- YT, Z <- TZ  from Y0 = B/s,
-//      Z0 = I (quadratically convergent, clustering-insensitive, all iterates are polynomials in B and
-//      hence symmetric -- which lets every MFMA operand be read in its coalesced orientation;
-//      iterates are kept EXACTLY symmetric by computing lower tiles only and mirroring).
-//   3. log det B from a single-workgroup Cholesky of B; the final Cholesky of fp32(Sigma) likewise.
-// Agreement with the LAPACK-eigh oracle: ~1e-15 relative (fp64), tests/test_gpu_parity.py.
-// `batch` matrices per launch (grid.z): covo-offline's 300-step table, env-batched configs.
+//   2. B^(-1/2), B = R + delta I: coupled Newton-Schulz  T = a_k I + b_k Z Y, Y <- Y T, Z <- T Z  from
+//      Y0 = B/s, Z0 = I, with the Chen-Chow scaling  a_k = 1.5 rho_k, b_k = -0.5 rho_k^3,
+//      rho_k^2 = 3/(1 + l_k + l_k^2),  l_{k+1} = l_k (a_k + b_k l_k^2),  l_0 = sqrt(1e-2/s)  -- lambda_min(B)
+//      is 1e-2 BY CONSTRUCTION, so the spectrum interval of every iterate is known a priori and the slow
+//      initial phase of the unscaled iteration (x1.5 per step) becomes x2.6 per step: 9-10 iterations
+//      instead of 17-18 on CoVO Hessians (s/1e-2 ~ 2e4).  Every iterate is stored together with its
+//      transpose (both MFMA operands are then read as 128-B runs); symmetry is neither assumed nor forced
+//      (mirroring the lower triangle makes the coupled iteration blow up after convergence).
+//      Iteration 0 needs no Z.Y product (Z0 = I): one launch forms Y1 = a0 Y0 + b0 Y0^2, Z1 = a0 I + b0 Y0.
+//   3. one workgroup: Cholesky of Z (blocked, MFMA trailing update, chol_lds.hpp) -> log det B; then the
+//      Cholesky of fp32(Sigma).
+// All reductions go through per-workgroup slots summed in a fixed order: results are bit-reproducible.
+// Agreement with the LAPACK-eigh oracle: ~1e-13 relative (fp64), tests/test_gpu_parity.py.
+// `batch` matrices per launch (grid.z / grid.y): covo-offline's 300-step table, env-batched configs.
 #include "covo_common.hpp"
 #include "wave_reduce.hpp"
 #include "chol_lds.hpp"
@@ -29,36 +40,80 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int SN = COVO_NA;  // 128
 constexpr int NS_SQUARINGS = 16;   // X^(2^16): a relative gap of 2e-4 between the bottom eigenvalue and the 5th one
                                    // (RITZ = 4 are resolved exactly by the Ritz step) is damped to 1e-11
-constexpr int NS_ITERS = 24;       // enough for scale/1e-2 up to ~1e6 (CoVO Hessians: 1e4-2e4 with the Gershgorin
-                                   // scale, 17-18 iterations); launches after convergence return at once
+constexpr int NS_ITERS = 14;       // scaled iteration: 10 for s/1e-2 = 2e4 (CoVO Hessians), 12 for 1e6; launches after
+                                   // convergence return at once (1.6 us each)
 constexpr double NS_TOL2 = 1e-10;  // iteration k+1 is skipped once |I - Z_k Y_k|_F^2 < 1e-10: step k itself squares
                                    // that residual to ~1e-20, far below the fp32 rounding Sigma gets anyway
 constexpr int RITZ = 4;            // Rayleigh-Ritz block: exact lambda_min for up to 4 near-degenerate bottom eigenvalues
 
-// per-matrix scalar slots (doubles)
-enum { SC_NORMSQ = 0 /* ..NS_SQUARINGS */, SC_SHIFT = 24, SC_LMIN = 25, SC_DELTA = 26, SC_SCALE = 27, SC_LOGDET = 28,
-       SC_ZBUF = 29, SC_ITERS = 30, SC_XBUF = 31, SC_SQ = 23, SC_ERR = 32 /* ..NS_ITERS */, SC_COUNT = 64 };
-static_assert(SC_ERR + NS_ITERS <= SC_COUNT && NS_SQUARINGS + 1 <= SC_SHIFT, "scalar slots");
+// per-matrix scratch (doubles): scalars, the Newton-Schulz coefficient table, per-row data of A, and the
+// per-workgroup reduction slots (no atomics anywhere: fixed summation order, bit-reproducible)
+enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, SC_XBUF, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
+       SC_FRO2, SC_TRACE, SC_GERSH, SC_N0,
+       SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
+       SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
+       SC_DIAG = 192,          // A[r][r]                    (128)
+       SC_PREP = 320,          // prep partials: 8 x {max rowabs, sum v^2, trace, -}
+       SC_SQN = 384,           // |X_i|_F^2 partials: (NS_SQUARINGS + 1) x 64 (36 used)
+       SC_ERR = SC_SQN + (NS_SQUARINGS + 1) * 64,  // |Z_k Y_k - I|_F^2 partials: NS_ITERS x 64
+       SC_COUNT = SC_ERR + NS_ITERS * 64 };
+static_assert(SC_COEF + 2 * NS_ITERS <= SC_ROWABS, "scalar slots");
 
-// ---- one wave = one 16x16 tile of C = At^T . B  (At, B row-major 128x128).
+// ---- one 256-thread workgroup = one 16x16 tile of C = At^T . B  (At, B row-major 128x128); wave q takes
+// the K-quarter [32q, 32q+32) (8 MFMAs), the four partial tiles are summed through LDS.
 // MFMA f64 16x16x4: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
 // The A operand is fetched as At[k][i], so BOTH operands are read as 128-B contiguous runs; callers pass
-// the stored TRANSPOSE of the left factor (every Newton-Schulz iterate is kept together with its
-// transpose, both written from the same registers).  No symmetry is assumed or enforced: forcing
-// symmetry (mirroring the lower triangle) makes the coupled iteration blow up after convergence.
-__device__ __forceinline__ f64x4 tile_mm(const double *__restrict__ A, const double *__restrict__ B, int ti, int tj, int lane)
+// the stored TRANSPOSE of the left factor.  `f(value, row, col)` maps the stored element to the operand
+// (identity; shift*I - A for the first squaring; (A + delta I)/s for the first Newton-Schulz step).
+struct LoadPlain {
+    __device__ __forceinline__ double operator()(double v, int, int) const { return v; }
+};
+struct LoadShiftMinus {
+    double shift;
+    __device__ __forceinline__ double operator()(double v, int r, int c) const { return ((r == c) ? shift : 0.0) - v; }
+};
+struct LoadScaledB {
+    double delta, inv;
+    __device__ __forceinline__ double operator()(double v, int r, int c) const { return (v + ((r == c) ? delta : 0.0)) * inv; }
+};
+
+template <class F>
+__device__ __forceinline__ f64x4 tile_mm_q(const double *__restrict__ A, const double *__restrict__ B, int ti, int tj, int lane,
+                                           int kq, F f)
 {
     const int lo = lane & 15, hi = lane >> 4;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    double a[32], b[32];
+    double a[8], b[8];
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-        a[kk] = A[(size_t)(4 * kk + hi) * SN + 16 * ti + lo];
-        b[kk] = B[(size_t)(4 * kk + hi) * SN + 16 * tj + lo];
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 32 * kq + 4 * kk + hi;
+        a[kk] = f(A[(size_t)k * SN + 16 * ti + lo], k, 16 * ti + lo);
+        b[kk] = f(B[(size_t)k * SN + 16 * tj + lo], k, 16 * tj + lo);
     }
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);
     return acc;
+}
+// sums the four K-quarters; wave wv returns the tile element (row, col) = ((lane>>4) + 4 wv, lane&15) it will store
+__device__ __forceinline__ double tile_reduce(const f64x4 &acc, double (*red)[4][64], int wv, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][r][lane] = acc[r];
+    __syncthreads();
+    return (red[0][wv][lane] + red[1][wv][lane]) + (red[2][wv][lane] + red[3][wv][lane]);
+}
+// workgroup sum (256 threads) of one double per lane, fixed order; valid in every thread
+__device__ __forceinline__ double wg_sum4(double v, double *part, int wv, int lane)
+{
+    v = wr::wave64_allsum(v);
+    if (lane == 0) part[wv] = v;
+    __syncthreads();
+    return (part[0] + part[1]) + (part[2] + part[3]);
+}
+// sum of n <= 64 slots, fixed order; valid in every lane
+__device__ __forceinline__ double slot_sum(const double *__restrict__ p, int n, int lane)
+{
+    return wr::wave64_allsum((lane < n) ? p[lane] : 0.0);
 }
 
 // The squaring stage (power iteration: self-correcting) works on exactly symmetric matrices: only tiles
@@ -83,116 +138,123 @@ __device__ __forceinline__ void store_sym(double *__restrict__ O, int row, int c
     }
 }
 
-// ---- prep: A = (R + R^T)/2, X0 = shift*I - A with a Gershgorin shift, |X0|_F^2
-__global__ __launch_bounds__(512) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ A,
-                                                      double *__restrict__ X, double *__restrict__ sc)
+// ---- prep (8 workgroups x 16 rows): A = (R + R^T)/2, per-row |.|-sums and diagonal, partials of
+// max-row-sum / |A|_F^2 / trace.  The shift and X0 = shift*I - A are formed by the first squaring on load.
+__global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ Aall,
+                                                      double *__restrict__ scall)
 {
-    __shared__ double red[512];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ double sm[3][16];
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const double *R = Rin + (size_t)b * SN * SN;
-    A += (size_t)b * SN * SN;
-    X += (size_t)b * SN * SN;
-    sc += (size_t)b * SC_COUNT;
-    // thread (q = tid/128, c = tid%128) owns rows r = q, q+4, ... of column c: coalesced in c
-    const int c = tid & (SN - 1), q = tid >> 7;
-    double colsum = 0.0;
-    for (int r = q; r < SN; r += 4) {
-        const double v = 0.5 * (R[(size_t)r * SN + c] + R[(size_t)c * SN + r]);  // covo.py:117
+    double *A = Aall + (size_t)b * SN * SN;
+    double *s = scall + (size_t)b * SC_COUNT;
+    if (g == 0 && tid < SC_COEF) s[tid] = 0.0;  // scalars and the two "done" flags
+    const int r = 16 * g + (tid >> 4), cq = tid & 15;
+    double rowabs = 0.0, fro = 0.0, diag = 0.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int c = cq + 16 * m;
+        const double v = 0.5 * (R[(size_t)r * SN + c] + R[(size_t)c * SN + r]);  // covo.py:117 (bitwise symmetric)
         A[(size_t)r * SN + c] = v;
-        colsum += fabs(v);
+        rowabs += fabs(v);
+        fro = fma(v, v, fro);
+        if (c == r) diag = v;
     }
-    red[tid] = colsum;
-    __syncthreads();
-    if (tid < SN) red[tid] = (red[tid] + red[tid + 128]) + (red[tid + 256] + red[tid + 384]);  // column = row abs-sum
-    __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
-        __syncthreads();
+    rowabs = wr::row16_allsum(rowabs);
+    fro = wr::row16_allsum(fro);
+    diag = wr::row16_allsum(diag);
+    if (cq == 0) {
+        s[SC_ROWABS + r] = rowabs;
+        s[SC_DIAG + r] = diag;
+        sm[0][tid >> 4] = rowabs;
+        sm[1][tid >> 4] = fro;
+        sm[2][tid >> 4] = diag;
     }
-    const double gersh = red[0];
-    __syncthreads();
-    double fro = 0.0;
-    for (int r = q; r < SN; r += 4) fro = fma(A[(size_t)r * SN + c], A[(size_t)r * SN + c], fro);
-    red[tid] = fro;
-    __syncthreads();
-    for (int o = 256; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    // any upper bound of lambda_max(A) works; the tighter it is the faster the power iteration separates
-    const double shift = fmin(gersh, sqrt(red[0])) * (1.0 + 1e-12) + 1e-3;
-    __syncthreads();
-    double nsq = 0.0;
-    for (int r = q; r < SN; r += 4) {
-        const double v = ((r == c) ? shift : 0.0) - A[(size_t)r * SN + c];
-        X[(size_t)r * SN + c] = v;
-        nsq = fma(v, v, nsq);
-    }
-    red[tid] = nsq;
-    __syncthreads();
-    for (int o = 256; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    if (tid < SC_COUNT) sc[tid] = 0.0;
     __syncthreads();
     if (tid == 0) {
-        sc[SC_SHIFT] = shift;
-        sc[SC_NORMSQ] = red[0];
+        double gm = 0.0, f2 = 0.0, tr = 0.0;
+        for (int i = 0; i < 16; ++i) {
+            gm = fmax(gm, sm[0][i]);
+            f2 += sm[1][i];
+            tr += sm[2][i];
+        }
+        s[SC_PREP + 4 * g + 0] = gm;
+        s[SC_PREP + 4 * g + 1] = f2;
+        s[SC_PREP + 4 * g + 2] = tr;
     }
 }
 
-// ---- squaring: Xout = Xin^2 / |Xin|_F^2, accumulates |Xout|_F^2 into sc[SC_NORMSQ + step + 1]
+// ---- squaring: Xout = Xin^2 / |Xin|_F^2 (36 lower tiles), |Xout|_F^2 partials into slot row step+1.
+// FIRST: Xin is A and the operand is X0 = shift*I - A with shift = min(Gershgorin, Frobenius) bound.
+template <bool FIRST>
 __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict__ Xin, double *__restrict__ Xout,
-                                                        double *__restrict__ sc, int step, int xbuf_out)
+                                                        double *__restrict__ scall, int step, int xbuf_out)
 {
-    const int b = blockIdx.z, lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);  // lower tile 0..35
+    __shared__ double red[4][4][64];
+    __shared__ double part[4];
+    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *X = Xin + (size_t)b * SN * SN;
     double *O = Xout + (size_t)b * SN * SN;
-    double *s = sc + (size_t)b * SC_COUNT;
-    // stationary: |X_k|_F^2 stopped moving (X is a projector onto the dominant eigenspace up to scale)
-    if (step >= 2 && fabs(s[SC_NORMSQ + step] - s[SC_NORMSQ + step - 1]) <= 1e-11 * s[SC_NORMSQ + step]) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) s[SC_NORMSQ + step + 1] = s[SC_NORMSQ + step];
-        return;
+    double *s = scall + (size_t)b * SC_COUNT;
+    double nrm, shift = 0.0;
+    if (FIRST) {
+        double gm = 0.0, f2 = 0.0, tr = 0.0;
+        for (int i = 0; i < 8; ++i) {
+            gm = fmax(gm, s[SC_PREP + 4 * i + 0]);
+            f2 += s[SC_PREP + 4 * i + 1];
+            tr += s[SC_PREP + 4 * i + 2];
+        }
+        // any upper bound of lambda_max(A) works; the tighter it is the faster the power iteration separates
+        shift = fmin(gm, sqrt(f2)) * (1.0 + 1e-12) + 1e-3;
+        nrm = fma((double)SN * shift, shift, fma(-2.0 * shift, tr, f2));  // |shift I - A|_F^2
+        if (w == 0 && tid == 0) {
+            s[SC_SHIFT] = shift;
+            s[SC_FRO2] = f2;
+            s[SC_TRACE] = tr;
+            s[SC_GERSH] = gm;
+            s[SC_N0] = nrm;
+        }
+    } else {
+        if (s[SC_SQ_DONE] != 0.0) return;
+        nrm = slot_sum(s + SC_SQN + step * 64, NS_TILES, lane);
+        if (step >= 2) {
+            // stationary: |X_k|_F^2 stopped moving (X is a projector onto the dominant eigenspace up to scale)
+            const double prev = slot_sum(s + SC_SQN + (step - 1) * 64, NS_TILES, lane);
+            if (fabs(nrm - prev) <= 1e-11 * nrm) {
+                if (w == 0 && tid == 0) s[SC_SQ_DONE] = 1.0;
+                return;
+            }
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (w == 0 && tid == 0) {
         s[SC_XBUF] = (double)xbuf_out;
         s[SC_SQ] = (double)(step + 1);
     }
     int ti, tj;
     tri_tile(w, ti, tj);
-    const f64x4 acc = tile_mm(X, X, ti, tj, lane);
-    const double inv = 1.0 / s[SC_NORMSQ + step];
-    double nsq = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double v = acc[r] * inv;
-        const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-        store_sym(O, row, col, v);
-        nsq += (row > col) ? 2.0 * v * v : ((row == col) ? v * v : 0.0);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nsq += __shfl_xor(nsq, o, 64);
-    if (lane == 0) atomicAdd(&s[SC_NORMSQ + step + 1], nsq);
+    const f64x4 acc = FIRST ? tile_mm_q(X, X, ti, tj, lane, wv, LoadShiftMinus{shift}) : tile_mm_q(X, X, ti, tj, lane, wv, LoadPlain{});
+    const double v = tile_reduce(acc, red, wv, lane) * (1.0 / nrm);
+    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+    store_sym(O, row, col, v);
+    const double tot = wg_sum4((row > col) ? 2.0 * v * v : ((row == col) ? v * v : 0.0), part, wv, lane);
+    if (tid == 0) s[SC_SQN + (step + 1) * 64 + w] = tot;
 }
 
-// ---- Rayleigh-Ritz on the RITZ largest-diagonal columns of X: lambda_min(A); then B = A + delta I,
-// Y0 = B/s (s = Gershgorin bound of B), Z0 = I.
+// ---- Rayleigh-Ritz on the RITZ largest-diagonal columns of X: lambda_min(A), delta; then the scale s of
+// B = A + delta I (min of its Gershgorin and Frobenius bounds, from the per-row data of prep) and the
+// Newton-Schulz coefficient table.
 __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__ Aall, const double *__restrict__ X0all,
-                                                      const double *__restrict__ X1all, double *__restrict__ Ball, double *__restrict__ Yall,
-                                                      double *__restrict__ Ytall, double *__restrict__ Zall,
-                                                      double *__restrict__ Ztall, double *__restrict__ sc)
+                                                      const double *__restrict__ X1all, double *__restrict__ scall)
 {
     __shared__ double V[RITZ][SN];
     __shared__ double AV[RITZ][SN];
     __shared__ double H[RITZ][RITZ];
-    __shared__ double red[512];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ double red[SN];
+    __shared__ double sh_delta;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *A = Aall + (size_t)b * SN * SN;
-    const double *X = ((sc[(size_t)b * SC_COUNT + SC_XBUF] != 0.0) ? X1all : X0all) + (size_t)b * SN * SN;
-    double *B = Ball + (size_t)b * SN * SN, *Y = Yall + (size_t)b * SN * SN, *Z = Zall + (size_t)b * SN * SN;
-    double *Yt = Ytall + (size_t)b * SN * SN, *Zt = Ztall + (size_t)b * SN * SN;
-    double *s = sc + (size_t)b * SC_COUNT;
+    double *s = scall + (size_t)b * SC_COUNT;
+    const double *X = ((s[SC_XBUF] != 0.0) ? X1all : X0all) + (size_t)b * SN * SN;
     if (tid < 64) {
         // ---- wave 0: pick the RITZ largest diagonal entries, orthonormalise those columns (two-pass MGS,
         // everything in registers: lane l owns rows l and l+64; reductions on the VALU)
@@ -242,19 +304,21 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     __syncthreads();
     // AV = A V (A symmetric: column reads are coalesced), then H = V^T A V
     {
-        const int r = tid & (SN - 1), kq = tid >> 7;  // 4 groups of 128 threads
-        for (int k = kq; k < RITZ; k += 4) {
-            double a0 = 0.0;
-            for (int c = 0; c < SN; ++c) a0 = fma(A[(size_t)c * SN + r], V[k][c], a0);
-            AV[k][r] = a0;
+        const int r = tid & (SN - 1), k = tid >> 7;  // 4 groups of 128 threads, one Ritz vector each
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < SN; c += 2) {
+            a0 = fma(A[(size_t)c * SN + r], V[k][c], a0);
+            a1 = fma(A[(size_t)(c + 1) * SN + r], V[k][c + 1], a1);
         }
+        AV[k][r] = a0 + a1;
     }
     __syncthreads();
-    if (tid < RITZ * RITZ) {
-        const int i = tid / RITZ, j = tid % RITZ;
-        double acc = 0.0;
-        for (int r = 0; r < SN; ++r) acc = fma(V[i][r], AV[j][r], acc);
-        H[i][j] = acc;
+#pragma unroll
+    for (int e = 2 * wave; e < 2 * wave + 2; ++e) {  // 8 waves x 2 entries of H
+        const int i = e / RITZ, j = e % RITZ;
+        const double d = wr::wave64_allsum(fma(V[i][lane], AV[j][lane], V[i][lane + 64] * AV[j][lane + 64]));
+        if (lane == 0) H[i][j] = d;
     }
     __syncthreads();
     if (tid == 0) {
@@ -289,70 +353,92 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         for (int i = 1; i < RITZ; ++i) lmin = fmin(lmin, h[i][i]);
         s[SC_LMIN] = lmin;
         s[SC_DELTA] = -lmin + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
+        sh_delta = -lmin + 1e-2;
     }
     __syncthreads();
-    const double delta = s[SC_DELTA];
-    // Gershgorin bound of B = A + delta I (column abs-sums; thread (q, c) owns rows q, q+4, ...)
-    const int c = tid & (SN - 1), q = tid >> 7;
-    double colsum = 0.0;
-    for (int r = q; r < SN; r += 4) colsum += fabs(A[(size_t)r * SN + c] + ((r == c) ? delta : 0.0));
-    red[tid] = colsum;
-    __syncthreads();
-    if (tid < SN) red[tid] = (red[tid] + red[tid + 128]) + (red[tid + 256] + red[tid + 384]);
+    const double delta = sh_delta;
+    // Gershgorin bound of B = A + delta I from the row sums of A: only the diagonal term changes
+    if (tid < SN) {
+        const double dg = s[SC_DIAG + tid];
+        red[tid] = s[SC_ROWABS + tid] - fabs(dg) + fabs(dg + delta);
+    }
     __syncthreads();
     for (int o = 64; o > 0; o >>= 1) {
         if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
         __syncthreads();
     }
-    const double gersh = red[0];
-    __syncthreads();
-    double fro = 0.0;
-    for (int r = q; r < SN; r += 4) {
-        const double bv = A[(size_t)r * SN + c] + ((r == c) ? delta : 0.0);
-        fro = fma(bv, bv, fro);
-    }
-    red[tid] = fro;
-    __syncthreads();
-    for (int o = 256; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    const double scale = fmin(gersh, sqrt(red[0])) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
-    if (tid == 0) s[SC_SCALE] = scale;
-    const double inv = 1.0 / scale;
-    for (int r = q; r < SN; r += 4) {
-        const size_t e = (size_t)r * SN + c;
-        const double bv = A[e] + ((r == c) ? delta : 0.0);  // A is exactly symmetric: Y0^T = Y0
-        B[e] = bv;
-        Y[e] = bv * inv;
-        Yt[e] = bv * inv;
-        Z[e] = (r == c) ? 1.0 : 0.0;
-        Zt[e] = (r == c) ? 1.0 : 0.0;
+    if (tid == 0) {
+        const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, s[SC_TRACE], s[SC_FRO2]));  // |A + delta I|_F^2
+        const double scale = fmin(red[0], sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
+        s[SC_SCALE] = scale;
+        // Chen-Chow scaled Newton-Schulz: x -> x (a + b x^2) on [l, 1] with a = 1.5 rho, b = -0.5 rho^3,
+        // rho^2 = 3/(1 + l + l^2) (equal values at both ends of the interval); lambda_min(Y0) = 1e-2/scale
+        double l = sqrt(1e-2 / scale);
+        for (int k = 0; k < NS_ITERS; ++k) {
+            double rho = (l < 1.0 - 1e-9) ? sqrt(3.0 / (1.0 + l + l * l)) : 1.0;
+            const double a = 1.5 * rho, bq = -0.5 * rho * rho * rho;
+            s[SC_COEF + 2 * k] = a;
+            s[SC_COEF + 2 * k + 1] = bq;
+            l = fmin(1.0, l * fma(bq * l, l, a));
+        }
     }
 }
 
-// ---- Newton-Schulz step, part 1:  T = 1.5 I - 0.5 Z.Y  (64 tiles; T and T^T are stored)
+// ---- Newton-Schulz iteration 0 (Z0 = I, Y0 = B/s read from A on load):  Y1 = a0 Y0 + b0 Y0^2,  Z1 = a0 I + b0 Y0
+__global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict__ Aall, double *__restrict__ Yout,
+                                                       double *__restrict__ Ytout, double *__restrict__ Zout,
+                                                       double *__restrict__ Ztout, double *__restrict__ scall, int zbuf_out)
+{
+    __shared__ double red[4][4][64];
+    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t off = (size_t)b * SN * SN;
+    const double *A = Aall + off;
+    double *s = scall + (size_t)b * SC_COUNT;
+    const double delta = s[SC_DELTA], inv = 1.0 / s[SC_SCALE], a0 = s[SC_COEF], b0 = s[SC_COEF + 1];
+    if (w == 0 && tid == 0) {
+        s[SC_ZBUF] = (double)zbuf_out;
+        s[SC_ITERS] = 1.0;
+    }
+    const int ti = w >> 3, tj = w & 7;
+    const LoadScaledB ld{delta, inv};
+    const f64x4 acc = tile_mm_q(A, A, ti, tj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
+    const double y2 = tile_reduce(acc, red, wv, lane);
+    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+    const double y0 = ld(A[(size_t)row * SN + col], row, col);
+    store_both(Yout + off, Ytout + off, row, col, fma(b0, y2, a0 * y0));
+    store_both(Zout + off, Ztout + off, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
+}
+
+__device__ __forceinline__ bool ns_converged(double *__restrict__ s, int iter, int lane, bool writer)
+{
+    if (s[SC_NS_DONE] != 0.0) return true;
+    if (iter >= 2 && slot_sum(s + SC_ERR + (iter - 1) * 64, 64, lane) < NS_TOL2) {
+        if (writer) s[SC_NS_DONE] = 1.0;
+        return true;
+    }
+    return false;
+}
+
+// ---- Newton-Schulz step k >= 1, part 1:  T = a_k I + b_k Z.Y  (64 tiles; T and T^T are stored)
 __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
                                                    double *__restrict__ Tall, double *__restrict__ Ttall,
-                                                   double *__restrict__ sc, int iter)
+                                                   double *__restrict__ scall, int iter)
 {
-    const int b = blockIdx.z, lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    double *s = sc + (size_t)b * SC_COUNT;
-    if (iter > 0 && s[SC_ERR + iter - 1] < NS_TOL2) return;  // converged: Y, Z are final
-    const double *Y = Yall + (size_t)b * SN * SN, *Zt = Ztall + (size_t)b * SN * SN;
-    double *T = Tall + (size_t)b * SN * SN, *Tt = Ttall + (size_t)b * SN * SN;
+    __shared__ double red[4][4][64];
+    __shared__ double part[4];
+    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *s = scall + (size_t)b * SC_COUNT;
+    if (ns_converged(s, iter, lane, w == 0 && tid == 0)) return;  // Y, Z are final
+    const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
-    const f64x4 acc = tile_mm(Zt, Y, ti, tj, lane);  // (Z^T)^T . Y = Z.Y
-    double err = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-        store_both(T, Tt, row, col, ((row == col) ? 1.5 : 0.0) - 0.5 * acc[r]);
-        const double d = acc[r] - ((row == col) ? 1.0 : 0.0);
-        err = fma(d, d, err);
-    }
-    err = wr::wave64_allsum(err);
-    if (lane == 0) atomicAdd(&s[SC_ERR + iter], err);  // |Z Y - I|_F^2
+    const f64x4 acc = tile_mm_q(Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double p = tile_reduce(acc, red, wv, lane);
+    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
+    store_both(Tall + off, Ttall + off, row, col, fma(bq, p, (row == col) ? a : 0.0));
+    const double d = p - ((row == col) ? 1.0 : 0.0);
+    const double tot = wg_sum4(d * d, part, wv, lane);
+    if (tid == 0) s[SC_ERR + iter * 64 + w] = tot;  // |Z Y - I|_F^2 partial
 }
 
 // ---- part 2:  Y' = Y.T (tiles 0..63),  Z' = T.Z (tiles 64..127); each with its transpose
@@ -360,67 +446,68 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
                                                     const double *__restrict__ Tall, const double *__restrict__ Ttall,
                                                     double *__restrict__ Yout, double *__restrict__ Ytout,
                                                     double *__restrict__ Zout, double *__restrict__ Ztout,
-                                                    double *__restrict__ sc, int iter, int zbuf_out)
+                                                    double *__restrict__ scall, int iter, int zbuf_out)
 {
-    const int b = blockIdx.z, lane = threadIdx.x & 63;
-    double *s = sc + (size_t)b * SC_COUNT;
-    if (iter > 0 && s[SC_ERR + iter - 1] < NS_TOL2) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __shared__ double red[4][4][64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *s = scall + (size_t)b * SC_COUNT;
+    if (ns_converged(s, iter, lane, false)) return;  // the T launch of this iteration raised the flag
+    if (blockIdx.x == 0 && tid == 0) {
         s[SC_ZBUF] = (double)zbuf_out;  // which Z buffer holds the newest iterate
         s[SC_ITERS] = (double)(iter + 1);
     }
-    int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int w = blockIdx.x;
     const bool isZ = w >= 64;
     w &= 63;
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
     // Y' = Y.T : left factor Y -> pass Y^T;   Z' = T.Z : left factor T -> pass T^T
-    const f64x4 acc = isZ ? tile_mm(Ttall + off, Zall + off, ti, tj, lane) : tile_mm(Ytall + off, Tall + off, ti, tj, lane);
-    double *O = (isZ ? Zout : Yout) + off, *Ot = (isZ ? Ztout : Ytout) + off;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) store_both(O, Ot, 16 * ti + (lane >> 4) + 4 * r, 16 * tj + (lane & 15), acc[r]);
+    const f64x4 acc = isZ ? tile_mm_q(Ttall + off, Zall + off, ti, tj, lane, wv, LoadPlain{})
+                          : tile_mm_q(Ytall + off, Tall + off, ti, tj, lane, wv, LoadPlain{});
+    const double v = tile_reduce(acc, red, wv, lane);
+    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+    store_both((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v);
 }
 
-// ---- log det B via Cholesky (one workgroup per matrix)
-__global__ __launch_bounds__(512) void ns_logdet_kernel(const double *__restrict__ Ball, double *__restrict__ sc)
+// ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  (1) Cholesky of Z -> log det B =
+// n log s - 2 log det Z;  (2) Sigma = c Z / sqrt(s) rounded to fp32;  (3) L = chol(fp32(Sigma)) in fp64 -> fp32.
+__global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restrict__ Z0all, const double *__restrict__ Z1all,
+                                                          double *__restrict__ scall, float sample_sigma,
+                                                          float *__restrict__ Sigma_out, float *__restrict__ L_out)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[512];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const double *B = Ball + (size_t)b * SN * SN;
-    for (int e = tid; e < SN * SN; e += 512) sm[(e / SN) * (SN + 1) + (e % SN)] = B[e];  // symmetric: row/col agnostic
-    chol_lds_fast(sm, SN, SN + 1, tid, 512);
-    red[tid] = (tid < SN) ? log(sm[tid * (SN + 1) + tid]) : 0.0;
+    double *s = scall + (size_t)b * SC_COUNT;
+    const double *Z = ((s[SC_ZBUF] != 0.0) ? Z1all : Z0all) + (size_t)b * SN * SN;
+    constexpr int LD = SN + 1;
+    const double n = (double)SN;
+    for (int e = tid; e < SN * SN; e += 512) {
+        const int r = e / SN, c = e % SN;
+        sm[c * LD + r] = 0.5 * (Z[e] + Z[(size_t)c * SN + r]);  // covo.py:132 symmetrise
+    }
+    chol128_lds_mfma(sm, LD, tid);
+    red[tid] = (tid < SN) ? log(sm[tid * LD + tid]) : 0.0;
     __syncthreads();
     for (int o = 256; o > 0; o >>= 1) {
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    if (tid == 0) sc[(size_t)b * SC_COUNT + SC_LOGDET] = 2.0 * red[0];
-}
-
-// ---- Sigma = c Z / sqrt(s), symmetrised, rounded to fp32; then L = chol(fp32(Sigma)) in fp64 -> fp32
-__global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restrict__ Z0all, const double *__restrict__ Z1all,
-                                                          const double *__restrict__ sc, float sample_sigma,
-                                                          float *__restrict__ Sigma_out, float *__restrict__ L_out)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const double *s = sc + (size_t)b * SC_COUNT;
-    const double *Z = ((s[SC_ZBUF] != 0.0) ? Z1all : Z0all) + (size_t)b * SN * SN;
-    const double n = (double)SN;
+    const double scale = s[SC_SCALE];
+    const double logdetB = fma(n, log(scale), -4.0 * red[0]);  // log det Z = 2 sum log diag(chol Z)
+    if (tid == 0) s[SC_LOGDET] = logdetB;
     // log_s = 0.5*log_const - 0.5*log_o with log_const = (2*log_det_a_cov + sum log_o)/n  (covo.py:124-128)
-    const double log_c = 0.5 * (2.0 * n * (log((double)sample_sigma) * 2.0) + s[SC_LOGDET]) / n;
-    const double cz = exp(log_c) / sqrt(s[SC_SCALE]);
+    const double log_c = 0.5 * (2.0 * n * (log((double)sample_sigma) * 2.0) + logdetB) / n;
+    const double cz = exp(log_c) / sqrt(scale);
     float *So = Sigma_out ? Sigma_out + (size_t)b * SN * SN : nullptr;
-    constexpr int LD = SN + 1;
+    __syncthreads();
     for (int e = tid; e < SN * SN; e += 512) {
         const int r = e / SN, c = e % SN;
-        const float v = (float)(cz * 0.5 * (Z[e] + Z[(size_t)c * SN + r]));  // covo.py:132 symmetrise, a_cov is fp32
+        const float v = (float)(cz * 0.5 * (Z[e] + Z[(size_t)c * SN + r]));  // a_cov is fp32
         if (So) So[e] = v;
         sm[c * LD + r] = (double)v;
     }
-    chol_lds_fast(sm, SN, LD, tid, 512);
+    chol128_lds_mfma(sm, LD, tid);
     float *Lo = L_out + (size_t)b * SN * SN;
     for (int e = tid; e < SN * SN; e += 512) {
         const int r = e / SN, c = e % SN;
@@ -428,50 +515,40 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     }
 }
 
-size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (12 * SN * SN + SC_COUNT) * sizeof(double); }
+size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
+                    hipStream_t s, hipStream_t, hipEvent_t, hipEvent_t)
 {
     double *ws = reinterpret_cast<double *>(workspace);
     const size_t M = (size_t)batch * SN * SN;
-    double *A = ws, *X0 = ws + M, *X1 = ws + 2 * M, *B = ws + 3 * M;
-    double *Y[2] = {ws + 4 * M, ws + 5 * M}, *Yt[2] = {ws + 6 * M, ws + 7 * M};
-    double *Z[2] = {ws + 8 * M, ws + 9 * M}, *Zt[2] = {ws + 10 * M, ws + 11 * M};
+    double *A = ws, *X0 = ws + M, *X1 = ws + 2 * M;
+    double *Y[2] = {ws + 3 * M, ws + 4 * M}, *Yt[2] = {ws + 5 * M, ws + 6 * M};
+    double *Z[2] = {ws + 7 * M, ws + 8 * M}, *Zt[2] = {ws + 9 * M, ws + 10 * M};
     double *T = X0, *Tt = X1;  // the squaring buffers are free once lambda_min is known
-    double *sc = ws + 12 * M;
+    double *sc = ws + 11 * M;
     const size_t lds = (size_t)SN * (SN + 1) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_logdet_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_finalize_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(ns_prep_kernel, dim3(batch), dim3(512), 0, s, R, A, X0, sc);
+    hipLaunchKernelGGL(ns_prep_kernel, dim3(8, batch), dim3(256), 0, s, R, A, sc);
+    hipLaunchKernelGGL(ns_square_kernel<true>, dim3(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0);
     double *xi = X0, *xo = X1;
-    for (int i = 0; i < NS_SQUARINGS; ++i) {
-        hipLaunchKernelGGL(ns_square_kernel, dim3(NS_TILES / 4, 1, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0);
+    for (int i = 1; i < NS_SQUARINGS; ++i) {
+        hipLaunchKernelGGL(ns_square_kernel<false>, dim3(NS_TILES, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0);
         double *t = xi; xi = xo; xo = t;
     }
-    hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, B, Y[0], Yt[0], Z[0], Zt[0], sc);
-    // log det B only meets the main line again in the finalize kernel: run its Cholesky beside the
-    // Newton-Schulz launches on a forked stream (fork/join by events; also valid under stream capture)
-    const bool fork = side != nullptr;
-    if (fork) {
-        COVO_CHECK_HIP(hipEventRecord(ev_fork, s));
-        COVO_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-    }
-    hipLaunchKernelGGL(ns_logdet_kernel, dim3(batch), dim3(512), lds, fork ? side : s, B, sc);
-    if (fork) COVO_CHECK_HIP(hipEventRecord(ev_join, side));
-    for (int i = 0; i < NS_ITERS; ++i) {
+    hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc);
+    hipLaunchKernelGGL(ns_first_kernel, dim3(64, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);
+    for (int i = 1; i < NS_ITERS; ++i) {
         const int in = i & 1, out = in ^ 1;
-        hipLaunchKernelGGL(ns_T_kernel, dim3(16, 1, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i);
-        hipLaunchKernelGGL(ns_YZ_kernel, dim3(32, 1, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
+        hipLaunchKernelGGL(ns_T_kernel, dim3(64, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i);
+        hipLaunchKernelGGL(ns_YZ_kernel, dim3(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
                            Zt[out], sc, i, out);
     }
-    if (fork) COVO_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
     hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch), dim3(512), lds, s, Z[0], Z[1], sc, sample_sigma, Sigma, L);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
