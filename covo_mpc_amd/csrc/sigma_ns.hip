@@ -26,8 +26,8 @@
 //      transpose (both MFMA operands are then read as 128-B runs); symmetry is neither assumed nor forced
 //      (mirroring the lower triangle makes the coupled iteration blow up after convergence).
 //      Iteration 0 needs no Z.Y product (Z0 = I): one launch forms Y1 = a0 Y0 + b0 Y0^2, Z1 = a0 I + b0 Y0.
-//   3. one workgroup: Cholesky of Z (blocked, MFMA trailing update, chol_lds.hpp) -> log det B; then the
-//      Cholesky of fp32(Sigma).
+//   3. one workgroup: ONE Cholesky of Z (every update on the matrix cores, chol_lds.hpp) gives both
+//      log det B and, scaled by sqrt(c/sqrt(s)), the factor L of Sigma.
 // All reductions go through per-workgroup slots summed in a fixed order: results are bit-reproducible.
 // Agreement with the LAPACK-eigh oracle: ~1e-13 relative (fp64), tests/test_gpu_parity.py.
 // `batch` matrices per launch (grid.z / grid.y): covo-offline's 300-step table, env-batched configs.
@@ -50,6 +50,7 @@ constexpr int RITZ = 4;            // Rayleigh-Ritz block: exact lambda_min for 
 // per-workgroup reduction slots (no atomics anywhere: fixed summation order, bit-reproducible)
 enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, SC_XBUF, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
        SC_FRO2, SC_TRACE, SC_GERSH, SC_N0,
+       SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug)
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
@@ -469,9 +470,16 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
     store_both((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v);
 }
 
-// ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  (1) Cholesky of Z -> log det B =
-// n log s - 2 log det Z;  (2) Sigma = c Z / sqrt(s) rounded to fp32;  (3) L = chol(fp32(Sigma)) in fp64 -> fp32.
+// ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  ONE Cholesky serves both needs:
+//   Lz = chol(Z)  ->  log det B = n log s - 2 log det Z = n log s - 4 sum log diag(Lz);
+//   Sigma = cz Z (cz = c / sqrt(s))  ->  chol(Sigma) = sqrt(cz) Lz.
+// Outputs: a_cov = fp32(Sigma) (covo.py:132) and L = fp32(chol(Sigma)).  The reference factors the ROUNDED
+// fp32 matrix in fp32 (jax.random.multivariate_normal, covo.py:216); the factor of the unrounded fp64 Sigma
+// differs from the exact factor of fp32(Sigma) by <= cond(Sigma) 2^-24 relative, the same size as (and not
+// correlated with) the rounding error of the reference's own fp32 factorisation; L L^T reproduces a_cov to
+// fp32 rounding (tests/test_gpu_parity.py).
 __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restrict__ Z0all, const double *__restrict__ Z1all,
+                                                          const double *__restrict__ Zt0all, const double *__restrict__ Zt1all,
                                                           double *__restrict__ scall, float sample_sigma,
                                                           float *__restrict__ Sigma_out, float *__restrict__ L_out)
 {
@@ -479,14 +487,24 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     __shared__ double red[512];
     const int b = blockIdx.x, tid = threadIdx.x;
     double *s = scall + (size_t)b * SC_COUNT;
-    const double *Z = ((s[SC_ZBUF] != 0.0) ? Z1all : Z0all) + (size_t)b * SN * SN;
+    const bool z1 = s[SC_ZBUF] != 0.0;
+    const double2 *Z = reinterpret_cast<const double2 *>((z1 ? Z1all : Z0all) + (size_t)b * SN * SN);
+    const double2 *Zt = reinterpret_cast<const double2 *>((z1 ? Zt1all : Zt0all) + (size_t)b * SN * SN);
     constexpr int LD = SN + 1;
     const double n = (double)SN;
-    for (int e = tid; e < SN * SN; e += 512) {
-        const int r = e / SN, c = e % SN;
-        sm[c * LD + r] = 0.5 * (Z[e] + Z[(size_t)c * SN + r]);  // covo.py:132 symmetrise
+    long long tk[5];
+    tk[0] = clock64();
+    // Z and its stored transpose are both read coalesced; the symmetrised matrix is row/column agnostic
+    for (int e2 = tid; e2 < SN * SN / 2; e2 += 512) {
+        const int r = (2 * e2) / SN, c = (2 * e2) % SN;
+        const double2 a = Z[e2], at = Zt[e2];
+        sm[r * LD + c] = 0.5 * (a.x + at.x);  // covo.py:132 symmetrise
+        sm[r * LD + c + 1] = 0.5 * (a.y + at.y);
     }
+    __syncthreads();
+    tk[1] = clock64();
     chol128_lds_mfma(sm, LD, tid);
+    tk[2] = clock64();
     red[tid] = (tid < SN) ? log(sm[tid * LD + tid]) : 0.0;
     __syncthreads();
     for (int o = 256; o > 0; o >>= 1) {
@@ -498,21 +516,23 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     if (tid == 0) s[SC_LOGDET] = logdetB;
     // log_s = 0.5*log_const - 0.5*log_o with log_const = (2*log_det_a_cov + sum log_o)/n  (covo.py:124-128)
     const double log_c = 0.5 * (2.0 * n * (log((double)sample_sigma) * 2.0) + logdetB) / n;
-    const double cz = exp(log_c) / sqrt(scale);
-    float *So = Sigma_out ? Sigma_out + (size_t)b * SN * SN : nullptr;
-    __syncthreads();
-    for (int e = tid; e < SN * SN; e += 512) {
-        const int r = e / SN, c = e % SN;
-        const float v = (float)(cz * 0.5 * (Z[e] + Z[(size_t)c * SN + r]));  // a_cov is fp32
-        if (So) So[e] = v;
-        sm[c * LD + r] = (double)v;
+    const double cz = exp(log_c) / sqrt(scale), sq = sqrt(cz);
+    tk[3] = clock64();
+    if (Sigma_out) {
+        float2 *So = reinterpret_cast<float2 *>(Sigma_out + (size_t)b * SN * SN);
+        for (int e2 = tid; e2 < SN * SN / 2; e2 += 512) {
+            const double2 a = Z[e2], at = Zt[e2];
+            So[e2] = make_float2((float)(cz * 0.5 * (a.x + at.x)), (float)(cz * 0.5 * (a.y + at.y)));  // a_cov is fp32
+        }
     }
-    chol128_lds_mfma(sm, LD, tid);
     float *Lo = L_out + (size_t)b * SN * SN;
     for (int e = tid; e < SN * SN; e += 512) {
         const int r = e / SN, c = e % SN;
-        Lo[e] = (c <= r) ? (float)sm[c * LD + r] : 0.0f;
+        Lo[e] = (c <= r) ? (float)(sq * sm[c * LD + r]) : 0.0f;
     }
+    tk[4] = clock64();
+    if (tid == 0)
+        for (int i = 0; i < 5; ++i) s[SC_PROF + i] = (double)(tk[i] - tk[0]);
 }
 
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
@@ -549,7 +569,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         hipLaunchKernelGGL(ns_YZ_kernel, dim3(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
                            Zt[out], sc, i, out);
     }
-    hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch), dim3(512), lds, s, Z[0], Z[1], sc, sample_sigma, Sigma, L);
+    hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma, Sigma, L);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }
