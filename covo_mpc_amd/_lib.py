@@ -71,6 +71,7 @@ _SIGS = {
     "covo_merge": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P]),
     "covo_shift_mean": (C.c_int, [_P, _P, _P, _P]),
     "covo_hessian": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, C.c_int32, _P, _P]),
+    "covo_hessian_pairs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, C.c_int32, _P, _P]),
     "covo_sigma": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "covo_debug_sigma_workspace": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "covo_sigma_jacobi": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),

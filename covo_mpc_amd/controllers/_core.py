@@ -136,10 +136,12 @@ class SamplingCore:
               "covo_rollout_cost")
         return self.cost
 
-    def hessian(self, packed, dstate, params_c, a_mean, batch=1):
+    def hessian(self, packed, dstate, params_c, a_mean, batch=1, method="adjoint"):
+        """d^2 C / da^2 (covo.py:134-185); method "adjoint" (default, hessian_adj.hip) or "pairs" (hessian.hip)."""
         R = self.torch.empty((batch, COVO_NA, COVO_NA), dtype=self.torch.float64, device=self.device)
-        check(self.lib.covo_hessian(self.h, ptr(packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj), dstate.T,
-                                    C.byref(params_c), ptr(a_mean), batch, ptr(R), self.stream()), "covo_hessian")
+        fn = self.lib.covo_hessian if method == "adjoint" else self.lib.covo_hessian_pairs
+        check(fn(self.h, ptr(packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj), dstate.T,
+                 C.byref(params_c), ptr(a_mean), batch, ptr(R), self.stream()), "covo_hessian")
         return R
 
     def sigma(self, R, sample_sigma, batch=1, method="ns"):

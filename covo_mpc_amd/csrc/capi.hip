@@ -44,6 +44,8 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)nb * COVO_H * 6 * sizeof(float)));
     h->ws_sigma_bytes = sigma_ns_workspace_bytes(1);
     COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, h->ws_sigma_bytes));
+    h->ws_hess_bytes = hessian_workspace_bytes(1);
+    COVO_CHECK_HIP(hipMalloc(&h->ws_hess, h->ws_hess_bytes));
     COVO_CHECK_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     COVO_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     COVO_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -55,15 +57,27 @@ int covo_destroy(covo_handle_t h)
 {
     if (!h) return COVO_E_NOHANDLE;
     step_state_destroy(h);
-    (void)hipFree(h->ws_partials);
-    (void)hipFree(h->ws_blockmin);
-    (void)hipFree(h->ws_stats);
-    (void)hipFree(h->ws_sigma);
-    (void)hipEventDestroy(h->ev_fork);
-    (void)hipEventDestroy(h->ev_join);
-    (void)hipStreamDestroy(h->side_stream);
+    int rc = 0;
+#define DESTROY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess && !rc) {                                                                  \
+            covo_set_error("covo_destroy: %s failed: %s", #expr, hipGetErrorString(_e));               \
+            rc = (int)_e;                                                                               \
+        }                                                                                               \
+    } while (0)
+    DESTROY(hipFree(h->ws_partials));
+    DESTROY(hipFree(h->ws_blockmin));
+    DESTROY(hipFree(h->ws_stats));
+    DESTROY(hipFree(h->ws_sigma));
+    DESTROY(hipFree(h->ws_hess));
+    DESTROY(hipEventDestroy(h->ev_fork));
+    DESTROY(hipEventDestroy(h->ev_join));
+    DESTROY(hipStreamDestroy(h->side_stream));
+#undef DESTROY
+    (void)hipGetLastError();  // never leave a sticky error behind for the caller's runtime (torch checks it)
     delete h;
-    return 0;
+    return rc;
 }
 
 int covo_randn(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t sample_offset, int32_t n_samples, int32_t n_cols,
@@ -158,7 +172,24 @@ int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, con
 {
     REQUIRE(h, "covo_hessian: null handle");
     REQUIRE(state && pos_traj && vel_traj && params && a_mean && R_out && T > 0 && batch > 0, "covo_hessian: bad argument");
-    return launch_hessian(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, (hipStream_t)stream);
+    const size_t need = hessian_workspace_bytes(batch);
+    if (need > h->ws_hess_bytes) {  // only for batch sizes not seen before (never inside the steady-state step)
+        COVO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        (void)hipFree(h->ws_hess);
+        h->ws_hess = nullptr;
+        h->ws_hess_bytes = 0;
+        COVO_CHECK_HIP(hipMalloc(&h->ws_hess, need));
+        h->ws_hess_bytes = need;
+    }
+    return launch_hessian(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, h->ws_hess, (hipStream_t)stream);
+}
+
+int covo_hessian_pairs(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                       const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream)
+{
+    REQUIRE(h, "covo_hessian_pairs: null handle");
+    REQUIRE(state && pos_traj && vel_traj && params && a_mean && R_out && T > 0 && batch > 0, "covo_hessian_pairs: bad argument");
+    return launch_hessian_pairs(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, (hipStream_t)stream);
 }
 
 int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out, float *L_out,

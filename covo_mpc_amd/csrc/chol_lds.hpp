@@ -93,7 +93,7 @@ __device__ __forceinline__ long long chol_tick() { __builtin_amdgcn_sched_barrie
 #define CHOL_CLOCK() chol_tick()
 #define CHOL_USE(v) asm volatile("" ::"v"(v))
 #else
-#define CHOL_STAMP(i, expr) do { } while (0)
+#define CHOL_STAMP(i, expr) do { (void)c0; (void)c1; (void)c2; (void)c3; } while (0)
 #define CHOL_CLOCK() 0
 #define CHOL_USE(v) do { } while (0)
 #endif

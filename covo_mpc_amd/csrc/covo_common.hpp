@@ -19,6 +19,8 @@ struct covo_ctx {
     float *ws_stats;      // [ceil(n_local/256)][H*6] per-block position statistics
     void *ws_sigma;       // scratch of the eigh-free Sigma pipeline (grown on demand, outside graph capture)
     size_t ws_sigma_bytes;
+    void *ws_hess;        // scratch of the second-order-adjoint Hessian (grown on demand, outside graph capture)
+    size_t ws_hess_bytes;
     void *step;               // StepState (step.hip): fused-step scratch + graph cache
     hipStream_t side_stream;  // forked work inside one call (joined before the call's last kernel)
     hipEvent_t ev_fork, ev_join;
@@ -86,8 +88,12 @@ int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N,
 int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
                  hipStream_t s);
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
+size_t hessian_workspace_bytes(int batch);
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                   const float *a_mean, int batch, double *R, hipStream_t s);
+                   const float *a_mean, int batch, double *R, void *workspace, hipStream_t s);
+// the per-pair hyper-dual rollout version (hessian.hip): slower, independent derivation, kept as a cross-check
+int launch_hessian_pairs(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
+                         const float *a_mean, int batch, double *R, hipStream_t s);
 int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, unsigned long long *prof,
                  hipStream_t s);
 size_t sigma_ns_workspace_bytes(int batch);

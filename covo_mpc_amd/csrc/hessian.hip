@@ -1,4 +1,5 @@
 // hessian.hip -- exact Hessian of the CoVO rollout objective by hyper-dual forward AD (gfx950, fp64).
+// (covo_hessian_pairs: the independent cross-check of the faster second-order-adjoint version, hessian_adj.hip)
 //
 // Replaces jax.jacfwd(jax.jacfwd(get_cumulated_cost)) of quadjax/controllers/covo.py:134-185:
 //     C(a) = -( sum_{k<H} r(s_k) + r(s_0) ),  s_{k+1} = step_env(s_k, a_k, deterministic=True)
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
     }
 }
 
-int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
+int launch_hessian_pairs(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, hipStream_t s)
 {
     HessArgs A;

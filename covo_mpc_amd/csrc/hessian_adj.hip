@@ -1,0 +1,378 @@
+// hessian_adj.hip -- exact Hessian of the CoVO rollout objective by the second-order adjoint (gfx950, fp64).
+//
+// Replaces jax.jacfwd(jax.jacfwd(get_cumulated_cost)) of quadjax/controllers/covo.py:134-185:
+//     C(a) = -( sum_{k<H} r(s_k) + r(s_0) ),  s_{k+1} = step_env(s_k, a_k, deterministic=True)
+// (no discount, no done-freeze; reward on the PRE-step state; r(s_0) constant).  R = d^2 C / da^2.
+//
+// hessian.hip (kept as covo_hessian_pairs) runs one hyper-dual ROLLOUT per pair (i, j): exact, but its critical
+// path is 31 hyper-dual steps (~1500 fp64 instructions each, one wave issues ~1 per 5 cycles) = 80 us.
+// The same matrix follows from ONE hyper-dual step per (time, pair of step inputs) plus two short
+// linear recursions.  With z_k = (x_k, u_k) in R^17 (state 13, raw action 4), x_{k+1} = f_k(z_k),
+// J = sum_{k>=1} r_k(x_k):
+//     costate    lam_31 = grad r_31,   lam_k = grad r_k + A_k^T lam_{k+1}          (A_k = df_k/dx)
+//     sensitivity S_0 = 0,  S_{k+1} = A_k S_k + B_k E_k                          (S_k = dx_k/da, 13 x 128)
+//     d^2 J/da^2 = sum_k [S_k; E_k]^T  Hess_z( r_k(x) + lam_{k+1} . f_k(z) )  [S_k; E_k]
+// (E_k selects the four actions of step k).  All derivatives of the step come from evaluating the SAME
+// templated model (quad_model.hpp) on hyper-dual numbers, so every JAX AD convention it mirrors (clip ties,
+// |x|', the double clip of quadrotor.py:223/:258) carries over.  Four launches:
+//   KB  32 waves: primal rollout to step k (plain fp64), then the step with 17 first-order seeds -> A_k, B_k, grad r_k
+//   KC  one workgroup: the costate recursion (one lane) beside the sensitivity recursion (one lane per
+//       action column), both on the block-sparse structure of A_k (p' = p + dt v; v' <- q, thrust; q' <- q, omega;
+//       omega' <- omega, rates): 52 multiply-adds per step instead of 169
+//   KM  32 x 153 lanes: one hyper-dual step per pair (a <= b) of step inputs -> M_k = Hess_z(r_k + lam_{k+1}.f_k)
+//   KD  36 lower 16x16 tiles: sum_k S_k^T Mxx_k S_k on the matrix cores (v_mfma_f64_16x16x4_f64; the product
+//       Mxx S leaves the MFMA in exactly the register layout the next MFMA wants as its B operand), the
+//       action blocks Mxu, Muu added in the epilogue.
+// Critical path: 30 plain steps + 2 hyper-dual steps + a 31-step recursion of 13-vectors ~ 25 us.
+#include "covo_common.hpp"
+#include "wave_reduce.hpp"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int NX = 13, NZ = 17, HH = COVO_H, NA = COVO_NA;
+// per-matrix workspace (doubles)
+constexpr size_t WS_X = 0;                       // [32][16]       x_k
+constexpr size_t WS_JF = WS_X + 32 * 16;         // [32][13][17]   df_k/dz (k = 31 unused)
+constexpr size_t WS_GL = WS_JF + 32 * NX * NZ;   // [32][16]       grad r_k (k = 0: zeros)
+constexpr size_t WS_LAM = WS_GL + 32 * 16;       // [33][16]       lam_k (lam_32 = 0)
+constexpr size_t WS_MXX = WS_LAM + 33 * 16;      // [32][16][16]   zero padded
+constexpr size_t WS_MXU = WS_MXX + 32 * 256;     // [32][16][4]
+constexpr size_t WS_MUU = WS_MXU + 32 * 64;      // [32][4][4]
+constexpr size_t WS_S = WS_MUU + 32 * 16;        // [32][16][128]  rows 13..15 zero
+constexpr size_t WS_COUNT = WS_S + (size_t)32 * 16 * NA;
+
+struct AdjArgs {
+    const float *state;     // [batch][COVO_STATE_FLOATS]
+    const float *pos_traj;  // [T][3] shared
+    const float *vel_traj;
+    const float *a_mean;    // [batch][128]
+    double *R;              // [batch][128][128]
+    double *ws;             // [batch][WS_COUNT]
+    int T;
+    qm::Consts<double> c;
+};
+
+__device__ __forceinline__ void adj_targets(const float *__restrict__ st, const AdjArgs &A, int time0, int k, double (&tar)[6])
+{
+    if (k == 0) {
+        for (int i = 0; i < 3; ++i) { tar[i] = st[ST_POSTAR + i]; tar[3 + i] = st[ST_VELTAR + i]; }
+    } else {
+        int idx = time0 + k;
+        idx = idx < 0 ? 0 : (idx > A.T - 1 ? A.T - 1 : idx);
+        for (int i = 0; i < 3; ++i) { tar[i] = A.pos_traj[3 * idx + i]; tar[3 + i] = A.vel_traj[3 * idx + i]; }
+    }
+}
+
+// the step's 13 outputs / inputs in z order
+#define ADJ_FOR_STATE(OP) OP(px, 0) OP(py, 1) OP(pz, 2) OP(vx, 3) OP(vy, 4) OP(vz, 5) OP(qx, 6) OP(qy, 7) OP(qz, 8) OP(qw, 9) OP(ox, 10) OP(oy, 11) OP(oz, 12)
+
+__device__ __forceinline__ void adj_store_state(const qm::State<double> &p, double *__restrict__ x)
+{
+#define OP(m, i) x[i] = p.m;
+    ADJ_FOR_STATE(OP)
+#undef OP
+}
+__device__ __forceinline__ void adj_load_state(qm::State<double> &p, const double *__restrict__ x)
+{
+#define OP(m, i) p.m = x[i];
+    ADJ_FOR_STATE(OP)
+#undef OP
+}
+
+// one step on hyper-dual numbers: z_a carries e1, z_b carries e2 (an index outside 0..16 seeds nothing).
+// r = r_k(x) (0 for k = 0), s = f_k(z) (left at x_k for k = H-1, whose dynamics never reach a reward).
+__device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const float *__restrict__ am, const AdjArgs &A, int time0,
+                                            int k, const qm::State<double> &p, int a, int b, qm::HD &r, qm::State<qm::HD> &s)
+{
+#define OP(m, i) s.m = qm::HD{p.m, a == i ? 1.0 : 0.0, b == i ? 1.0 : 0.0, 0.0};
+    ADJ_FOR_STATE(OP)
+#undef OP
+    r = qm::hd(0.0);
+    if (k >= 1) {
+        double tar[6];
+        adj_targets(st, A, time0, k, tar);
+        r = qm::reward<qm::HD, double>(s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
+    }
+    if (k <= HH - 2) {
+        qm::HD act[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const qm::HD x{(double)am[4 * k + d], a == NX + d ? 1.0 : 0.0, b == NX + d ? 1.0 : 0.0, 0.0};
+            act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
+        }
+        const double f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
+        qm::dyn_step<qm::HD, double>(s, act[0], act[1], act[2], act[3], A.c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
+                                     k == 0 ? f0z : 0.0);
+    }
+}
+
+// ---- KB: wave k: x_k by a plain fp64 rollout, then df_k/dz (13 x 17) and grad r_k from 17 first-order seeds
+__global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
+{
+    const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
+    const float *__restrict__ am = A.a_mean + (size_t)b * NA;
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    const int time0 = __float_as_int(st[ST_TIME]);
+    qm::State<double> p;
+    p.px = st[ST_POS + 0]; p.py = st[ST_POS + 1]; p.pz = st[ST_POS + 2];
+    p.vx = st[ST_VEL + 0]; p.vy = st[ST_VEL + 1]; p.vz = st[ST_VEL + 2];
+    p.qx = st[ST_QUAT + 0]; p.qy = st[ST_QUAT + 1]; p.qz = st[ST_QUAT + 2]; p.qw = st[ST_QUAT + 3];
+    p.ox = st[ST_OMEGA + 0]; p.oy = st[ST_OMEGA + 1]; p.oz = st[ST_OMEGA + 2];
+    const double f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
+    for (int t = 0; t < k; ++t) {
+        const double a0 = qm::clip11_((double)am[4 * t + 0]), a1 = qm::clip11_((double)am[4 * t + 1]);
+        const double a2 = qm::clip11_((double)am[4 * t + 2]), a3 = qm::clip11_((double)am[4 * t + 3]);
+        qm::dyn_step<double, double>(p, a0, a1, a2, a3, A.c, t == 0 ? f0x : 0.0, t == 0 ? f0y : 0.0, t == 0 ? f0z : 0.0);
+    }
+    if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
+    qm::HD r;
+    qm::State<qm::HD> s;
+    adj_hd_step(st, am, A, time0, k, p, lane, -1, r, s);
+    if (lane < NZ) {
+        if (lane < NX) ws[WS_GL + 16 * k + lane] = r.a;  // 0 for k = 0
+        if (k <= HH - 2) {
+            double *__restrict__ jf = ws + WS_JF + (size_t)k * NX * NZ;
+#define OP(m, i) jf[i * NZ + lane] = s.m.a;
+            ADJ_FOR_STATE(OP)
+#undef OP
+        }
+    }
+}
+
+// block-sparse structure of A_k = df_k/dx (quad_model.hpp dyn_step): rows p <- (p, v) diagonal; v <- v diagonal,
+// q dense; q <- q, omega dense; omega <- omega diagonal.  B_k = df_k/du is applied as a dense column.
+struct JacView {
+    const double *jf;  // [13][17] in LDS
+    __device__ __forceinline__ double operator()(int m, int c) const { return jf[m * NZ + c]; }
+};
+
+// ---- KC: costate (wave 0, lane 0) beside the sensitivities (waves 1..2: one lane per action column)
+__global__ __launch_bounds__(192) void adj_chain_kernel(const AdjArgs A)
+{
+    __shared__ double sjf[(HH - 1) * NX * NZ];
+    __shared__ double sgl[HH * 16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    for (int e = tid; e < (HH - 1) * NX * NZ; e += 192) sjf[e] = ws[WS_JF + e];
+    for (int e = tid; e < HH * 16; e += 192) sgl[e] = ws[WS_GL + e];
+    __syncthreads();
+    if (tid < 64) {
+        if (tid != 0) return;
+        double lam[NX];
+        double *__restrict__ L = ws + WS_LAM;
+        for (int m = 0; m < NX; ++m) {
+            lam[m] = sgl[16 * (HH - 1) + m];
+            L[16 * (HH - 1) + m] = lam[m];
+            L[16 * HH + m] = 0.0;
+        }
+        for (int k = HH - 2; k >= 1; --k) {
+            const JacView J{sjf + k * NX * NZ};
+            const double *g = sgl + 16 * k;
+            double n[NX];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                n[r] = fma(J(r, r), lam[r], g[r]);                                             // p <- p
+                n[3 + r] = fma(J(3 + r, 3 + r), lam[3 + r], fma(J(r, 3 + r), lam[r], g[3 + r]));  // v <- p, v
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {  // q <- v, q
+                double acc = g[6 + c];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) acc = fma(J(3 + r, 6 + c), lam[3 + r], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = fma(J(6 + r, 6 + c), lam[6 + r], acc);
+                n[6 + c] = acc;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {  // omega <- q, omega
+                double acc = fma(J(10 + c, 10 + c), lam[10 + c], g[10 + c]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = fma(J(6 + r, 10 + c), lam[6 + r], acc);
+                n[10 + c] = acc;
+            }
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+                lam[m] = n[m];
+                L[16 * k + m] = n[m];
+            }
+        }
+        return;
+    }
+    // ---- sensitivities: column i = 4 t_i + d of S_k is zero up to k = t_i, B_{t_i}[:, d] at k = t_i + 1
+    const int i = tid - 64, ti = i >> 2, d = i & 3;
+    const int wave_min_ti = ((tid >> 6) - 1) * 16;  // the first 64 columns start at t = 0, the others at t = 16
+    double *__restrict__ S = ws + WS_S;
+    double s[NX];
+#pragma unroll
+    for (int m = 0; m < NX; ++m) s[m] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) S[(size_t)m * NA + i] = 0.0;  // S_0
+    for (int k = 0; k < HH - 1; ++k) {
+        double *__restrict__ So = S + (size_t)(k + 1) * 16 * NA;
+        So[(size_t)13 * NA + i] = 0.0;
+        So[(size_t)14 * NA + i] = 0.0;
+        So[(size_t)15 * NA + i] = 0.0;
+        if (k >= wave_min_ti) {
+            const JacView J{sjf + k * NX * NZ};
+            double n[NX];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                n[r] = fma(J(r, r), s[r], J(r, 3 + r) * s[3 + r]);  // p' = p + dt v
+                double acc = J(3 + r, 3 + r) * s[3 + r];            // v' <- v, q
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = fma(J(3 + r, 6 + c), s[6 + c], acc);
+                n[3 + r] = acc;
+                n[10 + r] = J(10 + r, 10 + r) * s[10 + r];          // omega' <- omega
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                           // q' <- q, omega
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = fma(J(6 + r, 6 + c), s[6 + c], acc);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc = fma(J(6 + r, 10 + c), s[10 + c], acc);
+                n[6 + r] = acc;
+            }
+            if (k == ti) {
+#pragma unroll
+                for (int m = 0; m < NX; ++m) n[m] += J(m, NX + d);  // the action of step t_i enters: B_k[:, d]
+            }
+#pragma unroll
+            for (int m = 0; m < NX; ++m) s[m] = n[m];
+        }
+#pragma unroll
+        for (int m = 0; m < NX; ++m) So[(size_t)m * NA + i] = s[m];
+    }
+}
+
+// ---- KM: M_k = Hess_z( r_k(x) + lam_{k+1} . f_k(z) ), one hyper-dual step per pair a <= b of the 17 inputs
+__global__ __launch_bounds__(192) void adj_hess_kernel(const AdjArgs A)
+{
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
+    const float *__restrict__ am = A.a_mean + (size_t)b * NA;
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    const int time0 = __float_as_int(st[ST_TIME]);
+    double *__restrict__ Mxx = ws + WS_MXX + (size_t)k * 256, *__restrict__ Mxu = ws + WS_MXU + (size_t)k * 64;
+    double *__restrict__ Muu = ws + WS_MUU + (size_t)k * 16;
+    // zero padding of the x block (rows / columns 13..15)
+    for (int e = tid; e < 256; e += 192)
+        if ((e >> 4) >= NX || (e & 15) >= NX) Mxx[e] = 0.0;
+    if (tid < 12) Mxu[NX * 4 + tid] = 0.0;
+    constexpr int NPAIR = NZ * (NZ + 1) / 2;  // 153
+    int q = tid < NPAIR ? tid : 0, a = 0;
+    while (q >= NZ - a) { q -= NZ - a; ++a; }
+    const int bb = a + q;
+    qm::State<double> p;
+    adj_load_state(p, ws + WS_X + 16 * k);
+    qm::HD r;
+    qm::State<qm::HD> s;
+    adj_hd_step(st, am, A, time0, k, p, a, bb, r, s);
+    double g = r.ab;
+    if (k <= HH - 2) {
+        const double *__restrict__ lam = ws + WS_LAM + 16 * (k + 1);
+#define OP(m, i) g = fma(lam[i], s.m.ab, g);
+        ADJ_FOR_STATE(OP)
+#undef OP
+    }
+    if (tid < NPAIR) {
+        if (bb < NX) {
+            Mxx[a * 16 + bb] = g;
+            Mxx[bb * 16 + a] = g;
+        } else if (a < NX) {
+            Mxu[a * 4 + (bb - NX)] = g;
+        } else {
+            Muu[(a - NX) * 4 + (bb - NX)] = g;
+            Muu[(bb - NX) * 4 + (a - NX)] = g;
+        }
+    }
+}
+
+// ---- KD: R = -( sum_k S_k^T Mxx_k S_k  +  action blocks ), one lower 16x16 tile per workgroup, k split over 8 waves
+__device__ __forceinline__ void adj_tri_tile(int w, int &ti, int &tj)
+{
+    ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= w) ++ti;
+    tj = w - ti * (ti + 1) / 2;
+}
+
+__global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
+{
+    __shared__ double red[8][4][64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    const double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    double *__restrict__ R = A.R + (size_t)b * NA * NA;
+    int I, J;
+    adj_tri_tile(blockIdx.x, I, J);
+    const double *__restrict__ S = ws + WS_S, *__restrict__ Mxx = ws + WS_MXX;
+    // S_k[:, 16 I ..] is zero for k <= 4 I (I >= J): k = 4I+1 .. 31, round-robin over the 8 waves.
+    // MFMA f64 16x16x4: A[m = lo][kk = hi], B[kk = hi][n = lo]; C/D: column lo, rows hi + 4 r.
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 4 * I + 1 + wv; k < HH; k += 8) {
+        const double *__restrict__ Sk = S + (size_t)k * 16 * NA, *__restrict__ Mk = Mxx + (size_t)k * 256;
+        double ma[4], sj[4], si[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ma[g] = Mk[lo * 16 + 4 * g + hi];                    // Mxx[m = lo][4g + hi]
+            sj[g] = Sk[(size_t)(4 * g + hi) * NA + 16 * J + lo];  // S[4g + hi][n = 16J + lo]
+            si[g] = Sk[(size_t)(4 * g + hi) * NA + 16 * I + lo];  // S^T: A[m = lo][kk = hi] = S[4g + hi][16I + lo]
+        }
+        f64x4 Q = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Q = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[g], sj[g], Q, 0, 0, 0);
+        // Q = Mxx S_J in C layout: register g of lane (lo, hi) is row 4g + hi -- the B operand of k-group g as is
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(si[g], Q[g], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][r][lane] = acc[r];
+    __syncthreads();
+    if (wv >= 4) return;
+    double v = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) v += red[w8][wv][lane];
+    const int i = 16 * I + hi + 4 * wv, j = 16 * J + lo;
+    const int ti = i >> 2, di = i & 3, tj = j >> 2, dj = j & 3;
+    // action blocks: u_i enters at step t_i where column j has sensitivity S_{t_i}[:, j] (t_j < t_i), and vice versa
+    if (tj < ti) {
+        const double *__restrict__ Sk = S + (size_t)ti * 16 * NA, *__restrict__ Mu = ws + WS_MXU + (size_t)ti * 64;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) v = fma(Sk[(size_t)m * NA + j], Mu[m * 4 + di], v);
+    } else if (ti < tj) {
+        const double *__restrict__ Sk = S + (size_t)tj * 16 * NA, *__restrict__ Mu = ws + WS_MXU + (size_t)tj * 64;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) v = fma(Sk[(size_t)m * NA + i], Mu[m * 4 + dj], v);
+    } else {
+        v += ws[WS_MUU + (size_t)ti * 16 + di * 4 + dj];
+    }
+    // C = -J.  Off-diagonal tiles mirror; in diagonal tiles the lower half writes both copies (exactly symmetric R)
+    if (I != J || i >= j) {
+        R[(size_t)i * NA + j] = -v;
+        R[(size_t)j * NA + i] = -v;
+    }
+}
+}  // namespace
+
+size_t hessian_workspace_bytes(int batch) { return (size_t)batch * WS_COUNT * sizeof(double); }
+
+int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
+                   const float *a_mean, int batch, double *R, void *workspace, hipStream_t s)
+{
+    AdjArgs A;
+    A.state = state;
+    A.pos_traj = pos_traj;
+    A.vel_traj = vel_traj;
+    A.a_mean = a_mean;
+    A.R = R;
+    A.ws = reinterpret_cast<double *>(workspace);
+    A.T = T;
+    A.c = make_consts<double>(p);
+    hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(adj_chain_kernel, dim3(batch), dim3(192), 0, s, A);
+    hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);
+    hipLaunchKernelGGL(adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

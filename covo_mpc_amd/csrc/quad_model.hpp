@@ -50,8 +50,29 @@ __device__ __forceinline__ float atan2abs_(float y, float x)
 }
 
 // ---------------------------------------------------------------- double primitives (primal prefix of the Hessian)
-__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
-__device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
+// 1/sqrt(x) and 1/x without the libm division/sqrt expansions (~45-60 instructions each, and a lone fp64
+// wave issues one instruction per ~5 cycles): hardware seed (v_rsq_f64 / v_rcp_f64, ~2^-24 relative,
+// scripts/probe) + two Newton steps -> ~2e-16.  x = 0 gives NaN (libm: inf); every use below either has
+// x > 0 (quaternion norms, 1 + err_pos, yaw denominator) or propagates NaN tangents at 0 exactly like
+// jnp.linalg.norm's JVP does.
+__device__ __forceinline__ double rsq64_(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-(x * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(x * y), y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+__device__ __forceinline__ double rcp64_(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ double sqrt_(double x) { return (x == 0.0) ? 0.0 : x * rsq64_(x); }
+__device__ __forceinline__ double rsqrt_(double x) { return rsq64_(x); }
 __device__ __forceinline__ double log_(double x) { return log(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }
 __device__ __forceinline__ double sat01_(double x) { return fmin(fmax(x, 0.0), 1.0); }
@@ -87,19 +108,18 @@ __device__ __forceinline__ HD chain_(HD x, double f, double d1, double d2)
 }
 __device__ __forceinline__ HD sqrt_(HD x)
 {
-    const double s = sqrt(x.v);
-    const double d1 = 0.5 / s;  // inf at 0 => NaN tangents, as jnp.linalg.norm's JVP at 0
-    return chain_(x, s, d1, -0.5 * d1 / x.v);
+    const double r = rsq64_(x.v);            // NaN at 0 => NaN tangents, as jnp.linalg.norm's JVP at 0
+    const double s = (x.v == 0.0) ? 0.0 : x.v * r;
+    return chain_(x, s, 0.5 * r, -0.25 * r * r * r);
 }
 __device__ __forceinline__ HD rsqrt_(HD x)
 {
-    const double r = 1.0 / sqrt(x.v);
-    const double d1 = -0.5 * r / x.v;
-    return chain_(x, r, d1, -1.5 * d1 / x.v);
+    const double r = rsq64_(x.v), r2 = r * r, r3 = r2 * r;
+    return chain_(x, r, -0.5 * r3, 0.75 * r3 * r2);
 }
 __device__ __forceinline__ HD log_(HD x)
 {
-    const double r = 1.0 / x.v;
+    const double r = rcp64_(x.v);
     return chain_(x, log(x.v), r, -r * r);
 }
 // lax.abs JVP: g * sign(x), sign(0) = 0
@@ -123,12 +143,12 @@ __device__ __forceinline__ double value_(HD x) { return x.v; }
 // |atan2(y, x)| = abs_(atan2(y, x))
 __device__ __forceinline__ HD atan2abs_(HD y, HD x)
 {
-    const double den = x.v * x.v + y.v * y.v;
+    const double inv = rcp64_(x.v * x.v + y.v * y.v), inv2 = inv * inv;
     const double f = atan2(y.v, x.v);
-    const double fy = x.v / den, fx = -y.v / den;  // d/dy, d/dx
-    const double fyy = -2.0 * x.v * y.v / (den * den);
+    const double fy = x.v * inv, fx = -y.v * inv;  // d/dy, d/dx
+    const double fyy = -2.0 * x.v * y.v * inv2;
     const double fxx = -fyy;
-    const double fxy = (y.v * y.v - x.v * x.v) / (den * den);
+    const double fxy = (y.v * y.v - x.v * x.v) * inv2;
     HD r;
     r.v = f;
     r.a = fy * y.a + fx * x.a;

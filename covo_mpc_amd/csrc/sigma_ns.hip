@@ -78,22 +78,37 @@ struct LoadScaledB {
     __device__ __forceinline__ double operator()(double v, int r, int c) const { return (v + ((r == c) ? delta : 0.0)) * inv; }
 };
 
+struct TileOps {
+    double a[8], b[8];
+};
+// issue the 16 operand loads of this wave's K-quarter (callers issue them BEFORE looking at any flag: every
+// launch of the chain then pays one memory latency, not one per dependent scalar)
+template <class F>
+__device__ __forceinline__ void tile_load(TileOps &o, const double *__restrict__ A, const double *__restrict__ B, int ti, int tj,
+                                          int lane, int kq, F f)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 32 * kq + 4 * kk + hi;
+        o.a[kk] = f(A[(size_t)k * SN + 16 * ti + lo], k, 16 * ti + lo);
+        o.b[kk] = f(B[(size_t)k * SN + 16 * tj + lo], k, 16 * tj + lo);
+    }
+}
+__device__ __forceinline__ f64x4 tile_mma(const TileOps &o)
+{
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[kk], o.b[kk], acc, 0, 0, 0);
+    return acc;
+}
 template <class F>
 __device__ __forceinline__ f64x4 tile_mm_q(const double *__restrict__ A, const double *__restrict__ B, int ti, int tj, int lane,
                                            int kq, F f)
 {
-    const int lo = lane & 15, hi = lane >> 4;
-    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    double a[8], b[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        const int k = 32 * kq + 4 * kk + hi;
-        a[kk] = f(A[(size_t)k * SN + 16 * ti + lo], k, 16 * ti + lo);
-        b[kk] = f(B[(size_t)k * SN + 16 * tj + lo], k, 16 * tj + lo);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);
-    return acc;
+    TileOps o;
+    tile_load(o, A, B, ti, tj, lane, kq, f);
+    return tile_mma(o);
 }
 // sums the four K-quarters; wave wv returns the tile element (row, col) = ((lane>>4) + 4 wv, lane&15) it will store
 __device__ __forceinline__ double tile_reduce(const f64x4 &acc, double (*red)[4][64], int wv, int lane)
@@ -215,12 +230,21 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
             s[SC_GERSH] = gm;
             s[SC_N0] = nrm;
         }
-    } else {
-        if (s[SC_SQ_DONE] != 0.0) return;
-        nrm = slot_sum(s + SC_SQN + step * 64, NS_TILES, lane);
+    }
+    int ti, tj;
+    tri_tile(w, ti, tj);
+    TileOps ops;
+    if (FIRST) tile_load(ops, X, X, ti, tj, lane, wv, LoadShiftMinus{shift});
+    else tile_load(ops, X, X, ti, tj, lane, wv, LoadPlain{});
+    if (!FIRST) {
+        const double done = s[SC_SQ_DONE];
+        const double p1 = (lane < NS_TILES) ? s[SC_SQN + step * 64 + lane] : 0.0;
+        const double p0 = (lane < NS_TILES && step >= 2) ? s[SC_SQN + (step - 1) * 64 + lane] : 0.0;
+        if (done != 0.0) return;
+        nrm = wr::wave64_allsum(p1);
         if (step >= 2) {
             // stationary: |X_k|_F^2 stopped moving (X is a projector onto the dominant eigenspace up to scale)
-            const double prev = slot_sum(s + SC_SQN + (step - 1) * 64, NS_TILES, lane);
+            const double prev = wr::wave64_allsum(p0);
             if (fabs(nrm - prev) <= 1e-11 * nrm) {
                 if (w == 0 && tid == 0) s[SC_SQ_DONE] = 1.0;
                 return;
@@ -231,9 +255,7 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
         s[SC_XBUF] = (double)xbuf_out;
         s[SC_SQ] = (double)(step + 1);
     }
-    int ti, tj;
-    tri_tile(w, ti, tj);
-    const f64x4 acc = FIRST ? tile_mm_q(X, X, ti, tj, lane, wv, LoadShiftMinus{shift}) : tile_mm_q(X, X, ti, tj, lane, wv, LoadPlain{});
+    const f64x4 acc = tile_mma(ops);
     const double v = tile_reduce(acc, red, wv, lane) * (1.0 / nrm);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
     store_sym(O, row, col, v);
@@ -412,8 +434,11 @@ __global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict_
 
 __device__ __forceinline__ bool ns_converged(double *__restrict__ s, int iter, int lane, bool writer)
 {
-    if (s[SC_NS_DONE] != 0.0) return true;
-    if (iter >= 2 && slot_sum(s + SC_ERR + (iter - 1) * 64, 64, lane) < NS_TOL2) {
+    // both loads are issued before either is looked at
+    const double done = s[SC_NS_DONE];
+    const double e = (iter >= 2) ? s[SC_ERR + (iter - 1) * 64 + lane] : 0.0;
+    if (done != 0.0) return true;
+    if (iter >= 2 && wr::wave64_allsum(e) < NS_TOL2) {
         if (writer) s[SC_NS_DONE] = 1.0;
         return true;
     }
@@ -429,13 +454,15 @@ __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Ya
     __shared__ double part[4];
     const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
-    if (ns_converged(s, iter, lane, w == 0 && tid == 0)) return;  // Y, Z are final
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
-    const f64x4 acc = tile_mm_q(Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    TileOps ops;
+    tile_load(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
+    if (ns_converged(s, iter, lane, w == 0 && tid == 0)) return;  // Y, Z are final
+    const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
     store_both(Tall + off, Ttall + off, row, col, fma(bq, p, (row == col) ? a : 0.0));
     const double d = p - ((row == col) ? 1.0 : 0.0);
     const double tot = wg_sum4(d * d, part, wv, lane);
@@ -452,19 +479,20 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
     __shared__ double red[4][4][64];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
-    if (ns_converged(s, iter, lane, false)) return;  // the T launch of this iteration raised the flag
-    if (blockIdx.x == 0 && tid == 0) {
-        s[SC_ZBUF] = (double)zbuf_out;  // which Z buffer holds the newest iterate
-        s[SC_ITERS] = (double)(iter + 1);
-    }
     int w = blockIdx.x;
     const bool isZ = w >= 64;
     w &= 63;
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
     // Y' = Y.T : left factor Y -> pass Y^T;   Z' = T.Z : left factor T -> pass T^T
-    const f64x4 acc = isZ ? tile_mm_q(Ttall + off, Zall + off, ti, tj, lane, wv, LoadPlain{})
-                          : tile_mm_q(Ytall + off, Tall + off, ti, tj, lane, wv, LoadPlain{});
+    TileOps ops;
+    tile_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
+    if (ns_converged(s, iter, lane, false)) return;  // the T launch of this iteration raised the flag
+    if (blockIdx.x == 0 && tid == 0) {
+        s[SC_ZBUF] = (double)zbuf_out;  // which Z buffer holds the newest iterate
+        s[SC_ITERS] = (double)(iter + 1);
+    }
+    const f64x4 acc = tile_mma(ops);
     const double v = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
     store_both((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v);

@@ -86,7 +86,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     int rc;
     if ((rc = launch_shift_mean(a.a_mean, am_shift, s))) return rc;               // covo.py:201-203
     if (a.mode == COVO_MODE_COVO_ONLINE) {
-        if ((rc = launch_hessian(a.state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, s))) return rc;  // :134-185
+        if ((rc = launch_hessian(a.state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
         if ((rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
         if ((rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;

@@ -166,11 +166,18 @@ int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, 
 
 /* Exact Hessian of the CoVO objective -(sum_k r(s_k) + r(s_0)) w.r.t. the flattened mean
  * actions: jax.jacfwd(jax.jacfwd(get_cumulated_cost)) of controllers/covo.py:134-185
- * (deterministic, no discount, no done-freeze).  Hyper-dual fp64 rollout, one lane per
- * unordered pair.  R_out: double[batch][128][128]; state/a_mean are strided by
+ * (deterministic, no discount, no done-freeze), fp64.  Second-order adjoint: one hyper-dual evaluation of
+ * the step model per (time, pair of step inputs), a costate and a sensitivity recursion, and
+ * sum_k S_k^T M_k S_k on the matrix cores (hessian_adj.hip).  May (re)allocate scratch, with a stream sync,
+ * the first time a batch size is seen.  R_out: double[batch][128][128]; state/a_mean are strided by
  * COVO_STATE_FLOATS / 128 per batch entry; traj is shared. */
 int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
                  const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream);
+
+/* The same Hessian by one hyper-dual ROLLOUT per unordered pair of actions (hessian.hip): ~4x slower,
+ * derived independently; kept as the cross-check of covo_hessian. */
+int covo_hessian_pairs(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                       const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream);
 
 /* CoVO's optimal covariance (controllers/covo.py:116-132) and the lower Cholesky factor
  * jax.random.multivariate_normal takes of it (covo.py:216-218).  The reference's

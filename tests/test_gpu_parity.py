@@ -255,7 +255,8 @@ def test_shift_mean():
 
 
 # ------------------------------------------------------------------------------------------ Sigma path
-def test_hessian_vs_ad_oracle():
+@pytest.mark.parametrize("method", ["adjoint", "pairs"])
+def test_hessian_vs_ad_oracle(method):
     from oracle import ref_torch as RT
     s, p, rng = make_problem(seed=0, time=37)
     a = (R.hover_action(p, 32, np.float64) + 0.1 * rng.normal(size=(32, 4))).astype(np.float32)
@@ -263,7 +264,8 @@ def test_hessian_vs_ad_oracle():
     a[5, 2] = -1.0
     core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
     ds = dev_state(s)
-    Rm = core.hessian(ds.packed, ds, EnvParams3D().to_c(), torch.from_numpy(a.reshape(-1)).to(DEV))[0].cpu().numpy()
+    Rm = core.hessian(ds.packed, ds, EnvParams3D().to_c(), torch.from_numpy(a.reshape(-1)).to(DEV),
+                      method=method)[0].cpu().numpy()
     ref = RT.hessian(s, p, a.reshape(-1).astype(np.float64), 32)
     assert np.abs(Rm - Rm.T).max() == 0.0 and np.abs(Rm[124:]).max() == 0.0  # KAT 8
     assert np.abs(Rm - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), np.abs(Rm - ref).max()
