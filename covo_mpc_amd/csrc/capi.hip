@@ -221,6 +221,15 @@ int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doub
     return 0;
 }
 
+int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)
+{
+    REQUIRE(h && out, "covo_debug_hess_workspace: bad argument");
+    REQUIRE((size_t)(offset_doubles + count) * sizeof(double) <= h->ws_hess_bytes, "covo_debug_hess_workspace: range");
+    COVO_CHECK_HIP(hipMemcpyAsync(out, (const double *)h->ws_hess + offset_doubles, (size_t)count * sizeof(double),
+                                  hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
 int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out, float *L_out,
                       void *stream)
 {

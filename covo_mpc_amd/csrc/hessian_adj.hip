@@ -16,9 +16,9 @@
 // templated model (quad_model.hpp) on hyper-dual numbers, so every JAX AD convention it mirrors (clip ties,
 // |x|', the double clip of quadrotor.py:223/:258) carries over.  Four launches:
 //   KB  32 waves: primal rollout to step k (plain fp64), then the step with 17 first-order seeds -> A_k, B_k, grad r_k
-//   KC  one workgroup: the costate recursion (one lane) beside the sensitivity recursion (one lane per
-//       action column), both on the block-sparse structure of A_k (p' = p + dt v; v' <- q, thrust; q' <- q, omega;
-//       omega' <- omega, rates): 52 multiply-adds per step instead of 169
+//   KC  33 waves: the sensitivity recursion (wave t: the four actions of step t, one 16-lane row per column) and
+//       the costate recursion (wave 32); a step is a dense 13x13 matrix-vector product with the vector
+//       broadcast inside its row by ds_swizzle -- no barriers, no sparsity assumptions
 //   KM  32 x 153 lanes: one hyper-dual step per pair (a <= b) of step inputs -> M_k = Hess_z(r_k + lam_{k+1}.f_k)
 //   KD  36 lower 16x16 tiles: sum_k S_k^T Mxx_k S_k on the matrix cores (v_mfma_f64_16x16x4_f64; the product
 //       Mxx S leaves the MFMA in exactly the register layout the next MFMA wants as its B operand), the
@@ -141,109 +141,86 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     }
 }
 
-// block-sparse structure of A_k = df_k/dx (quad_model.hpp dyn_step): rows p <- (p, v) diagonal; v <- v diagonal,
-// q dense; q <- q, omega dense; omega <- omega diagonal.  B_k = df_k/du is applied as a dense column.
-struct JacView {
-    const double *jf;  // [13][17] in LDS
-    __device__ __forceinline__ double operator()(int m, int c) const { return jf[m * NZ + c]; }
-};
+// ---- KC: the two linear recursions, one 16-lane row per 13-vector.
+// A wave holds four vectors (lane = 16*row + m, m < 13 the component): the four sensitivity columns of ONE
+// time step t (they all start at k = t), or -- wave 32 -- the costate.  One step is a dense 13x13
+// matrix-vector product: the vector's components are broadcast inside each row with ds_swizzle (bit-mask
+// mode: lane' = (lane & 0x10) | n), the matrix row/column of lane m comes from LDS, 13 multiply-adds.  No
+// barrier, no assumption about the sparsity of df/dx.  (A first version ran one lane per column with the
+// whole vector in registers: 2000 cycles per step, 29 us; this one: ~300 cycles per step.)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v)
+{
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (N << 5) | 0x10);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (N << 5) | 0x10);
+    return __hiloint2double(hi, lo);
+}
+// out[m] = sum_n M[m][n] v[n] (TRANSPOSE = false) or sum_n M[n][m] v[n] (true), M = jf[.][0..12] of a [13][17] block
+template <bool TRANSPOSE>
+__device__ __forceinline__ double row_matvec(const double *__restrict__ jf, int m, double v)
+{
+    double c[NX];
+#pragma unroll
+    for (int n = 0; n < NX; ++n) c[n] = (m < NX) ? (TRANSPOSE ? jf[n * NZ + m] : jf[m * NZ + n]) : 0.0;
+    double acc0 = 0.0, acc1 = 0.0;
+#define STEP(n)                                             \
+    if ((n) < NX) {                                         \
+        const double vn = row_bcast<((n) < NX ? (n) : 0)>(v); \
+        if ((n) & 1) acc1 = fma(c[(n) < NX ? (n) : 0], vn, acc1); \
+        else acc0 = fma(c[(n) < NX ? (n) : 0], vn, acc0);   \
+    }
+    STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12)
+#undef STEP
+    return acc0 + acc1;
+}
 
-// ---- KC: costate (wave 0, lane 0) beside the sensitivities (waves 1..2: one lane per action column)
-__global__ __launch_bounds__(192) void adj_chain_kernel(const AdjArgs A)
+__global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
 {
     __shared__ double sjf[(HH - 1) * NX * NZ];
-    __shared__ double sgl[HH * 16];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));  // 0..31: time step, 32: costate
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
-    for (int e = tid; e < (HH - 1) * NX * NZ; e += 192) sjf[e] = ws[WS_JF + e];
-    for (int e = tid; e < HH * 16; e += 192) sgl[e] = ws[WS_GL + e];
+    {
+        // all global loads in flight before the first LDS store (a rolled loop pays one L2 latency per trip)
+        constexpr int NJ = (HH - 1) * NX * NZ, TJ = (NJ + 255) / 256;
+        double vj[TJ];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) vj[t] = (tid + 256 * t < NJ) ? ws[WS_JF + tid + 256 * t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < TJ; ++t)
+            if (tid + 256 * t < NJ) sjf[tid + 256 * t] = vj[t];
+    }
     __syncthreads();
-    if (tid < 64) {
-        if (tid != 0) return;
-        double lam[NX];
+    const int m = lane & 15, row = lane >> 4;
+    if (w == HH) {
+        // ---- costate: lam_31 = grad r_31, lam_k = grad r_k + A_k^T lam_{k+1}; row 0 of the wave
+        if (row != 0) return;
+        const double *__restrict__ G = ws + WS_GL;
         double *__restrict__ L = ws + WS_LAM;
-        for (int m = 0; m < NX; ++m) {
-            lam[m] = sgl[16 * (HH - 1) + m];
-            L[16 * (HH - 1) + m] = lam[m];
-            L[16 * HH + m] = 0.0;
-        }
+        double lam = (m < NX) ? G[16 * (HH - 1) + m] : 0.0;
+        L[16 * (HH - 1) + m] = lam;
+        L[16 * HH + m] = 0.0;
+        double g = (m < NX) ? G[16 * (HH - 2) + m] : 0.0;
         for (int k = HH - 2; k >= 1; --k) {
-            const JacView J{sjf + k * NX * NZ};
-            const double *g = sgl + 16 * k;
-            double n[NX];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                n[r] = fma(J(r, r), lam[r], g[r]);                                             // p <- p
-                n[3 + r] = fma(J(3 + r, 3 + r), lam[3 + r], fma(J(r, 3 + r), lam[r], g[3 + r]));  // v <- p, v
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {  // q <- v, q
-                double acc = g[6 + c];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) acc = fma(J(3 + r, 6 + c), lam[3 + r], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc = fma(J(6 + r, 6 + c), lam[6 + r], acc);
-                n[6 + c] = acc;
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {  // omega <- q, omega
-                double acc = fma(J(10 + c, 10 + c), lam[10 + c], g[10 + c]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc = fma(J(6 + r, 10 + c), lam[6 + r], acc);
-                n[10 + c] = acc;
-            }
-#pragma unroll
-            for (int m = 0; m < NX; ++m) {
-                lam[m] = n[m];
-                L[16 * k + m] = n[m];
-            }
+            const double gk = g;
+            if (k > 1) g = (m < NX) ? G[16 * (k - 1) + m] : 0.0;  // next step's gradient in flight
+            lam = gk + row_matvec<true>(sjf + k * NX * NZ, m, lam);
+            L[16 * k + m] = lam;
         }
         return;
     }
-    // ---- sensitivities: column i = 4 t_i + d of S_k is zero up to k = t_i, B_{t_i}[:, d] at k = t_i + 1
-    const int i = tid - 64, ti = i >> 2, d = i & 3;
-    const int wave_min_ti = ((tid >> 6) - 1) * 16;  // the first 64 columns start at t = 0, the others at t = 16
+    if (w > HH) return;
+    // ---- sensitivities of the four actions of step t = w: S_k[:, i] = 0 for k <= t, B_t[:, d] at k = t + 1,
+    // A_k S_k[:, i] afterwards.  Rows 13..15 of every S_k are zero (lanes m >= 13 carry zeros).
+    const int t = w, i = 4 * t + row;
     double *__restrict__ S = ws + WS_S;
-    double s[NX];
-#pragma unroll
-    for (int m = 0; m < NX; ++m) s[m] = 0.0;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) S[(size_t)m * NA + i] = 0.0;  // S_0
-    for (int k = 0; k < HH - 1; ++k) {
-        double *__restrict__ So = S + (size_t)(k + 1) * 16 * NA;
-        So[(size_t)13 * NA + i] = 0.0;
-        So[(size_t)14 * NA + i] = 0.0;
-        So[(size_t)15 * NA + i] = 0.0;
-        if (k >= wave_min_ti) {
-            const JacView J{sjf + k * NX * NZ};
-            double n[NX];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                n[r] = fma(J(r, r), s[r], J(r, 3 + r) * s[3 + r]);  // p' = p + dt v
-                double acc = J(3 + r, 3 + r) * s[3 + r];            // v' <- v, q
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc = fma(J(3 + r, 6 + c), s[6 + c], acc);
-                n[3 + r] = acc;
-                n[10 + r] = J(10 + r, 10 + r) * s[10 + r];          // omega' <- omega
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {                           // q' <- q, omega
-                double acc = 0.0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc = fma(J(6 + r, 6 + c), s[6 + c], acc);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) acc = fma(J(6 + r, 10 + c), s[10 + c], acc);
-                n[6 + r] = acc;
-            }
-            if (k == ti) {
-#pragma unroll
-                for (int m = 0; m < NX; ++m) n[m] += J(m, NX + d);  // the action of step t_i enters: B_k[:, d]
-            }
-#pragma unroll
-            for (int m = 0; m < NX; ++m) s[m] = n[m];
-        }
-#pragma unroll
-        for (int m = 0; m < NX; ++m) So[(size_t)m * NA + i] = s[m];
+    for (int k = 0; k <= t; ++k) S[((size_t)k * 16 + m) * NA + i] = 0.0;
+    if (t >= HH - 1) return;
+    double s = (m < NX) ? sjf[(t * NX + m) * NZ + NX + row] : 0.0;  // B_t[m][d = row]
+    S[((size_t)(t + 1) * 16 + m) * NA + i] = s;
+    for (int k = t + 1; k < HH - 1; ++k) {
+        s = row_matvec<false>(sjf + k * NX * NZ, m, s);
+        S[((size_t)(k + 1) * 16 + m) * NA + i] = s;
     }
 }
 
@@ -310,21 +287,43 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
     // S_k[:, 16 I ..] is zero for k <= 4 I (I >= J): k = 4I+1 .. 31, round-robin over the 8 waves.
     // MFMA f64 16x16x4: A[m = lo][kk = hi], B[kk = hi][n = lo]; C/D: column lo, rows hi + 4 r.
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k = 4 * I + 1 + wv; k < HH; k += 8) {
-        const double *__restrict__ Sk = S + (size_t)k * 16 * NA, *__restrict__ Mk = Mxx + (size_t)k * 256;
-        double ma[4], sj[4], si[4];
+    // epilogue operands of the element this lane will finish (waves 0..3: register wv of the tile), loaded up front
+    const int i = 16 * I + hi + 4 * (wv & 3), j = 16 * J + lo;
+    const int ti = i >> 2, di = i & 3, tj = j >> 2, dj = j & 3;
+    double es[NX], em[NX];
+    {
+        const int tk = ti > tj ? ti : tj, col = ti > tj ? j : i, dk = ti > tj ? di : dj;
+        const double *__restrict__ Sk = S + (size_t)tk * 16 * NA, *__restrict__ Mu = ws + WS_MXU + (size_t)tk * 64;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+            es[m] = Sk[(size_t)m * NA + col];
+            em[m] = Mu[m * 4 + dk];
+        }
+        if (ti == tj) em[0] = ws[WS_MUU + (size_t)ti * 16 + di * 4 + dj];
+    }
+    // at most 4 values of k per wave: all operand loads are issued before the first MFMA
+    double ma[4][4], sj[4][4], si[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = 4 * I + 1 + wv + 8 * it;
+        const bool on = k < HH;
+        const double *__restrict__ Sk = S + (size_t)(on ? k : 0) * 16 * NA, *__restrict__ Mk = Mxx + (size_t)(on ? k : 0) * 256;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            ma[g] = Mk[lo * 16 + 4 * g + hi];                    // Mxx[m = lo][4g + hi]
-            sj[g] = Sk[(size_t)(4 * g + hi) * NA + 16 * J + lo];  // S[4g + hi][n = 16J + lo]
-            si[g] = Sk[(size_t)(4 * g + hi) * NA + 16 * I + lo];  // S^T: A[m = lo][kk = hi] = S[4g + hi][16I + lo]
+            ma[it][g] = on ? Mk[lo * 16 + 4 * g + hi] : 0.0;                    // Mxx[m = lo][4g + hi]
+            sj[it][g] = on ? Sk[(size_t)(4 * g + hi) * NA + 16 * J + lo] : 0.0;  // S[4g + hi][n = 16J + lo]
+            si[it][g] = on ? Sk[(size_t)(4 * g + hi) * NA + 16 * I + lo] : 0.0;  // S^T: A[m = lo][kk = hi] = S[4g + hi][16I + lo]
         }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (4 * I + 1 + wv + 8 * it >= HH) break;
         f64x4 Q = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) Q = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[g], sj[g], Q, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) Q = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[it][g], sj[it][g], Q, 0, 0, 0);
         // Q = Mxx S_J in C layout: register g of lane (lo, hi) is row 4g + hi -- the B operand of k-group g as is
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(si[g], Q[g], acc, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(si[it][g], Q[g], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv][r][lane] = acc[r];
@@ -333,19 +332,12 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
     double v = 0.0;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) v += red[w8][wv][lane];
-    const int i = 16 * I + hi + 4 * wv, j = 16 * J + lo;
-    const int ti = i >> 2, di = i & 3, tj = j >> 2, dj = j & 3;
     // action blocks: u_i enters at step t_i where column j has sensitivity S_{t_i}[:, j] (t_j < t_i), and vice versa
-    if (tj < ti) {
-        const double *__restrict__ Sk = S + (size_t)ti * 16 * NA, *__restrict__ Mu = ws + WS_MXU + (size_t)ti * 64;
+    if (ti != tj) {
 #pragma unroll
-        for (int m = 0; m < NX; ++m) v = fma(Sk[(size_t)m * NA + j], Mu[m * 4 + di], v);
-    } else if (ti < tj) {
-        const double *__restrict__ Sk = S + (size_t)tj * 16 * NA, *__restrict__ Mu = ws + WS_MXU + (size_t)tj * 64;
-#pragma unroll
-        for (int m = 0; m < NX; ++m) v = fma(Sk[(size_t)m * NA + i], Mu[m * 4 + dj], v);
+        for (int m = 0; m < NX; ++m) v = fma(es[m], em[m], v);
     } else {
-        v += ws[WS_MUU + (size_t)ti * 16 + di * 4 + dj];
+        v += em[0];
     }
     // C = -J.  Off-diagonal tiles mirror; in diagonal tiles the lower half writes both copies (exactly symmetric R)
     if (I != J || i >= j) {
@@ -370,7 +362,7 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.T = T;
     A.c = make_consts<double>(p);
     hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
-    hipLaunchKernelGGL(adj_chain_kernel, dim3(batch), dim3(192), 0, s, A);
+    hipLaunchKernelGGL(adj_chain_kernel, dim3(9, batch), dim3(256), 0, s, A);
     hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);
     hipLaunchKernelGGL(adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());

@@ -523,11 +523,20 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     long long tk[5];
     tk[0] = clock64();
     // Z and its stored transpose are both read coalesced; the symmetrised matrix is row/column agnostic
-    for (int e2 = tid; e2 < SN * SN / 2; e2 += 512) {
-        const int r = (2 * e2) / SN, c = (2 * e2) % SN;
-        const double2 a = Z[e2], at = Zt[e2];
-        sm[r * LD + c] = 0.5 * (a.x + at.x);  // covo.py:132 symmetrise
-        sm[r * LD + c + 1] = 0.5 * (a.y + at.y);
+    {
+        constexpr int TR = SN * SN / 2 / 512;  // 16 double2 per thread and matrix: all loads in flight first
+        double2 za[TR], zt[TR];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            za[t] = Z[tid + 512 * t];
+            zt[t] = Zt[tid + 512 * t];
+        }
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            const int e2 = tid + 512 * t, r = (2 * e2) / SN, c = (2 * e2) % SN;
+            sm[r * LD + c] = 0.5 * (za[t].x + zt[t].x);  // covo.py:132 symmetrise
+            sm[r * LD + c + 1] = 0.5 * (za[t].y + zt[t].y);
+        }
     }
     __syncthreads();
     tk[1] = clock64();
@@ -548,10 +557,16 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     tk[3] = clock64();
     if (Sigma_out) {
         float2 *So = reinterpret_cast<float2 *>(Sigma_out + (size_t)b * SN * SN);
-        for (int e2 = tid; e2 < SN * SN / 2; e2 += 512) {
-            const double2 a = Z[e2], at = Zt[e2];
-            So[e2] = make_float2((float)(cz * 0.5 * (a.x + at.x)), (float)(cz * 0.5 * (a.y + at.y)));  // a_cov is fp32
+        constexpr int TR = SN * SN / 2 / 512;
+        double2 za[TR], zt[TR];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            za[t] = Z[tid + 512 * t];
+            zt[t] = Zt[tid + 512 * t];
         }
+#pragma unroll
+        for (int t = 0; t < TR; ++t)  // a_cov is fp32
+            So[tid + 512 * t] = make_float2((float)(cz * 0.5 * (za[t].x + zt[t].x)), (float)(cz * 0.5 * (za[t].y + zt[t].y)));
     }
     float *Lo = L_out + (size_t)b * SN * SN;
     for (int e = tid; e < SN * SN; e += 512) {

@@ -201,6 +201,7 @@ int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sam
 /* Debug aid: copy `count` doubles from offset `offset_doubles` of the Sigma pipeline's scratch (layout in
  * sigma_ns.hip: 12 matrices [batch][128][128], then 64 scalars per matrix) to `out` (device). */
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
+int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 
 /* Profiling aid: covo_sigma for ONE matrix that also stores shader-clock ticks (s_memtime) at the kernel's
  * phase boundaries into ticks_out (device uint64[32]): [0] start, [1] loaded+shifted, [2+i] end of sweep i,
