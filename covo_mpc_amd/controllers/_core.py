@@ -194,11 +194,21 @@ class SamplingCore:
         fs = (C.c_float * 3)(*[float(x) for x in f_shared]) if f_shared is not None else None
         check(self.lib.covo_mpc_step(self.h, C.byref(params_c), C.byref(args), int(key[0]), int(key[1]), fs, self.stream()),
               "covo_mpc_step")
+        self._last_step = (params_c, args)
         if self.world > 1:
             exchange_records(self.partial, self.gathered, self.pg)  # the ONE collective per step
             check(self.lib.covo_merge(self.h, ptr(self.gathered), self.world, ptr(am_shift), float(gamma_mean), ptr(am),
                                       self.stream()), "covo_merge")
         return am, cov_out
+
+    def time_phases(self, step_mask=63, hess_mask=15, sigma_stages=4, reps=20):
+        """GPU microseconds of the selected launches of the LAST step() call, replayed `reps` times from one graph."""
+        params_c, args = self._last_step
+        us = C.c_float(0.0)
+        self.torch.cuda.synchronize()
+        check(self.lib.covo_debug_time_step(self.h, C.byref(params_c), C.byref(args), step_mask, hess_mask, sigma_stages,
+                                            reps, C.byref(us), self.stream()), "covo_debug_time_step")
+        return float(us.value)
 
     def update(self, a_mean_shifted, gamma_mean):
         """softmax weights + weighted mean (+ the one collective when sharded) -> new mean (H,4)."""

@@ -221,6 +221,13 @@ int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doub
     return 0;
 }
 
+int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
+                         int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream)
+{
+    REQUIRE(h && params && args && us_out && reps > 0, "covo_debug_time_step: bad argument");
+    return covo_debug_time_step_impl(h, params, args, step_mask, hess_mask, sigma_stages, reps, us_out, (hipStream_t)stream);
+}
+
 int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)
 {
     REQUIRE(h && out, "covo_debug_hess_workspace: bad argument");

@@ -29,6 +29,11 @@ struct covo_ctx {
 
 void covo_set_error(const char *fmt, ...);
 
+// debug/profiling switches (covo_debug_set): which launches of the Hessian (bit k = kernel k of hessian_adj.hip) and how
+// many stages of the Sigma pipeline (1 prep+squarings, 2 +Ritz, 3 +Newton-Schulz, 4 +finalize) are enqueued.
+// Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
+extern int g_dbg_hess_mask, g_dbg_sigma_stages;
+
 #define COVO_CHECK_HIP(expr)                                                         \
     do {                                                                             \
         hipError_t _e = (expr);                                                      \
@@ -103,3 +108,5 @@ void step_state_destroy(covo_ctx *h);
 int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, uint32_t key0, uint32_t key1,
                    const float *f_shared, hipStream_t s);
 int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);
+int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, int step_mask,
+                              int hess_mask, int sigma_stages, int reps, float *us_out, hipStream_t run);

@@ -16,9 +16,9 @@
 // templated model (quad_model.hpp) on hyper-dual numbers, so every JAX AD convention it mirrors (clip ties,
 // |x|', the double clip of quadrotor.py:223/:258) carries over.  Four launches:
 //   KB  32 waves: primal rollout to step k (plain fp64), then the step with 17 first-order seeds -> A_k, B_k, grad r_k
-//   KC  33 waves: the sensitivity recursion (wave t: the four actions of step t, one 16-lane row per column) and
-//       the costate recursion (wave 32); a step is a dense 13x13 matrix-vector product with the vector
-//       broadcast inside its row by ds_swizzle -- no barriers, no sparsity assumptions
+//   KC  9 waves: the sensitivity recursion (8 column tiles of S held in MFMA C/D layout, which IS the B operand
+//       of the next step: four dependent v_mfma_f64_16x16x4_f64 per step, nothing leaves the registers) and
+//       the costate recursion (the same product with A^T) -- no barriers, no sparsity assumptions
 //   KM  32 x 153 lanes: one hyper-dual step per pair (a <= b) of step inputs -> M_k = Hess_z(r_k + lam_{k+1}.f_k)
 //   KD  36 lower 16x16 tiles: sum_k S_k^T Mxx_k S_k on the matrix cores (v_mfma_f64_16x16x4_f64; the product
 //       Mxx S leaves the MFMA in exactly the register layout the next MFMA wants as its B operand), the
@@ -141,44 +141,22 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     }
 }
 
-// ---- KC: the two linear recursions, one 16-lane row per 13-vector.
-// A wave holds four vectors (lane = 16*row + m, m < 13 the component): the four sensitivity columns of ONE
-// time step t (they all start at k = t), or -- wave 32 -- the costate.  One step is a dense 13x13
-// matrix-vector product: the vector's components are broadcast inside each row with ds_swizzle (bit-mask
-// mode: lane' = (lane & 0x10) | n), the matrix row/column of lane m comes from LDS, 13 multiply-adds.  No
-// barrier, no assumption about the sparsity of df/dx.  (A first version ran one lane per column with the
-// whole vector in registers: 2000 cycles per step, 29 us; this one: ~300 cycles per step.)
-template <int N>
-__device__ __forceinline__ double row_bcast(double v)
-{
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (N << 5) | 0x10);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (N << 5) | 0x10);
-    return __hiloint2double(hi, lo);
-}
-// out[m] = sum_n M[m][n] v[n] (TRANSPOSE = false) or sum_n M[n][m] v[n] (true), M = jf[.][0..12] of a [13][17] block
-template <bool TRANSPOSE>
-__device__ __forceinline__ double row_matvec(const double *__restrict__ jf, int m, double v)
-{
-    double c[NX];
-#pragma unroll
-    for (int n = 0; n < NX; ++n) c[n] = (m < NX) ? (TRANSPOSE ? jf[n * NZ + m] : jf[m * NZ + n]) : 0.0;
-    double acc0 = 0.0, acc1 = 0.0;
-#define STEP(n)                                             \
-    if ((n) < NX) {                                         \
-        const double vn = row_bcast<((n) < NX ? (n) : 0)>(v); \
-        if ((n) & 1) acc1 = fma(c[(n) < NX ? (n) : 0], vn, acc1); \
-        else acc0 = fma(c[(n) < NX ? (n) : 0], vn, acc0);   \
-    }
-    STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12)
-#undef STEP
-    return acc0 + acc1;
-}
-
+// ---- KC: the two linear recursions on the matrix cores.
+// S_{k+1} = A_k S_k + B_k E_k is a (13x13).(13x128) product per step: wave w keeps a 16-column tile of S in
+// the MFMA C/D layout (lane (lo, hi), register g = row 4g + hi, column lo) -- which is exactly the B operand
+// of k-group g of the next step's v_mfma_f64_16x16x4_f64, so the tile never leaves its registers; A_k
+// (zero padded to 16x16) comes from LDS as the A operand.  The costate lam_k = grad r_k + A_k^T lam_{k+1} is
+// the same product with A^T and the vector in column 0 of a tile (wave 8).  ~330 cycles per step (four
+// dependent MFMAs + the MFMA -> operand hazard), 31 steps.  (One lane per column with the vector in
+// registers: 2000 cycles per step; 16-lane rows with ds_swizzle broadcasts: 1000.)
 __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
 {
     __shared__ double sjf[(HH - 1) * NX * NZ];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));  // 0..31: time step, 32: costate
+    __shared__ double sgl[HH * 16];
+    // one chain per WORKGROUP (the f64 MFMA pipe of a SIMD is not shared with another chain: nine chains in one
+    // workgroup put 76 steps on one SIMD); the four waves fill LDS together, wave 0 runs the chain
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
+    const int w = blockIdx.x;  // 0..7: column tile of S, 8: costate
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
     {
         // all global loads in flight before the first LDS store (a rolled loop pays one L2 latency per trip)
@@ -186,41 +164,87 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
         double vj[TJ];
 #pragma unroll
         for (int t = 0; t < TJ; ++t) vj[t] = (tid + 256 * t < NJ) ? ws[WS_JF + tid + 256 * t] : 0.0;
+        const double vg0 = ws[WS_GL + tid], vg1 = ws[WS_GL + 256 + tid];
 #pragma unroll
         for (int t = 0; t < TJ; ++t)
             if (tid + 256 * t < NJ) sjf[tid + 256 * t] = vj[t];
+        sgl[tid] = vg0;
+        sgl[256 + tid] = vg1;
     }
     __syncthreads();
-    const int m = lane & 15, row = lane >> 4;
-    if (w == HH) {
-        // ---- costate: lam_31 = grad r_31, lam_k = grad r_k + A_k^T lam_{k+1}; row 0 of the wave
-        if (row != 0) return;
-        const double *__restrict__ G = ws + WS_GL;
+    if (tid >= 64) return;
+    if (w == 8) {
+        // ---- costate: lam_31 = grad r_31, lam_k = grad r_k + A_k^T lam_{k+1}; the vector is column 0 of the tile
+        const double *__restrict__ G = sgl;  // grad r_k, staged in LDS: a global load per step would BE the step time
         double *__restrict__ L = ws + WS_LAM;
-        double lam = (m < NX) ? G[16 * (HH - 1) + m] : 0.0;
-        L[16 * (HH - 1) + m] = lam;
-        L[16 * HH + m] = 0.0;
-        double g = (m < NX) ? G[16 * (HH - 2) + m] : 0.0;
+        f64x4 lam;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lam[r] = (lo == 0 && hi + 4 * r < NX) ? G[16 * (HH - 1) + hi + 4 * r] : 0.0;
+        if (lo == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                L[16 * (HH - 1) + hi + 4 * r] = lam[r];
+                L[16 * HH + hi + 4 * r] = 0.0;
+            }
+        }
+        double an[4];
+        f64x4 gn;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[((HH - 2) * NX + 4 * g + hi) * NZ + lo] : 0.0;  // A^T[lo][4g+hi]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gn[r] = (lo == 0 && hi + 4 * r < NX) ? G[16 * (HH - 2) + hi + 4 * r] : 0.0;
         for (int k = HH - 2; k >= 1; --k) {
-            const double gk = g;
-            if (k > 1) g = (m < NX) ? G[16 * (k - 1) + m] : 0.0;  // next step's gradient in flight
-            lam = gk + row_matvec<true>(sjf + k * NX * NZ, m, lam);
-            L[16 * k + m] = lam;
+            double ac[4];
+            f64x4 acc = gn;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = an[g];
+            if (k > 1) {  // next step's operands in flight
+#pragma unroll
+                for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[((k - 1) * NX + 4 * g + hi) * NZ + lo] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gn[r] = (lo == 0 && hi + 4 * r < NX) ? G[16 * (k - 1) + hi + 4 * r] : 0.0;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g], lam[g], acc, 0, 0, 0);
+            lam = acc;
+            if (lo == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L[16 * k + hi + 4 * r] = lam[r];
+            }
         }
         return;
     }
-    if (w > HH) return;
-    // ---- sensitivities of the four actions of step t = w: S_k[:, i] = 0 for k <= t, B_t[:, d] at k = t + 1,
-    // A_k S_k[:, i] afterwards.  Rows 13..15 of every S_k are zero (lanes m >= 13 carry zeros).
-    const int t = w, i = 4 * t + row;
+    // ---- sensitivities: tile w = columns 16w .. 16w+15 = the actions of steps 4w .. 4w+3; S_k tile = 0 for k <= 4w
+    const int col = 16 * w + lo, tcol = col >> 2, dcol = col & 3, k0 = 4 * w;
     double *__restrict__ S = ws + WS_S;
-    for (int k = 0; k <= t; ++k) S[((size_t)k * 16 + m) * NA + i] = 0.0;
-    if (t >= HH - 1) return;
-    double s = (m < NX) ? sjf[(t * NX + m) * NZ + NX + row] : 0.0;  // B_t[m][d = row]
-    S[((size_t)(t + 1) * 16 + m) * NA + i] = s;
-    for (int k = t + 1; k < HH - 1; ++k) {
-        s = row_matvec<false>(sjf + k * NX * NZ, m, s);
-        S[((size_t)(k + 1) * 16 + m) * NA + i] = s;
+    for (int k = 0; k <= k0; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[((size_t)k * 16 + hi + 4 * r) * NA + col] = 0.0;
+    }
+    f64x4 sv = {0.0, 0.0, 0.0, 0.0};
+    double an[4];
+    f64x4 bn;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[(k0 * NX + lo) * NZ + 4 * g + hi] : 0.0;  // A[lo][4g+hi]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bn[r] = (tcol == k0 && hi + 4 * r < NX) ? sjf[(k0 * NX + hi + 4 * r) * NZ + NX + dcol] : 0.0;  // B_k E_k
+    for (int k = k0; k < HH - 1; ++k) {
+        double ac[4];
+        f64x4 acc = bn;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ac[g] = an[g];
+        if (k + 1 < HH - 1) {  // next step's operands in flight
+#pragma unroll
+            for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[((k + 1) * NX + lo) * NZ + 4 * g + hi] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bn[r] = (tcol == k + 1 && hi + 4 * r < NX) ? sjf[((k + 1) * NX + hi + 4 * r) * NZ + NX + dcol] : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g], sv[g], acc, 0, 0, 0);
+        sv = acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[((size_t)(k + 1) * 16 + hi + 4 * r) * NA + col] = sv[r];
     }
 }
 
@@ -361,10 +385,10 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.ws = reinterpret_cast<double *>(workspace);
     A.T = T;
     A.c = make_consts<double>(p);
-    hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
-    hipLaunchKernelGGL(adj_chain_kernel, dim3(9, batch), dim3(256), 0, s, A);
-    hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);
-    hipLaunchKernelGGL(adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);
+    if (g_dbg_hess_mask & 1) hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
+    if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(adj_chain_kernel, dim3(9, batch), dim3(256), 0, s, A);
+    if (g_dbg_hess_mask & 4) hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);
+    if (g_dbg_hess_mask & 8) hipLaunchKernelGGL(adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -40,7 +40,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int SN = COVO_NA;  // 128
 constexpr int NS_SQUARINGS = 16;   // X^(2^16): a relative gap of 2e-4 between the bottom eigenvalue and the 5th one
                                    // (RITZ = 4 are resolved exactly by the Ritz step) is damped to 1e-11
-constexpr int NS_ITERS = 14;       // scaled iteration: 10 for s/1e-2 = 2e4 (CoVO Hessians), 12 for 1e6; launches after
+constexpr int NS_ITERS = 12;       // scaled iteration: 8 for s/1e-2 = 1e3 (real CoVO Hessians), 10 for 2e4, 12 for 1e6; launches after
                                    // convergence return at once (1.6 us each)
 constexpr double NS_TOL2 = 1e-10;  // iteration k+1 is skipped once |I - Z_k Y_k|_F^2 < 1e-10: step k itself squares
                                    // that residual to ~1e-20, far below the fp32 rounding Sigma gets anyway
@@ -604,7 +604,9 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         hipLaunchKernelGGL(ns_square_kernel<false>, dim3(NS_TILES, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0);
         double *t = xi; xi = xo; xo = t;
     }
+    if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc);
+    if (g_dbg_sigma_stages < 3) return 0;
     hipLaunchKernelGGL(ns_first_kernel, dim3(64, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);
     for (int i = 1; i < NS_ITERS; ++i) {
         const int in = i & 1, out = in ^ 1;
@@ -612,6 +614,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         hipLaunchKernelGGL(ns_YZ_kernel, dim3(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
                            Zt[out], sc, i, out);
     }
+    if (g_dbg_sigma_stages < 4) return 0;
     hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma, Sigma, L);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;

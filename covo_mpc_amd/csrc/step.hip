@@ -77,21 +77,25 @@ void step_state_destroy(covo_ctx *h)
     h->step = nullptr;
 }
 
+int g_dbg_hess_mask = 15, g_dbg_sigma_stages = 4;
+static int g_dbg_step_mask = 63;  // 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
+
 // the launch sequence of one step (everything reads per-step scalars from st->dyn)
 static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, const covo_step_args &a, hipStream_t s)
 {
+    const int M = g_dbg_step_mask;
     const int N = a.n_samples;
     const float *fdev = reinterpret_cast<const float *>(st->dyn + 2);
     float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
     int rc;
-    if ((rc = launch_shift_mean(a.a_mean, am_shift, s))) return rc;               // covo.py:201-203
+    if ((M & 1) && (rc = launch_shift_mean(a.a_mean, am_shift, s))) return rc;               // covo.py:201-203
     if (a.mode == COVO_MODE_COVO_ONLINE) {
-        if ((rc = launch_hessian(a.state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
+        if ((M & 2) && (rc = launch_hessian(a.state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
-        if ((rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
-        if ((rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
+        if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
+        if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
     } else if (a.mode == COVO_MODE_COVO_OFFLINE) {
-        if ((rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, a.state,
+        if ((M & 8) && (rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, a.state,
                                     a.n_table)))
             return rc;
     } else {  // MPPI: shift a_cov, factor the 4x4 blocks, per-step draws (mppi.py:43-66)
@@ -101,9 +105,10 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
     }
     const bool clipped = true;  // a comes straight from the noise kernels above
-    if ((rc = launch_rollout(a.state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
-                             a.groupmin, a.pos_stats, h->ws_stats, s, fdev)))
+    if ((M & 16) && (rc = launch_rollout(a.state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
+                                         a.groupmin, a.pos_stats, h->ws_stats, s, fdev)))
         return rc;
+    if (!(M & 32)) return 0;
     // weights + update: finish locally, or leave this shard's record for the all-gather (covo.py:266-275)
     if (a.partial_out != nullptr)
         return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, a.partial_out, nullptr, 1.0f, nullptr, s);
@@ -169,4 +174,56 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     st->key = k;
     st->have_key = true;
     return enqueue_step(h, st, *params, *args, s);
+}
+
+
+// ---- profiling aid: `reps` copies of the selected part of one step captured into ONE graph and replayed; returns
+// the average time per copy (GPU time between two events around the replay).  Inside a graph the launches cost
+// what they cost in the product (no host launch overhead, no profiler inflation).  step_mask: enqueue_step's
+// phases; hess_mask / sigma_stages: see covo_common.hpp.  The step must have been called once before (scratch).
+int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, int step_mask,
+                              int hess_mask, int sigma_stages, int reps, float *us_out, hipStream_t run)
+{
+    if (!h->step) {
+        int rc = step_state_init(h);
+        if (rc) return rc;
+    }
+    StepState *st = reinterpret_cast<StepState *>(h->step);
+    hipStream_t cs = h->side_stream;
+    g_dbg_step_mask = step_mask;
+    g_dbg_hess_mask = hess_mask;
+    g_dbg_sigma_stages = sigma_stages;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    int rc = 0;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        for (int r = 0; r < reps && !rc; ++r) rc = enqueue_step(h, st, *params, *args, cs);
+        e = hipStreamEndCapture(cs, &g);
+    }
+    g_dbg_step_mask = 63;
+    g_dbg_hess_mask = 15;
+    g_dbg_sigma_stages = 4;
+    if (rc) return rc;
+    COVO_CHECK_HIP(e);
+    COVO_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t e0, e1;
+    COVO_CHECK_HIP(hipEventCreate(&e0));
+    COVO_CHECK_HIP(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        COVO_CHECK_HIP(hipEventRecord(e0, run));
+        COVO_CHECK_HIP(hipGraphLaunch(ge, run));
+        COVO_CHECK_HIP(hipEventRecord(e1, run));
+        COVO_CHECK_HIP(hipStreamSynchronize(run));
+        float ms = 0.f;
+        COVO_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0 && ms < best) best = ms;
+    }
+    *us_out = best * 1e3f / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+    return 0;
 }

@@ -246,6 +246,13 @@ int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_ste
  * factorisation inside jax.random.multivariate_normal (covo.py:216, mppi.py:59). */
 int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, float *L_out, void *stream);
 
+/* Profiling aid: `reps` copies of the selected launches of one control step, captured into one hipGraph and
+ * replayed; *us_out = GPU microseconds per copy.  step_mask bits: 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM,
+ * 16 rollout, 32 softmax update; hess_mask bits: the four kernels of the adjoint Hessian; sigma_stages 1..4:
+ * prep+squarings, +Ritz, +Newton-Schulz, +finalize.  Uses the buffers in `args` exactly like covo_mpc_step. */
+int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
+                         int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

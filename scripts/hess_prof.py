@@ -18,9 +18,11 @@ am = torch.from_numpy(a.reshape(-1)).cuda()
 for _ in range(3):
     Rm = core.hessian(ds.packed, ds, EnvParams3D().to_c(), am)
 torch.cuda.synchronize()
-WS_GL = 32 * 16 + 32 * 13 * 17
-out = torch.zeros(64, dtype=torch.float64).pin_memory()
-_lib.check(core.lib.covo_debug_hess_workspace(core.h, _lib.ptr(out), WS_GL, 64, core.stream()))
+WS_LAM = 32 * 16 + 32 * 13 * 17 + 32 * 16
+out = torch.zeros(33 * 16, dtype=torch.float64).pin_memory()
+_lib.check(core.lib.covo_debug_hess_workspace(core.h, _lib.ptr(out), WS_LAM, 33 * 16, core.stream()))
 torch.cuda.synchronize()
-o = out.numpy()
-print("fill %.0f  lambda-end %.0f  S-end wave1 %.0f  wave2 %.0f   (ticks)" % (o[13], o[14], o[16 + 13], o[32 + 13]))
+o = out.numpy().reshape(33, 16)
+print("wave: after-fill / end (ticks)")
+for w in range(9):
+    print(w, int(o[w, 13]), int(o[w, 14]))
