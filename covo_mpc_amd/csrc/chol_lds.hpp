@@ -87,7 +87,7 @@ __device__ void chol_lds_fast(double *A, int n, int ld, int tid, int nthreads)
 // Column-major with stride ld (element (r, c) at A[c*ld + r]); only the lower triangle is referenced/valid.
 typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
 #ifdef CHOL_PROBE
-__device__ long long chol_prof[4];
+__device__ long long chol_prof[32];
 #define CHOL_STAMP(i, expr) do { if (tid == 0) chol_prof[i] += (expr); } while (0)
 __device__ __forceinline__ long long chol_tick() { __builtin_amdgcn_sched_barrier(0); long long t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); return t; }
 #define CHOL_CLOCK() chol_tick()
@@ -114,7 +114,8 @@ __device__ __forceinline__ void chol_tri(int t, int &a, int &b)
     b = t - a * (a + 1) / 2;
 }
 
-__device__ void chol128_lds_mfma(double *A, int ld, int tid)
+template <int ld>  // compile-time stride: every LDS address is base + immediate
+__device__ void chol128_lds_mfma(double *A, int tid)
 {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lo = lane & 15, hi = lane >> 4;
     double maskg[4];
@@ -122,7 +123,7 @@ __device__ void chol128_lds_mfma(double *A, int ld, int tid)
     for (int g = 0; g < 4; ++g) maskg[g] = (hi == g) ? 1.0 : 0.0;
     __syncthreads();
 #ifdef CHOL_PROBE
-    if (tid == 0) chol_prof[0] = chol_prof[1] = chol_prof[2] = chol_prof[3] = 0;
+    if (tid == 0) for (int q = 0; q < 32; ++q) chol_prof[q] = 0;
 #endif
     for (int p = 0; p < 8; ++p) {
         const long long c0 = CHOL_CLOCK();
@@ -229,7 +230,8 @@ __device__ void chol128_lds_mfma(double *A, int ld, int tid)
         }
         __syncthreads();
         CHOL_STAMP(0, c2 - c1);
-        CHOL_STAMP(1, CHOL_CLOCK() - c3);
+        CHOL_STAMP(16 + p, c2 - c1);
+        { const long long c4 = CHOL_CLOCK(); (void)c4; CHOL_STAMP(1, c4 - c3); CHOL_STAMP(8 + p, c4 - c3); }
         CHOL_STAMP(2, c1 - c0);
         CHOL_STAMP(3, c3 - c2);
     }

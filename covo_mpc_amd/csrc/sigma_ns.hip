@@ -270,14 +270,20 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
                                                       const double *__restrict__ X1all, double *__restrict__ scall)
 {
     __shared__ double V[RITZ][SN];
-    __shared__ double AV[RITZ][SN];
+    __shared__ double AVp[4][RITZ][SN];  // partial A V over the four column quarters
     __shared__ double H[RITZ][RITZ];
-    __shared__ double red[SN];
+    __shared__ double red[2];
     __shared__ double sh_delta;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *A = Aall + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
     const double *X = ((s[SC_XBUF] != 0.0) ? X1all : X0all) + (size_t)b * SN * SN;
+    // A V, first half of the work: thread (r = tid & 127, cq = tid >> 7) owns A[32 cq .. 32 cq + 31][r]; the 32 loads
+    // are issued now and land while wave 0 builds V
+    const int r_av = tid & (SN - 1), cq = tid >> 7;
+    double acol[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acol[c] = A[(size_t)(32 * cq + c) * SN + r_av];  // A symmetric: coalesced in r
     if (tid < 64) {
         // ---- wave 0: pick the RITZ largest diagonal entries, orthonormalise those columns (two-pass MGS,
         // everything in registers: lane l owns rows l and l+64; reductions on the VALU)
@@ -286,15 +292,10 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         int pick_k[RITZ];
 #pragma unroll
         for (int k = 0; k < RITZ; ++k) {
-            // argmax over 128 values: max via butterfly on (value, index) pairs
-            double bv = (d0 >= d1) ? d0 : d1;
-            int bi = (d0 >= d1) ? lane : lane + 64;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
+            // argmax over 128 values: wave maximum (DPP), then the first lane/slot holding it
+            const double mx = wr::wave64_allmax(fmax(d0, d1));
+            const unsigned long long m0 = __ballot(d0 == mx), m1 = __ballot(d1 == mx);
+            const int bi = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
             pick_k[k] = bi;
             if (bi == lane) d0 = -1e300;
             if (bi == lane + 64) d1 = -1e300;
@@ -311,9 +312,9 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
                     v[k][0] = fma(-dot, v[j][0], v[k][0]);
                     v[k][1] = fma(-dot, v[j][1], v[k][1]);
                 }
-            const double nrm = sqrt(wr::wave64_allsum(fma(v[k][0], v[k][0], v[k][1] * v[k][1])));
-            if (nrm > 1e-280) {
-                const double inv = 1.0 / nrm;
+            const double n2 = wr::wave64_allsum(fma(v[k][0], v[k][0], v[k][1] * v[k][1]));
+            if (n2 > 1e-280) {
+                const double inv = qm::rsq64_(n2);
                 v[k][0] *= inv;
                 v[k][1] *= inv;
             } else {  // column numerically inside the span of the previous ones: any unit vector will do
@@ -325,27 +326,30 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         }
     }
     __syncthreads();
-    // AV = A V (A symmetric: column reads are coalesced), then H = V^T A V
+    // A V: partial sums over this thread's column quarter, then H = V^T A V from the four partials
     {
-        const int r = tid & (SN - 1), k = tid >> 7;  // 4 groups of 128 threads, one Ritz vector each
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < SN; c += 2) {
-            a0 = fma(A[(size_t)c * SN + r], V[k][c], a0);
-            a1 = fma(A[(size_t)(c + 1) * SN + r], V[k][c + 1], a1);
+        double av[RITZ] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+#pragma unroll
+            for (int k = 0; k < RITZ; ++k) av[k] = fma(acol[c], V[k][32 * cq + c], av[k]);
         }
-        AV[k][r] = a0 + a1;
+#pragma unroll
+        for (int k = 0; k < RITZ; ++k) AVp[cq][k][r_av] = av[k];
     }
     __syncthreads();
 #pragma unroll
     for (int e = 2 * wave; e < 2 * wave + 2; ++e) {  // 8 waves x 2 entries of H
         const int i = e / RITZ, j = e % RITZ;
-        const double d = wr::wave64_allsum(fma(V[i][lane], AV[j][lane], V[i][lane + 64] * AV[j][lane + 64]));
+        const double a0 = (AVp[0][j][lane] + AVp[1][j][lane]) + (AVp[2][j][lane] + AVp[3][j][lane]);
+        const double a1 = (AVp[0][j][lane + 64] + AVp[1][j][lane + 64]) + (AVp[2][j][lane + 64] + AVp[3][j][lane + 64]);
+        const double d = wr::wave64_allsum(fma(V[i][lane], a0, V[i][lane + 64] * a1));
         if (lane == 0) H[i][j] = d;
     }
     __syncthreads();
     if (tid == 0) {
-        // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, eigenvalues only, exits when diagonal)
+        // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, eigenvalues only, exits when diagonal);
+        // reciprocals / square roots by hardware seed + Newton (qm::rcp64_, qm::rsq64_), not libm
         double h[RITZ][RITZ];
         for (int i = 0; i < RITZ; ++i)
             for (int j = 0; j < RITZ; ++j) h[i][j] = 0.5 * (H[i][j] + H[j][i]);
@@ -357,9 +361,10 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
             for (int p = 0; p < RITZ - 1; ++p)
                 for (int q2 = p + 1; q2 < RITZ; ++q2) {
                     if (h[p][q2] * h[p][q2] <= 1e-34 * fabs(h[p][p] * h[q2][q2])) continue;
-                    const double zeta = (h[q2][q2] - h[p][p]) / (2.0 * h[p][q2]);
-                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                    const double zeta = (h[q2][q2] - h[p][p]) * 0.5 * qm::rcp64_(h[p][q2]);
+                    const double z2 = fma(zeta, zeta, 1.0);
+                    const double t = copysign(1.0, zeta) * qm::rcp64_(fabs(zeta) + z2 * qm::rsq64_(z2));
+                    const double c = qm::rsq64_(fma(t, t, 1.0)), sn = c * t;
                     for (int k = 0; k < RITZ; ++k) {  // columns
                         const double hp = h[k][p], hq = h[k][q2];
                         h[k][p] = c * hp - sn * hq;
@@ -383,22 +388,19 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     // Gershgorin bound of B = A + delta I from the row sums of A: only the diagonal term changes
     if (tid < SN) {
         const double dg = s[SC_DIAG + tid];
-        red[tid] = s[SC_ROWABS + tid] - fabs(dg) + fabs(dg + delta);
+        const double m = wr::wave64_allmax(s[SC_ROWABS + tid] - fabs(dg) + fabs(dg + delta));
+        if (lane == 0) red[wave] = m;
     }
     __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
-        __syncthreads();
-    }
     if (tid == 0) {
         const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, s[SC_TRACE], s[SC_FRO2]));  // |A + delta I|_F^2
-        const double scale = fmin(red[0], sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
+        const double scale = fmin(fmax(red[0], red[1]), sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
         s[SC_SCALE] = scale;
         // Chen-Chow scaled Newton-Schulz: x -> x (a + b x^2) on [l, 1] with a = 1.5 rho, b = -0.5 rho^3,
         // rho^2 = 3/(1 + l + l^2) (equal values at both ends of the interval); lambda_min(Y0) = 1e-2/scale
         double l = sqrt(1e-2 / scale);
         for (int k = 0; k < NS_ITERS; ++k) {
-            double rho = (l < 1.0 - 1e-9) ? sqrt(3.0 / (1.0 + l + l * l)) : 1.0;
+            const double rho = (l < 1.0 - 1e-9) ? 1.7320508075688772 * qm::rsq64_(1.0 + l + l * l) : 1.0;
             const double a = 1.5 * rho, bq = -0.5 * rho * rho * rho;
             s[SC_COEF + 2 * k] = a;
             s[SC_COEF + 2 * k + 1] = bq;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     }
     __syncthreads();
     tk[1] = clock64();
-    chol128_lds_mfma(sm, LD, tid);
+    chol128_lds_mfma<LD>(sm, tid);
     tk[2] = clock64();
     red[tid] = (tid < SN) ? log(sm[tid * LD + tid]) : 0.0;
     __syncthreads();

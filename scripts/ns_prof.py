@@ -33,8 +33,11 @@ for name, Rm in mats.items():
     out = out_t.numpy()
     print(f"== {name}: covo_sigma eager {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
     print("   " + "  ".join(f"{k}={out[i]:.6g}" for i, k in enumerate(names)))
-    t = out[16:23]
-    lab = ["load Z", "chol(Z)", "logdet+scalars", "fill Sigma32", "chol(Sigma)", "store L"]
-    print("   finalize: " + "  ".join(f"{lab[i]} {10 * (t[i + 1] - t[i]) / 1e3:.1f}us" for i in range(6)))
+    t = out[16:21]
+    lab = ["load Z", "chol(Z)", "logdet+scalars", "outputs"]
+    print("   finalize (s_memtime ticks ~ core cycles): " + "  ".join(f"{lab[i]} {t[i + 1] - t[i]:.0f}" for i in range(4)))
+    t = out[24:30]
+    lab = ["pick+MGS", "A V", "H", "4x4 Jacobi", "scale+coef"]
+    print("   ritz: " + "  ".join(f"{lab[i]} {t[i + 1] - t[i]:.0f}" for i in range(5)))
     w_ = np.linalg.eigvalsh(0.5 * (Rm + Rm.T))
     print(f"   lmin err {out[1] - w_[0]:.3e}")

@@ -8,7 +8,7 @@
 #define CHOL_PROBE 1
 #include "../../covo_mpc_amd/csrc/chol_lds.hpp"
 
-constexpr int N = 128, LD = 129;
+constexpr int N = 128, LD = 144;
 
 template <int VARIANT>
 __global__ __launch_bounds__(512) void chol_k(const double *__restrict__ Ain, double *__restrict__ Lout, long long *stamps)
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(512) void chol_k(const double *__restrict__ Ain, do
     __syncthreads();
     const long long t0 = clock64();
     if (VARIANT == 0) chol_lds_fast(sm, N, LD, tid, 512);
-    else chol128_lds_mfma(sm, LD, tid);
+    else chol128_lds_mfma<LD>(sm, tid);
     const long long t1 = clock64();
     for (int e = tid; e < N * N; e += 512) {
         const int r = e / N, c = e % N;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(512) void chol_k(const double *__restrict__ Ain, do
     }
     if (tid == 0) {
         stamps[0] = t1 - t0;
-        for (int i = 0; i < 4; ++i) stamps[1 + i] = chol_prof[i];
+        for (int i = 0; i < 24; ++i) stamps[1 + i] = chol_prof[i];
     }
 }
 
@@ -50,13 +50,14 @@ void run(const char *name, const double *dA, double *dL, long long *dS, const st
         if (ms < best) best = ms;
     }
     std::vector<double> L(N * N);
-    long long st[8];
+    long long st[32];
     hipMemcpy(L.data(), dL, N * N * 8, hipMemcpyDeviceToHost);
     hipMemcpy(st, dS, sizeof(st), hipMemcpyDeviceToHost);
     double err = 0, nrm = 0;
     for (int i = 0; i < N * N; ++i) { err = fmax(err, fabs(L[i] - ref[i])); nrm = fmax(nrm, fabs(ref[i])); }
     printf("%-10s kernel %7.2f us   chol %8lld ticks  [factor %lld  syrk %lld  load %lld store %lld]  max err %.3e (rel %.3e)\n", name, best * 1e3, st[0],
            st[1], st[2], st[3], st[4], err, err / nrm);
+    if (VARIANT) { printf("   syrk per panel:"); for (int q = 0; q < 8; ++q) printf(" %lld", st[9 + q]); printf("\n   factor per panel:"); for (int q = 0; q < 8; ++q) printf(" %lld", st[17 + q]); printf("\n"); }
 }
 
 int main()
@@ -86,7 +87,7 @@ int main()
     long long *dS;
     hipMalloc(&dA, N * N * 8);
     hipMalloc(&dL, N * N * 8);
-    hipMalloc(&dS, 64);
+    hipMalloc(&dS, 256);
     hipMemcpy(dA, A.data(), N * N * 8, hipMemcpyHostToDevice);
     run<0>("valu-p8", dA, dL, dS, ref);
     run<1>("mfma-p16", dA, dL, dS, ref);
