@@ -166,15 +166,18 @@ class SamplingCore:
         """covo_mpc_step: returns (a_mean_new, a_cov_out) as views of persistent buffers (clone to keep).
         Inputs are copied into fixed-address buffers so the captured graph stays valid."""
         torch = self.torch
-        state_buf = self._persistent("state", (_lib.COVO_STATE_FLOATS,))
-        state_buf.copy_(dstate.packed, non_blocking=True)
+        # the state is read through a pointer that travels with the per-step scalars (step.hip): no copy, and a
+        # new address does not invalidate the captured graph.  The tensor must stay alive until the step has run.
+        packed = dstate.packed
+        assert packed.is_contiguous() and packed.dtype == torch.float32 and packed.numel() == _lib.COVO_STATE_FLOATS
+        self._state_ref = packed
         am = self._persistent("a_mean", (COVO_NA,))
         if a_mean.data_ptr() != am.data_ptr():
             am.copy_(a_mean.reshape(-1), non_blocking=True)
         am_shift = self._persistent("a_mean_shift", (COVO_NA,))
         args = _lib.StepArgsC()
         args.mode, args.n_samples, args.T = mode, self.n_local, dstate.T
-        args.state, args.pos_traj, args.vel_traj = state_buf.data_ptr(), dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr()
+        args.state, args.pos_traj, args.vel_traj = packed.data_ptr(), dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr()
         args.a_mean, args.a_mean_shift = am.data_ptr(), am_shift.data_ptr()
         cov_out = None
         if mode == _lib.MODE_COVO_ONLINE:

@@ -17,6 +17,20 @@ __global__ void shift_cov_kernel(const float *__restrict__ in, float *__restrict
 }
 __global__ void copy512_kernel(const float *__restrict__ in, float *__restrict__ out) { out[threadIdx.x] = in[threadIdx.x]; }
 
+// first launch of every step: shift the mean (covo.py:201-203) and bring this step's state into the fixed-address
+// buffer the captured launches read (its address changes from step to step and travels in the dyn block)
+__global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
+                                  const uint32_t *__restrict__ dyn, float *__restrict__ state_buf)
+{
+    const int i = threadIdx.x;  // 128 + 32 threads
+    if (i < COVO_NA) {
+        a_mean_shift[i] = (i < COVO_NA - COVO_DU) ? a_mean[i + COVO_DU] : a_mean[i];
+    } else {
+        const float *src = *reinterpret_cast<const float *const *>(dyn + 8);
+        state_buf[i - COVO_NA] = src[i - COVO_NA];
+    }
+}
+
 struct StepKey {
     covo_step_args args;
     covo_env_params params;
@@ -25,7 +39,8 @@ struct StepKey {
 
 struct StepState {
     // device
-    uint32_t *dyn;        // {key0, key1, f_shared[3] as float bits, pad[3]}
+    uint32_t *dyn;        // {key0, key1, f_shared[3] as float bits, pad[3], state pointer (8 bytes)}
+    float *state_buf;     // [COVO_STATE_FLOATS] this step's state at a fixed address
     float *a_mean_shift;  // [128]
     double *R;            // [128][128]
     float *Sigma, *L;     // [128][128]
@@ -39,20 +54,21 @@ struct StepState {
     hipGraph_t graph;
     hipGraphExec_t exec;
 };
-constexpr int DYN_RING = 256;
+constexpr int DYN_RING = 256, DYN_BYTES = 48, DYN_WORDS = DYN_BYTES / 4;
 
 static int step_state_init(covo_ctx *h)
 {
     StepState *st = new StepState();
     std::memset(st, 0, sizeof(*st));
-    COVO_CHECK_HIP(hipMalloc(&st->dyn, 32));
+    COVO_CHECK_HIP(hipMalloc(&st->dyn, DYN_BYTES));
+    COVO_CHECK_HIP(hipMalloc(&st->state_buf, COVO_STATE_FLOATS * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->a_mean_shift, COVO_NA * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->R, (size_t)COVO_NA * COVO_NA * sizeof(double)));
     COVO_CHECK_HIP(hipMalloc(&st->Sigma, (size_t)COVO_NA * COVO_NA * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->L, (size_t)COVO_NA * COVO_NA * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->cov_shift, COVO_H * 16 * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->Ls, COVO_H * 16 * sizeof(float)));
-    COVO_CHECK_HIP(hipHostMalloc((void **)&st->dyn_host, (size_t)DYN_RING * 32, hipHostMallocDefault));
+    COVO_CHECK_HIP(hipHostMalloc((void **)&st->dyn_host, (size_t)DYN_RING * DYN_BYTES, hipHostMallocDefault));
     h->step = st;
     return 0;
 }
@@ -66,6 +82,7 @@ void step_state_destroy(covo_ctx *h)
         (void)hipGraphDestroy(st->graph);
     }
     (void)hipFree(st->dyn);
+    (void)hipFree(st->state_buf);
     (void)hipFree(st->a_mean_shift);
     (void)hipFree(st->R);
     (void)hipFree(st->Sigma);
@@ -88,14 +105,15 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     const float *fdev = reinterpret_cast<const float *>(st->dyn + 2);
     float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
     int rc;
-    if ((M & 1) && (rc = launch_shift_mean(a.a_mean, am_shift, s))) return rc;               // covo.py:201-203
+    const float *state = st->state_buf;
+    if (M & 1) hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS), 0, s, a.a_mean, am_shift, st->dyn, st->state_buf);
     if (a.mode == COVO_MODE_COVO_ONLINE) {
-        if ((M & 2) && (rc = launch_hessian(a.state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
+        if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
         if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
         if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
     } else if (a.mode == COVO_MODE_COVO_OFFLINE) {
-        if ((M & 8) && (rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, a.state,
+        if ((M & 8) && (rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, state,
                                     a.n_table)))
             return rc;
     } else {  // MPPI: shift a_cov, factor the 4x4 blocks, per-step draws (mppi.py:43-66)
@@ -105,7 +123,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
     }
     const bool clipped = true;  // a comes straight from the noise kernels above
-    if ((M & 16) && (rc = launch_rollout(a.state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
+    if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
                                          a.groupmin, a.pos_stats, h->ws_stats, s, fdev)))
         return rc;
     if (!(M & 32)) return 0;
@@ -125,7 +143,7 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     }
     StepState *st = reinterpret_cast<StepState *>(h->step);
     // per-step scalars -> device block (pinned ring slot so the async copy never races the next call's write)
-    uint32_t *slot = st->dyn_host + (size_t)st->ring_pos * 8;
+    uint32_t *slot = st->dyn_host + (size_t)st->ring_pos * DYN_WORDS;
     st->ring_pos = (st->ring_pos + 1) % DYN_RING;
     slot[0] = key0;
     slot[1] = key1;
@@ -133,11 +151,13 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
         const float f = f_shared ? f_shared[i] : 0.0f;
         std::memcpy(&slot[2 + i], &f, 4);
     }
-    COVO_CHECK_HIP(hipMemcpyAsync(st->dyn, slot, 32, hipMemcpyHostToDevice, s));
+    std::memcpy(&slot[8], &args->state, sizeof(const float *));
+    COVO_CHECK_HIP(hipMemcpyAsync(st->dyn, slot, DYN_BYTES, hipMemcpyHostToDevice, s));
 
     StepKey k;
     std::memset(&k, 0, sizeof(k));
     k.args = *args;
+    k.args.state = nullptr;  // read through the dyn block: a new state address does not invalidate the graph
     k.params = *params;
     k.stream = s;
     const bool same = st->have_key && std::memcmp(&k, &st->key, sizeof(k)) == 0;
