@@ -13,8 +13,9 @@ the sample axis is sharded (N/G per GPU, "strong" scaling: total work fixed) and
 132-float online-softmax records crosses xGMI per step.
 
 Rank 0 prints ONE JSON line with `roofline` (the fused rollout kernel, HBM bound, 516 B/sample
-algorithmic, duration measured with events on the launch stream inside the timed region) and, at
-N=1, `cpu_baseline` (the plain-C oracle port of the same sampling step on the host cores).
+algorithmic, launch duration measured live with events on the launch stream; `traffic` from the committed
+PMC passes of this command) and, at N=1, `cpu_baseline` (the plain-C oracle port of the same sampling
+step on the host cores).
 """
 from __future__ import annotations
 
@@ -81,6 +82,17 @@ def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
             "sample": f"{n_done} full-size control steps (N={N}, H={H}) of the C oracle port: fp32 noise GEMM + rollout + "
                       f"softmax update with OpenMP over samples, + fp64 LAPACK eigh/cholesky for Sigma; the Hessian "
                       f"(jacfwd^2, covo.py:134-185) is NOT included in the CPU figure; {el:.1f} s of CPU work"}
+
+
+def pmc_traffic(n_local):
+    """HBM-side bytes per rollout launch from the committed rocprofv3 --pmc passes of this command
+    (profiles/r01_bench_pmc_summary.json, scripts/pmc_summary.py); null when the shard size differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")) as f:
+            d = json.load(f)
+        return d["traffic_bytes_per_launch"] if n_local == 65536 else None
+    except Exception:
+        return None
 
 
 def main():
@@ -163,8 +175,9 @@ def main():
     # The rollout kernel of the timed steps runs inside the fused step (one hipGraph replay per step) and
     # cannot be bracketed individually from the host.  Its launch duration is measured here, right after the
     # timed region, with events on the launch stream over back-to-back launches of the SAME kernel on the
-    # SAME buffers (the action stripes the last step's GEMM left in HBM/L2); the rocprofv3 kernel-trace of
-    # this command (profiles/) gives the in-step average of the same kernel for cross-checking.
+    # SAME buffers; `in_step_us` is the graph-replay time of the (noise GEMM -> rollout) pair minus the GEMM
+    # alone (covo_debug_time_step: 20 copies in one graph), i.e. the rollout reading stripes the GEMM has
+    # just written.  The rocprofv3 kernel-trace of this command (profiles/) gives the same kernel's average.
     reps = 50
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     pc = params.to_c()
@@ -176,6 +189,12 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     rollout_b2b_ms = e0.elapsed_time(e1) / reps
+    in_step_us = None
+    if world == 1:
+        try:
+            in_step_us = core.time_phases(8 | 16) - core.time_phases(8)
+        except Exception:
+            in_step_us = None
 
     if rank == 0:
         n_local = core.n_local
@@ -191,8 +210,9 @@ def main():
                        "controller": args.controller, "N_global": args.N, "N_local": n_local, "H": H,
                        "pos_stats_info": bool(args.info)},
             "roofline": {"bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_us": 1e3 * rollout_b2b_ms},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_local),
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_us": 1e3 * rollout_b2b_ms,
+                         "in_step_us": in_step_us},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_states, params, args.N, H, args.lam, args.cpu_budget)
