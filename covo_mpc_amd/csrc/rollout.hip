@@ -26,6 +26,7 @@ struct RolloutArgs {
     float discount;
     float f_shared[3];
     const float *f_shared_dev;  // nullable: {fx, fy, fz} in device memory (graph replays), overrides f_shared
+    int xcd_remap;              // 1: workgroup -> sample chunks follow the noise GEMM's XCD placement (see kernel)
     qm::Consts<float> c;
 };
 
@@ -48,7 +49,12 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
     const float *__restrict__ st = A.state;
     const int time0 = __float_as_int(st[ST_TIME]);
 
-    const int n_raw = blockIdx.x * RO_BLOCK + tid;
+    // XCD affinity (speed only, never correctness): the noise GEMM's workgroup g writes the stripes of samples
+    // [128 g, 128 g + 128) and runs on XCD g % 8 (observed dispatch order); this workgroup (XCD blockIdx % 8) takes
+    // the two 128-sample chunks g = x + 16 i and x + 16 i + 8 (x = blockIdx % 8, i = blockIdx / 8), so its reads hit
+    // the 4 MiB L2 that has just absorbed those writes instead of going out to HBM.  Needs N % 2048 == 0.
+    int n_raw = blockIdx.x * RO_BLOCK + tid;
+    if (A.xcd_remap) n_raw = 128 * ((int)(blockIdx.x & 7) + 16 * (int)(blockIdx.x >> 3) + 8 * (tid >> 7)) + (tid & 127);
     const bool valid = n_raw < A.N;
     const int n = valid ? n_raw : A.N - 1;
     const float4 *__restrict__ ap = A.a + n;
@@ -302,6 +308,7 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     A.discount = discount;
     for (int i = 0; i < 3; ++i) A.f_shared[i] = f_shared ? f_shared[i] : 0.0f;
     A.f_shared_dev = f_shared_dev;
+    A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? 1 : 0;  // the GEMM runs one 32-sample tile per wave up to 512 workgroups
     A.c = make_consts<float>(p);
     const int grid = (N + RO_BLOCK - 1) / RO_BLOCK;
     const bool deep = grid <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
