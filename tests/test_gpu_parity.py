@@ -398,6 +398,40 @@ def test_fused_step_equals_kernel_by_kernel(name, task):
         obs, state, reward, done, info = env.step(k_step, state, ua.cpu().numpy(), params)
 
 
+def test_env_instances_with_domain_randomisation():
+    """BASELINE configs[4] (reduced: 4 of the 256 instances, N = 4096): independent env instances of the lissajous
+    `tracking` task, each with its own domain-randomised parameters (quadrotor.py:135-160), each its own complete
+    covo-online MPC problem ("replicas only").  Per instance: cost trajectories against the fp64
+    oracle run with THAT instance's parameters, and the instances really differ."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    N, E = 4096, 4
+    env = cm.envs.Quad3D(task="tracking", obs_type="quad_params", enable_randomizer=True, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    masses, means = [], []
+    for e in range(E):
+        params = env.sample_params(cr.PRNGKey(100 + e))
+        masses.append(float(params.m))
+        controller, cp = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV)
+        controller.materialize_eps = True
+        obs, info, state = env.reset(cr.PRNGKey(200 + e), params)
+        cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(2))
+        key = cr.PRNGKey(300 + e)
+        po = R.Params(m=float(params.m), action_scale=float(params.action_scale),
+                      alpha_bodyrate=float(params.alpha_bodyrate)).fp32()
+        for step in range(3):
+            key, k_act, k_step = cr.split(key, 3)
+            so = _oracle_state_from(info["noisy_state"])
+            u, cp, _ = controller(obs, state, params, k_act, cp, info)
+            a_dev = controller.core.a.permute(1, 0, 2).contiguous().cpu().numpy()
+            cost_ref = CO.rollout(so, po, a_dev.astype(np.float64), 1.0, np.zeros(3), dtype=np.float64)
+            assert rel_err(controller.core.cost.cpu().numpy(), cost_ref).max() < 1e-5, (e, step)
+            obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+        means.append(cp.a_mean.cpu().numpy())
+    assert np.ptp(masses) > 1e-4                       # the instances are different plants ...
+    assert np.abs(means[0] - means[1]).max() > 1e-4    # ... and get different plans
+
+
 def test_closed_loop_tracking_sanity():
     """Free-running covo-offline on tracking_zigzag: tracking error stays at the few-cm level after the
     start-up transient."""
