@@ -84,6 +84,52 @@ def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
                       f"(jacfwd^2, covo.py:134-185) is NOT included in the CPU figure; {el:.1f} s of CPU work"}
 
 
+def closed_loop(env, controller, params, T):
+    """the same controller in CLOSED loop for one episode (env step included): with the env step as a
+    device kernel (one host sync per episode, envs.DeviceEpisode) and with the Python env on the host (one sync and
+    one 128-B upload per step) -- reported next to the teacher-forced `value`, never in place of it."""
+    import torch
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    core = controller.core
+    res = {"unit": "control-steps/s", "steps": int(T)}
+    # --- warm-up (first-use module loads of the env kernel and of torch's gather kernels), untimed
+    ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(20), params, (core.lib, core.h), core.device)
+    cp = controller.reset(ep.state0, params, controller.init_control_params, cr.PRNGKey(22))
+    for i in range(5):
+        u, cp, _ = controller(None, None, params, cr.PRNGKey(i), cp, {"noisy_state": ep.noisy_state})
+        ep.step(cr.PRNGKey(100 + i), u)
+    # --- device env
+    ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(21), params, (core.lib, core.h), core.device)
+    cp = controller.reset(ep.state0, params, controller.init_control_params, cr.PRNGKey(22))
+    key = cr.PRNGKey(23)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(T):
+        key, k_act, k_step = cr.split(key, 3)
+        u, cp, _ = controller(None, None, params, k_act, cp, {"noisy_state": ep.noisy_state})
+        ep.step(k_step, u)
+    log = ep.read_log()
+    res["device_env"] = T / (time.perf_counter() - t0)
+    res["device_env_err_pos_mean_m"] = float(log[:, 1].mean())
+    # --- host env
+    obs, info, state = env.reset(cr.PRNGKey(21), params)
+    cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(22))
+    key = cr.PRNGKey(23)
+    errs = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(T):
+        key, k_act, k_step = cr.split(key, 3)
+        u, cp, _ = controller(obs, state, params, k_act, cp, info)
+        obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+        errs.append(info["err_pos"])
+    torch.cuda.synchronize()
+    res["host_env"] = T / (time.perf_counter() - t0)
+    res["host_env_err_pos_mean_m"] = float(np.mean(errs))
+    return res
+
+
 def pmc_traffic(n_local):
     """HBM-side bytes per rollout launch from the committed rocprofv3 --pmc passes of this command
     (profiles/r01_bench_pmc_summary.json, scripts/pmc_summary.py); null when the shard size differs."""
@@ -214,6 +260,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_us": 1e3 * rollout_b2b_ms,
                          "in_step_us": in_step_us},
         }
+        if world == 1:
+            out["closed_loop"] = closed_loop(env, controller, params, n_states)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_states, params, args.N, H, args.lam, args.cpu_budget)
         print(json.dumps(out))

@@ -221,6 +221,19 @@ int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doub
     return 0;
 }
 
+int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float *pos_traj, const float *vel_traj,
+                  const float *acc_traj, int32_t T, const covo_env_params *params, const float *action,
+                  const uint32_t *leaf_keys, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
+                  float obs_noise_scale, float *log, int32_t log_index, void *stream)
+{
+    REQUIRE(h, "covo_env_step: null handle");
+    REQUIRE(state && noisy_state && pos_traj && vel_traj && acc_traj && params && action && leaf_keys && T > 0 &&
+                log_index >= 0,
+            "covo_env_step: bad argument");
+    return launch_env_step(state, noisy_state, pos_traj, vel_traj, acc_traj, T, *params, action, leaf_keys, disturb_gaussian,
+                           noisy_on, dyn_noise_scale, obs_noise_scale, log, log_index, (hipStream_t)stream);
+}
+
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
                          int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream)
 {

@@ -1,0 +1,139 @@
+// env_step.hip -- one closed-loop environment step on the device (gfx950): SURVEY.md 8f-1.
+//
+// Replaces, for the quadrotor env the controllers are evaluated on, one call of
+//   Quad3D.step_env (quadjax/envs/quadrotor.py:215-248) = clip -> raw_step (250-263) ->
+//   free_dynamics_3d_bodyrate (dynamics/free.py:114-202: Euler step, re-normalised quaternion, gaussian
+//   disturbance for the NEXT step (66-70), time+1, targets = traj[time+1]) -> reward / done of the PRE-step
+//   state (243-244) -> get_info (314-361: err_pos/err_vel of the pre-step state, the noisy copy of the NEXT
+//   state that the controller plans from).
+// The reference runs a whole episode as one XLA program (quadrotor.py:506-591); with this kernel between
+// two controller graph replays an episode is 300 x (one async 48-byte copy + one graph + this launch) with
+// ONE host sync at the end.  The host derives the five leaf keys of the step exactly as the Python env
+// does (covo_mpc_amd/envs/quadrotor.py, random.py); the kernel evaluates normal(key, (n,)) with the same
+// counter layout: block j = Philox4x32-10(counter (j,0,0,0xB175), key), words b[0..2n), u1 = b[i], u2 = b[n+i],
+// z = sqrt(-2 ln u1) cos(2 pi u2) in fp64, rounded to fp32.  Auto-reset on done (base.py:33-39) stays on the
+// host: the done flag is logged, an episode of max_steps_in_episode steps never raises it before its end.
+#include "covo_common.hpp"
+#include "rng_device.hpp"
+
+struct EnvStepArgs {
+    float *state;          // [32] true state, updated in place
+    float *noisy;          // [32] the noisy copy of the new state (what the controller reads)
+    const float *pos_traj, *vel_traj, *acc_traj;  // [T][3]
+    const float *action;   // [4] (device): the controller's u = a_mean[0]
+    float *log;            // [max_steps][4]: reward, err_pos, err_vel, done of the PRE-step state (nullable)
+    int T, log_index, gaussian, noisy_on;
+    float dyn_noise_scale, obs_noise_scale;
+    uint32_t keys[5][2];   // disturb, pos, vel, quat, omega
+    qm::Consts<float> c;
+    int max_steps;
+};
+
+// element i of normal(key, (n,)) -- host formula (random.py) in fp64
+__device__ __forceinline__ float host_normal(const uint32_t (&key)[2], int n, int i)
+{
+    uint32_t b1[4], b2[4];
+    rngd::philox4x32_10((uint32_t)(i >> 2), 0u, 0u, 0xB175u, key[0], key[1], b1);
+    rngd::philox4x32_10((uint32_t)((n + i) >> 2), 0u, 0u, 0xB175u, key[0], key[1], b2);
+    const double u1 = ((double)(b1[i & 3] >> 8) + 0.5) / 16777216.0;
+    const double u2 = ((double)(b2[(n + i) & 3] >> 8) + 0.5) / 16777216.0;
+    return (float)(sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2));
+}
+
+__global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
+{
+    __shared__ float z[16];
+    const int lane = threadIdx.x;
+    // ---- the 16 normals of the step: disturb(3) pos(3) vel(3) quat(4) omega(3)
+    if (lane < 16) {
+        const int grp = lane < 3 ? 0 : lane < 6 ? 1 : lane < 9 ? 2 : lane < 13 ? 3 : 4;
+        const int base = grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 6 : grp == 3 ? 9 : 13;
+        const int n = grp == 3 ? 4 : 3;
+        const uint32_t key[2] = {A.keys[grp][0], A.keys[grp][1]};
+        z[lane] = host_normal(key, n, lane - base);
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    float *__restrict__ st = A.state;
+    qm::State<float> s;
+    s.px = st[ST_POS + 0]; s.py = st[ST_POS + 1]; s.pz = st[ST_POS + 2];
+    s.vx = st[ST_VEL + 0]; s.vy = st[ST_VEL + 1]; s.vz = st[ST_VEL + 2];
+    s.qx = st[ST_QUAT + 0]; s.qy = st[ST_QUAT + 1]; s.qz = st[ST_QUAT + 2]; s.qw = st[ST_QUAT + 3];
+    s.ox = st[ST_OMEGA + 0]; s.oy = st[ST_OMEGA + 1]; s.oz = st[ST_OMEGA + 2];
+    const float fx = st[ST_FDIST + 0], fy = st[ST_FDIST + 1], fz = st[ST_FDIST + 2];
+    const float tx = st[ST_POSTAR + 0], ty = st[ST_POSTAR + 1], tz = st[ST_POSTAR + 2];
+    const float tvx = st[ST_VELTAR + 0], tvy = st[ST_VELTAR + 1], tvz = st[ST_VELTAR + 2];
+    const int time = __float_as_int(st[ST_TIME]);
+    // ---- reward / errors / termination of the PRE-step state (quadrotor.py:243-244, 479-490; utils.py:285-294)
+    if (A.log != nullptr) {
+        const float r = qm::reward<float, float>(s, tx, ty, tz, tvx, tvy, tvz);
+        const float ex = tx - s.px, ey = ty - s.py, ez = tz - s.pz;
+        const float wx = tvx - s.vx, wy = tvy - s.vy, wz = tvz - s.vz;
+        const bool done = (time >= A.max_steps) || fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz)) > A.c.pos_limit;
+        float *__restrict__ lg = A.log + 4 * A.log_index;
+        lg[0] = r;
+        lg[1] = sqrtf(ex * ex + ey * ey + ez * ez);
+        lg[2] = sqrtf(wx * wx + wy * wy + wz * wz);
+        lg[3] = done ? 1.0f : 0.0f;
+    }
+    // ---- one Euler step with the state's current disturbance (free.py:91,98)
+    const float a0 = qm::clip11_(qm::clip11_(A.action[0])), a1 = qm::clip11_(qm::clip11_(A.action[1]));
+    const float a2 = qm::clip11_(qm::clip11_(A.action[2])), a3 = qm::clip11_(qm::clip11_(A.action[3]));
+    qm::dyn_step<float, float>(s, a0, a1, a2, a3, A.c, fx, fy, fz);
+    const int t1 = time + 1;
+    const int idx = t1 < 0 ? 0 : (t1 > A.T - 1 ? A.T - 1 : t1);  // JAX gather clamps (free.py:150-155)
+    st[ST_POS + 0] = s.px; st[ST_POS + 1] = s.py; st[ST_POS + 2] = s.pz;
+    st[ST_VEL + 0] = s.vx; st[ST_VEL + 1] = s.vy; st[ST_VEL + 2] = s.vz;
+    st[ST_QUAT + 0] = s.qx; st[ST_QUAT + 1] = s.qy; st[ST_QUAT + 2] = s.qz; st[ST_QUAT + 3] = s.qw;
+    st[ST_OMEGA + 0] = s.ox; st[ST_OMEGA + 1] = s.oy; st[ST_OMEGA + 2] = s.oz;
+    const float sc = A.gaussian ? A.dyn_noise_scale : 0.0f;  // free.py:66-72
+    st[ST_FDIST + 0] = sc * z[0]; st[ST_FDIST + 1] = sc * z[1]; st[ST_FDIST + 2] = sc * z[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        st[ST_POSTAR + i] = A.pos_traj[3 * idx + i];
+        st[ST_VELTAR + i] = A.vel_traj[3 * idx + i];
+        st[ST_ACCTAR + i] = A.acc_traj[3 * idx + i];
+    }
+    st[ST_TIME] = __int_as_float(t1);
+    // ---- the noisy copy the controller plans from (quadrotor.py:322-350; quaternion NOT re-normalised)
+    float *__restrict__ ns = A.noisy;
+    const float on = A.noisy_on ? A.obs_noise_scale : 0.0f;
+    for (int i = 0; i < COVO_STATE_FLOATS; ++i) ns[i] = st[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ns[ST_POS + i] = st[ST_POS + i] + z[3 + i] * on * 0.25f;
+        ns[ST_VEL + i] = st[ST_VEL + i] + z[6 + i] * on * 0.5f;
+        ns[ST_OMEGA + i] = st[ST_OMEGA + i] + z[13 + i] * on * 0.5f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ns[ST_QUAT + i] = st[ST_QUAT + i] + z[9 + i] * on * 0.02f;
+}
+
+int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
+                    const covo_env_params &p, const float *action, const uint32_t *keys10, int gaussian, int noisy_on,
+                    float dyn_noise_scale, float obs_noise_scale, float *log, int log_index, hipStream_t s)
+{
+    EnvStepArgs A;
+    A.state = state;
+    A.noisy = noisy;
+    A.pos_traj = pos_traj;
+    A.vel_traj = vel_traj;
+    A.acc_traj = acc_traj;
+    A.action = action;
+    A.log = log;
+    A.T = T;
+    A.log_index = log_index;
+    A.gaussian = gaussian;
+    A.noisy_on = noisy_on;
+    A.dyn_noise_scale = dyn_noise_scale;
+    A.obs_noise_scale = obs_noise_scale;
+    for (int i = 0; i < 5; ++i) {
+        A.keys[i][0] = keys10[2 * i];
+        A.keys[i][1] = keys10[2 * i + 1];
+    }
+    A.c = make_consts<float>(p);
+    A.max_steps = p.max_steps_in_episode;
+    hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), 0, s, A);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -21,7 +21,7 @@ import numpy as np
 from .. import controllers
 from .. import random as crandom
 from ..dynamics import utils
-from ..dynamics.dataclass import Action3D, EnvParams3D, EnvState3D
+from ..dynamics.dataclass import Action3D, DeviceState, EnvParams3D, EnvState3D
 from ..dynamics.free import get_quadrotor_1st_order_dyn
 from .base import BaseEnvironment
 
@@ -198,6 +198,109 @@ class Quad3D(BaseEnvironment):
         if not self.disable_rollover_terminate:
             done = done or (state.quat[3] < np.cos(np.pi / 4.0)) or bool(np.any(np.abs(state.omega) > 100.0))
         return done
+
+
+class DeviceEpisode:
+    """One episode whose env state lives on the device: the true state, its noisy copy (what the
+    controller plans from), the reference trajectory and the per-step log {reward, err_pos, err_vel, done}.
+    `reset` is host plumbing (trajectory generation, quadrotor.py:265-312) followed by one upload; `step` derives the
+    five noise keys of `Quad3D.step` on the host exactly as the Python env does and launches covo_env_step -- no sync,
+    so an episode is 300 x (controller graph + this launch) with one read-back of the log at the end."""
+
+    def __init__(self, env: "Quad3D", key, params, lib_handle, device):
+        import torch
+        from .. import _lib
+        self.env, self.params, self.device = env, params, device
+        self.lib, self.h = lib_handle
+        self._lib = _lib
+        obs, info, state = env.reset(key, params)
+        self.state0 = state
+        ns = info["noisy_state"] if info["noisy_state"] is not None else state
+        self.true = torch.from_numpy(state.pack()).to(device)
+        self.noisy = torch.from_numpy(ns.pack()).to(device)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        self.pos_traj, self.vel_traj, self.acc_traj = up(state.pos_traj), up(state.vel_traj), up(state.acc_traj)
+        self.T = int(state.pos_traj.shape[0])
+        self.log = torch.zeros((params.max_steps_in_episode + 1, 4), dtype=torch.float32, device=device)
+        self.params_c = params.to_c()
+        self.n_steps = 0
+        if env.disturb_type not in ("gaussian", "none"):
+            raise NotImplementedError(f"disturb_type={env.disturb_type!r} in the device env step")
+
+    @property
+    def noisy_state(self) -> DeviceState:
+        return DeviceState(packed=self.noisy, pos_traj=self.pos_traj, vel_traj=self.vel_traj, time=None)
+
+    @staticmethod
+    def leaf_keys(step_key):
+        """(disturb, pos, vel, quat, omega) keys of Quad3D.step(step_key, ...): base.py:22 -> step_env (split for
+        raw_step and for get_info from the same key, quadrotor.py:262 / :246) -> free.py:136,144 -> quadrotor.py:324."""
+        k = crandom.split(step_key)[0]            # base.step: key, key_reset = split(key)
+        info_key, raw_key = crandom.split(k)      # step_env: info_key = split(key)[0]; raw_step: step_key = split(key)[1]
+        dk = crandom.split(crandom.split(raw_key)[0])[0]   # step_fn: key, key_dyn = split(key); disturb_key, key = split(key)
+        return np.concatenate([dk[None], crandom.split(info_key, 5)[:4]]).astype(np.uint32)
+
+    def step(self, step_key, action, stream=None):
+        """action: float32[4] device tensor (the controller's u).  Asynchronous."""
+        import ctypes as C
+        import torch
+        keys = np.ascontiguousarray(self.leaf_keys(step_key).reshape(-1), dtype=np.uint32)
+        ptr = self._lib.ptr
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if stream is None else stream
+        self._lib.check(self.lib.covo_env_step(
+            self.h, ptr(self.true), ptr(self.noisy), ptr(self.pos_traj), ptr(self.vel_traj), ptr(self.acc_traj), self.T,
+            C.byref(self.params_c), ptr(action), keys.ctypes.data_as(C.POINTER(C.c_uint32)),
+            1 if self.env.disturb_type == "gaussian" else 0, 1 if self.env.generate_noisy_state else 0,
+            float(self.params.dyn_noise_scale), float(self.env.default_params.obs_noise_scale), ptr(self.log),
+            self.n_steps, st), "covo_env_step")
+        self._keep = (keys, action)
+        self.n_steps += 1
+
+    def read_log(self):
+        """-> float32[n_steps, 4] = reward, err_pos, err_vel, done (pre-step state); synchronises."""
+        return self.log[:self.n_steps].cpu().numpy()
+
+
+def eval_env_device(env: Quad3D, controller, total_steps=30000, num_trajs=4, seed=1, verbose=True):
+    """eval_env (quadrotor.py:506-591) with the env step on the device: same key threading, same protocol (num_trajs
+    reset keys x episodes x max_steps_in_episode steps, mean/std over episodes of the mean position error), one host
+    sync per EPISODE instead of one per step."""
+    rng = crandom.PRNGKey(seed)
+    T = env.default_params.max_steps_in_episode
+    core = controller.core
+    keep_alias = getattr(controller, "alias_outputs", False)
+    controller.alias_outputs = True  # u stays a view of the controller's mean buffer: nothing leaves the device
+
+    def run_one_ep(rng_reset, rng):
+        env_params = env.default_params  # :543 (default params even under DR)
+        ep = DeviceEpisode(env, rng_reset, env_params, (core.lib, core.h), core.device)
+        rng_control, rng = crandom.split(rng)
+        control_params = controller.reset(ep.state0, env_params, controller.init_control_params, rng_control)
+        for _ in range(T):  # run_one_step, :520-538
+            rng, rng_act, rng_step, rng_control = crandom.split(rng, 4)
+            action, control_params, _ = controller(None, None, env_params, rng_act, control_params,
+                                                   {"noisy_state": ep.noisy_state})
+            ep.step(rng_step, action)
+            rng, rng_control = crandom.split(rng)
+        log = ep.read_log()
+        # info["err_pos"] of step t is the error of the state BEFORE that step (quadrotor.py:352); the host loop
+        # records it after each env.step, i.e. rows 0..T-1 of the log
+        return rng, log[:, 1]
+
+    t0 = time_module.time()
+    num_eps = int(total_steps // T)
+    err_pos_ep = []
+    rng, rng_reset_meta = crandom.split(rng)
+    for i, rng_reset in enumerate(crandom.split(rng_reset_meta, num_trajs)):
+        for _ in range(max(num_eps // num_trajs, 1)):
+            rng, err_pos = run_one_ep(rng_reset, rng)
+            err_pos_ep.append(err_pos.mean())
+    controller.alias_outputs = keep_alias
+    err_pos_ep = np.asarray(err_pos_ep)
+    if verbose:
+        print(f"env running time: {time_module.time()-t0:.2f}s")
+        print(f"err_pos mean: {err_pos_ep.mean():.3f}, std: {err_pos_ep.std():.3f}")
+    return err_pos_ep
 
 
 def eval_env(env: Quad3D, controller, total_steps=30000, filename="", num_trajs=4, seed=1, save=True, verbose=True):

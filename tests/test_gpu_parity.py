@@ -443,6 +443,48 @@ def test_closed_loop_tracking_sanity():
     assert err[0] < 0.15, err
 
 
+def test_env_step_kernel_vs_host_env():
+    """covo_env_step (device) against the Python env (the restatement of quadrotor.py:215-263,314-361
+    + free.py:114-202) on the same keys and the same action sequence: true state, noisy state, reward, err_pos, done."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    params = env.default_params
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(11), params, (core.lib, core.h), DEV)
+    obs, info, state = env.reset(cr.PRNGKey(11), params)
+    assert np.array_equal(ep.true.cpu().numpy(), state.pack()) and np.array_equal(ep.noisy.cpu().numpy(), info["noisy_state"].pack())
+    rng = np.random.default_rng(5)
+    key = cr.PRNGKey(12)
+    rewards, errs = [], []
+    for t in range(60):
+        key, k_step = cr.split(key)
+        u = np.clip(np.array([-0.3378, 0, 0, 0]) + 0.3 * rng.normal(size=4), -1.2, 1.2).astype(np.float32)  # also exercises the clip
+        ep.step(k_step, torch.from_numpy(u).to(DEV))
+        obs, state, reward, done, info = env.step(k_step, state, u, params)
+        rewards.append(reward)
+        errs.append(info["err_pos"])
+        t_dev, n_dev = ep.true.cpu().numpy(), ep.noisy.cpu().numpy()
+        assert np.abs(t_dev - state.pack()).max() < 2e-5, (t, np.abs(t_dev - state.pack()).max())
+        assert t_dev[25:26].view(np.int32)[0] == state.time
+        assert np.abs(n_dev - info["noisy_state"].pack()).max() < 2e-5, t
+    log = ep.read_log()
+    assert log.shape == (60, 4) and np.all(log[:, 3] == 0)
+    assert np.abs(log[:, 0] - np.asarray(rewards)).max() < 2e-5 and np.abs(log[:, 1] - np.asarray(errs)).max() < 2e-5
+
+
+def test_closed_loop_on_device():
+    """The eval protocol with the env step on the device (one sync per episode): tracking error at the same few-cm
+    level as the host-driven loop."""
+    import covo_mpc_amd as cm
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    controller, _ = cm.envs.get_controller(env, "covo-online", "N4096_H32_lam0.01", device=DEV, compute_info=False)
+    err = cm.envs.eval_env_device(env, controller, total_steps=300, num_trajs=1, verbose=False)
+    assert err.shape == (1,) and err[0] < 0.15, err
+
+
 def test_errors_are_reported_through_the_abi():
     core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
     with pytest.raises(_lib.CovoError):
