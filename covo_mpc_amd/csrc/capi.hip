@@ -223,14 +223,14 @@ int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doub
 
 int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float *pos_traj, const float *vel_traj,
                   const float *acc_traj, int32_t T, const covo_env_params *params, const float *action,
-                  const uint32_t *leaf_keys, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
+                  const uint32_t *step_key, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
                   float obs_noise_scale, float *log, int32_t log_index, void *stream)
 {
     REQUIRE(h, "covo_env_step: null handle");
-    REQUIRE(state && noisy_state && pos_traj && vel_traj && acc_traj && params && action && leaf_keys && T > 0 &&
+    REQUIRE(state && noisy_state && pos_traj && vel_traj && acc_traj && params && action && step_key && T > 0 &&
                 log_index >= 0,
             "covo_env_step: bad argument");
-    return launch_env_step(state, noisy_state, pos_traj, vel_traj, acc_traj, T, *params, action, leaf_keys, disturb_gaussian,
+    return launch_env_step(state, noisy_state, pos_traj, vel_traj, acc_traj, T, *params, action, step_key, disturb_gaussian,
                            noisy_on, dyn_noise_scale, obs_noise_scale, log, log_index, (hipStream_t)stream);
 }
 

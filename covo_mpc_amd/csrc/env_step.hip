@@ -8,8 +8,8 @@
 //   state that the controller plans from).
 // The reference runs a whole episode as one XLA program (quadrotor.py:506-591); with this kernel between
 // two controller graph replays an episode is 300 x (one async 48-byte copy + one graph + this launch) with
-// ONE host sync at the end.  The host derives the five leaf keys of the step exactly as the Python env
-// does (covo_mpc_amd/envs/quadrotor.py, random.py); the kernel evaluates normal(key, (n,)) with the same
+// ONE host sync at the end.  The kernel derives the five noise keys from the step key exactly as the Python
+// env does (covo_mpc_amd/envs/quadrotor.py, random.py) and evaluates normal(key, (n,)) with the same
 // counter layout: block j = Philox4x32-10(counter (j,0,0,0xB175), key), words b[0..2n), u1 = b[i], u2 = b[n+i],
 // z = sqrt(-2 ln u1) cos(2 pi u2) in fp64, rounded to fp32.  Auto-reset on done (base.py:33-39) stays on the
 // host: the done flag is logged, an episode of max_steps_in_episode steps never raises it before its end.
@@ -24,7 +24,7 @@ struct EnvStepArgs {
     float *log;            // [max_steps][4]: reward, err_pos, err_vel, done of the PRE-step state (nullable)
     int T, log_index, gaussian, noisy_on;
     float dyn_noise_scale, obs_noise_scale;
-    uint32_t keys[5][2];   // disturb, pos, vel, quat, omega
+    uint32_t step_key[2];  // the key Quad3D.step receives; the five noise keys are derived from it on the device
     qm::Consts<float> c;
     int max_steps;
 };
@@ -40,16 +40,41 @@ __device__ __forceinline__ float host_normal(const uint32_t (&key)[2], int n, in
     return (float)(sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2));
 }
 
+// child i of split(key, num) (random.py: Philox counter (i, 0, 0, 0x5EED), first two words)
+__device__ __forceinline__ void host_split(const uint32_t (&key)[2], uint32_t i, uint32_t (&child)[2])
+{
+    uint32_t r[4];
+    rngd::philox4x32_10(i, 0u, 0u, 0x5EEDu, key[0], key[1], r);
+    child[0] = r[0];
+    child[1] = r[1];
+}
+
 __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
 {
     __shared__ float z[16];
     const int lane = threadIdx.x;
-    // ---- the 16 normals of the step: disturb(3) pos(3) vel(3) quat(4) omega(3)
+    // ---- the 16 normals of the step: disturb(3) pos(3) vel(3) quat(4) omega(3).  Key tree of Quad3D.step(key, ...):
+    //   k = split(key)[0]                       base.py:22 (child 1 is the reset key)
+    //   info_key = split(k)[0], raw = split(k)[1]      quadrotor.py:246 / :262 (both split the SAME key)
+    //   disturb = split(split(raw)[0])[0]       free.py:136 (key, key_dyn), :144 (disturb_key, key)
+    //   pos, vel, quat, omega = split(info_key, 5)[0..3]   quadrotor.py:324
     if (lane < 16) {
         const int grp = lane < 3 ? 0 : lane < 6 ? 1 : lane < 9 ? 2 : lane < 13 ? 3 : 4;
         const int base = grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 6 : grp == 3 ? 9 : 13;
         const int n = grp == 3 ? 4 : 3;
-        const uint32_t key[2] = {A.keys[grp][0], A.keys[grp][1]};
+        const uint32_t sk[2] = {A.step_key[0], A.step_key[1]};
+        uint32_t k[2], t[2], key[2];
+        host_split(sk, 0u, k);
+        if (grp == 0) {
+            host_split(k, 1u, t);     // raw_step's step_key
+            host_split(t, 0u, key);   // step_fn: key
+            host_split(key, 0u, t);   // disturb_key
+            key[0] = t[0];
+            key[1] = t[1];
+        } else {
+            host_split(k, 0u, t);                      // info_key
+            host_split(t, (uint32_t)(grp - 1), key);   // rng_pos / vel / quat / omega
+        }
         z[lane] = host_normal(key, n, lane - base);
     }
     __syncthreads();
@@ -110,7 +135,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
 }
 
 int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
-                    const covo_env_params &p, const float *action, const uint32_t *keys10, int gaussian, int noisy_on,
+                    const covo_env_params &p, const float *action, const uint32_t *step_key, int gaussian, int noisy_on,
                     float dyn_noise_scale, float obs_noise_scale, float *log, int log_index, hipStream_t s)
 {
     EnvStepArgs A;
@@ -127,10 +152,8 @@ int launch_env_step(float *state, float *noisy, const float *pos_traj, const flo
     A.noisy_on = noisy_on;
     A.dyn_noise_scale = dyn_noise_scale;
     A.obs_noise_scale = obs_noise_scale;
-    for (int i = 0; i < 5; ++i) {
-        A.keys[i][0] = keys10[2 * i];
-        A.keys[i][1] = keys10[2 * i + 1];
-    }
+    A.step_key[0] = step_key[0];
+    A.step_key[1] = step_key[1];
     A.c = make_consts<float>(p);
     A.max_steps = p.max_steps_in_episode;
     hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), 0, s, A);

@@ -203,8 +203,8 @@ class Quad3D(BaseEnvironment):
 class DeviceEpisode:
     """One episode whose env state lives on the device: the true state, its noisy copy (what the
     controller plans from), the reference trajectory and the per-step log {reward, err_pos, err_vel, done}.
-    `reset` is host plumbing (trajectory generation, quadrotor.py:265-312) followed by one upload; `step` derives the
-    five noise keys of `Quad3D.step` on the host exactly as the Python env does and launches covo_env_step -- no sync,
+    `reset` is host plumbing (trajectory generation, quadrotor.py:265-312) followed by one upload; `step` launches
+    covo_env_step, which derives the five noise keys of `Quad3D.step` from the step key on the device -- no sync,
     so an episode is 300 x (controller graph + this launch) with one read-back of the log at the end."""
 
     def __init__(self, env: "Quad3D", key, params, lib_handle, device):
@@ -244,7 +244,7 @@ class DeviceEpisode:
         """action: float32[4] device tensor (the controller's u).  Asynchronous."""
         import ctypes as C
         import torch
-        keys = np.ascontiguousarray(self.leaf_keys(step_key).reshape(-1), dtype=np.uint32)
+        keys = np.ascontiguousarray(np.asarray(step_key).reshape(-1)[:2], dtype=np.uint32)  # leaf keys derived on the device
         ptr = self._lib.ptr
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if stream is None else stream
         self._lib.check(self.lib.covo_env_step(

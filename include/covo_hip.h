@@ -249,12 +249,12 @@ int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, flo
 /* One closed-loop ENVIRONMENT step on the device: Quad3D.step_env + get_info for the controllers'
  * eval loop (envs/quadrotor.py:215-263, 314-361; dynamics/free.py:66-72, 114-202).  `state` (float[32], layout above) is
  * the true state, advanced in place; `noisy_state` receives the noisy copy of the NEW state (the controller's input);
- * `action` = float[4] on the device (the controller's u); `leaf_keys` = uint32[10] on the HOST: the (disturbance, pos,
- * vel, quat, omega) noise keys the Python env derives from the step key; log (nullable) float[..][4] gets
+ * `action` = float[4] on the device (the controller's u); `step_key` = uint32[2] on the HOST: the key Quad3D.step
+ * receives -- the kernel derives the (disturbance, pos, vel, quat, omega) noise keys from it like the Python env; log (nullable) float[..][4] gets
  * {reward, err_pos, err_vel, done} of the PRE-step state at row log_index.  acc_traj: float[T][3]. */
 int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float *pos_traj, const float *vel_traj,
                   const float *acc_traj, int32_t T, const covo_env_params *params, const float *action,
-                  const uint32_t *leaf_keys, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
+                  const uint32_t *step_key, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
                   float obs_noise_scale, float *log, int32_t log_index, void *stream);
 
 /* Profiling aid: `reps` copies of the selected launches of one control step, captured into one hipGraph and
