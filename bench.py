@@ -53,8 +53,9 @@ def make_states(env, params, n_states, seed):
 
 
 def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
-    """The oracle's C port of the sampling step (noise GEMM -> rollout -> softmax update, fp32, OpenMP
-    over samples) + LAPACK eigh/cholesky for Sigma, timed on this box's host cores."""
+    """The oracle's C port of the WHOLE covo-online step on this box's host cores: hyper-dual Hessian (fp64, OpenMP
+    over the 8 256 action pairs) -> LAPACK eigh/cholesky for Sigma -> noise GEMM -> rollout -> softmax update (fp32,
+    OpenMP over samples).  epsilon is drawn once outside the loop (the reference's threefry draw is not ported)."""
     from oracle import c_oracle as CO
     from oracle import ref_np as R
     cores = os.cpu_count() or 1
@@ -63,25 +64,27 @@ def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
     so = R.State(pos=ns.pos, vel=ns.vel, quat=ns.quat, omega=ns.omega, f_disturb=ns.f_disturb, pos_tar=ns.pos_tar,
                  vel_tar=ns.vel_tar, acc_tar=ns.acc_tar, time=ns.time, pos_traj=ns.pos_traj, vel_traj=ns.vel_traj,
                  acc_traj=ns.acc_traj).astype(np.float32)
+    so64 = so.astype(np.float64)
     p = R.Params()
     rng = np.random.default_rng(0)
     eps = rng.standard_normal((N, H * 4), dtype=np.float32)
-    A = rng.standard_normal((128, 128))
-    Rm = 0.05 * (A + A.T)
     a_mean = R.hover_action(p, H, np.float32)
-    n_done, t0 = 0, time.perf_counter()
+    n_done, t_h, t0 = 0, 0.0, time.perf_counter()
     while True:
+        th = time.perf_counter()
+        Rm = CO.hessian(so64, p.fp32(), R.shift_mean(a_mean.astype(np.float64)).reshape(-1), H)  # covo.py:134-185
+        t_h += time.perf_counter() - th
         Sigma = R.optimize_sigma(Rm, 0.5, H, 4)                      # covo.py:116-132 (LAPACK)
         L = np.linalg.cholesky(Sigma).astype(np.float32)             # covo.py:216
-        a_new, cost, _ = CO.sampling_step(so, p, L, a_mean, eps, lam)  # covo.py:212-278
+        a_mean, cost, _ = CO.sampling_step(so, p, L, R.shift_mean(a_mean), eps, lam)  # covo.py:201-278
         n_done += 1
         el = time.perf_counter() - t0
         if el > budget_s or n_done >= 200:
             break
     return {"value": n_done / el, "unit": "control-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_done} full-size control steps (N={N}, H={H}) of the C oracle port: fp32 noise GEMM + rollout + "
-                      f"softmax update with OpenMP over samples, + fp64 LAPACK eigh/cholesky for Sigma; the Hessian "
-                      f"(jacfwd^2, covo.py:134-185) is NOT included in the CPU figure; {el:.1f} s of CPU work"}
+            "sample": f"{n_done} full-size covo-online control steps (N={N}, H={H}) of the C oracle port: fp64 hyper-dual "
+                      f"Hessian ({1e3 * t_h / n_done:.1f} ms/step) + fp64 LAPACK eigh/cholesky + fp32 noise GEMM, rollout and "
+                      f"softmax update, OpenMP on all host cores; {el:.1f} s of CPU work"}
 
 
 def closed_loop(env, controller, params, T):

@@ -132,3 +132,22 @@ def sampling_step(s, p, L, a_mean, eps, lam, gamma_mean=1.0, discount=1.0, threa
       C.c_int(pt.shape[0]), _p(L, cf), _p(am, cf), _p(eps, cf), C.c_long(N), C.c_int(H), cf(lam), cf(gamma_mean),
       cf(discount), _p(a_work, cf), _p(cost, cf), _p(out, cf))
     return out.reshape(H, 4), cost, a_work
+
+
+def hessian(s, p, a_flat, H=32, threads=None):
+    """covo.py:134-185 by hyper-dual forward-over-forward AD in C (fp64, OpenMP over the n(n+1)/2 pairs)."""
+    if threads is not None:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+    prm = params_vec(p)
+    st = state22(s, np.float64)
+    pt = np.ascontiguousarray(s.pos_traj, dtype=np.float64)
+    vt = np.ascontiguousarray(s.vel_traj, dtype=np.float64)
+    a = np.ascontiguousarray(a_flat, dtype=np.float64).reshape(-1)
+    n = 4 * H
+    R = np.zeros((n, n), dtype=np.float64)
+    f = lib().oracle_hessian_f64
+    f.restype = None
+    cd = C.c_double
+    f(_p(prm, cd), _p(st, cd), C.c_int(int(s.time)), _p(pt, cd), _p(vt, cd), C.c_int(pt.shape[0]), _p(a, cd), C.c_int(H),
+      _p(R, cd))
+    return R

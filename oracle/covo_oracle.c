@@ -93,3 +93,157 @@ void oracle_sampling_step_f32(const double *prm, int max_steps, const float *sta
     oracle_softmax_partial_f32(cost_work, a_work, N, n, lam, &m, &s, v);
     for (int j = 0; j < n; ++j) a_mean_out[j] = v[j] / s * gamma_mean + a_mean[j] * (1.0f - gamma_mean);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * controllers/covo.py:134-185: R = jacfwd(jacfwd(get_cumulated_cost))(a_mean), the exact Hessian of
+ *   C(a) = -( sum_{k<H} r(s_k) + r(s_0) ),  s_{k+1} = step_env(s_k, a_k, deterministic=True)
+ * (no discount, no done-freeze).  Forward-over-forward AD = hyper-dual arithmetic: one rollout per unordered
+ * pair (i <= j) with a_i carrying e1 and a_j carrying e2; R_ij = the e1e2 part.  fp64, OpenMP over pairs.
+ * JAX AD conventions: |x|' = sign(x) (0 at 0); jnp.clip = min(max(x,lo),hi) whose lax.max/min JVPs split an
+ * exact tie 0.5/0.5 -- the action passes two clips (quadrotor.py:223,258).
+ * Part of the timed CPU baseline of bench.py (the reference computes this Hessian every covo-online step). */
+typedef struct { double v, a, b, ab; } hd_t;
+static inline hd_t hd_c(double v) { hd_t r = {v, 0, 0, 0}; return r; }
+static inline hd_t hd_add(hd_t x, hd_t y) { hd_t r = {x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; return r; }
+static inline hd_t hd_sub(hd_t x, hd_t y) { hd_t r = {x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; return r; }
+static inline hd_t hd_neg(hd_t x) { hd_t r = {-x.v, -x.a, -x.b, -x.ab}; return r; }
+static inline hd_t hd_scale(hd_t x, double c) { hd_t r = {x.v * c, x.a * c, x.b * c, x.ab * c}; return r; }
+static inline hd_t hd_addc(hd_t x, double c) { x.v += c; return x; }
+static inline hd_t hd_mul(hd_t x, hd_t y)
+{
+    hd_t r = {x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b, x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab};
+    return r;
+}
+static inline hd_t hd_chain(hd_t x, double f, double d1, double d2)
+{
+    hd_t r = {f, d1 * x.a, d1 * x.b, d1 * x.ab + d2 * x.a * x.b};
+    return r;
+}
+static inline hd_t hd_sqrt(hd_t x) { double s = sqrt(x.v), d1 = 0.5 / s; return hd_chain(x, s, d1, -0.5 * d1 / x.v); }
+static inline hd_t hd_recip(hd_t x) { double r = 1.0 / x.v; return hd_chain(x, r, -r * r, 2.0 * r * r * r); }
+static inline hd_t hd_log(hd_t x) { double r = 1.0 / x.v; return hd_chain(x, log(x.v), r, -r * r); }
+static inline hd_t hd_abs(hd_t x)
+{
+    double sg = x.v > 0 ? 1.0 : (x.v < 0 ? -1.0 : 0.0);
+    hd_t r = {fabs(x.v), sg * x.a, sg * x.b, sg * x.ab};
+    return r;
+}
+static inline hd_t hd_clip(hd_t x, double lo, double hi)
+{
+    double g = 1.0, v = x.v;
+    if (v < lo) { v = lo; g = 0.0; } else if (v == lo) { g = 0.5; }
+    if (v > hi) { v = hi; g = 0.0; } else if (v == hi) { g *= 0.5; }
+    hd_t r = {v, g * x.a, g * x.b, g * x.ab};
+    return r;
+}
+static inline hd_t hd_atan2(hd_t y, hd_t x)
+{
+    double den = x.v * x.v + y.v * y.v, fy = x.v / den, fx = -y.v / den;
+    double fyy = -2.0 * x.v * y.v / (den * den), fxx = -fyy, fxy = (y.v * y.v - x.v * x.v) / (den * den);
+    hd_t r;
+    r.v = atan2(y.v, x.v);
+    r.a = fy * y.a + fx * x.a;
+    r.b = fy * y.b + fx * x.b;
+    r.ab = fy * y.ab + fx * x.ab + fyy * y.a * y.b + fxx * x.a * x.b + fxy * (y.a * x.b + x.a * y.b);
+    return r;
+}
+
+typedef struct { hd_t pos[3], vel[3], quat[4], omega[3]; } hd_state;
+
+/* dynamics/utils.py:266-274, 285-294 */
+static hd_t hd_reward(const hd_state *s, const double *pos_tar, const double *vel_tar)
+{
+    hd_t ep = hd_c(0), ev = hd_c(0);
+    for (int i = 0; i < 3; ++i) {
+        hd_t dp = hd_neg(hd_addc(s->pos[i], -pos_tar[i])), dv = hd_neg(hd_addc(s->vel[i], -vel_tar[i]));
+        ep = hd_add(ep, hd_mul(dp, dp));
+        ev = hd_add(ev, hd_mul(dv, dv));
+    }
+    hd_t err_pos = hd_sqrt(ep), err_vel = hd_sqrt(ev);
+    const hd_t *q = s->quat;
+    hd_t yn = hd_scale(hd_add(hd_mul(q[3], q[2]), hd_mul(q[0], q[1])), 2.0);
+    hd_t yd = hd_addc(hd_scale(hd_add(hd_mul(q[1], q[1]), hd_mul(q[2], q[2])), -2.0), 1.0);
+    hd_t yaw = hd_abs(hd_atan2(yn, yd));
+    hd_t l = hd_log(hd_addc(err_pos, 1.0));
+    hd_t lp = hd_scale(err_pos, 0.4);
+    lp = hd_add(lp, hd_scale(hd_clip(hd_scale(l, 4.0), 0.0, 1.0), 0.4));
+    lp = hd_add(lp, hd_scale(hd_clip(hd_scale(l, 8.0), 0.0, 1.0), 0.2));
+    lp = hd_add(lp, hd_scale(hd_clip(hd_scale(l, 16.0), 0.0, 1.0), 0.1));
+    lp = hd_add(lp, hd_scale(hd_clip(hd_scale(l, 32.0), 0.0, 1.0), 0.1));
+    hd_t r = hd_addc(hd_neg(hd_scale(err_vel, 0.05)), 1.3);
+    r = hd_sub(r, lp);
+    return hd_sub(r, hd_scale(yaw, 0.2));
+}
+
+/* envs/quadrotor.py:250-263 + dynamics/free.py:74-155; prm as in dyn_step above; f = disturbance of THIS step */
+static void hd_dyn_step(hd_state *s, const hd_t *act, const double *prm, const double *f)
+{
+    const double max_thrust = prm[0], dt = prm[7], g = prm[8], m = prm[9], ascale = prm[10], alpha = prm[11];
+    hd_t a[4], u[4];
+    for (int i = 0; i < 4; ++i) a[i] = hd_clip(hd_clip(act[i], -1.0, 1.0), -1.0, 1.0); /* quadrotor.py:223,258 */
+    u[0] = hd_scale(hd_scale(hd_addc(a[0], 1.0), 0.5 * max_thrust), ascale);
+    for (int i = 0; i < 3; ++i) u[1 + i] = hd_scale(hd_scale(hd_scale(a[1 + i], prm[1 + i]), 1.0 / prm[1 + i] * prm[4 + i]), ascale);
+    hd_t n2 = hd_c(0);
+    for (int i = 0; i < 4; ++i) n2 = hd_add(n2, hd_mul(s->quat[i], s->quat[i]));
+    hd_t rn = hd_recip(hd_sqrt(n2));
+    hd_t x = hd_mul(s->quat[0], rn), y = hd_mul(s->quat[1], rn), z = hd_mul(s->quat[2], rn), w = hd_mul(s->quat[3], rn);
+    const hd_t *om = s->omega;
+    hd_t Qz[3];
+    Qz[0] = hd_scale(hd_add(hd_mul(x, z), hd_mul(y, w)), 2.0);
+    Qz[1] = hd_scale(hd_sub(hd_mul(y, z), hd_mul(x, w)), 2.0);
+    Qz[2] = hd_add(hd_sub(hd_sub(hd_mul(w, w), hd_mul(x, x)), hd_mul(y, y)), hd_mul(z, z));
+    hd_t qd[4];
+    qd[0] = hd_scale(hd_add(hd_mul(w, om[0]), hd_sub(hd_mul(y, om[2]), hd_mul(z, om[1]))), 0.5);
+    qd[1] = hd_scale(hd_add(hd_mul(w, om[1]), hd_sub(hd_mul(z, om[0]), hd_mul(x, om[2]))), 0.5);
+    qd[2] = hd_scale(hd_add(hd_mul(w, om[2]), hd_sub(hd_mul(x, om[1]), hd_mul(y, om[0]))), 0.5);
+    qd[3] = hd_scale(hd_neg(hd_add(hd_add(hd_mul(x, om[0]), hd_mul(y, om[1])), hd_mul(z, om[2]))), 0.5);
+    hd_t qq[4] = {hd_add(x, hd_scale(qd[0], dt)), hd_add(y, hd_scale(qd[1], dt)), hd_add(z, hd_scale(qd[2], dt)),
+                  hd_add(w, hd_scale(qd[3], dt))};
+    for (int i = 0; i < 3; ++i) {
+        hd_t vd = hd_addc(hd_scale(hd_addc(hd_mul(Qz[i], u[0]), f[i]), 1.0 / m), i == 2 ? -g : 0.0);
+        s->pos[i] = hd_add(s->pos[i], hd_scale(s->vel[i], dt));
+        s->vel[i] = hd_add(s->vel[i], hd_scale(vd, dt));
+        s->omega[i] = hd_add(hd_scale(om[i], alpha), hd_scale(u[1 + i], 1.0 - alpha));
+    }
+    hd_t m2 = hd_c(0);
+    for (int i = 0; i < 4; ++i) m2 = hd_add(m2, hd_mul(qq[i], qq[i]));
+    hd_t rn2 = hd_recip(hd_sqrt(m2));
+    for (int i = 0; i < 4; ++i) s->quat[i] = hd_mul(qq[i], rn2);
+}
+
+/* state22 = [pos vel quat omega f_disturb pos_tar vel_tar] (fp64); a_mean (H*4); R (H*4, H*4) row-major */
+void oracle_hessian_f64(const double *prm, const double *state22, int time, const double *pos_traj, const double *vel_traj,
+                        int T, const double *a_mean, int H, double *R)
+{
+    const int n = H * 4;
+    const long npairs = (long)n * (n + 1) / 2;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long q = 0; q < npairs; ++q) {
+        int i = 0;
+        long rem = q;
+        while (rem >= n - i) { rem -= n - i; ++i; }
+        const int j = i + (int)rem;
+        hd_state s;
+        for (int c = 0; c < 3; ++c) { s.pos[c] = hd_c(state22[c]); s.vel[c] = hd_c(state22[3 + c]); s.omega[c] = hd_c(state22[10 + c]); }
+        for (int c = 0; c < 4; ++c) s.quat[c] = hd_c(state22[6 + c]);
+        double f[3] = {state22[13], state22[14], state22[15]};
+        double pos_tar[3] = {state22[16], state22[17], state22[18]}, vel_tar[3] = {state22[19], state22[20], state22[21]};
+        double acc = 0.0;
+        for (int k = 0; k < H; ++k) {
+            acc += hd_reward(&s, pos_tar, vel_tar).ab; /* covo.py:169-174 (pre-step reward) */
+            hd_t act[4];
+            for (int d = 0; d < 4; ++d) {
+                const int idx = 4 * k + d;
+                hd_t x = {a_mean[idx], idx == i ? 1.0 : 0.0, idx == j ? 1.0 : 0.0, 0.0};
+                act[d] = x;
+            }
+            hd_dyn_step(&s, act, prm, f);
+            f[0] = f[1] = f[2] = 0.0; /* deterministic=True: disturb_func returns 0 (quadrotor.py:234) */
+            int idx = time + k + 1;
+            idx = idx < 0 ? 0 : (idx > T - 1 ? T - 1 : idx);
+            for (int c = 0; c < 3; ++c) { pos_tar[c] = pos_traj[3 * idx + c]; vel_tar[c] = vel_traj[3 * idx + c]; }
+        }
+        R[(size_t)i * n + j] = -acc; /* r(s_0) (covo.py:176-178) is constant */
+        R[(size_t)j * n + i] = -acc;
+    }
+}

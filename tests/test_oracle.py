@@ -147,3 +147,19 @@ def test_hessian_ad_oracle_structure():
     assert np.abs(Rm - Rm.T).max() < 1e-12 and np.abs(Rm[-4:]).max() == 0.0
     Rfd = R.hessian_fd(s, p, a, H, h=1e-4)
     assert np.abs(Rfd - Rm).max() < 1e-5 * max(1.0, np.abs(Rm).max())
+
+
+def test_c_hessian_matches_torch_ad():
+    """oracle/covo_oracle.c::oracle_hessian_f64 (hyper-dual, the CPU-baseline Hessian) against the torch
+    forward-over-forward AD oracle, including two exact clip ties (gradient factor 0.25 through the two clips)."""
+    from oracle import c_oracle as CO
+    from oracle import ref_torch as RT
+
+    s, p, rng = make_problem(seed=0, time=37)
+    a = (R.hover_action(p, 32, np.float64) + 0.1 * rng.normal(size=(32, 4))).astype(np.float32)
+    a[3, 1] = 1.0
+    a[5, 2] = -1.0
+    Rc = CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32)
+    Rt = RT.hessian(s, p, a.reshape(-1).astype(np.float64), 32)
+    assert np.abs(Rc - Rt).max() < 1e-12 and np.abs(Rc - Rc.T).max() == 0.0 and np.abs(Rc[124:]).max() == 0.0
+    assert np.abs(Rt[13]).max() > 0
