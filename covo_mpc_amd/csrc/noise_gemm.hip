@@ -76,11 +76,36 @@ __device__ __forceinline__ BGroup gen_group(uint64_t id, int g, int kh, uint32_t
     return b;
 }
 
+// A fragments of one float4 chunk of k's (4 k-steps x the row tiles G..3), read from the LDS image of L
+template <int G>
+struct AFrag {
+    float v[4][4 - G];  // [q][rt - G]
+};
+template <int G>
+__device__ __forceinline__ AFrag<G> load_afrag(const float *__restrict__ La, int i)
+{
+    AFrag<G> f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ks = 16 * G + 4 * i + q;  // k-step (k0 = 2 ks)
+#pragma unroll
+        for (int rt = G; rt < 4; ++rt) f.v[q][rt - G] = La[32 * rt * NG_LDA + 2 * ks];
+    }
+    return f;
+}
+
+// One k-group (32 k's) of the tile.  The A fragments of chunk i+1 are requested from LDS BEFORE the MFMAs of chunk
+// i are issued (a ds_read -> s_waitcnt -> 2 dependent MFMAs sequence, as hipcc schedules the naive loop, leaves the
+// matrix pipe idle for an LDS round trip per pair: 26.8 us; with the fragments one chunk ahead the MFMAs of a chunk
+// go out back to back on four independent accumulators).
 template <int G>
 __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup b, f32x16 (&acc)[4])
 {
+    AFrag<G> cur = load_afrag<G>(La, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        AFrag<G> nxt = cur;
+        if (i < 3) nxt = load_afrag<G>(La, i + 1);
         float x = b.c[i].x, y = b.c[i].y, z = b.c[i].z, w = b.c[i].w;
         // lanes 32-63 of vdst <-> lanes 0-31 of src
         auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -90,13 +115,14 @@ __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup 
         const float bk2 = __uint_as_float(r1[0]);  // k = 8c+2 | 8c+3
         const float bk6 = __uint_as_float(r1[1]);  // k = 8c+6 | 8c+7
         const float bb[4] = {bk0, bk2, bk4, bk6};
+        __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's LDS reads above this chunk's MFMAs
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ks = 16 * G + 4 * i + q;  // k-step (k0 = 2 ks)
 #pragma unroll
             for (int rt = G; rt < 4; ++rt)
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(La[32 * rt * NG_LDA + 2 * ks], bb[q], acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[q][rt - G], bb[q], acc[rt], 0, 0, 0);
         }
+        cur = nxt;
     }
 }
 
@@ -143,7 +169,17 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
         }
         return load_tile(rowptr(t), kh);
     };
-    BTile cur = tile_of(tile < ntiles ? tile : 0);
+    // PHILOX: only k-group 0 of the first tile is drawn up front; every later group is drawn right behind the MFMAs
+    // of the group before it (program order), so it executes while the matrix pipe works through those MFMAs --
+    // this wave's own and those of the other wave resident on the SIMD.
+    auto id_of = [&](int t) {
+        int row = t * 32 + j;
+        row = row < N ? row : N - 1;
+        return (uint64_t)(sample_offset + row);
+    };
+    BTile cur;
+    if (PHILOX) cur.g[0] = gen_group(id_of(tile < ntiles ? tile : 0), 0, kh, k0, k1);
+    else cur = tile_of(tile < ntiles ? tile : 0);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- stage L (masked to its lower triangle) and mu
@@ -172,32 +208,19 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
 
         const int next_tile = tile + wave_stride;
         BTile nxt;
-        uint64_t next_id = 0;
-        if (PHILOX) {
-            int row = (next_tile < ntiles ? next_tile : tile) * 32 + j;
-            row = row < N ? row : N - 1;
-            next_id = (uint64_t)(sample_offset + row);
-        } else {
+        const uint64_t id = PHILOX ? id_of(tile) : 0;
+        if (!PHILOX) {
             // whole next tile in flight while this one is multiplied (10 240 MFMA cycles of cover)
             nxt = load_tile(rowptr(next_tile < ntiles ? next_tile : tile), kh);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // PHILOX: each k-group of the next tile is drawn in place right behind the MFMAs that consumed
-        // the current one, i.e. in the shadow of the matrix pipe
-        mfma_group<0>(La, cur.g[0], acc);
-        if (PHILOX) cur.g[0] = gen_group(next_id, 0, kh, k0, k1);
-        mfma_group<1>(La, cur.g[1], acc);
-        if (PHILOX) cur.g[1] = gen_group(next_id, 1, kh, k0, k1);
-        mfma_group<2>(La, cur.g[2], acc);
-        if (PHILOX) cur.g[2] = gen_group(next_id, 2, kh, k0, k1);
-        mfma_group<3>(La, cur.g[3], acc);
-        if (PHILOX) cur.g[3] = gen_group(next_id, 3, kh, k0, k1);
-
-        // ---- epilogue: + mu, clip, stripe-ordered float4 stores
+        // L is lower triangular: row tile rt (actions of steps 8 rt .. 8 rt + 7) is complete after k-group rt, so its
+        // epilogue (+ mu, clip, stripe-ordered float4 stores) goes out right there and its 8 KiB per wave drain to HBM
+        // under the remaining MFMAs.  (With all four row tiles stored at the end, a launch in which every wave owns
+        // one tile computes for ~11 us and then waits for 33.5 MB of stores to drain.)
         const int n = tile * 32 + j;
-        if (n < N) {
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+        auto store_rt = [&](int rt) {
+            if (n < N) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int t = 8 * rt + 2 * g + kh;
@@ -209,7 +232,20 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
                     v.w = qm::clip11_(m4.w + acc[rt][4 * g + 3]);
                     a_out[(size_t)t * N + n] = v;
                 }
-        }
+            }
+        };
+        mfma_group<0>(La, cur.g[0], acc);
+        store_rt(0);
+        if (PHILOX) cur.g[1] = gen_group(id, 1, kh, k0, k1);
+        mfma_group<1>(La, cur.g[1], acc);
+        store_rt(1);
+        if (PHILOX) cur.g[2] = gen_group(id, 2, kh, k0, k1);
+        mfma_group<2>(La, cur.g[2], acc);
+        store_rt(2);
+        if (PHILOX) cur.g[3] = gen_group(id, 3, kh, k0, k1);
+        mfma_group<3>(La, cur.g[3], acc);
+        store_rt(3);
+        if (PHILOX && next_tile < ntiles) cur.g[0] = gen_group(id_of(next_tile), 0, kh, k0, k1);
         if (!PHILOX) cur = nxt;
     }
 }
