@@ -41,7 +41,7 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     const int nb = (cfg->n_local + 255) / 256, ng = (cfg->n_local + 63) / 64;
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
-    COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)nb * COVO_H * 6 * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)nb * COVO_H * 6 * sizeof(double)));
     h->ws_sigma_bytes = sigma_ns_workspace_bytes(1);
     COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, h->ws_sigma_bytes));
     h->ws_hess_bytes = hessian_workspace_bytes(1);

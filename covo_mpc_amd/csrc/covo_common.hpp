@@ -16,7 +16,7 @@ struct covo_ctx {
     // workspace (device)
     float *ws_partials;   // [max_blocks][COVO_PARTIAL_FLOATS] stage-1 records of the softmax reduce
     float *ws_blockmin;   // [ceil(n_local/64)] per-wave cost minima when the caller passes none
-    float *ws_stats;      // [ceil(n_local/256)][H*6] per-block position statistics
+    double *ws_stats;     // [ceil(n_local/256)][H*6] per-block position statistics
     void *ws_sigma;       // scratch of the eigh-free Sigma pipeline (grown on demand, outside graph capture)
     size_t ws_sigma_bytes;
     void *ws_hess;        // scratch of the second-order-adjoint Hessian (grown on demand, outside graph capture)
@@ -85,7 +85,7 @@ int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, u
                            int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr);
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
-                   float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr);
+                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr);
 // a_mean_out != null: finish on this GPU (normalise + blend); else write the merged record to partial_out
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,

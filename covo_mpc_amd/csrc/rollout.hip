@@ -21,7 +21,7 @@ struct RolloutArgs {
     const float4 *a;   // [H][N]
     float *cost;       // [N]
     float *groupmin;   // [ceil(N/64)] per-wave cost minima, or null
-    float *stats_ws;   // [gridDim.x][H*6] or null
+    double *stats_ws;  // [gridDim.x][H*6] or null
     int N, T, max_steps;
     float discount;
     float f_shared[3];
@@ -44,7 +44,8 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // v_readlane_b3
 template <bool STATS, bool DISC1, bool CLIP, int PF>
 __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
 {
-    __shared__ float sacc[STATS ? (RO_BLOCK / COVO_WAVE) * COVO_H * 6 : 1];  // one slot per wave: no atomics, fixed order
+    __shared__ double sacc[STATS ? (RO_BLOCK / COVO_WAVE) * COVO_H * 6 : 1];  // one slot per wave: no atomics, fixed order
+    __shared__ float spanel[STATS ? (RO_BLOCK / COVO_WAVE) * 8 * 3 * COVO_WAVE : 1];  // 8 steps x 3 axes x 64 lanes per wave
     const int tid = threadIdx.x, lane = tid & (COVO_WAVE - 1), wave = tid / COVO_WAVE;
     const float *__restrict__ st = A.state;
     const int time0 = __float_as_int(st[ST_TIME]);
@@ -122,12 +123,30 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
         const float fz = (k == 0) ? f0z : fsz;
         qm::dyn_step<float, float>(s, av.x, av.y, av.z, av.w, c, fx, fy, fz);
         if (STATS) {  // covo.py:234-237: post-step positions, shifted by the initial position
-            const float dx = valid ? s.px - p0x : 0.0f, dy = valid ? s.py - p0y : 0.0f, dz = valid ? s.pz - p0z : 0.0f;
-            const float v0 = wave_sum(dx), v1 = wave_sum(dy), v2 = wave_sum(dz);
-            const float v3 = wave_sum(dx * dx), v4 = wave_sum(dy * dy), v5 = wave_sum(dz * dz);
-            if (lane == 0) {
-                float *sl = sacc + wave * (COVO_H * 6) + k * 6;
-                sl[0] = v0; sl[1] = v1; sl[2] = v2; sl[3] = v3; sl[4] = v4; sl[5] = v5;
+            // No cross-lane reduction per step (6 butterfly sums x 32 steps = 192 dependent ds_bpermute chains per
+            // wave made this variant 7x slower than the plain kernel): every lane parks its three offsets in a
+            // wave-private LDS panel; after every 8 steps, lane p < 24 owns one (step, axis) column, walks its 64
+            // entries (rotated by p: conflict-free banks) and forms sum and sum of squares in a fixed order.
+            float *pan = spanel + wave * (8 * 3 * COVO_WAVE);
+            const int kk = k & 7;
+            pan[(kk * 3 + 0) * COVO_WAVE + lane] = valid ? s.px - p0x : 0.0f;
+            pan[(kk * 3 + 1) * COVO_WAVE + lane] = valid ? s.py - p0y : 0.0f;
+            pan[(kk * 3 + 2) * COVO_WAVE + lane] = valid ? s.pz - p0z : 0.0f;
+            if (kk == 7) {
+                if (lane < 24) {
+                    const float *col = pan + lane * COVO_WAVE;  // lane = kk' * 3 + axis
+                    double s1 = 0.0, s2 = 0.0;  // fp64: 64 identical offsets (step 0) must sum without rounding
+#pragma unroll 8
+                    for (int jj = 0; jj < COVO_WAVE; ++jj) {
+                        const double v = (double)col[(jj + lane) & (COVO_WAVE - 1)];
+                        s1 += v;
+                        s2 = fma(v, v, s2);
+                    }
+                    const int ks = (k - 7) + lane / 3, ax = lane % 3;
+                    double *sl = sacc + wave * (COVO_H * 6) + ks * 6;
+                    sl[ax] = s1;
+                    sl[3 + ax] = s2;
+                }
             }
         }
     }
@@ -271,14 +290,22 @@ __global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel
 }
 
 // sums the per-block position statistics in fp64: out[k*6+i]
-__global__ __launch_bounds__(256) void pos_stats_finalize_kernel(const float *__restrict__ ws, int nblocks,
+// one workgroup per (step, statistic) column: 256 threads stride over the per-block partials, fixed-order tree
+// (a single 192-thread workgroup walking all blocks serially took 77 us at N = 65 536 and 1.4 ms at N = 1 048 576)
+__global__ __launch_bounds__(256) void pos_stats_finalize_kernel(const double *__restrict__ ws, int nblocks,
                                                                  double *__restrict__ out)
 {
-    const int i = threadIdx.x;
-    if (i >= COVO_H * 6) return;
+    __shared__ double red[256];
+    const int i = blockIdx.x, tid = threadIdx.x;
     double acc = 0.0;
-    for (int b = 0; b < nblocks; ++b) acc += (double)ws[(size_t)b * (COVO_H * 6) + i];
-    out[i] = acc;
+    for (int b = tid; b < nblocks; b += 256) acc += ws[(size_t)b * (COVO_H * 6) + i];
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) out[i] = red[0];
 }
 
 template <bool STATS, bool DISC1, bool CLIP>
@@ -292,7 +319,7 @@ static void launch_rollout_pf(const RolloutArgs &A, int grid, bool deep, hipStre
 
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
-                   float *groupmin, double *pos_stats, float *stats_ws, hipStream_t s, const float *f_shared_dev)
+                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev)
 {
     RolloutArgs A;
     A.state = state;
@@ -327,7 +354,7 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     if (stats) {
         if (d1) { if (trust_clipped) RO_DISPATCH(true, true, false); else RO_DISPATCH(true, true, true); }
         else    { if (trust_clipped) RO_DISPATCH(true, false, false); else RO_DISPATCH(true, false, true); }
-        hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(1), dim3(256), 0, s, stats_ws, grid, pos_stats);
+        hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(COVO_H * 6), dim3(256), 0, s, stats_ws, grid, pos_stats);
     } else {
         if (d1) { if (trust_clipped) RO_DISPATCH(false, true, false); else RO_DISPATCH(false, true, true); }
         else    { if (trust_clipped) RO_DISPATCH(false, false, false); else RO_DISPATCH(false, false, true); }
