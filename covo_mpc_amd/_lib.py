@@ -49,7 +49,8 @@ class StepArgsC(C.Structure):
     _fields_ = [("mode", C.c_int32), ("n_samples", C.c_int32), ("T", C.c_int32), ("n_table", C.c_int32),
                 ("state", _P), ("pos_traj", _P), ("vel_traj", _P), ("a_mean", _P), ("a_mean_shift", _P), ("a_cov", _P),
                 ("L_table", _P), ("a", _P), ("cost", _P), ("groupmin", _P), ("pos_stats", _P), ("partial_out", _P),
-                ("sample_offset", C.c_int64), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float)]
+                ("sample_offset", C.c_int64), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float),
+                ("derive_keys", C.c_int32), ("shared_noise_scale", C.c_float)]
 
 
 MODE_MPPI, MODE_COVO_ONLINE, MODE_COVO_OFFLINE = 0, 1, 2

@@ -64,6 +64,7 @@ class SamplingCore:
         n = self.n_local
         self._eps = None  # (n, 128) epsilon buffer, only materialised on request (parity tests)
         self._bufs = {}   # fixed-address buffers of the fused step
+        self._args_cache = None
         self.a = torch.empty((COVO_H, n, 4), **f32)
         self.cost = torch.empty((n,), **f32)
         self.blockmin = torch.empty(((n + 63) // 64,), **f32)  # per-64-sample cost minima
@@ -162,38 +163,51 @@ class SamplingCore:
         return t
 
     def step(self, mode, dstate, params_c, a_mean, key, *, a_cov=None, L_table=None, gamma_mean=1.0, sample_sigma=0.5,
-             f_shared=None, want_stats=False):
+             f_shared=None, want_stats=False, derive_keys=False, shared_noise_scale=0.0):
         """covo_mpc_step: returns (a_mean_new, a_cov_out) as views of persistent buffers (clone to keep).
-        Inputs are copied into fixed-address buffers so the captured graph stays valid."""
+        Inputs are copied into fixed-address buffers so the captured graph stays valid.
+        derive_keys: `key` is the controller's raw rng_act; the sampling key and MPPI's shared disturbance are derived
+        from it on the device (step.hip) -- the host does no RNG work on the per-step path."""
         torch = self.torch
         # the state is read through a pointer that travels with the per-step scalars (step.hip): no copy, and a
         # new address does not invalidate the captured graph.  The tensor must stay alive until the step has run.
         packed = dstate.packed
-        assert packed.is_contiguous() and packed.dtype == torch.float32 and packed.numel() == _lib.COVO_STATE_FLOATS
         self._state_ref = packed
         am = self._persistent("a_mean", (COVO_NA,))
         if a_mean.data_ptr() != am.data_ptr():
             am.copy_(a_mean.reshape(-1), non_blocking=True)
         am_shift = self._persistent("a_mean_shift", (COVO_NA,))
-        args = _lib.StepArgsC()
-        args.mode, args.n_samples, args.T = mode, self.n_local, dstate.T
-        args.state, args.pos_traj, args.vel_traj = packed.data_ptr(), dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr()
-        args.a_mean, args.a_mean_shift = am.data_ptr(), am_shift.data_ptr()
         cov_out = None
         if mode == _lib.MODE_COVO_ONLINE:
             cov_out = self._persistent("a_cov", (COVO_NA, COVO_NA))
-            args.a_cov = cov_out.data_ptr()
         elif mode == _lib.MODE_MPPI:
             cov_out = self._persistent("a_cov_mppi", (COVO_H, 4, 4))
             if a_cov.data_ptr() != cov_out.data_ptr():
                 cov_out.copy_(a_cov, non_blocking=True)
-            args.a_cov = cov_out.data_ptr()
+        # the argument block only changes when a buffer does (new episode -> new trajectory tensors): it is rebuilt
+        # then, otherwise only the state pointer is refreshed (this call sits on the per-step host path)
+        sig = (mode, dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr(), L_table.data_ptr() if L_table is not None else 0,
+               bool(want_stats), float(gamma_mean), float(sample_sigma), bool(derive_keys), float(shared_noise_scale))
+        cached = self._args_cache
+        if cached is not None and cached[0] == sig:
+            args = cached[1]
         else:
-            args.L_table, args.n_table = L_table.data_ptr(), int(L_table.shape[0])
-        args.a, args.cost, args.groupmin = self.a.data_ptr(), self.cost.data_ptr(), self.blockmin.data_ptr()
-        args.pos_stats = self.stats.data_ptr() if want_stats else None
-        args.partial_out = self.partial.data_ptr() if self.world > 1 else None
-        args.sample_offset, args.gamma_mean, args.sample_sigma = self.offset, float(gamma_mean), float(sample_sigma)
+            assert packed.is_contiguous() and packed.dtype == torch.float32 and packed.numel() == _lib.COVO_STATE_FLOATS
+            args = _lib.StepArgsC()
+            args.mode, args.n_samples, args.T = mode, self.n_local, dstate.T
+            args.pos_traj, args.vel_traj = dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr()
+            args.a_mean, args.a_mean_shift = am.data_ptr(), am_shift.data_ptr()
+            if cov_out is not None:
+                args.a_cov = cov_out.data_ptr()
+            if mode == _lib.MODE_COVO_OFFLINE:
+                args.L_table, args.n_table = L_table.data_ptr(), int(L_table.shape[0])
+            args.a, args.cost, args.groupmin = self.a.data_ptr(), self.cost.data_ptr(), self.blockmin.data_ptr()
+            args.pos_stats = self.stats.data_ptr() if want_stats else None
+            args.partial_out = self.partial.data_ptr() if self.world > 1 else None
+            args.sample_offset, args.gamma_mean, args.sample_sigma = self.offset, float(gamma_mean), float(sample_sigma)
+            args.derive_keys, args.shared_noise_scale = (1 if derive_keys else 0), float(shared_noise_scale)
+            self._args_cache = (sig, args, (dstate.pos_traj, dstate.vel_traj, L_table))  # keep the tensors alive
+        args.state = packed.data_ptr()
         fs = (C.c_float * 3)(*[float(x) for x in f_shared]) if f_shared is not None else None
         check(self.lib.covo_mpc_step(self.h, C.byref(params_c), C.byref(args), int(key[0]), int(key[1]), fs, self.stream()),
               "covo_mpc_step")

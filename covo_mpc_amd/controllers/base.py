@@ -9,6 +9,14 @@ class BaseController:
     def update_params(self, env_params, control_params):
         return control_params
 
+    def _params_c(self, env_params):
+        """struct covo_env_params of `env_params`, cached on object identity (frozen dataclass: never mutated)."""
+        cache = getattr(self, "_params_c_cache", None)
+        if cache is None or cache[0] is not env_params:
+            cache = (env_params, env_params.to_c())
+            self._params_c_cache = cache
+        return cache[1]
+
     def reset(self, env_state=None, env_params=None, control_params=None, key=None):
         return self.init_control_params
 

@@ -106,17 +106,18 @@ class CoVOController(BaseController):
         from .. import _lib
         core = self.core
         dstate = as_device_state(info["noisy_state"], core.device)  # covo.py:198
-        params_c = env_params.to_c()
+        params_c = self._params_c(env_params)
         if self.mode == "offline" and control_params.a_chol_offline is None:
             raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
         if not self.materialize_eps:
             # ---- production path: the whole step is one C call / one hipGraph replay (csrc/step.hip)
-            rng_act, act_key = crandom.split(rng_act)   # covo.py:212
-            rng_act, step_key = crandom.split(rng_act)  # covo.py:225 (deterministic rollouts draw nothing from it)
+            # rng_act, act_key = split(rng_act) (covo.py:212) and the unused step_key (covo.py:225: deterministic
+            # rollouts draw nothing) are derived on the device from the raw key (step.hip: step_begin_kernel)
             mode = _lib.MODE_COVO_ONLINE if self.mode == "online" else _lib.MODE_COVO_OFFLINE
-            am, cov = core.step(mode, dstate, params_c, control_params.a_mean, act_key,
+            am, cov = core.step(mode, dstate, params_c, control_params.a_mean, rng_act,
                                 L_table=control_params.a_chol_offline, gamma_mean=control_params.gamma_mean,
-                                sample_sigma=control_params.sample_sigma, want_stats=core.compute_info)
+                                sample_sigma=control_params.sample_sigma, want_stats=core.compute_info,
+                                derive_keys=True)
             a_mean_new = am.view(self.H, 4)
             if self.mode == "online":
                 a_cov = cov

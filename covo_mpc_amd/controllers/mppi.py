@@ -49,12 +49,20 @@ class MPPIController(BaseController):
         if not self.materialize_eps:
             # ---- production path: one C call / one hipGraph replay (csrc/step.hip)
             from .. import _lib
-            rng_act, act_key = crandom.split(rng_act)   # mppi.py:53
-            rng_act, step_key = crandom.split(rng_act)  # mppi.py:69: deterministic=False -> shared disturbance draw
-            f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)
-            am, cov = core.step(_lib.MODE_MPPI, dstate, env_params.to_c(), control_params.a_mean, act_key,
+            # rng_act, act_key = split(rng_act) (mppi.py:53); rng_act, step_key = split(rng_act) and the ONE shared
+            # disturbance vector every sample/step draws from step_key (mppi.py:69,74, deterministic=False;
+            # env.rollout_disturbance is the host restatement) are derived on the device (step.hip: step_begin_kernel)
+            if self.env.disturb_type == "gaussian":
+                noise_scale = float(env_params.dyn_noise_scale)
+            elif self.env.disturb_type == "none":
+                noise_scale = 0.0
+            else:
+                raise NotImplementedError(f"disturb_type={self.env.disturb_type!r} inside the fused rollout "
+                                          "(state/time-dependent models are outside the kernel's first scope)")
+            am, cov = core.step(_lib.MODE_MPPI, dstate, self._params_c(env_params), control_params.a_mean, rng_act,
                                 a_cov=control_params.a_cov, gamma_mean=control_params.gamma_mean,
-                                sample_sigma=control_params.sample_sigma, f_shared=f_shared, want_stats=core.compute_info)
+                                sample_sigma=control_params.sample_sigma, want_stats=core.compute_info,
+                                derive_keys=True, shared_noise_scale=noise_scale)
             a_mean_new = am.view(self.H, 4)
             if not self.alias_outputs:
                 a_mean_new, cov = a_mean_new.clone(), cov.clone()

@@ -9,6 +9,7 @@
 // device block refreshed by one async copy before each replay, so the captured kernel arguments stay valid.
 #include <cstring>
 #include "covo_common.hpp"
+#include "rng_device.hpp"
 
 __global__ void shift_cov_kernel(const float *__restrict__ in, float *__restrict__ out)
 {
@@ -17,17 +18,60 @@ __global__ void shift_cov_kernel(const float *__restrict__ in, float *__restrict
 }
 __global__ void copy512_kernel(const float *__restrict__ in, float *__restrict__ out) { out[threadIdx.x] = in[threadIdx.x]; }
 
-// first launch of every step: shift the mean (covo.py:201-203) and bring this step's state into the fixed-address
-// buffer the captured launches read (its address changes from step to step and travels in the dyn block)
-__global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
-                                  const uint32_t *__restrict__ dyn, float *__restrict__ state_buf)
+// child i of split(key, 2) / element i of normal(key, (3,)) exactly as covo_mpc_amd/random.py forms them
+__device__ __forceinline__ void host_split(const uint32_t (&key)[2], uint32_t i, uint32_t (&child)[2])
 {
-    const int i = threadIdx.x;  // 128 + 32 threads
+    uint32_t r[4];
+    rngd::philox4x32_10(i, 0u, 0u, 0x5EEDu, key[0], key[1], r);
+    child[0] = r[0];
+    child[1] = r[1];
+}
+__device__ __forceinline__ float host_normal3(const uint32_t (&key)[2], int i)
+{
+    uint32_t b1[4], b2[4];
+    rngd::philox4x32_10(0u, 0u, 0u, 0xB175u, key[0], key[1], b1);
+    rngd::philox4x32_10((uint32_t)((3 + i) >> 2), 0u, 0u, 0xB175u, key[0], key[1], b2);
+    const double u1 = ((double)(b1[i] >> 8) + 0.5) / 16777216.0;
+    const double u2 = ((double)(b2[(3 + i) & 3] >> 8) + 0.5) / 16777216.0;
+    return (float)(sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2));
+}
+
+// first launch of every step: shift the mean (covo.py:201-203), bring this step's state into the fixed-address
+// buffer the captured launches read (its address changes from step to step and travels in the dyn block), and --
+// derive_keys -- turn the controller's raw rng_act into what the host would have computed:
+//   rng, act_key = split(rng_act); rng, step_key = split(rng)                (covo.py:212,225 / mppi.py:53,69)
+//   MPPI: f_shared = scale * normal(split(split(split(step_key)[1])[0])[0], (3,))   (quadrotor.py:262, free.py:136,144)
+__global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
+                                  uint32_t *__restrict__ dyn, float *__restrict__ state_buf, int derive_keys,
+                                  float shared_noise_scale)
+{
+    const int i = threadIdx.x;  // 128 + 32 + 4 threads
+    const uint32_t raw[2] = {dyn[0], dyn[1]};
+    __syncthreads();
     if (i < COVO_NA) {
         a_mean_shift[i] = (i < COVO_NA - COVO_DU) ? a_mean[i + COVO_DU] : a_mean[i];
-    } else {
+    } else if (i < COVO_NA + COVO_STATE_FLOATS) {
         const float *src = *reinterpret_cast<const float *const *>(dyn + 8);
         state_buf[i - COVO_NA] = src[i - COVO_NA];
+    } else if (derive_keys) {
+        const int q = i - (COVO_NA + COVO_STATE_FLOATS);  // 0: act_key, 1..3: f_shared
+        uint32_t rng1[2], k[2], t[2];
+        host_split(raw, 0u, rng1);
+        if (q == 0) {
+            host_split(raw, 1u, k);
+            dyn[0] = k[0];
+            dyn[1] = k[1];
+        } else {
+            float f = 0.0f;
+            if (shared_noise_scale != 0.0f) {
+                host_split(rng1, 1u, k);  // step_key
+                host_split(k, 1u, t);     // raw_step: key, step_key = split(key)
+                host_split(t, 0u, k);     // step_fn:  key, key_dyn = split(key)
+                host_split(k, 0u, t);     // disturb_key, key = split(key)
+                f = shared_noise_scale * host_normal3(t, q - 1);
+            }
+            dyn[2 + (q - 1)] = __float_as_uint(f);
+        }
     }
 }
 
@@ -106,7 +150,9 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
     int rc;
     const float *state = st->state_buf;
-    if (M & 1) hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS), 0, s, a.a_mean, am_shift, st->dyn, st->state_buf);
+    if (M & 1)
+        hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s, a.a_mean, am_shift, st->dyn,
+                           st->state_buf, a.derive_keys, a.shared_noise_scale);
     if (a.mode == COVO_MODE_COVO_ONLINE) {
         if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;

@@ -216,7 +216,7 @@ int covo_sigma_profile(covo_handle_t h, const double *R, float sample_sigma, flo
  *   -> (partial_out == NULL) new mean written back to a_mean, or (partial_out != NULL) this shard's record.
  * All pointers are device pointers that must stay valid and UNCHANGED from call to call for the sequence to be
  * captured into a hipGraph (second identical call) and replayed (later calls); changing any of them or
- * `params` falls back to eager launches and re-captures.  key0/key1 and f_disturb_shared may change freely. */
+ * `params` falls back to eager launches and re-captures.  key0/key1, f_disturb_shared and `state` may change freely. */
 typedef struct covo_step_args {
     int32_t mode;            /* COVO_MODE_* */
     int32_t n_samples;       /* <= n_local */
@@ -237,6 +237,10 @@ typedef struct covo_step_args {
     int64_t sample_offset;   /* global id of this shard's first sample */
     float gamma_mean;
     float sample_sigma;
+    int32_t derive_keys;     /* 1: key0/key1 are the controller's raw rng_act; the sampling key (covo.py:212, mppi.py:53)
+                              *    and, for MPPI, the shared disturbance draw (mppi.py:69,74) are derived from it on the
+                              *    device exactly as the Python host does (random.py) -- f_disturb_shared is ignored */
+    float shared_noise_scale;/* derive_keys: dyn_noise_scale of the shared gaussian disturbance (0 -> none; CoVO: 0) */
 } covo_step_args;
 
 int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, uint32_t key0,
