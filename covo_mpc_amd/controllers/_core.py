@@ -30,7 +30,15 @@ def exchange_records(record, gathered_flat, process_group=None):
     records (RCCL over xGMI under the nccl backend; gloo in the CPU tests).  `gathered_flat` is a flat
     (world * len(record)) tensor; returns it viewed as (world, len(record))."""
     import torch.distributed as dist
-    dist.all_gather_into_tensor(gathered_flat, record, group=process_group)
+    if record.is_cuda and dist.get_backend(process_group) == "gloo":
+        # gloo has no device all-gather: stage the 528-byte records through the host (multi-process runs that share
+        # one GPU, e.g. tests/test_gpu_parity.py::test_two_ranks_one_gpu; the product backend is nccl = RCCL)
+        import torch
+        g = torch.empty(gathered_flat.shape, dtype=gathered_flat.dtype)
+        dist.all_gather_into_tensor(g, record.cpu(), group=process_group)
+        gathered_flat.copy_(g)
+    else:
+        dist.all_gather_into_tensor(gathered_flat, record, group=process_group)
     return gathered_flat.view(-1, record.numel())
 
 

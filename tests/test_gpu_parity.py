@@ -485,6 +485,24 @@ def test_closed_loop_on_device():
     assert err.shape == (1,) and err[0] < 0.15, err
 
 
+@pytest.mark.parametrize("name", ["covo-online", "mppi"])
+def test_two_ranks_one_gpu(name):
+    """SURVEY.md 8e through the PRODUCT path: two processes (gloo rendezvous, both on cuda:0) run the sample-sharded
+    controller -- fused step writing this shard's record, ONE all-gather, device merge -- and each checks it against
+    the unsharded controller on the same keys (tests/_dist_gpu_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "_dist_gpu_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", script, name],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DIST_GPU_OK" in r.stdout
+
+
 def test_errors_are_reported_through_the_abi():
     core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
     with pytest.raises(_lib.CovoError):
