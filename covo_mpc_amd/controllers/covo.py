@@ -70,9 +70,10 @@ class CoVOController(BaseController):
         return Sigma[0], L[0]
 
     # ---- covo-offline reset (covo.py:58-104) --------------------------------------------------------
-    def reset_a_cov_offline(self, env_state, env_params, control_params, key):
+    def _nominal_host(self, env_state, env_params, key):
+        """The nominal states / means of covo.py:58-99 by the Python env and PID (300 x 33 scalar steps, ~1.5 s):
+        the restatement the device kernels (csrc/pid_nominal.hip) are tested against."""
         from .. import random as crandom
-        torch = self.core.torch
         env = self.env
         T = env.default_params.max_steps_in_episode
         packed = np.zeros((T, 32), dtype=np.float32)
@@ -93,11 +94,41 @@ class CoVOController(BaseController):
             action, _, _ = self.expansion_controller(None, s, env_params, rng_step, self.expansion_control_params)
             rng_step, key = crandom.split(key)
             _, s, _, _, _ = env.step_env(rng_step, s, action, env_params, need_info=False)
-        dstate = as_device_state(env_state, self.core.device)
-        packed_d = torch.from_numpy(packed).to(self.core.device)
-        a_means_d = torch.from_numpy(a_means).to(self.core.device)
-        R = self.core.hessian(packed_d, dstate, env_params.to_c(), a_means_d, batch=T)
-        Sigma, L = self.core.sigma(R, control_params.sample_sigma, batch=T)
+        return packed, a_means
+
+    def _nominal_device(self, env_state, env_params, key):
+        """The same on the device: one launch walks the PID-tracked chain of start states, one rolls the H nominal steps
+        of every start state (covo_pid_nominal)."""
+        import ctypes as C
+        from .. import _lib
+        core, env = self.core, self.env
+        torch = core.torch
+        if env.disturb_type not in ("gaussian", "none"):
+            raise NotImplementedError(f"disturb_type={env.disturb_type!r} in the device nominal rollout")
+        T = env.default_params.max_steps_in_episode
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(core.device)
+        dstate = as_device_state(env_state, core.device)
+        state0, acc_traj = up(env_state.pack()), up(env_state.acc_traj)
+        packed_d = torch.empty((T, 32), dtype=torch.float32, device=core.device)
+        a_means_d = torch.empty((T, COVO_NA), dtype=torch.float32, device=core.device)
+        g = self.expansion_control_params
+        assert float(g.Ki) == 0.0, "the device PID law carries no integral state (covo.py:48-53 uses Ki = 0)"
+        scale = float(env_params.dyn_noise_scale) if env.disturb_type == "gaussian" else 0.0
+        pc, pid_pc = env_params.to_c(), self.expansion_controller.param.to_c()
+        _lib.check(core.lib.covo_pid_nominal(core.h, _lib.ptr(state0), _lib.ptr(dstate.pos_traj), _lib.ptr(dstate.vel_traj),
+                                             _lib.ptr(acc_traj), dstate.T, C.byref(pc), C.byref(pid_pc), float(g.Kp),
+                                             float(g.Kd), float(g.Kp_att), scale, int(key[0]), int(key[1]), T,
+                                             _lib.ptr(packed_d), _lib.ptr(a_means_d), core.stream()), "covo_pid_nominal")
+        self._nominal_keep = (state0, acc_traj)  # alive until the stream has consumed them
+        return packed_d, a_means_d
+
+    def reset_a_cov_offline(self, env_state, env_params, control_params, key):
+        core = self.core
+        T = self.env.default_params.max_steps_in_episode
+        dstate = as_device_state(env_state, core.device)
+        packed_d, a_means_d = self._nominal_device(env_state, env_params, key)
+        R = core.hessian(packed_d, dstate, env_params.to_c(), a_means_d, batch=T)
+        Sigma, L = core.sigma(R, control_params.sample_sigma, batch=T)
         return control_params.replace(a_cov_offline=Sigma, a_chol_offline=L)
 
     # ---- one MPC control step (covo.py:187-283) -----------------------------------------------------

@@ -234,6 +234,19 @@ int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float
                            noisy_on, dyn_noise_scale, obs_noise_scale, log, log_index, (hipStream_t)stream);
 }
 
+int covo_pid_nominal(covo_handle_t h, const float *state0, const float *pos_traj, const float *vel_traj,
+                     const float *acc_traj, int32_t T, const covo_env_params *params, const covo_env_params *pid_params,
+                     float Kp, float Kd, float Kp_att, float noise_scale, uint32_t key0, uint32_t key1, int32_t n_steps,
+                     float *states_out, float *a_means_out, void *stream)
+{
+    REQUIRE(h, "covo_pid_nominal: null handle");
+    REQUIRE(state0 && pos_traj && vel_traj && acc_traj && params && pid_params && states_out && a_means_out && T > 0 &&
+                n_steps > 0,
+            "covo_pid_nominal: bad argument");
+    return launch_pid_nominal(state0, pos_traj, vel_traj, acc_traj, T, *params, *pid_params, Kp, Kd, Kp_att, noise_scale, key0,
+                              key1, n_steps, states_out, a_means_out, (hipStream_t)stream);
+}
+
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
                          int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream)
 {

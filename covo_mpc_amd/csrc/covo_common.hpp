@@ -111,5 +111,9 @@ int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);
 int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
                     const covo_env_params &p, const float *action, const uint32_t *step_key, int gaussian, int noisy_on,
                     float dyn_noise_scale, float obs_noise_scale, float *log, int log_index, hipStream_t s);
+int launch_pid_nominal(const float *state0, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
+                       const covo_env_params &p, const covo_env_params &pid_params, float Kp, float Kd, float Kp_att,
+                       float noise_scale, uint32_t key0, uint32_t key1, int n_steps, float *states, float *a_means,
+                       hipStream_t s);
 int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, int step_mask,
                               int hess_mask, int sigma_stages, int reps, float *us_out, hipStream_t run);

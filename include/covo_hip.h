@@ -261,6 +261,17 @@ int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float
                   const uint32_t *step_key, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
                   float obs_noise_scale, float *log, int32_t log_index, void *stream);
 
+/* covo-offline's nominal trajectory (controllers/covo.py:58-99 with the PID law of controllers/pid.py:38-84 and the
+ * expansion gains of covo.py:48-53): from `state0` (float[32], true reset state) `n_steps` PID-tracked,
+ * NON-deterministic env steps (keys split from key0/key1 as the Python loop does) give states_out float[n_steps][32];
+ * from each of them H deterministic PID steps give the nominal means a_means_out float[n_steps][128] -- the inputs of
+ * the batched covo_hessian / covo_sigma that build the per-episode Sigma table.  `pid_params`: the parameters the PID
+ * law uses (pid.py:33: the env's DEFAULT m, g, max_thrust, max_omega even under domain randomisation). */
+int covo_pid_nominal(covo_handle_t h, const float *state0, const float *pos_traj, const float *vel_traj,
+                     const float *acc_traj, int32_t T, const covo_env_params *params, const covo_env_params *pid_params,
+                     float Kp, float Kd, float Kp_att, float noise_scale, uint32_t key0, uint32_t key1, int32_t n_steps,
+                     float *states_out, float *a_means_out, void *stream);
+
 /* Profiling aid: `reps` copies of the selected launches of one control step, captured into one hipGraph and
  * replayed; *us_out = GPU microseconds per copy.  step_mask bits: 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM,
  * 16 rollout, 32 softmax update; hess_mask bits: the four kernels of the adjoint Hessian; sigma_stages 1..4:

@@ -443,6 +443,25 @@ def test_closed_loop_tracking_sanity():
     assert err[0] < 0.15, err
 
 
+def test_offline_nominal_trajectory_device_vs_host():
+    """covo-offline reset (covo.py:58-99): the device kernels (covo_pid_nominal: PID law pid.py:38-84 + env steps, keys
+    split on the device) against the Python env + PID loop: the 300 start states and their 32-step nominal means."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    controller, cp = cm.envs.get_controller(env, "covo-offline", "N1024_H32_lam0.01", device=DEV)
+    params = env.default_params
+    obs, info, state = env.reset(cr.PRNGKey(31), params)
+    ph, ah = controller._nominal_host(state, params, cr.PRNGKey(32))
+    pd, ad = controller._nominal_device(state, params, cr.PRNGKey(32))
+    pd, ad = pd.cpu().numpy(), ad.cpu().numpy()
+    assert np.array_equal(pd[:, 25].view(np.int32), ph[:, 25].view(np.int32))      # time
+    assert np.abs(pd[:, :25] - ph[:, :25]).max() < 5e-5, np.abs(pd[:, :25] - ph[:, :25]).max()
+    assert np.abs(ad - ah).max() < 2e-4, np.abs(ad - ah).max()
+    assert np.abs(ph[:, 13:16]).max() > 0  # the chain really draws disturbances
+
+
 def test_env_step_kernel_vs_host_env():
     """covo_env_step (device) against the Python env (the restatement of quadrotor.py:215-263,314-361
     + free.py:114-202) on the same keys and the same action sequence: true state, noisy state, reward, err_pos, done."""
