@@ -62,6 +62,27 @@ __global__ __launch_bounds__(256) void gemm4_k(const double *__restrict__ A, con
         }
 }
 
+// gemm4 confined to one XCD: grid of 8 x 64 workgroups, only blockIdx % 8 == 0 work (round-robin dispatch puts them
+// on the same XCD, whose L2 then serves every operand of the chain)
+__global__ __launch_bounds__(256) void gemm4x_k(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C)
+{
+    __shared__ double red[3][4][64];
+    if (blockIdx.x & 7) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = blockIdx.x >> 3;
+    const int ti = w >> 3, tj = w & 7;
+    f64x4 acc = tile_mm_k(A, B, ti, tj, lane, 32 * wv, 8);
+    if (wv > 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv - 1][r][lane] = acc[r];
+    __syncthreads();
+    if (wv == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = (acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane]);
+            C[(size_t)(16 * ti + (lane >> 4) + 4 * r) * SN + 16 * tj + (lane & 15)] = v * 1e-2;
+        }
+}
+
 __device__ __forceinline__ bool grid_barrier(unsigned *ctr, unsigned target)
 {
     __shared__ int ok;
@@ -164,6 +185,7 @@ static double *gA, *gB;
 static void l_empty1(hipStream_t s, int) { hipLaunchKernelGGL(empty_k, dim3(1), dim3(64), 0, s, nullptr); }
 static void l_empty64(hipStream_t s, int) { hipLaunchKernelGGL(empty_k, dim3(64), dim3(256), 0, s, nullptr); }
 static void l_gemm1(hipStream_t s, int i) { hipLaunchKernelGGL(gemm1_k, dim3(16), dim3(256), 0, s, (i & 1) ? gB : gA, (i & 1) ? gB : gA, (i & 1) ? gA : gB); }
+static void l_gemm4x(hipStream_t s, int i) { hipLaunchKernelGGL(gemm4x_k, dim3(512), dim3(256), 0, s, (i & 1) ? gB : gA, (i & 1) ? gB : gA, (i & 1) ? gA : gB); }
 static void l_gemm4(hipStream_t s, int i) { hipLaunchKernelGGL(gemm4_k, dim3(64), dim3(256), 0, s, (i & 1) ? gB : gA, (i & 1) ? gB : gA, (i & 1) ? gA : gB); }
 
 int main()
@@ -182,6 +204,7 @@ int main()
     printf("C gemm1 16x256       eager %6.2f us/launch   graph %6.2f\n", time_chain(s, n, l_gemm1), time_graph(s, n, l_gemm1));
     printf("D gemm4 64x256       eager %6.2f us/launch   graph %6.2f\n", time_chain(s, n, l_gemm4), time_graph(s, n, l_gemm4));
 
+    printf("D2 gemm4 one XCD 512x256 eager %6.2f us/launch   graph %6.2f\n", time_chain(s, n, l_gemm4x), time_graph(s, n, l_gemm4x));
     unsigned *ctr;
     int *xcc;
     hipMalloc(&ctr, 4);
