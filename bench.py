@@ -89,7 +89,7 @@ def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
 
 def closed_loop(env, controller, params, T):
     """the same controller in CLOSED loop for one episode (env step included): with the env step as a
-    device kernel (one host sync per episode, envs.DeviceEpisode) and with the Python env on the host (one sync and
+    device kernel and the whole episode enqueued by one C call (covo_run_episode: one host sync per episode) and with the Python env on the host (one sync and
     one 128-B upload per step) -- reported next to the teacher-forced `value`, never in place of it."""
     import torch
     import covo_mpc_amd as cm
@@ -99,20 +99,15 @@ def closed_loop(env, controller, params, T):
     # --- warm-up (first-use module loads of the env kernel and of torch's gather kernels), untimed
     ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(20), params, (core.lib, core.h), core.device)
     cp = controller.reset(ep.state0, params, controller.init_control_params, cr.PRNGKey(22))
-    for i in range(5):
-        u, cp, _ = controller(None, None, params, cr.PRNGKey(i), cp, {"noisy_state": ep.noisy_state})
-        ep.step(cr.PRNGKey(100 + i), u)
+    cp, _ = controller.run_episode(ep, params, cp, cr.PRNGKey(19), 5)
     # --- device env
     ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(21), params, (core.lib, core.h), core.device)
     cp = controller.reset(ep.state0, params, controller.init_control_params, cr.PRNGKey(22))
     key = cr.PRNGKey(23)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(T):
-        key, k_act, k_step = cr.split(key, 3)
-        u, cp, _ = controller(None, None, params, k_act, cp, {"noisy_state": ep.noisy_state})
-        ep.step(k_step, u)
-    log = ep.read_log()
+    cp, key = controller.run_episode(ep, params, cp, key, T)  # ONE C call enqueues T x {control step, env step}
+    log = ep.read_log()                                        # the one host sync of the episode
     res["device_env"] = T / (time.perf_counter() - t0)
     res["device_env_err_pos_mean_m"] = float(log[:, 1].mean())
     # --- host env

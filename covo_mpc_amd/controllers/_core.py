@@ -170,12 +170,10 @@ class SamplingCore:
             self._bufs[name] = t
         return t
 
-    def step(self, mode, dstate, params_c, a_mean, key, *, a_cov=None, L_table=None, gamma_mean=1.0, sample_sigma=0.5,
-             f_shared=None, want_stats=False, derive_keys=False, shared_noise_scale=0.0):
-        """covo_mpc_step: returns (a_mean_new, a_cov_out) as views of persistent buffers (clone to keep).
-        Inputs are copied into fixed-address buffers so the captured graph stays valid.
-        derive_keys: `key` is the controller's raw rng_act; the sampling key and MPPI's shared disturbance are derived
-        from it on the device (step.hip) -- the host does no RNG work on the per-step path."""
+    def _prepare_step(self, mode, dstate, a_mean, *, a_cov=None, L_table=None, gamma_mean=1.0, sample_sigma=0.5,
+                      want_stats=False, derive_keys=False, shared_noise_scale=0.0):
+        """Fixed-address buffers + struct covo_step_args of the fused step -> (args, a_mean buffer, shifted-mean
+        buffer, a_cov buffer or None)."""
         torch = self.torch
         # the state is read through a pointer that travels with the per-step scalars (step.hip): no copy, and a
         # new address does not invalidate the captured graph.  The tensor must stay alive until the step has run.
@@ -216,6 +214,13 @@ class SamplingCore:
             args.derive_keys, args.shared_noise_scale = (1 if derive_keys else 0), float(shared_noise_scale)
             self._args_cache = (sig, args, (dstate.pos_traj, dstate.vel_traj, L_table))  # keep the tensors alive
         args.state = packed.data_ptr()
+        return args, am, am_shift, cov_out
+
+    def step(self, mode, dstate, params_c, a_mean, key, *, f_shared=None, gamma_mean=1.0, **kw):
+        """covo_mpc_step: returns (a_mean_new, a_cov_out) as views of persistent buffers (clone to keep).
+        derive_keys: `key` is the controller's raw rng_act; the sampling key and MPPI's shared disturbance are derived
+        from it on the device (step.hip) -- the host does no RNG work on the per-step path."""
+        args, am, am_shift, cov_out = self._prepare_step(mode, dstate, a_mean, gamma_mean=gamma_mean, **kw)
         fs = (C.c_float * 3)(*[float(x) for x in f_shared]) if f_shared is not None else None
         check(self.lib.covo_mpc_step(self.h, C.byref(params_c), C.byref(args), int(key[0]), int(key[1]), fs, self.stream()),
               "covo_mpc_step")
@@ -225,6 +230,25 @@ class SamplingCore:
             check(self.lib.covo_merge(self.h, ptr(self.gathered), self.world, ptr(am_shift), float(gamma_mean), ptr(am),
                                       self.stream()), "covo_merge")
         return am, cov_out
+
+    def run_episode(self, mode, episode, params_c, a_mean, rng, n_steps, **kw):
+        """covo_run_episode: n_steps x (fused control step on episode.noisy -> env step on the device) enqueued by ONE
+        C call, keys threaded like eval_env's run_one_step (quadrotor.py:520-538).  -> (a_mean buffer, a_cov buffer,
+        rng after the segment).  Asynchronous; episode.read_log() synchronises."""
+        if self.world > 1:
+            raise NotImplementedError("run_episode: a sample-sharded step needs its all-gather between the launches")
+        args, am, _, cov_out = self._prepare_step(mode, episode.noisy_state, a_mean, derive_keys=True, **kw)
+        key = (C.c_uint32 * 2)(int(rng[0]), int(rng[1]))
+        env = episode.env
+        check(self.lib.covo_run_episode(self.h, C.byref(params_c), C.byref(args), ptr(episode.true), ptr(episode.acc_traj),
+                                        1 if env.disturb_type == "gaussian" else 0, 1 if env.generate_noisy_state else 0,
+                                        float(episode.params.dyn_noise_scale), float(env.default_params.obs_noise_scale),
+                                        ptr(episode.log[episode.n_steps:]), key, int(n_steps), self.stream()),
+              "covo_run_episode")
+        episode.n_steps += int(n_steps)
+        self._last_step = (params_c, args)
+        import numpy as np
+        return am, cov_out, np.array([key[0], key[1]], dtype=np.uint32)
 
     def time_phases(self, step_mask=63, hess_mask=15, sigma_stages=4, reps=20):
         """GPU microseconds of the selected launches of the LAST step() call, replayed `reps` times from one graph."""

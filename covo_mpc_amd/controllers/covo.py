@@ -131,6 +131,23 @@ class CoVOController(BaseController):
         Sigma, L = core.sigma(R, control_params.sample_sigma, batch=T)
         return control_params.replace(a_cov_offline=Sigma, a_chol_offline=L)
 
+    def run_episode(self, episode, env_params, control_params, rng, n_steps):
+        """n_steps closed-loop steps (this controller + the device env step) enqueued by one C call; keys threaded like
+        eval_env's run_one_step.  -> (control_params with the final mean / Sigma, rng).  See SamplingCore.run_episode."""
+        from .. import _lib
+        if self.mode == "offline" and control_params.a_chol_offline is None:
+            raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
+        mode = _lib.MODE_COVO_ONLINE if self.mode == "online" else _lib.MODE_COVO_OFFLINE
+        am, cov, rng = self.core.run_episode(mode, episode, self._params_c(env_params), control_params.a_mean, rng, n_steps,
+                                             L_table=control_params.a_chol_offline, gamma_mean=control_params.gamma_mean,
+                                             sample_sigma=control_params.sample_sigma)
+        a_mean = am.view(self.H, 4) if self.alias_outputs else am.view(self.H, 4).clone()
+        if self.mode == "online":
+            control_params = control_params.replace(a_mean=a_mean, a_cov=cov if self.alias_outputs else cov.clone())
+        else:
+            control_params = control_params.replace(a_mean=a_mean)
+        return control_params, rng
+
     # ---- one MPC control step (covo.py:187-283) -----------------------------------------------------
     def __call__(self, obs, env_state, env_params, rng_act, control_params: CoVOParams, info):
         from .. import random as crandom

@@ -38,6 +38,26 @@ class MPPIController(BaseController):
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
 
+    def run_episode(self, episode, env_params, control_params, rng, n_steps):
+        """n_steps closed-loop steps (this controller + the device env step) enqueued by one C call; keys threaded like
+        eval_env's run_one_step.  -> (control_params with the final mean / shifted covariances, rng)."""
+        from .. import _lib
+        if control_params.gamma_sigma != 0.0:
+            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0, mppi.py:119-125) is not built")
+        if self.env.disturb_type == "gaussian":
+            noise_scale = float(env_params.dyn_noise_scale)
+        elif self.env.disturb_type == "none":
+            noise_scale = 0.0
+        else:
+            raise NotImplementedError(f"disturb_type={self.env.disturb_type!r} inside the fused rollout")
+        am, cov, rng = self.core.run_episode(_lib.MODE_MPPI, episode, self._params_c(env_params), control_params.a_mean, rng,
+                                             n_steps, a_cov=control_params.a_cov, gamma_mean=control_params.gamma_mean,
+                                             sample_sigma=control_params.sample_sigma, shared_noise_scale=noise_scale)
+        a_mean = am.view(self.H, 4)
+        if not self.alias_outputs:
+            a_mean, cov = a_mean.clone(), cov.clone()
+        return control_params.replace(a_mean=a_mean, a_cov=cov), rng
+
     def __call__(self, obs, env_state, env_params, rng_act, control_params: MPPIParams, info):
         from .. import random as crandom
         core = self.core

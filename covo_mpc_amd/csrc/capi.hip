@@ -247,6 +247,53 @@ int covo_pid_nominal(covo_handle_t h, const float *state0, const float *pos_traj
                               key1, n_steps, states_out, a_means_out, (hipStream_t)stream);
 }
 
+// Philox4x32-10 on the host: child i of split(key, num) as covo_mpc_amd/random.py forms it
+static void host_philox_split(const uint32_t key[2], uint32_t i, uint32_t child[2])
+{
+    uint32_t c0 = i, c1 = 0, c2 = 0, c3 = 0x5EEDu, k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    child[0] = c0;
+    child[1] = c1;
+}
+
+int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, float *state_true,
+                     const float *acc_traj, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
+                     float obs_noise_scale, float *log, uint32_t *rng, int32_t n_steps, void *stream)
+{
+    REQUIRE(h, "covo_run_episode: null handle");
+    REQUIRE(params && args && state_true && acc_traj && rng && n_steps > 0, "covo_run_episode: bad argument");
+    REQUIRE(args->derive_keys == 1, "covo_run_episode: args->derive_keys must be 1 (the controller key is the raw rng_act)");
+    REQUIRE(args->partial_out == nullptr, "covo_run_episode: a sample-sharded step needs its all-gather between the calls");
+    REQUIRE(args->state && args->pos_traj && args->vel_traj && args->a_mean && args->a && args->cost && args->groupmin &&
+                args->T > 0 && args->mode >= 0 && args->mode <= 2,
+            "covo_run_episode: bad step arguments");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t key[2] = {rng[0], rng[1]};
+    for (int t = 0; t < n_steps; ++t) {
+        // run_one_step (quadrotor.py:520-538): rng, rng_act, rng_step, rng_control = split(rng, 4); ...; rng, _ = split(rng)
+        uint32_t nrng[2], rng_act[2], rng_step[2];
+        host_philox_split(key, 0u, nrng);
+        host_philox_split(key, 1u, rng_act);
+        host_philox_split(key, 2u, rng_step);
+        int rc = covo_step_impl(h, params, args, rng_act[0], rng_act[1], nullptr, s);
+        if (rc) return rc;
+        rc = launch_env_step(state_true, const_cast<float *>(args->state), args->pos_traj, args->vel_traj, acc_traj, args->T,
+                             *params, args->a_mean, rng_step, disturb_gaussian, noisy_on, dyn_noise_scale, obs_noise_scale, log,
+                             t, s);
+        if (rc) return rc;
+        host_philox_split(nrng, 0u, key);
+    }
+    rng[0] = key[0];
+    rng[1] = key[1];
+    return 0;
+}
+
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
                          int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream)
 {

@@ -276,12 +276,16 @@ def eval_env_device(env: Quad3D, controller, total_steps=30000, num_trajs=4, see
         ep = DeviceEpisode(env, rng_reset, env_params, (core.lib, core.h), core.device)
         rng_control, rng = crandom.split(rng)
         control_params = controller.reset(ep.state0, env_params, controller.init_control_params, rng_control)
-        for _ in range(T):  # run_one_step, :520-538
-            rng, rng_act, rng_step, rng_control = crandom.split(rng, 4)
-            action, control_params, _ = controller(None, None, env_params, rng_act, control_params,
-                                                   {"noisy_state": ep.noisy_state})
-            ep.step(rng_step, action)
-            rng, rng_control = crandom.split(rng)
+        if hasattr(controller, "run_episode") and core.world == 1:
+            # the whole episode is enqueued by ONE C call (covo_run_episode), keys threaded as run_one_step does
+            control_params, rng = controller.run_episode(ep, env_params, control_params, rng, T)
+        else:
+            for _ in range(T):  # run_one_step, :520-538
+                rng, rng_act, rng_step, rng_control = crandom.split(rng, 4)
+                action, control_params, _ = controller(None, None, env_params, rng_act, control_params,
+                                                       {"noisy_state": ep.noisy_state})
+                ep.step(rng_step, action)
+                rng, rng_control = crandom.split(rng)
         log = ep.read_log()
         # info["err_pos"] of step t is the error of the state BEFORE that step (quadrotor.py:352); the host loop
         # records it after each env.step, i.e. rows 0..T-1 of the log

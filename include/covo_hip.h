@@ -272,6 +272,16 @@ int covo_pid_nominal(covo_handle_t h, const float *state0, const float *pos_traj
                      float Kp, float Kd, float Kp_att, float noise_scale, uint32_t key0, uint32_t key1, int32_t n_steps,
                      float *states_out, float *a_means_out, void *stream);
 
+/* A whole closed-loop episode segment with no host work between the steps (the reference traces
+ * eval_env's run_one_step into one XLA program, envs/quadrotor.py:506-591): n_steps x { covo_mpc_step on the noisy state
+ * -> covo_env_step with u = a_mean[0] }, keys threaded as run_one_step does (rng, rng_act, rng_step, _ = split(rng, 4);
+ * rng, _ = split(rng)).  `args` as for covo_mpc_step with derive_keys = 1, partial_out = NULL and args->state = the
+ * NOISY state buffer (float[32], rewritten by every env step); state_true float[32]; rng uint32[2] in/out (host);
+ * log float[n_steps][4] (nullable).  Asynchronous: returns after enqueueing; one sync at the end of the episode. */
+int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, float *state_true,
+                     const float *acc_traj, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
+                     float obs_noise_scale, float *log, uint32_t *rng, int32_t n_steps, void *stream);
+
 /* Profiling aid: `reps` copies of the selected launches of one control step, captured into one hipGraph and
  * replayed; *us_out = GPU microseconds per copy.  step_mask bits: 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM,
  * 16 rollout, 32 softmax update; hess_mask bits: the four kernels of the adjoint Hessian; sigma_stages 1..4:

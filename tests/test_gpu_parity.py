@@ -493,6 +493,39 @@ def test_env_step_kernel_vs_host_env():
     assert np.abs(log[:, 0] - np.asarray(rewards)).max() < 2e-5 and np.abs(log[:, 1] - np.asarray(errs)).max() < 2e-5
 
 
+@pytest.mark.parametrize("name", ["mppi", "covo-online", "covo-offline"])
+def test_run_episode_equals_python_loop(name):
+    """covo_run_episode (one C call enqueues n x {fused step, env step}, host Philox splits in C) must reproduce the
+    Python loop over controller.__call__ + DeviceEpisode.step bit for bit: same log, same final mean, same rng."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    task = "hovering" if name == "mppi" else "tracking_zigzag"
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params
+    n = 24
+    outs = []
+    for fused in (False, True):
+        controller, _ = cm.envs.get_controller(env, name, "N2048_H32_lam0.01", device=DEV, compute_info=False)
+        controller.alias_outputs = True
+        core = controller.core
+        ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(41), params, (core.lib, core.h), DEV)
+        cp = controller.reset(ep.state0, params, controller.init_control_params, cr.PRNGKey(42))
+        rng = cr.PRNGKey(43)
+        if fused:
+            cp, rng = controller.run_episode(ep, params, cp, rng, n)
+        else:
+            for _ in range(n):  # eval_env's run_one_step (quadrotor.py:520-538)
+                rng, rng_act, rng_step, rng_control = cr.split(rng, 4)
+                u, cp, _ = controller(None, None, params, rng_act, cp, {"noisy_state": ep.noisy_state})
+                ep.step(rng_step, u)
+                rng, rng_control = cr.split(rng)
+        outs.append((ep.read_log().copy(), cp.a_mean.cpu().numpy().copy(), ep.true.cpu().numpy().copy(), np.asarray(rng).copy()))
+    assert np.array_equal(outs[0][3], outs[1][3])
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert outs[0][0].shape == (n, 4) and np.any(outs[0][0][:, 1] > 0)
+
+
 def test_closed_loop_on_device():
     """The eval protocol with the env step on the device (one sync per episode): tracking error at the same few-cm
     level as the host-driven loop."""
