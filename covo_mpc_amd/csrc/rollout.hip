@@ -175,9 +175,10 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
 // One raw s_barrier per step (lgkmcnt only -- a __syncthreads() would also drain vmcnt and stall on
 // the whole prefetched action stream).  Same arithmetic as rollout_kernel (quad_model.hpp).
 constexpr int RS_RING = 3;
-constexpr int RS_PAIRS = 1;  // sample groups per workgroup (1: a dynamics wave + a reward wave).  Measured: the split
-                             // pays when each wave gets a SIMD to itself (7.6 vs 11.2 us at N = 8 192); packing both
-                             // kinds on one SIMD (RS_PAIRS = 4, N = 65 536) is no faster than the plain kernel.
+constexpr int RS_PAIRS = 2;  // sample groups per workgroup: 256 threads = 2 dynamics waves + 2 reward waves, one per SIMD.
+                             // Measured (scripts/kbench.py, N = 8 192 .. 32 768): 8.7-9.2 us (RS_PAIRS = 1: 8.4-9.8;
+                             // RS_PAIRS = 4, both kinds sharing a SIMD: 12 us).  At N = 65 536 (2 waves per SIMD in either
+                             // scheme) the split is slower than the plain kernel (13.0 vs 11.5 us).
 
 __device__ __forceinline__ void lds_phase_barrier()
 {
