@@ -36,8 +36,5 @@ for name, Rm in mats.items():
     t = out[16:21]
     lab = ["load Z", "chol(Z)", "logdet+scalars", "outputs"]
     print("   finalize (s_memtime ticks ~ core cycles): " + "  ".join(f"{lab[i]} {t[i + 1] - t[i]:.0f}" for i in range(4)))
-    t = out[24:30]
-    lab = ["pick+MGS", "A V", "H", "4x4 Jacobi", "scale+coef"]
-    print("   ritz: " + "  ".join(f"{lab[i]} {t[i + 1] - t[i]:.0f}" for i in range(5)))
     w_ = np.linalg.eigvalsh(0.5 * (Rm + Rm.T))
     print(f"   lmin err {out[1] - w_[0]:.3e}")
