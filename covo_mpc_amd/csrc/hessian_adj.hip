@@ -15,7 +15,7 @@
 // (E_k selects the four actions of step k).  All derivatives of the step come from evaluating the SAME
 // templated model (quad_model.hpp) on hyper-dual numbers, so every JAX AD convention it mirrors (clip ties,
 // |x|', the double clip of quadrotor.py:223/:258) carries over.  Four launches:
-//   KB  32 waves: primal rollout to step k (plain fp64), then the step with 17 first-order seeds -> A_k, B_k, grad r_k
+//   KB  32 waves: primal rollout to step k (plain fp64), then the step on first-order duals (17 seeds) -> A_k, B_k, grad r_k
 //   KC  9 waves: the sensitivity recursion (8 column tiles of S held in MFMA C/D layout, which IS the B operand
 //       of the next step: four dependent v_mfma_f64_16x16x4_f64 per step, nothing leaves the registers) and
 //       the costate recursion (the same product with A^T) -- no barriers, no sparsity assumptions
@@ -127,9 +127,27 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
         qm::dyn_step<double, double>(p, a0, a1, a2, a3, A.c, t == 0 ? f0x : 0.0, t == 0 ? f0y : 0.0, t == 0 ? f0z : 0.0);
     }
     if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
-    qm::HD r;
-    qm::State<qm::HD> s;
-    adj_hd_step(st, am, A, time0, k, p, lane, -1, r, s);
+    // the step with ONE first-order seed per lane (17 lanes): reward gradient and column `lane` of df/dz
+    qm::State<qm::D1> s;
+#define OP(m, i) s.m = qm::D1{p.m, lane == i ? 1.0 : 0.0};
+    ADJ_FOR_STATE(OP)
+#undef OP
+    qm::D1 r{0.0, 0.0};
+    if (k >= 1) {
+        double tar[6];
+        adj_targets(st, A, time0, k, tar);
+        r = qm::reward<qm::D1, double>(s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
+    }
+    if (k <= HH - 2) {
+        qm::D1 act[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const qm::D1 x{(double)am[4 * k + d], lane == NX + d ? 1.0 : 0.0};
+            act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
+        }
+        qm::dyn_step<qm::D1, double>(s, act[0], act[1], act[2], act[3], A.c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
+                                     k == 0 ? f0z : 0.0);
+    }
     if (lane < NZ) {
         if (lane < NX) ws[WS_GL + 16 * k + lane] = r.a;  // 0 for k = 0
         if (k <= HH - 2) {

@@ -157,6 +157,55 @@ __device__ __forceinline__ HD atan2abs_(HD y, HD x)
     return abs_(r);
 }
 
+// ---------------------------------------------------------------- first-order dual fp64
+// x = v + a e (e^2 = 0): one forward-mode tangent.  Used for the step Jacobians of the adjoint Hessian
+// (hessian_adj.hip: 17 seeds per step); same conventions as HD above (clip ties 0.5, |x|' = sign, norm'(0) = NaN).
+struct D1 {
+    double v, a;
+};
+__device__ __forceinline__ D1 operator+(D1 x, D1 y) { return D1{x.v + y.v, x.a + y.a}; }
+__device__ __forceinline__ D1 operator-(D1 x, D1 y) { return D1{x.v - y.v, x.a - y.a}; }
+__device__ __forceinline__ D1 operator-(D1 x) { return D1{-x.v, -x.a}; }
+__device__ __forceinline__ D1 operator+(D1 x, double c) { return D1{x.v + c, x.a}; }
+__device__ __forceinline__ D1 operator+(double c, D1 x) { return D1{x.v + c, x.a}; }
+__device__ __forceinline__ D1 operator-(D1 x, double c) { return D1{x.v - c, x.a}; }
+__device__ __forceinline__ D1 operator-(double c, D1 x) { return D1{c - x.v, -x.a}; }
+__device__ __forceinline__ D1 operator*(D1 x, double c) { return D1{x.v * c, x.a * c}; }
+__device__ __forceinline__ D1 operator*(double c, D1 x) { return D1{x.v * c, x.a * c}; }
+__device__ __forceinline__ D1 operator*(D1 x, D1 y) { return D1{x.v * y.v, x.a * y.v + x.v * y.a}; }
+__device__ __forceinline__ D1 sqrt_(D1 x)
+{
+    const double r = rsq64_(x.v);
+    return D1{(x.v == 0.0) ? 0.0 : x.v * r, 0.5 * r * x.a};
+}
+__device__ __forceinline__ D1 rsqrt_(D1 x)
+{
+    const double r = rsq64_(x.v);
+    return D1{r, -0.5 * r * r * r * x.a};
+}
+__device__ __forceinline__ D1 log_(D1 x) { return D1{log(x.v), rcp64_(x.v) * x.a}; }
+__device__ __forceinline__ D1 abs_(D1 x)
+{
+    const double sg = (x.v > 0.0) ? 1.0 : ((x.v < 0.0) ? -1.0 : 0.0);
+    return D1{fabs(x.v), sg * x.a};
+}
+__device__ __forceinline__ D1 clip_(D1 x, double lo, double hi)
+{
+    double g = 1.0;
+    double v = x.v;
+    if (v < lo) { v = lo; g = 0.0; } else if (v == lo) { g = 0.5; }
+    if (v > hi) { v = hi; g = 0.0; } else if (v == hi) { g *= 0.5; }
+    return D1{v, g * x.a};
+}
+__device__ __forceinline__ D1 sat01_(D1 x) { return clip_(x, 0.0, 1.0); }
+__device__ __forceinline__ D1 clip11_(D1 x) { return clip_(x, -1.0, 1.0); }
+__device__ __forceinline__ double value_(D1 x) { return x.v; }
+__device__ __forceinline__ D1 atan2abs_(D1 y, D1 x)
+{
+    const double inv = rcp64_(x.v * x.v + y.v * y.v);
+    return abs_(D1{atan2(y.v, x.v), (x.v * y.a - y.v * x.a) * inv});
+}
+
 // ---------------------------------------------------------------- model
 template <class S>
 struct State {
