@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--info", action="store_true", help="also compute pos_mean/pos_std (covo.py:281); XLA drops "
                     "them as dead code in the reference's eval loop (quadrotor.py:523-538)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop episodes (profiler counter passes)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -258,7 +259,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_us": 1e3 * rollout_b2b_ms,
                          "in_step_us": in_step_us},
         }
-        if world == 1:
+        if world == 1 and not args.no_closed_loop:
             out["closed_loop"] = closed_loop(env, controller, params, n_states)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_states, params, args.N, H, args.lam, args.cpu_budget)

@@ -22,6 +22,6 @@ for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             out[counter + "_KB"] = sum(v) / len(v)
 out["traffic_bytes_per_launch"] = int(round((2.0 * out["FETCH_SIZE_KB"] + out["WRITE_SIZE_KB"]) * 1024))
 out["note"] = "rollout_kernel at N_local=65536: 2 x FETCH_SIZE (gfx950 16-B/lane correction) + WRITE_SIZE; fabric counters include Infinity-Cache hits"
-out["command"] = "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline"
+out["command"] = "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-closed-loop"
 json.dump(out, open(os.path.join(root, "profiles", "r01_bench_pmc_summary.json"), "w"), indent=1)
 print(out)
