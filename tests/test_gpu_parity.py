@@ -183,8 +183,9 @@ def test_rollout_full_size_properties():
 
 @pytest.mark.parametrize("N", [70016, 600000])
 def test_rollout_plain_kernel_paths(N):
-    """N > 65 536 uses the one-wave-per-64-samples kernel (whole-horizon prefetch up to 2 waves/SIMD, 8-deep
-    ring beyond); N <= 65 536 without pos_stats uses the dynamics/reward split kernel (other tests)."""
+    """N > 32 768 uses the one-wave-per-64-samples kernel (whole-horizon prefetch up to 2 waves/SIMD, 8-deep
+    ring beyond; XCD-affine chunks at N = 65 536, test_rollout_full_size_properties); N <= 32 768 without pos_stats
+    uses the dynamics/reward split kernel (other tests)."""
     s, p, rng = make_problem(seed=21, time=200)
     a = sample_actions(p, rng, N)
     core = SamplingCore(N, 32, 0.01, 0.99, device=DEV)
@@ -194,6 +195,31 @@ def test_rollout_plain_kernel_paths(N):
     assert rel_err(cost[idx], ref).max() < 1e-5
     gm = core.blockmin.cpu().numpy()
     assert np.array_equal(gm, np.array([cost[i:i + 64].min() for i in range(0, N, 64)], dtype=np.float32))
+
+
+@pytest.mark.parametrize("N", [1, 33, 63, 65, 129])
+def test_tiny_and_ragged_sample_counts(N):
+    """Edge sizes: a single sample, partial waves / MFMA tiles / reduce groups.  Whole sampling path (in-kernel Philox
+    noise GEMM -> rollout -> softmax update) against the oracle on the materialised epsilon."""
+    s, p, rng = make_problem(seed=N, time=150)
+    A = rng.normal(size=(128, 128))
+    L = np.linalg.cholesky(A @ A.T / 128 + 0.05 * np.eye(128)).astype(np.float32)
+    am = (R.hover_action(p, 32, np.float64) + 0.05 * rng.normal(size=(32, 4))).astype(np.float32)
+    core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
+    core.randn((5, N))
+    eps = core.eps.cpu().numpy()
+    assert eps.shape == (N, 128) and np.all(np.isfinite(eps))
+    core.noise_gemm_philox(torch.from_numpy(L).to(DEV), torch.from_numpy(am.reshape(-1)).to(DEV), (5, N))
+    a_dev = core.a.permute(1, 0, 2).contiguous().cpu().numpy()
+    a_ref = CO.noise_gemm(L, am.reshape(-1), eps).reshape(N, 32, 4)
+    assert np.array_equal(a_dev, a_ref)
+    cost = core.rollout(dev_state(s), EnvParams3D().to_c(), (0.0, 0.0, 0.0), False).cpu().numpy()
+    ref = CO.rollout(s, p, a_dev.astype(np.float64), 1.0, np.zeros(3), dtype=np.float64)
+    assert cost.shape == (N,) and rel_err(cost, ref).max() < 1e-5
+    out = core.update(torch.from_numpy(am.reshape(-1)).to(DEV), 1.0).cpu().numpy().reshape(32, 4)
+    upd, w = R.softmax_update(ref, a_dev.astype(np.float64), 0.01, 1.0, am.astype(np.float64))
+    gap = np.diff(np.sort(ref)[:2])[0] if N > 1 else 1.0
+    assert np.abs(out - upd).max() < 1e-4 or gap < 1e-3
 
 
 # ------------------------------------------------------------------------------------------ reduce
