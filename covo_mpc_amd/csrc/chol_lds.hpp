@@ -107,16 +107,35 @@ __device__ __forceinline__ double rsqrt_f64_nr1(double x)
     return fma(0.5 * y, e, y);
 }
 
-// lower-triangle tile enumeration t -> (a, b), a >= b, a(a+1)/2 + b = t  (t < 28)
-__device__ __forceinline__ void chol_tri(int t, int &a, int &b)
+// Left-looking by 16-column panels, three phases per panel, two barriers:
+//   U  wave w takes tile (p + w, p) of the panel (w = 0: the diagonal block) and applies ALL previous panels to it:
+//      tile -= L(i, q) L(p, q)^T for q < p, 4 p MFMAs on an accumulator that stays in registers (a right-looking
+//      version re-reads and re-writes every trailing tile once per panel through LDS: 19k of its 64k cycles);
+//   F  wave 0 factors the diagonal block column by column (rank-1 MFMA updates, see above) and carries the SAME
+//      operations on an identity tile, which ends up as W = L_pp^-1 -- two MFMAs per column on one SIMD's pipe
+//      (factoring the block redundantly in every wave next to its own tile made the pipe the bottleneck: 285
+//      cycles per column);
+//   T  the other waves finish their tiles with one 16x16x16 product  L(i, p)^T = W . tile^T  (4 MFMAs).
+// Column-major with stride ld (element (r, c) at A[c*ld + r]); the input must be the FULL symmetric matrix (the
+// diagonal blocks are read as stored); on return the lower triangle holds L.
+// tile^T (panel pc, tile row ti) -= L(pc, q) L(ti, q)^T  as four MFMAs; Tt in C/D layout (register g = panel column 4g + hi)
+template <int ld>
+__device__ __forceinline__ void chol_tile_update(const double *A, chol_f64x4 &Tt, int q, int pc, int ti, int lo, int hi)
 {
-    a = (t >= 21) ? 6 : (t >= 15) ? 5 : (t >= 10) ? 4 : (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0;
-    b = t - a * (a + 1) / 2;
+    double av[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        av[kk] = -A[(16 * q + 4 * kk + hi) * ld + 16 * pc + lo];  // A-operand [m = k = lo][c = hi]: L(pc, q)
+        bv[kk] = A[(16 * q + 4 * kk + hi) * ld + 16 * ti + lo];   // B-operand [c = hi][n = r = lo]: L(ti, q)
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) Tt = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], Tt, 0, 0, 0);
 }
 
 template <int ld>  // compile-time stride: every LDS address is base + immediate
 __device__ void chol128_lds_mfma(double *A, int tid)
 {
+    __shared__ double Wsm[16 * 16];
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lo = lane & 15, hi = lane >> 4;
     double maskg[4];
 #pragma unroll
@@ -128,111 +147,77 @@ __device__ void chol128_lds_mfma(double *A, int tid)
     for (int p = 0; p < 8; ++p) {
         const long long c0 = CHOL_CLOCK();
         const int j0 = 16 * p;
-        long long c1 = 0, c2 = 0;
-        if (wave < 4) {
-            // ---- panel factorisation: waves 0..3 (one per SIMD: the f64 MFMA pipe is the shared resource),
-            // each with its own copy of the diagonal block and up to two tiles below it
-            const int tiA = p + 1 + wave, tiB = p + 5 + wave;
-            const bool hasA = tiA < 8, hasB = tiB < 8;
-            chol_f64x4 D, Ta = {0.0, 0.0, 0.0, 0.0}, Tb = {0.0, 0.0, 0.0, 0.0};
+        const int ti = p + wave;  // this wave's tile row in the panel
+        const bool has = ti < 8;
+        // ---- U: tile^T (k = panel column, r = row in tile) in C/D layout: register g, lane (lo = r, hi) = column 4g + hi
+        chol_f64x4 Tt = {0.0, 0.0, 0.0, 0.0};
+        if (has) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = hi + 4 * r;
-                D[r] = A[(j0 + min(row, lo)) * ld + j0 + max(row, lo)];   // symmetric fill from the lower triangle
-                if (hasA) Ta[r] = A[(j0 + row) * ld + 16 * tiA + lo];     // tile^T: (k = row, i = lo)
-                if (hasB) Tb[r] = A[(j0 + row) * ld + 16 * tiB + lo];
-            }
-            CHOL_USE(D[0]); CHOL_USE(Ta[0]); CHOL_USE(Tb[0]);
-            c1 = CHOL_CLOCK();
-            chol_f64x4 LD_ = {0.0, 0.0, 0.0, 0.0}, LA = LD_, LB = LD_;  // the finished columns, in tile layout
-            double a_prev = 0.0, ta_prev = 0.0, tb_prev = 0.0, inv_prev = 0.0;
+            for (int r = 0; r < 4; ++r) Tt[r] = A[(j0 + hi + 4 * r) * ld + 16 * ti + lo];
+            if (p > 0) chol_tile_update<ld>(A, Tt, p - 1, p, ti, lo, hi);  // panels q < p-1 were applied during F(p-1)
+        }
+        CHOL_USE(Tt[0]);
+        const long long c1 = CHOL_CLOCK();
+        if (wave == 0) {
+            // ---- F: D = Tt (the symmetric diagonal block), W = identity; per column j: pivot -> rsqrt -> scaled row
+            chol_f64x4 D = Tt, W, LD_ = {0.0, 0.0, 0.0, 0.0}, LW = LD_;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[r] = (hi + 4 * r == lo) ? 1.0 : 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int hj = j & 3, rj = j >> 2;
                 const double piv = wr::bcast_lane(D[rj], 16 * hj + j);
-                if (j > 0) {  // the tiles run one column behind: their MFMAs fill the pipe while the rsqrt chain runs
-                    Ta = __builtin_amdgcn_mfma_f64_16x16x4f64(a_prev, ta_prev, Ta, 0, 0, 0);
-                    Tb = __builtin_amdgcn_mfma_f64_16x16x4f64(a_prev, tb_prev, Tb, 0, 0, 0);
-                }
-                // 1/sqrt(piv) restricted to the lanes of group hj (0 elsewhere): v_rsq_f64 + one Newton step
                 const double y = __builtin_amdgcn_rsq(piv);
                 const double ym = y * maskg[hj], yhm = 0.5 * ym;
                 const double e = fma(-(piv * y), y, 1.0);
-                const double inv_m = fma(yhm, e, ym);
-                const double lrow = D[rj] * inv_m;                            // L[j0+lo][j0+j] in group hj, 0 elsewhere
+                const double inv_m = fma(yhm, e, ym);                          // 1/sqrt(piv) in group hj, 0 elsewhere
+                const double lrow = D[rj] * inv_m;                             // L[j0+lo][j0+j] in group hj
                 const double a_op = D[rj] * (inv_m * ((lo > j) ? -1.0 : 0.0));  // rows > j only
+                const double wrow = W[rj] * inv_m;                             // row j of L_pp^-1 (final)
                 LD_[rj] += lrow;
+                LW[rj] += wrow;
+                // both rank-1 updates go out back to back: the wait for the D result then also covers W
+                __builtin_amdgcn_sched_barrier(0);
                 D = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, lrow, D, 0, 0, 0);
-                if (j > 0) {  // column j-1 of the tiles has its final value now
-                    (void)inv_prev;
-                }
-                const double ta = Ta[rj] * inv_m, tb = Tb[rj] * inv_m;        // L[16ti+lo][j0+j]
-                LA[rj] += ta;
-                LB[rj] += tb;
-                a_prev = a_op;
-                ta_prev = ta;
-                tb_prev = tb;
-                inv_prev = inv_m;
+                W = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, wrow, W, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            CHOL_USE(D[0]); CHOL_USE(Ta[0]); CHOL_USE(Tb[0]);
-            c2 = CHOL_CLOCK();
-            // rows j = hi + 4r of the finished columns sit in group hi: plain tile stores (the diagonal block's
-            // upper triangle receives don't-care values)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = hi + 4 * r;
-                if (wave == 0) A[(j0 + row) * ld + j0 + lo] = LD_[r];
-                if (hasA) A[(j0 + row) * ld + 16 * tiA + lo] = LA[r];
-                if (hasB) A[(j0 + row) * ld + 16 * tiB + lo] = LB[r];
+                A[(j0 + hi + 4 * r) * ld + j0 + lo] = LD_[r];   // row j = hi + 4r of L^T; the upper triangle gets don't-cares
+                Wsm[(hi + 4 * r) * 16 + lo] = LW[r];            // W[k][c]
             }
+        } else if (p + wave < 8 && p > 0) {
+            // ---- look-ahead (the waves that wait for W): apply the panels q < p, already final, to tile (p + wave, p + 1)
+            // of the NEXT panel in place, so that its U phase only has panel p left (4 MFMAs instead of 4 (p + 1))
+            const int tn = p + wave;
+            chol_f64x4 Nt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Nt[r] = A[(j0 + 16 + hi + 4 * r) * ld + 16 * tn + lo];
+            for (int q = 0; q < p; ++q) chol_tile_update<ld>(A, Nt, q, p + 1, tn, lo, hi);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(j0 + 16 + hi + 4 * r) * ld + 16 * tn + lo] = Nt[r];
+        }
+        __syncthreads();
+        const long long c2 = CHOL_CLOCK();
+        // ---- T: L(ti, p)^T = W . tile^T
+        if (has && wave > 0) {
+            chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            double wv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wv[kk] = Wsm[lo * 16 + 4 * kk + hi];  // A-operand [m = k = lo][c = hi]
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[kk], Tt[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(j0 + hi + 4 * r) * ld + 16 * ti + lo] = acc[r];
         }
         __syncthreads();
         const long long c3 = CHOL_CLOCK();
-        // ---- trailing tiles (ui >= uj > p), round-robin over the 8 waves, two tiles in flight per wave.  The MFMA
-        // computes the TRANSPOSED tile D[m][n] = sum_k L[16uj+m][k] L[16ui+n][k] so that lanes (n = lo) run
-        // down a column of A in LDS.
-        const int T = 7 - p, ntiles = T * (T + 1) / 2;
-        for (int t = wave; t < ntiles; t += 16) {
-            const bool two = t + 8 < ntiles;
-            int a0, b0, a1, b1;
-            chol_tri(t, a0, b0);
-            chol_tri(two ? t + 8 : t, a1, b1);
-            const int ui0 = p + 1 + a0, uj0 = p + 1 + b0, ui1 = p + 1 + a1, uj1 = p + 1 + b1;
-            chol_f64x4 acc0, acc1;
-            double av0[4], bv0[4], av1[4], bv1[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                av0[kk] = -A[(j0 + 4 * kk + hi) * ld + 16 * uj0 + lo];  // A-operand [m = lo][k = hi]
-                bv0[kk] = A[(j0 + 4 * kk + hi) * ld + 16 * ui0 + lo];   // B-operand [k = hi][n = lo]
-                av1[kk] = -A[(j0 + 4 * kk + hi) * ld + 16 * uj1 + lo];
-                bv1[kk] = A[(j0 + 4 * kk + hi) * ld + 16 * ui1 + lo];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc0[r] = A[(16 * uj0 + hi + 4 * r) * ld + 16 * ui0 + lo];
-                acc1[r] = A[(16 * uj1 + hi + 4 * r) * ld + 16 * ui1 + lo];
-            }
-            if (two) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[kk], bv0[kk], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[kk], bv1[kk], acc1, 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[kk], bv0[kk], acc0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                A[(16 * uj0 + hi + 4 * r) * ld + 16 * ui0 + lo] = acc0[r];
-                if (two) A[(16 * uj1 + hi + 4 * r) * ld + 16 * ui1 + lo] = acc1[r];
-            }
-        }
-        __syncthreads();
         CHOL_STAMP(0, c2 - c1);
-        CHOL_STAMP(16 + p, c2 - c1);
-        { const long long c4 = CHOL_CLOCK(); (void)c4; CHOL_STAMP(1, c4 - c3); CHOL_STAMP(8 + p, c4 - c3); }
+        CHOL_STAMP(1, c3 - c2);
         CHOL_STAMP(2, c1 - c0);
-        CHOL_STAMP(3, c3 - c2);
+        CHOL_STAMP(3, 0);
+        CHOL_STAMP(8 + p, c1 - c0);
+        CHOL_STAMP(16 + p, c2 - c1);
     }
 }

@@ -55,9 +55,9 @@ void run(const char *name, const double *dA, double *dL, long long *dS, const st
     hipMemcpy(st, dS, sizeof(st), hipMemcpyDeviceToHost);
     double err = 0, nrm = 0;
     for (int i = 0; i < N * N; ++i) { err = fmax(err, fabs(L[i] - ref[i])); nrm = fmax(nrm, fabs(ref[i])); }
-    printf("%-10s kernel %7.2f us   chol %8lld ticks  [factor %lld  syrk %lld  load %lld store %lld]  max err %.3e (rel %.3e)\n", name, best * 1e3, st[0],
+    printf("%-10s kernel %7.2f us   chol %8lld ticks  [factor %lld  trsm %lld  update %lld  - %lld]  max err %.3e (rel %.3e)\n", name, best * 1e3, st[0],
            st[1], st[2], st[3], st[4], err, err / nrm);
-    if (VARIANT) { printf("   syrk per panel:"); for (int q = 0; q < 8; ++q) printf(" %lld", st[9 + q]); printf("\n   factor per panel:"); for (int q = 0; q < 8; ++q) printf(" %lld", st[17 + q]); printf("\n"); }
+    if (VARIANT) { printf("   update per panel:"); for (int q = 0; q < 8; ++q) printf(" %lld", st[9 + q]); printf("\n   factor per panel:"); for (int q = 0; q < 8; ++q) printf(" %lld", st[17 + q]); printf("\n"); }
 }
 
 int main()
