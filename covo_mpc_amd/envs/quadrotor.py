@@ -412,6 +412,7 @@ class Args:
     noDR: bool = False
     disturb_type: str = "gaussian"
     name: str = ""
+    host_env: bool = False  # (not in quadjax) eval with the Python env step instead of the device one
 
 
 def main(args: Args):
@@ -422,6 +423,9 @@ def main(args: Args):
     print("starting test...")
     controller, control_params = get_controller(env, args.controller, args.controller_params)
     if args.mode == "eval":
+        if not args.host_env and hasattr(controller, "core"):
+            # same protocol, env step on the device, whole episodes enqueued by one C call (eval_env_device)
+            return eval_env_device(env, controller=controller, total_steps=300 * 4 * 10)
         return eval_env(env, controller=controller, total_steps=300 * 4 * 10, filename=args.name)
     raise NotImplementedError(args.mode)
 
