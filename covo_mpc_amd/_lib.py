@@ -53,6 +53,14 @@ class StepArgsC(C.Structure):
                 ("derive_keys", C.c_int32), ("shared_noise_scale", C.c_float)]
 
 
+class BatchArgsC(C.Structure):
+    """struct covo_batch_args (include/covo_hip.h)."""
+    _fields_ = [("n_envs", C.c_int32), ("n_samples", C.c_int32), ("T", C.c_int32), ("pad_", C.c_int32),
+                ("states", _P), ("pos_traj", _P), ("vel_traj", _P), ("a_mean", _P), ("a_cov", _P), ("a", _P), ("cost", _P),
+                ("groupmin", _P), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float)]
+
+
+COVO_MAX_ENVS = 64
 MODE_MPPI, MODE_COVO_ONLINE, MODE_COVO_OFFLINE = 0, 1, 2
 COVO_FLAG_NO_GRAPH = 2
 _SIGS = {
@@ -82,6 +90,7 @@ _SIGS = {
                                    C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_int32, _P, _P, _P]),
     "covo_run_episode": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), _P, _P, C.c_int32, C.c_int32, C.c_float,
                                    C.c_float, _P, C.POINTER(C.c_uint32), C.c_int32, _P]),
+    "covo_mpc_step_batched": (C.c_int, [_P, C.POINTER(BatchArgsC), C.POINTER(EnvParamsC), C.POINTER(C.c_uint32), _P]),
     "covo_debug_time_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_sigma_jacobi": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),

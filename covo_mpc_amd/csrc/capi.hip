@@ -57,6 +57,7 @@ int covo_destroy(covo_handle_t h)
 {
     if (!h) return COVO_E_NOHANDLE;
     step_state_destroy(h);
+    batch_state_destroy(h);
     int rc = 0;
 #define DESTROY(expr)                                                                                   \
     do {                                                                                                \
@@ -292,6 +293,21 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
     rng[0] = key[0];
     rng[1] = key[1];
     return 0;
+}
+
+int covo_mpc_step_batched(covo_handle_t h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,
+                          void *stream)
+{
+    REQUIRE(h, "covo_mpc_step_batched: null handle");
+    REQUIRE(args && params && keys, "covo_mpc_step_batched: null argument");
+    REQUIRE(args->n_envs > 0 && args->n_envs <= COVO_MAX_ENVS, "covo_mpc_step_batched: n_envs=%d outside (0, %d]", args->n_envs,
+            COVO_MAX_ENVS);
+    REQUIRE(args->n_samples > 0 && args->n_samples <= h->cfg.n_local, "covo_mpc_step_batched: n_samples=%d outside (0, %d]",
+            args->n_samples, h->cfg.n_local);
+    REQUIRE(args->states && args->pos_traj && args->vel_traj && args->a_mean && args->a && args->cost && args->groupmin &&
+                args->T > 0,
+            "covo_mpc_step_batched: null buffer");
+    return covo_step_batched_impl(h, args, params, keys, (hipStream_t)stream);
 }
 
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,

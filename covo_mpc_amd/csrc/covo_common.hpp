@@ -22,6 +22,7 @@ struct covo_ctx {
     void *ws_hess;        // scratch of the second-order-adjoint Hessian (grown on demand, outside graph capture)
     size_t ws_hess_bytes;
     void *step;               // StepState (step.hip): fused-step scratch + graph cache
+    void *batch;              // BatchState (step.hip): env-batched step scratch + graph cache
     hipStream_t side_stream;  // forked work inside one call (joined before the call's last kernel)
     hipEvent_t ev_fork, ev_join;
     int max_red_blocks;
@@ -95,7 +96,10 @@ int launch_merge(const float *partials, int G, float lam, const float *a_mean_ol
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
 size_t hessian_workspace_bytes(int batch);
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                   const float *a_mean, int batch, double *R, void *workspace, hipStream_t s);
+                   const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev = nullptr,
+                   size_t traj_stride = 0);
+size_t hessian_consts_bytes(int n);
+void hessian_fill_consts(const covo_env_params *params, int n, void *out);
 // the per-pair hyper-dual rollout version (hessian.hip): slower, independent derivation, kept as a cross-check
 int launch_hessian_pairs(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                          const float *a_mean, int batch, double *R, hipStream_t s);
@@ -105,6 +109,9 @@ size_t sigma_ns_workspace_bytes(int batch);
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
                     hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
 void step_state_destroy(covo_ctx *h);
+void batch_state_destroy(covo_ctx *h);
+int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,
+                           hipStream_t s);
 int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, uint32_t key0, uint32_t key1,
                    const float *f_shared, hipStream_t s);
 int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);

@@ -50,17 +50,20 @@ struct AdjArgs {
     double *R;              // [batch][128][128]
     double *ws;             // [batch][WS_COUNT]
     int T;
-    qm::Consts<double> c;
+    qm::Consts<double> c;            // shared model constants ...
+    const qm::Consts<double> *cs;    // ... or one per batch entry (device, nullable): env instances with their own parameters
+    size_t traj_stride;              // floats between the trajectories of consecutive batch entries (0: shared)
 };
 
-__device__ __forceinline__ void adj_targets(const float *__restrict__ st, const AdjArgs &A, int time0, int k, double (&tar)[6])
+__device__ __forceinline__ void adj_targets(const float *__restrict__ st, const float *__restrict__ pos_traj,
+                                            const float *__restrict__ vel_traj, int T, int time0, int k, double (&tar)[6])
 {
     if (k == 0) {
         for (int i = 0; i < 3; ++i) { tar[i] = st[ST_POSTAR + i]; tar[3 + i] = st[ST_VELTAR + i]; }
     } else {
         int idx = time0 + k;
-        idx = idx < 0 ? 0 : (idx > A.T - 1 ? A.T - 1 : idx);
-        for (int i = 0; i < 3; ++i) { tar[i] = A.pos_traj[3 * idx + i]; tar[3 + i] = A.vel_traj[3 * idx + i]; }
+        idx = idx < 0 ? 0 : (idx > T - 1 ? T - 1 : idx);
+        for (int i = 0; i < 3; ++i) { tar[i] = pos_traj[3 * idx + i]; tar[3 + i] = vel_traj[3 * idx + i]; }
     }
 }
 
@@ -82,16 +85,18 @@ __device__ __forceinline__ void adj_load_state(qm::State<double> &p, const doubl
 
 // one step on hyper-dual numbers: z_a carries e1, z_b carries e2 (an index outside 0..16 seeds nothing).
 // r = r_k(x) (0 for k = 0), s = f_k(z) (left at x_k for k = H-1, whose dynamics never reach a reward).
-__device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const float *__restrict__ am, const AdjArgs &A, int time0,
-                                            int k, const qm::State<double> &p, int a, int b, qm::HD &r, qm::State<qm::HD> &s)
+__device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const float *__restrict__ am, const AdjArgs &A, int bi,
+                                            int time0, int k, const qm::State<double> &p, int a, int b, qm::HD &r,
+                                            qm::State<qm::HD> &s)
 {
+    const qm::Consts<double> c = A.cs ? A.cs[bi] : A.c;
 #define OP(m, i) s.m = qm::HD{p.m, a == i ? 1.0 : 0.0, b == i ? 1.0 : 0.0, 0.0};
     ADJ_FOR_STATE(OP)
 #undef OP
     r = qm::hd(0.0);
     if (k >= 1) {
         double tar[6];
-        adj_targets(st, A, time0, k, tar);
+        adj_targets(st, A.pos_traj + bi * A.traj_stride, A.vel_traj + bi * A.traj_stride, A.T, time0, k, tar);
         r = qm::reward<qm::HD, double>(s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
     }
     if (k <= HH - 2) {
@@ -102,7 +107,7 @@ __device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const 
             act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
         }
         const double f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
-        qm::dyn_step<qm::HD, double>(s, act[0], act[1], act[2], act[3], A.c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
+        qm::dyn_step<qm::HD, double>(s, act[0], act[1], act[2], act[3], c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
                                      k == 0 ? f0z : 0.0);
     }
 }
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     const float *__restrict__ am = A.a_mean + (size_t)b * NA;
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
     const int time0 = __float_as_int(st[ST_TIME]);
+    const qm::Consts<double> c = A.cs ? A.cs[b] : A.c;
     qm::State<double> p;
     p.px = st[ST_POS + 0]; p.py = st[ST_POS + 1]; p.pz = st[ST_POS + 2];
     p.vx = st[ST_VEL + 0]; p.vy = st[ST_VEL + 1]; p.vz = st[ST_VEL + 2];
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     for (int t = 0; t < k; ++t) {
         const double a0 = qm::clip11_((double)am[4 * t + 0]), a1 = qm::clip11_((double)am[4 * t + 1]);
         const double a2 = qm::clip11_((double)am[4 * t + 2]), a3 = qm::clip11_((double)am[4 * t + 3]);
-        qm::dyn_step<double, double>(p, a0, a1, a2, a3, A.c, t == 0 ? f0x : 0.0, t == 0 ? f0y : 0.0, t == 0 ? f0z : 0.0);
+        qm::dyn_step<double, double>(p, a0, a1, a2, a3, c, t == 0 ? f0x : 0.0, t == 0 ? f0y : 0.0, t == 0 ? f0z : 0.0);
     }
     if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
     // the step with ONE first-order seed per lane (17 lanes): reward gradient and column `lane` of df/dz
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     qm::D1 r{0.0, 0.0};
     if (k >= 1) {
         double tar[6];
-        adj_targets(st, A, time0, k, tar);
+        adj_targets(st, A.pos_traj + b * A.traj_stride, A.vel_traj + b * A.traj_stride, A.T, time0, k, tar);
         r = qm::reward<qm::D1, double>(s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
     }
     if (k <= HH - 2) {
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
             const qm::D1 x{(double)am[4 * k + d], lane == NX + d ? 1.0 : 0.0};
             act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
         }
-        qm::dyn_step<qm::D1, double>(s, act[0], act[1], act[2], act[3], A.c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
+        qm::dyn_step<qm::D1, double>(s, act[0], act[1], act[2], act[3], c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
                                      k == 0 ? f0z : 0.0);
     }
     if (lane < NZ) {
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(192) void adj_hess_kernel(const AdjArgs A)
     adj_load_state(p, ws + WS_X + 16 * k);
     qm::HD r;
     qm::State<qm::HD> s;
-    adj_hd_step(st, am, A, time0, k, p, a, bb, r, s);
+    adj_hd_step(st, am, A, b, time0, k, p, a, bb, r, s);
     double g = r.ab;
     if (k <= HH - 2) {
         const double *__restrict__ lam = ws + WS_LAM + 16 * (k + 1);
@@ -392,7 +398,8 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
 size_t hessian_workspace_bytes(int batch) { return (size_t)batch * WS_COUNT * sizeof(double); }
 
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                   const float *a_mean, int batch, double *R, void *workspace, hipStream_t s)
+                   const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev,
+                   size_t traj_stride)
 {
     AdjArgs A;
     A.state = state;
@@ -403,10 +410,20 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.ws = reinterpret_cast<double *>(workspace);
     A.T = T;
     A.c = make_consts<double>(p);
+    A.cs = reinterpret_cast<const qm::Consts<double> *>(consts_dev);
+    A.traj_stride = traj_stride;
     if (g_dbg_hess_mask & 1) hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
     if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(adj_chain_kernel, dim3(9, batch), dim3(256), 0, s, A);
     if (g_dbg_hess_mask & 4) hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);
     if (g_dbg_hess_mask & 8) hipLaunchKernelGGL(adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+// host side of the per-instance constants: covo_env_params[n] -> qm::Consts<double>[n] (to be copied to the device)
+size_t hessian_consts_bytes(int n) { return (size_t)n * sizeof(qm::Consts<double>); }
+void hessian_fill_consts(const covo_env_params *params, int n, void *out)
+{
+    qm::Consts<double> *c = reinterpret_cast<qm::Consts<double> *>(out);
+    for (int i = 0; i < n; ++i) c[i] = make_consts<double>(params[i]);
 }

@@ -8,6 +8,7 @@
 // Quantities that change every step (Philox key, MPPI's shared disturbance draw) live in a 32-byte
 // device block refreshed by one async copy before each replay, so the captured kernel arguments stay valid.
 #include <cstring>
+#include <vector>
 #include "covo_common.hpp"
 #include "rng_device.hpp"
 
@@ -301,4 +302,186 @@ int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const 
     (void)hipGraphExecDestroy(ge);
     (void)hipGraphDestroy(g);
     return 0;
+}
+
+
+// =====================================================================================================================
+// Env-batched covo-online step (BASELINE configs[4]: E independent env instances, each with its own state, reference
+// trajectory, domain-randomised parameters, mean and noise key): ONE graph for all instances.  The latency-bound part
+// -- Hessian and the eigh-free Sigma chain -- runs once for all E matrices (every kernel of both takes `batch`), so its
+// ~50 launches are amortised over the instances; noise GEMM, rollout and softmax update are enqueued per instance.
+// "Replicas only" (SURVEY.md 8e): no exchange between instances, env instances shard over GPUs without a collective.
+struct BatchDyn {
+    uint32_t w[COVO_MAX_ENVS][4];  // {rng_act[2] -> act_key[2]} per instance
+};
+__global__ void batch_set_dyn_kernel(uint32_t *__restrict__ dyn, const BatchDyn b, int n)
+{
+    const int i = threadIdx.x;
+    if (i < 4 * n) dyn[12 * (i >> 2) + (i & 3)] = b.w[i >> 2][i & 3];
+}
+// per instance: shift the mean (covo.py:201-203); act_key = split(rng_act)[1] (covo.py:212); f_shared = 0 (deterministic)
+__global__ void batch_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift, uint32_t *__restrict__ dyn)
+{
+    const int e = blockIdx.x, i = threadIdx.x;
+    uint32_t *d = dyn + 12 * e;
+    const uint32_t raw[2] = {d[0], d[1]};
+    __syncthreads();
+    if (i < COVO_NA) {
+        a_mean_shift[e * COVO_NA + i] = (i < COVO_NA - COVO_DU) ? a_mean[e * COVO_NA + i + COVO_DU] : a_mean[e * COVO_NA + i];
+    } else if (i == COVO_NA) {
+        uint32_t k[2];
+        host_split(raw, 1u, k);
+        d[0] = k[0];
+        d[1] = k[1];
+        d[2] = d[3] = d[4] = 0u;
+    }
+}
+
+struct BatchState {
+    int n_envs = 0;
+    uint32_t *dyn = nullptr;        // [E][12]
+    float *a_mean_shift = nullptr;  // [E][128]
+    double *R = nullptr;            // [E][128][128]
+    float *Sigma = nullptr, *L = nullptr;  // [E][128][128]
+    void *consts = nullptr;         // qm::Consts<double>[E]
+    std::vector<covo_env_params> params;
+    covo_batch_args key;
+    hipStream_t stream = nullptr;
+    bool have_key = false, have_graph = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+static void batch_state_free(BatchState *b)
+{
+    if (b->have_graph) {
+        (void)hipGraphExecDestroy(b->exec);
+        (void)hipGraphDestroy(b->graph);
+    }
+    (void)hipFree(b->dyn);
+    (void)hipFree(b->a_mean_shift);
+    (void)hipFree(b->R);
+    (void)hipFree(b->Sigma);
+    (void)hipFree(b->L);
+    (void)hipFree(b->consts);
+}
+void batch_state_destroy(covo_ctx *h)
+{
+    BatchState *b = reinterpret_cast<BatchState *>(h->batch);
+    if (!b) return;
+    batch_state_free(b);
+    delete b;
+    h->batch = nullptr;
+}
+
+static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, hipStream_t s)
+{
+    const int E = a.n_envs, N = a.n_samples;
+    int rc;
+    hipLaunchKernelGGL(batch_begin_kernel, dim3(E), dim3(COVO_NA + 64), 0, s, a.a_mean, b->a_mean_shift, b->dyn);
+    if ((rc = launch_hessian(a.states, a.pos_traj, a.vel_traj, a.T, b->params[0], b->a_mean_shift, E, b->R, h->ws_hess, s,
+                             b->consts, (size_t)a.T * 3)))
+        return rc;
+    float *Sig = a.a_cov ? a.a_cov : b->Sigma;
+    if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
+    const size_t M = (size_t)COVO_NA * COVO_NA;
+    for (int e = 0; e < E; ++e) {
+        float *ae = a.a + (size_t)e * COVO_H * N * 4, *ce = a.cost + (size_t)e * N, *ge = a.groupmin + (size_t)e * ((N + 63) / 64);
+        float *ams = b->a_mean_shift + (size_t)e * COVO_NA;
+        const float *st = a.states + (size_t)e * COVO_STATE_FLOATS;
+        const float *pt = a.pos_traj + (size_t)e * a.T * 3, *vt = a.vel_traj + (size_t)e * a.T * 3;
+        if ((rc = launch_noise_gemm(b->L + e * M, ams, nullptr, 0, 0, 0, N, ae, s, b->dyn + 12 * e))) return rc;
+        if ((rc = launch_rollout(st, pt, vt, a.T, b->params[e], nullptr, ae, N, h->cfg.discount, true, ce, ge, nullptr,
+                                 h->ws_stats, s, reinterpret_cast<const float *>(b->dyn + 12 * e + 2))))
+            return rc;
+        if ((rc = launch_softmax_reduce(h, ce, ae, N, ge, (N + 63) / 64, nullptr, ams, a.gamma_mean,
+                                        a.a_mean + (size_t)e * COVO_NA, s)))
+            return rc;
+    }
+    return 0;
+}
+
+int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,
+                           hipStream_t s)
+{
+    const int E = args->n_envs;
+    BatchState *b = reinterpret_cast<BatchState *>(h->batch);
+    if (!b) {
+        b = new BatchState();
+        h->batch = b;
+    }
+    bool same = b->have_key && b->n_envs == E && std::memcmp(&b->key, args, sizeof(*args)) == 0 && b->stream == s &&
+                std::memcmp(b->params.data(), params, (size_t)E * sizeof(covo_env_params)) == 0;
+    if (!same) {
+        // new buffers / parameters / instance count: (re)allocate scratch and drop the stale graph (outside the steady state)
+        COVO_CHECK_HIP(hipStreamSynchronize(s));
+        if (b->have_graph) {
+            (void)hipGraphExecDestroy(b->exec);
+            (void)hipGraphDestroy(b->graph);
+            b->have_graph = false;
+        }
+        if (b->n_envs != E) {
+            batch_state_free(b);
+            b->have_graph = false;
+            const size_t M = (size_t)COVO_NA * COVO_NA;
+            COVO_CHECK_HIP(hipMalloc(&b->dyn, (size_t)E * 12 * sizeof(uint32_t)));
+            COVO_CHECK_HIP(hipMalloc(&b->a_mean_shift, (size_t)E * COVO_NA * sizeof(float)));
+            COVO_CHECK_HIP(hipMalloc(&b->R, (size_t)E * M * sizeof(double)));
+            COVO_CHECK_HIP(hipMalloc(&b->Sigma, (size_t)E * M * sizeof(float)));
+            COVO_CHECK_HIP(hipMalloc(&b->L, (size_t)E * M * sizeof(float)));
+            COVO_CHECK_HIP(hipMalloc(&b->consts, hessian_consts_bytes(E)));
+            b->n_envs = E;
+        }
+        b->params.assign(params, params + E);
+        std::vector<char> tmp(hessian_consts_bytes(E));
+        hessian_fill_consts(params, E, tmp.data());
+        COVO_CHECK_HIP(hipMemcpy(b->consts, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+        const size_t need_s = sigma_ns_workspace_bytes(E), need_h = hessian_workspace_bytes(E);
+        if (need_s > h->ws_sigma_bytes) {
+            (void)hipFree(h->ws_sigma);
+            h->ws_sigma = nullptr;
+            h->ws_sigma_bytes = 0;
+            COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, need_s));
+            h->ws_sigma_bytes = need_s;
+        }
+        if (need_h > h->ws_hess_bytes) {
+            (void)hipFree(h->ws_hess);
+            h->ws_hess = nullptr;
+            h->ws_hess_bytes = 0;
+            COVO_CHECK_HIP(hipMalloc(&h->ws_hess, need_h));
+            h->ws_hess_bytes = need_h;
+        }
+        b->key = *args;
+        b->stream = s;
+        b->have_key = true;
+    }
+    BatchDyn blk;
+    std::memset(&blk, 0, sizeof(blk));
+    for (int e = 0; e < E; ++e) {
+        blk.w[e][0] = keys[2 * e];
+        blk.w[e][1] = keys[2 * e + 1];
+    }
+    hipLaunchKernelGGL(batch_set_dyn_kernel, dim3(1), dim3(256), 0, s, b->dyn, blk, E);
+    if (b->have_graph) {
+        COVO_CHECK_HIP(hipGraphLaunch(b->exec, s));
+        return 0;
+    }
+    if (same && (h->cfg.flags & COVO_FLAG_NO_GRAPH) == 0) {  // second identical call: capture
+        hipStream_t cs = h->side_stream;
+        COVO_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        const int rc = batch_enqueue(h, b, *args, cs);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc) return rc;
+        if (e != hipSuccess) {
+            covo_set_error("covo_mpc_step_batched: stream capture failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        COVO_CHECK_HIP(hipGraphInstantiate(&b->exec, g, nullptr, nullptr, 0));
+        b->graph = g;
+        b->have_graph = true;
+        COVO_CHECK_HIP(hipGraphLaunch(b->exec, s));
+        return 0;
+    }
+    return batch_enqueue(h, b, *args, s);
 }

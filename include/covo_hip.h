@@ -246,6 +246,33 @@ typedef struct covo_step_args {
 int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, uint32_t key0,
                   uint32_t key1, const float *f_disturb_shared /* [host float[3]] or NULL */, void *stream);
 
+/* covo-online for n_envs INDEPENDENT env instances in one call / one hipGraph (BASELINE configs[4]; "replicas only": no
+ * exchange between instances).  Every instance has its own noisy state, reference trajectory (T rows), parameters
+ * (domain randomisation), mean and key; the Hessians and the Sigma chain of all instances run as ONE batched set of
+ * launches, the sampling path (noise GEMM, rollout, softmax update) per instance.  Results per instance are bit-identical
+ * to covo_mpc_step on that instance alone.  params: host array [n_envs]; keys: host uint32[n_envs][2], each the raw
+ * rng_act of that instance's controller call (the sampling key is derived on the device, covo.py:212). */
+#define COVO_MAX_ENVS 64
+typedef struct covo_batch_args {
+    int32_t n_envs;          /* <= COVO_MAX_ENVS */
+    int32_t n_samples;       /* per instance, <= n_local */
+    int32_t T;               /* rows of every instance's pos_traj / vel_traj */
+    int32_t pad_;
+    const float *states;     /* float[n_envs][32] noisy states */
+    const float *pos_traj;   /* float[n_envs][T][3] */
+    const float *vel_traj;   /* float[n_envs][T][3] */
+    float *a_mean;           /* float[n_envs][128] in/out */
+    float *a_cov;            /* float[n_envs][128][128] Sigma out (nullable) */
+    float *a;                /* work: float[n_envs][H][n_samples][4] */
+    float *cost;             /* work: float[n_envs][n_samples] */
+    float *groupmin;         /* work: float[n_envs][ceil(n_samples/64)] */
+    float gamma_mean;
+    float sample_sigma;
+} covo_batch_args;
+
+int covo_mpc_step_batched(covo_handle_t h, const covo_batch_args *args, const covo_env_params *params,
+                          const uint32_t *keys, void *stream);
+
 /* Lower Cholesky factors of `batch` symmetric PD n x n fp32 matrices (n <= 128), the
  * factorisation inside jax.random.multivariate_normal (covo.py:216, mppi.py:59). */
 int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, float *L_out, void *stream);

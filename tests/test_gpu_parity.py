@@ -458,6 +458,41 @@ def test_env_instances_with_domain_randomisation():
     assert np.abs(means[0] - means[1]).max() > 1e-4    # ... and get different plans
 
 
+def test_batched_step_equals_replicas():
+    """covo_mpc_step_batched (one graph, ONE Hessian + Sigma launch set for all env instances; BASELINE configs[4]
+    reduced to 3 instances, N = 4096) against 3 separate covo-online controllers on the same states / keys: plans and
+    Sigmas bit-identical at every step -- eager first call, capture on the second, graph replay afterwards."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    N, E = 4096, 3
+    env = cm.envs.Quad3D(task="tracking", obs_type="quad_params", enable_randomizer=True, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    inst = []
+    for e in range(E):
+        params = env.sample_params(cr.PRNGKey(100 + e))
+        controller, cp = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV, compute_info=False)
+        obs, info, state = env.reset(cr.PRNGKey(200 + e), params)
+        cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(2))
+        inst.append(dict(params=params, controller=controller, cp=cp, obs=obs, info=info, state=state, key=cr.PRNGKey(300 + e)))
+    cp0 = inst[0]["cp"]
+    batched = cm.controllers.BatchedCoVOController(env, E, N, 32, 0.01, discount=cp0.discount, gamma_mean=cp0.gamma_mean,
+                                                   sample_sigma=cp0.sample_sigma, a_mean_init=cp0.a_mean, device=DEV)
+    batched.set_instances([i["state"] for i in inst], [i["params"] for i in inst])
+    for step in range(5):
+        k_acts = []
+        for i in inst:
+            i["key"], k_act, i["k_step"] = cr.split(i["key"], 3)
+            k_acts.append(np.asarray(k_act))
+        u_b = batched([i["info"]["noisy_state"] for i in inst], np.stack(k_acts)).clone()
+        for e, i in enumerate(inst):
+            u, i["cp"], _ = i["controller"](i["obs"], i["state"], i["params"], k_acts[e], i["cp"], i["info"])
+            assert torch.equal(batched.a_mean[e].view(32, 4), i["cp"].a_mean), (step, e)
+            assert torch.equal(batched.a_cov[e], i["cp"].a_cov), (step, e)
+            assert torch.equal(u_b[e], u), (step, e)
+            i["obs"], i["state"], _, _, i["info"] = env.step(i["k_step"], i["state"], u.cpu().numpy(), i["params"])
+    assert (batched.a_mean[0] - batched.a_mean[1]).abs().max() > 1e-4  # different plants, different plans
+
+
 def test_closed_loop_tracking_sanity():
     """Free-running covo-offline on tracking_zigzag: tracking error stays at the few-cm level after the
     start-up transient."""
