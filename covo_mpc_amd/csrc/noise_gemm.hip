@@ -137,6 +137,14 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
     // dyn (nullable): {key0, key1} in device memory -- lets a captured graph see a fresh key every replay.
     // state_for_time (nullable): L is a table [n_table][128][128]; use row state.time (covo.py:107-108, clamped
     // like a JAX gather).
+    // blockIdx.y (env-batched step): instance y has its own factor, mean, key block and action stripes, all dense
+    {
+        const size_t y = blockIdx.y;
+        L += y * (COVO_NA * COVO_NA);
+        mu += y * COVO_NA;
+        a_out += y * ((size_t)COVO_H * N);
+        if (dyn != nullptr) dyn += y * 12;
+    }
     if (dyn != nullptr) { k0 = dyn[0]; k1 = dyn[1]; }
     if (state_for_time != nullptr) {
         int t = __float_as_int(state_for_time[ST_TIME]);
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
 }
 
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
-                      int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table)
+                      int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table, int batch)
 {
     const int ntiles = (N + 31) / 32;
     const int waves_per_block = NG_BLOCK / 64;
@@ -304,7 +312,7 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
         hipLaunchKernelGGL(noise_gemm_kernel<false>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
                            ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table);
     else
-        hipLaunchKernelGGL(noise_gemm_kernel<true>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, (const float *)nullptr, k0,
+        hipLaunchKernelGGL(noise_gemm_kernel<true>, dim3(grid, batch), dim3(NG_BLOCK), lds, s, L, mu, (const float *)nullptr, k0,
                            k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn, state_for_time, n_table);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;

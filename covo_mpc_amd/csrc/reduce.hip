@@ -39,6 +39,13 @@ __global__ __launch_bounds__(RD_BLOCK) void softmax_partial_kernel(const float *
     __shared__ float sv[RD_WAVES][COVO_NA];
     __shared__ float ss[RD_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // blockIdx.y (env-batched step): instance y's dense slices; its records follow those of instance y - 1
+        const size_t y = blockIdx.y;
+        cost += y * N;
+        a += y * ((size_t)COVO_H * N);
+        blockmin += y * nbm;
+        partials += y * gridDim.x * COVO_PARTIAL_FLOATS;
+    }
 
     // ---- exact global minimum of cost from the per-block minima
     float m = __builtin_inff();
@@ -120,6 +127,12 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
     __shared__ float reds[MG_THREADS / 64];
     __shared__ float sv[MG_SLICES][COVO_NA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // blockIdx.x (env-batched step): instance x merges its own G records into its own mean
+        const size_t x = blockIdx.x;
+        partials += x * G * COVO_PARTIAL_FLOATS;
+        if (FINAL) a_mean_old += x * COVO_NA;
+        out += x * (FINAL ? COVO_NA : COVO_PARTIAL_FLOATS);
+    }
     // phase 1: m = min_g m_g
     float m = __builtin_inff();
     for (int g = tid; g < G; g += MG_THREADS) m = fminf(m, partials[(size_t)g * COVO_PARTIAL_FLOATS]);
@@ -175,9 +188,10 @@ __global__ void shift_mean_kernel(const float *__restrict__ in, float *__restric
 
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,
-                          hipStream_t s)
+                          hipStream_t s, float *partials_ws, int batch)
 {
     const float inv_lam = 1.0f / h->cfg.lam;
+    if (partials_ws == nullptr) partials_ws = h->ws_partials;
     if (blockmin == nullptr) {
         n_blockmin = (N + 63) / 64;
         hipLaunchKernelGGL(groupmin_kernel, dim3((N + 255) / 256), dim3(256), 0, s, cost, N, h->ws_blockmin);
@@ -186,13 +200,13 @@ int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N,
     const int ngroups = (N + 63) / 64;
     int grid = (ngroups + RD_WAVES - 1) / RD_WAVES;
     if (grid > h->max_red_blocks) grid = h->max_red_blocks;
-    hipLaunchKernelGGL(softmax_partial_kernel, dim3(grid), dim3(RD_BLOCK), 0, s, cost,
-                       reinterpret_cast<const float4 *>(a), N, blockmin, n_blockmin, inv_lam, h->ws_partials);
+    hipLaunchKernelGGL(softmax_partial_kernel, dim3(grid, batch), dim3(RD_BLOCK), 0, s, cost,
+                       reinterpret_cast<const float4 *>(a), N, blockmin, n_blockmin, inv_lam, partials_ws);
     if (a_mean_out != nullptr)
-        hipLaunchKernelGGL(merge_kernel<true>, dim3(1), dim3(MG_THREADS), 0, s, h->ws_partials, grid, inv_lam, a_mean_old,
+        hipLaunchKernelGGL(merge_kernel<true>, dim3(batch), dim3(MG_THREADS), 0, s, partials_ws, grid, inv_lam, a_mean_old,
                            gamma_mean, a_mean_out);
     else
-        hipLaunchKernelGGL(merge_kernel<false>, dim3(1), dim3(MG_THREADS), 0, s, h->ws_partials, grid, inv_lam,
+        hipLaunchKernelGGL(merge_kernel<false>, dim3(batch), dim3(MG_THREADS), 0, s, partials_ws, grid, inv_lam,
                            (const float *)nullptr, 1.0f, partial_out);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;

@@ -41,9 +41,12 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // v_readlane_b3
 // CLIP: re-apply step_env's clip (quadrotor.py:223,258); off when the producer guarantees clipped
 // stripes.  PF: how many action stripes are in flight (32 = the whole horizon is issued up front:
 // right at <= 2 waves/SIMD where nothing else hides HBM latency; 8 keeps VGPRs low for big N).
-template <bool STATS, bool DISC1, bool CLIP, int PF>
-__global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A)
+// BATCHED (env-batched step): workgroup row blockIdx.y rolls out instance y, whose argument block -- own state,
+// trajectory, parameters, action stripes, cost slice -- is batch[y] in device memory (wave-uniform scalar loads).
+template <bool STATS, bool DISC1, bool CLIP, int PF, bool BATCHED = false>
+__global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
 {
+    const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
     __shared__ double sacc[STATS ? (RO_BLOCK / COVO_WAVE) * COVO_H * 6 : 1];  // one slot per wave: no atomics, fixed order
     __shared__ float spanel[STATS ? (RO_BLOCK / COVO_WAVE) * 8 * 3 * COVO_WAVE : 1];  // 8 steps x 3 axes x 64 lanes per wave
     const int tid = threadIdx.x, lane = tid & (COVO_WAVE - 1), wave = tid / COVO_WAVE;
@@ -185,9 +188,11 @@ __device__ __forceinline__ void lds_phase_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool DISC1, bool CLIP>
-__global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel(const RolloutArgs A)
+template <bool DISC1, bool CLIP, bool BATCHED = false>
+__global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel(const RolloutArgs A_,
+                                                                                 const RolloutArgs *__restrict__ batch)
 {
+    const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
     __shared__ float4 ring_all[RS_PAIRS][RS_RING][2][COVO_WAVE];
     const int lane = threadIdx.x & (COVO_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -309,20 +314,19 @@ __global__ __launch_bounds__(256) void pos_stats_finalize_kernel(const double *_
     if (tid == 0) out[i] = red[0];
 }
 
-template <bool STATS, bool DISC1, bool CLIP>
-static void launch_rollout_pf(const RolloutArgs &A, int grid, bool deep, hipStream_t s)
+template <bool STATS, bool DISC1, bool CLIP, bool BATCHED = false>
+static void launch_rollout_pf(const RolloutArgs &A, const RolloutArgs *batch, int nbatch, int grid, bool deep, hipStream_t s)
 {
     if (deep)
-        hipLaunchKernelGGL((rollout_kernel<STATS, DISC1, CLIP, COVO_H>), dim3(grid), dim3(RO_BLOCK), 0, s, A);
+        hipLaunchKernelGGL((rollout_kernel<STATS, DISC1, CLIP, COVO_H, BATCHED>), dim3(grid, nbatch), dim3(RO_BLOCK), 0, s, A, batch);
     else
-        hipLaunchKernelGGL((rollout_kernel<STATS, DISC1, CLIP, 8>), dim3(grid), dim3(RO_BLOCK), 0, s, A);
+        hipLaunchKernelGGL((rollout_kernel<STATS, DISC1, CLIP, 8, BATCHED>), dim3(grid, nbatch), dim3(RO_BLOCK), 0, s, A, batch);
 }
 
-int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                   const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
-                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev)
+static void fill_rollout_args(RolloutArgs &A, const float *state, const float *pos_traj, const float *vel_traj, int T,
+                              const covo_env_params &p, const float *f_shared, const float *a, int N, float discount,
+                              float *cost, float *groupmin, double *stats_ws, const float *f_shared_dev)
 {
-    RolloutArgs A;
     A.state = state;
     A.pos_traj = pos_traj;
     A.vel_traj = vel_traj;
@@ -338,24 +342,36 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     A.f_shared_dev = f_shared_dev;
     A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? 1 : 0;  // the GEMM runs one 32-sample tile per wave up to 512 workgroups
     A.c = make_consts<float>(p);
+}
+
+// nbatch == 0: one rollout described by A; else nbatch instances described by the device array `batch` (all with A's
+// N, discount and clip contract -- A is only used to pick the kernel variant, the same one a single launch would get)
+template <bool BATCHED>
+static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int nbatch, bool trust_clipped, double *pos_stats,
+                            hipStream_t s)
+{
+    const int N = A.N;
+    const int nb = BATCHED ? nbatch : 1;
     const int grid = (N + RO_BLOCK - 1) / RO_BLOCK;
-    const bool deep = grid <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
-    const bool d1 = (discount == 1.0f);
-    const bool stats = pos_stats != nullptr;
+    const bool deep = grid * nb <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
+    const bool d1 = (A.discount == 1.0f);
+    const bool stats = !BATCHED && pos_stats != nullptr;
     if (!stats && 2 * ((N + COVO_WAVE - 1) / COVO_WAVE) <= 1024) {  // both waves of every pair get their own SIMD
-        const int g2 = (N + RS_PAIRS * COVO_WAVE - 1) / (RS_PAIRS * COVO_WAVE);
-        if (d1) { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<true, false>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A);
-                  else hipLaunchKernelGGL((rollout_split_kernel<true, true>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A); }
-        else    { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<false, false>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A);
-                  else hipLaunchKernelGGL((rollout_split_kernel<false, true>), dim3(g2), dim3(2 * RS_PAIRS * COVO_WAVE), 0, s, A); }
+        const dim3 g2((N + RS_PAIRS * COVO_WAVE - 1) / (RS_PAIRS * COVO_WAVE), nb), blk(2 * RS_PAIRS * COVO_WAVE);
+        if (d1) { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<true, false, BATCHED>), g2, blk, 0, s, A, batch);
+                  else hipLaunchKernelGGL((rollout_split_kernel<true, true, BATCHED>), g2, blk, 0, s, A, batch); }
+        else    { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<false, false, BATCHED>), g2, blk, 0, s, A, batch);
+                  else hipLaunchKernelGGL((rollout_split_kernel<false, true, BATCHED>), g2, blk, 0, s, A, batch); }
         COVO_CHECK_HIP(hipGetLastError());
         return 0;
     }
-#define RO_DISPATCH(ST, D1, CL) launch_rollout_pf<ST, D1, CL>(A, grid, deep, s)
+#define RO_DISPATCH(ST, D1, CL) launch_rollout_pf<ST, D1, CL, BATCHED>(A, batch, nb, grid, deep, s)
     if (stats) {
-        if (d1) { if (trust_clipped) RO_DISPATCH(true, true, false); else RO_DISPATCH(true, true, true); }
-        else    { if (trust_clipped) RO_DISPATCH(true, false, false); else RO_DISPATCH(true, false, true); }
-        hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(COVO_H * 6), dim3(256), 0, s, stats_ws, grid, pos_stats);
+        if constexpr (!BATCHED) {
+            if (d1) { if (trust_clipped) RO_DISPATCH(true, true, false); else RO_DISPATCH(true, true, true); }
+            else    { if (trust_clipped) RO_DISPATCH(true, false, false); else RO_DISPATCH(true, false, true); }
+            hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(COVO_H * 6), dim3(256), 0, s, A.stats_ws, grid, pos_stats);
+        }
     } else {
         if (d1) { if (trust_clipped) RO_DISPATCH(false, true, false); else RO_DISPATCH(false, true, true); }
         else    { if (trust_clipped) RO_DISPATCH(false, false, false); else RO_DISPATCH(false, false, true); }
@@ -363,4 +379,30 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
 #undef RO_DISPATCH
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
+                   const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
+                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev)
+{
+    RolloutArgs A;
+    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev);
+    return dispatch_rollout<false>(A, nullptr, 0, trust_clipped, pos_stats, s);
+}
+
+// ---- env-batched rollout: one launch, workgroup row y = instance y (step.hip: covo_mpc_step_batched)
+size_t rollout_args_bytes(int n) { return (size_t)n * sizeof(RolloutArgs); }
+
+void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
+                       const covo_env_params &p, const float *a, int N, float discount, float *cost, float *groupmin,
+                       const float *f_shared_dev)
+{
+    fill_rollout_args(reinterpret_cast<RolloutArgs *>(out)[index], state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost,
+                      groupmin, nullptr, f_shared_dev);
+}
+
+int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, bool trust_clipped, hipStream_t s)
+{
+    return dispatch_rollout<true>(reinterpret_cast<const RolloutArgs *>(args_host)[0],
+                                  reinterpret_cast<const RolloutArgs *>(args_dev), nbatch, trust_clipped, nullptr, s);
 }

@@ -7,6 +7,7 @@
 // The second call with the same buffers captures the sequence into a hipGraph, later calls replay it.
 // Quantities that change every step (Philox key, MPPI's shared disturbance draw) live in a 32-byte
 // device block refreshed by one async copy before each replay, so the captured kernel arguments stay valid.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "covo_common.hpp"
@@ -343,7 +344,10 @@ struct BatchState {
     float *a_mean_shift = nullptr;  // [E][128]
     double *R = nullptr;            // [E][128][128]
     float *Sigma = nullptr, *L = nullptr;  // [E][128][128]
-    void *consts = nullptr;         // qm::Consts<double>[E]
+    void *consts = nullptr;         // qm::Consts<double>[E]   (Hessian)
+    void *ro_args = nullptr;        // RolloutArgs[E]          (rollout)
+    float *partials = nullptr;      // [E][max_red_blocks][COVO_PARTIAL_FLOATS]: the instances' softmax stage-1 records
+    std::vector<char> ro_args_host;
     std::vector<covo_env_params> params;
     covo_batch_args key;
     hipStream_t stream = nullptr;
@@ -357,6 +361,7 @@ static void batch_state_free(BatchState *b)
     if (b->have_graph) {
         (void)hipGraphExecDestroy(b->exec);
         (void)hipGraphDestroy(b->graph);
+        b->have_graph = false;
     }
     (void)hipFree(b->dyn);
     (void)hipFree(b->a_mean_shift);
@@ -364,6 +369,10 @@ static void batch_state_free(BatchState *b)
     (void)hipFree(b->Sigma);
     (void)hipFree(b->L);
     (void)hipFree(b->consts);
+    (void)hipFree(b->ro_args);
+    (void)hipFree(b->partials);
+    b->dyn = nullptr; b->a_mean_shift = nullptr; b->R = nullptr; b->Sigma = b->L = nullptr; b->consts = nullptr;
+    b->ro_args = nullptr; b->partials = nullptr;
 }
 void batch_state_destroy(covo_ctx *h)
 {
@@ -374,6 +383,10 @@ void batch_state_destroy(covo_ctx *h)
     h->batch = nullptr;
 }
 
+// Seven batched launch sets for all E instances: begin, Hessian (4 kernels), Sigma chain (~47), noise GEMM, rollout,
+// softmax partials, merge -- every kernel takes the instance as a grid dimension.  (Measured alternative, E = 32,
+// N = 4096: per-instance GEMM/rollout/softmax launches 1 452 us per call; the same spread over 2 / 4 / 8 forked
+// branches of the graph 1 103 / 1 140 / 1 153 us, while hipGraphLaunch's host cost grew from 47 to >300 us.)
 static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, hipStream_t s)
 {
     const int E = a.n_envs, N = a.n_samples;
@@ -384,21 +397,10 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
     if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
-    const size_t M = (size_t)COVO_NA * COVO_NA;
-    for (int e = 0; e < E; ++e) {
-        float *ae = a.a + (size_t)e * COVO_H * N * 4, *ce = a.cost + (size_t)e * N, *ge = a.groupmin + (size_t)e * ((N + 63) / 64);
-        float *ams = b->a_mean_shift + (size_t)e * COVO_NA;
-        const float *st = a.states + (size_t)e * COVO_STATE_FLOATS;
-        const float *pt = a.pos_traj + (size_t)e * a.T * 3, *vt = a.vel_traj + (size_t)e * a.T * 3;
-        if ((rc = launch_noise_gemm(b->L + e * M, ams, nullptr, 0, 0, 0, N, ae, s, b->dyn + 12 * e))) return rc;
-        if ((rc = launch_rollout(st, pt, vt, a.T, b->params[e], nullptr, ae, N, h->cfg.discount, true, ce, ge, nullptr,
-                                 h->ws_stats, s, reinterpret_cast<const float *>(b->dyn + 12 * e + 2))))
-            return rc;
-        if ((rc = launch_softmax_reduce(h, ce, ae, N, ge, (N + 63) / 64, nullptr, ams, a.gamma_mean,
-                                        a.a_mean + (size_t)e * COVO_NA, s)))
-            return rc;
-    }
-    return 0;
+    if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E))) return rc;
+    if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, true, s))) return rc;
+    return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, b->a_mean_shift, a.gamma_mean, a.a_mean, s,
+                                 b->partials, E);
 }
 
 int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,
@@ -430,12 +432,22 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
             COVO_CHECK_HIP(hipMalloc(&b->Sigma, (size_t)E * M * sizeof(float)));
             COVO_CHECK_HIP(hipMalloc(&b->L, (size_t)E * M * sizeof(float)));
             COVO_CHECK_HIP(hipMalloc(&b->consts, hessian_consts_bytes(E)));
+            COVO_CHECK_HIP(hipMalloc(&b->ro_args, rollout_args_bytes(E)));
+            COVO_CHECK_HIP(hipMalloc(&b->partials, (size_t)E * h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
             b->n_envs = E;
         }
         b->params.assign(params, params + E);
         std::vector<char> tmp(hessian_consts_bytes(E));
         hessian_fill_consts(params, E, tmp.data());
         COVO_CHECK_HIP(hipMemcpy(b->consts, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+        b->ro_args_host.assign(rollout_args_bytes(E), 0);
+        const int N = args->n_samples, ng = (N + 63) / 64;
+        for (int e = 0; e < E; ++e)
+            rollout_fill_args(b->ro_args_host.data(), e, args->states + (size_t)e * COVO_STATE_FLOATS,
+                              args->pos_traj + (size_t)e * args->T * 3, args->vel_traj + (size_t)e * args->T * 3, args->T,
+                              params[e], args->a + (size_t)e * COVO_H * N * 4, N, h->cfg.discount, args->cost + (size_t)e * N,
+                              args->groupmin + (size_t)e * ng, reinterpret_cast<const float *>(b->dyn + 12 * e + 2));
+        COVO_CHECK_HIP(hipMemcpy(b->ro_args, b->ro_args_host.data(), b->ro_args_host.size(), hipMemcpyHostToDevice));
         const size_t need_s = sigma_ns_workspace_bytes(E), need_h = hessian_workspace_bytes(E);
         if (need_s > h->ws_sigma_bytes) {
             (void)hipFree(h->ws_sigma);
