@@ -32,6 +32,25 @@ struct RolloutArgs {
 
 constexpr int RO_BLOCK = 256;
 
+// scripts/probe/rollout_probe.hip compiles this file with ROLLOUT_PROBE: every workgroup leaves {XCC, HW_ID, start, end}
+// (s_memrealtime, 100 MHz) -- where the dispatcher put it and when it ran.  Compiled out of the library.
+#ifdef ROLLOUT_PROBE
+__device__ unsigned long long *g_ro_probe;
+#define RO_PROBE_BEGIN()                                                                                   \
+    unsigned long long ro_t0_ = wall_clock64();
+#define RO_PROBE_END(TID)                                                                                  \
+    if (threadIdx.x == (TID) && g_ro_probe) {                                                                  \
+        unsigned xcc_, hw_;                                                                                \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                  \
+        unsigned long long *o_ = g_ro_probe + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);           \
+        o_[0] = xcc_; o_[1] = hw_; o_[2] = ro_t0_; o_[3] = wall_clock64();                                 \
+    }
+#else
+#define RO_PROBE_BEGIN()
+#define RO_PROBE_END(TID)
+#endif
+
 __device__ __forceinline__ float lane_bcast(float v, int lane)  // v_readlane_b32 -> SGPR operand
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -47,6 +66,7 @@ template <bool STATS, bool DISC1, bool CLIP, int PF, bool BATCHED = false>
 __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
 {
     const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
+    RO_PROBE_BEGIN();
     __shared__ double sacc[STATS ? (RO_BLOCK / COVO_WAVE) * COVO_H * 6 : 1];  // one slot per wave: no atomics, fixed order
     __shared__ float spanel[STATS ? (RO_BLOCK / COVO_WAVE) * 8 * 3 * COVO_WAVE : 1];  // 8 steps x 3 axes x 64 lanes per wave
     const int tid = threadIdx.x, lane = tid & (COVO_WAVE - 1), wave = tid / COVO_WAVE;
@@ -166,6 +186,7 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
             A.stats_ws[(size_t)blockIdx.x * (COVO_H * 6) + i] =
                 (sacc[i] + sacc[COVO_H * 6 + i]) + (sacc[2 * COVO_H * 6 + i] + sacc[3 * COVO_H * 6 + i]);
     }
+    RO_PROBE_END(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -193,6 +214,7 @@ __global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel
                                                                                  const RolloutArgs *__restrict__ batch)
 {
     const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
+    RO_PROBE_BEGIN();
     __shared__ float4 ring_all[RS_PAIRS][RS_RING][2][COVO_WAVE];
     const int lane = threadIdx.x & (COVO_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,6 +315,7 @@ __global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel
             if (lane == 0 && group * COVO_WAVE < A.N) A.groupmin[group] = wm;
         }
     }
+    RO_PROBE_END(RS_PAIRS * COVO_WAVE);
 }
 
 // sums the per-block position statistics in fp64: out[k*6+i]

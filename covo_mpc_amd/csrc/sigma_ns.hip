@@ -14,8 +14,17 @@
 // 16x16 tile with K = 128: 4.2 us; one 256-thread workgroup per tile with K split over its 4 waves:
 // 2.6 us; the same phases inside ONE persistent launch separated by a counter barrier: 6.1 us (spread
 // over the XCDs) / 22.8 us (confined to one XCD) -- so: separate launches, K-split tiles.
-//   1. lambda_min:  X <- X^2 / |X|_F^2  (NS_SQUARINGS times) on X0 = shift*I - R drives X to the
-//      dominant eigenspace; a Rayleigh-Ritz step on its RITZ largest-diagonal columns gives lambda_min
+//   1. lambda_min:  a Chebyshev filter of degree 2^k built by repeated squaring.  Y0 = affine map of A that sends
+//      [cut, hi] to [-1, 1] and everything BELOW cut above 1 (hi >= lambda_max: min of the Gershgorin and Frobenius
+//      bounds; cut = min_i A_ii + 2^-10 (hi - min_i A_ii) > lambda_min, a Rayleigh quotient).  T_2(x) = 2x^2 - 1
+//      composed k times is T_(2^k): eigenvalues inside [cut, hi] stay bounded by 1 while those below grow like
+//      cosh(2^k sqrt(2 eps)), eps = their relative distance below cut -- the square root is what a plain power
+//      iteration on hi*I - A lacks: closed-loop CoVO Hessians are indefinite with lambda_max ~ 10^2..10^3 and
+//      bottom gaps ~ 0.5 (relative 1e-3), where X <- X^2 needed 14-16 squarings (and hit its cap of 16 in 44 % of the
+//      steps of an episode) and the filter needs 10-12 (scripts/ns_counts.py).  In normalised form
+//          X_(k+1) = X_k^2 / |X_k|_F^2 - I / t_(k+1),   t_(k+1) = 2 t_k^2 |X_k|_F^2,  t_0 = 1  (T_(2^k) = t_k X_k),
+//      so once t_k is large the iteration IS the old normalised squaring and X tends to the projector onto the bottom
+//      eigenspace; a Rayleigh-Ritz step on its RITZ largest-diagonal columns gives lambda_min
 //      (exact as soon as the eigenvector lies in the span -- robust to near-degenerate bottoms).
 //   2. B^(-1/2), B = R + delta I: coupled Newton-Schulz  T = a_k I + b_k Z Y, Y <- Y T, Z <- T Z  from
 //      Y0 = B/s, Z0 = I, with the Chen-Chow scaling  a_k = 1.5 rho_k, b_k = -0.5 rho_k^3,
@@ -38,8 +47,12 @@
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SN = COVO_NA;  // 128
-constexpr int NS_SQUARINGS = 16;   // X^(2^16): a relative gap of 2e-4 between the bottom eigenvalue and the 5th one
-                                   // (RITZ = 4 are resolved exactly by the Ritz step) is damped to 1e-11
+constexpr int NS_SQUARINGS = 13;   // Chebyshev degree 2^13: at least as selective as X^(2^16) was (numpy study on closed-loop
+                                   // Hessians and synthetic spectra); RITZ = 4 near-degenerate bottom
+                                   // eigenvalues are resolved exactly by the Ritz step
+constexpr double NS_CUT_MARGIN = 1.0 / 1024.0;  // cut = min diag + margin * (hi - min diag): lambda_min is strictly amplified
+constexpr double NS_SQ_TOL = 1e-7;     // squaring k+1 is skipped once |X_k|_F^2 moved by < 1e-7 relative ...
+constexpr double NS_SQ_TGUARD = 1e10;  // ... and t_k > 1e10 (the bounded part of the spectrum is down at 1e-10)
 constexpr int NS_ITERS = 12;       // scaled iteration: 8 for s/1e-2 = 1e3 (real CoVO Hessians), 10 for 2e4, 12 for 1e6; launches after
                                    // convergence return at once (1.6 us each)
 constexpr double NS_TOL2 = 1e-10;  // iteration k+1 is skipped once |I - Z_k Y_k|_F^2 < 1e-10: step k itself squares
@@ -54,7 +67,7 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
-       SC_PREP = 320,          // prep partials: 8 x {max rowabs, sum v^2, trace, -}
+       SC_PREP = 320,          // prep partials: 8 x {max rowabs, sum v^2, trace, min diag}
        SC_SQN = 384,           // |X_i|_F^2 partials: (NS_SQUARINGS + 1) x 64 (36 used)
        SC_ERR = SC_SQN + (NS_SQUARINGS + 1) * 64,  // |Z_k Y_k - I|_F^2 partials: NS_ITERS x 64
        SC_COUNT = SC_ERR + NS_ITERS * 64 };
@@ -65,13 +78,13 @@ static_assert(SC_COEF + 2 * NS_ITERS <= SC_ROWABS, "scalar slots");
 // MFMA f64 16x16x4: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
 // The A operand is fetched as At[k][i], so BOTH operands are read as 128-B contiguous runs; callers pass
 // the stored TRANSPOSE of the left factor.  `f(value, row, col)` maps the stored element to the operand
-// (identity; shift*I - A for the first squaring; (A + delta I)/s for the first Newton-Schulz step).
+// (identity; alpha I - beta A for the first squaring; (A + delta I)/s for the first Newton-Schulz step).
 struct LoadPlain {
     __device__ __forceinline__ double operator()(double v, int, int) const { return v; }
 };
-struct LoadShiftMinus {
-    double shift;
-    __device__ __forceinline__ double operator()(double v, int r, int c) const { return ((r == c) ? shift : 0.0) - v; }
+struct LoadAffine {  // alpha I - beta A
+    double alpha, beta;
+    __device__ __forceinline__ double operator()(double v, int r, int c) const { return fma(-beta, v, (r == c) ? alpha : 0.0); }
 };
 struct LoadScaledB {
     double delta, inv;
@@ -132,7 +145,7 @@ __device__ __forceinline__ double slot_sum(const double *__restrict__ p, int n, 
     return wr::wave64_allsum((lane < n) ? p[lane] : 0.0);
 }
 
-// The squaring stage (power iteration: self-correcting) works on exactly symmetric matrices: only tiles
+// The squaring stage (a filter iteration: self-correcting) works on exactly symmetric matrices: only tiles
 // with ti >= tj are computed and every value is stored together with its mirror image (36 tiles).
 constexpr int NS_TILES = 36;
 __device__ __forceinline__ void tri_tile(int w, int &ti, int &tj)
@@ -155,7 +168,7 @@ __device__ __forceinline__ void store_sym(double *__restrict__ O, int row, int c
 }
 
 // ---- prep (8 workgroups x 16 rows): A = (R + R^T)/2, per-row |.|-sums and diagonal, partials of
-// max-row-sum / |A|_F^2 / trace.  The shift and X0 = shift*I - A are formed by the first squaring on load.
+// max-row-sum / |A|_F^2 / trace / min diagonal.  The affine map Y0 = alpha I - beta A is formed by the first squaring on load.
 __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ Aall,
                                                       double *__restrict__ scall)
 {
@@ -188,20 +201,23 @@ __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__
     }
     __syncthreads();
     if (tid == 0) {
-        double gm = 0.0, f2 = 0.0, tr = 0.0;
+        double gm = 0.0, f2 = 0.0, tr = 0.0, md = sm[2][0];
         for (int i = 0; i < 16; ++i) {
             gm = fmax(gm, sm[0][i]);
             f2 += sm[1][i];
             tr += sm[2][i];
+            md = fmin(md, sm[2][i]);
         }
         s[SC_PREP + 4 * g + 0] = gm;
         s[SC_PREP + 4 * g + 1] = f2;
         s[SC_PREP + 4 * g + 2] = tr;
+        s[SC_PREP + 4 * g + 3] = md;
     }
 }
 
-// ---- squaring: Xout = Xin^2 / |Xin|_F^2 (36 lower tiles), |Xout|_F^2 partials into slot row step+1.
-// FIRST: Xin is A and the operand is X0 = shift*I - A with shift = min(Gershgorin, Frobenius) bound.
+// ---- one doubling of the Chebyshev degree: Xout = Xin^2 / |Xin|_F^2 - I / t_out, t_out = 2 t_in^2 |Xin|_F^2 (36 lower
+// tiles); |Xout|_F^2 partials go to slot row step+1, t_out to slot 63 of that row.
+// FIRST: Xin is A and the operand is Y0 = alpha I - beta A (see the header), t_in = 1.
 template <bool FIRST>
 __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict__ Xin, double *__restrict__ Xout,
                                                         double *__restrict__ scall, int step, int xbuf_out)
@@ -212,19 +228,24 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
     const double *X = Xin + (size_t)b * SN * SN;
     double *O = Xout + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
-    double nrm, shift = 0.0;
+    double nrm, t_in = 1.0, alpha = 0.0, beta = 0.0;
     if (FIRST) {
-        double gm = 0.0, f2 = 0.0, tr = 0.0;
+        double gm = 0.0, f2 = 0.0, tr = 0.0, md = s[SC_PREP + 3];
         for (int i = 0; i < 8; ++i) {
             gm = fmax(gm, s[SC_PREP + 4 * i + 0]);
             f2 += s[SC_PREP + 4 * i + 1];
             tr += s[SC_PREP + 4 * i + 2];
+            md = fmin(md, s[SC_PREP + 4 * i + 3]);
         }
-        // any upper bound of lambda_max(A) works; the tighter it is the faster the power iteration separates
-        shift = fmin(gm, sqrt(f2)) * (1.0 + 1e-12) + 1e-3;
-        nrm = fma((double)SN * shift, shift, fma(-2.0 * shift, tr, f2));  // |shift I - A|_F^2
+        // any hi >= lambda_max(A) and any cut > lambda_min(A) work; the tighter they are the faster the filter separates
+        const double hi = fmin(gm, sqrt(f2)) * (1.0 + 1e-12) + 1e-3;
+        const double cut = fma(NS_CUT_MARGIN, hi - md, md);
+        const double inv = 1.0 / (hi - cut);
+        alpha = (hi + cut) * inv;
+        beta = 2.0 * inv;
+        nrm = fma((double)SN * alpha, alpha, fma(-2.0 * alpha * beta, tr, beta * beta * f2));  // |alpha I - beta A|_F^2
         if (w == 0 && tid == 0) {
-            s[SC_SHIFT] = shift;
+            s[SC_SHIFT] = hi;
             s[SC_FRO2] = f2;
             s[SC_TRACE] = tr;
             s[SC_GERSH] = gm;
@@ -234,30 +255,35 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
     int ti, tj;
     tri_tile(w, ti, tj);
     TileOps ops;
-    if (FIRST) tile_load(ops, X, X, ti, tj, lane, wv, LoadShiftMinus{shift});
+    if (FIRST) tile_load(ops, X, X, ti, tj, lane, wv, LoadAffine{alpha, beta});
     else tile_load(ops, X, X, ti, tj, lane, wv, LoadPlain{});
     if (!FIRST) {
         const double done = s[SC_SQ_DONE];
         const double p1 = (lane < NS_TILES) ? s[SC_SQN + step * 64 + lane] : 0.0;
         const double p0 = (lane < NS_TILES && step >= 2) ? s[SC_SQN + (step - 1) * 64 + lane] : 0.0;
+        t_in = s[SC_SQN + step * 64 + 63];
         if (done != 0.0) return;
         nrm = wr::wave64_allsum(p1);
-        if (step >= 2) {
-            // stationary: |X_k|_F^2 stopped moving (X is a projector onto the dominant eigenspace up to scale)
+        if (step >= 2 && t_in > NS_SQ_TGUARD) {
+            // stationary: the bounded part of the spectrum is gone and |X_k|_F^2 stopped moving (X is a projector
+            // onto the bottom eigenspace up to scale)
             const double prev = wr::wave64_allsum(p0);
-            if (fabs(nrm - prev) <= 1e-11 * nrm) {
+            if (fabs(nrm - prev) <= NS_SQ_TOL * nrm) {
                 if (w == 0 && tid == 0) s[SC_SQ_DONE] = 1.0;
                 return;
             }
         }
     }
+    const double t_out = 2.0 * t_in * t_in * nrm;  // overflows to +inf once the filter has separated: 1 / t_out = 0
+    const double inv_t = 1.0 / t_out;
     if (w == 0 && tid == 0) {
         s[SC_XBUF] = (double)xbuf_out;
         s[SC_SQ] = (double)(step + 1);
+        s[SC_SQN + (step + 1) * 64 + 63] = t_out;
     }
     const f64x4 acc = tile_mma(ops);
-    const double v = tile_reduce(acc, red, wv, lane) * (1.0 / nrm);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+    const double v = tile_reduce(acc, red, wv, lane) * (1.0 / nrm) - ((row == col) ? inv_t : 0.0);
     store_sym(O, row, col, v);
     const double tot = wg_sum4((row > col) ? 2.0 * v * v : ((row == col) ? v * v : 0.0), part, wv, lane);
     if (tid == 0) s[SC_SQN + (step + 1) * 64 + w] = tot;
