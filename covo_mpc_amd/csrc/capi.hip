@@ -207,10 +207,7 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
         COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, need));
         h->ws_sigma_bytes = need;
     }
-    // single stream: a fork/join by events costs more here than the ~70 us it hides (measured 770 vs 458 us);
-    // pass h->side_stream / h->ev_* instead of nulls to enable it (free as graph edges under capture)
-    return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream, nullptr, nullptr,
-                           nullptr);
+    return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream);
 }
 
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)

@@ -81,7 +81,8 @@ int launch_randn(uint32_t k0, uint32_t k1, int64_t off, int n_samples, int n_col
 // eps == null: epsilon is drawn in-kernel from (k0, k1, sample_offset + n) (rng_device.hpp)
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr, const float *state_for_time = nullptr,
-                      int n_table = 0, int batch = 1);  // batch > 1 (in-kernel Philox only): dense per-instance L, mu, dyn, a
+                      int n_table = 0, int batch = 1,  // batch > 1 (in-kernel Philox only): dense per-instance L, mu, dyn, a
+                      bool eps_tiled = false);       // eps is the tile-ordered image of eps_tiles.hpp
 int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
                            int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr);
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
@@ -111,8 +112,10 @@ int launch_hessian_pairs(const float *state, const float *pos_traj, const float 
 int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, unsigned long long *prof,
                  hipStream_t s);
 size_t sigma_ns_workspace_bytes(int batch);
+struct EpsGenArgs;  // eps_tiles.hpp
+// gen != null (fused step): the finalize launch also draws the step's epsilon in tile order (eps_tiles.hpp)
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
+                    hipStream_t s, const EpsGenArgs *gen = nullptr);
 void step_state_destroy(covo_ctx *h);
 void batch_state_destroy(covo_ctx *h);
 int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,

@@ -1,0 +1,35 @@
+// eps_tiles.hpp -- epsilon in the noise GEMM's B-operand order, so that it can be drawn AHEAD of the GEMM.
+//
+// The noise draw a = clip(mu + L eps) needs L, the very last product of the covo-online Sigma chain, but eps itself
+// (covo.py:212-221: N(0, I) from the step's act key) depends on nothing but the key.  In the fused step the finalize
+// kernel of the chain -- ONE workgroup factoring Z for ~30 us while 255 CUs idle -- carries extra workgroups that
+// draw the whole (N, 128) epsilon into HBM/Infinity Cache (parallel branches of a hipGraph were measured to cost more
+// than they hide); the GEMM that follows then only loads it.  Layout: wave-tile t = samples
+// [32 t, 32 t + 32); for chunk q = 4 g + i (g = k-group, i = 0..3) lane (j = lane & 31, kh = lane >> 5) owns the
+// float4 normal4(2 q + kh, sample 32 t + j) -- exactly the register image noise_gemm_kernel builds (BTile), stored as
+// eps_tiled[(16 t + q) * 64 + lane]: every load / store instruction of a wave moves one contiguous 1 KiB.
+// Same Philox counters as everywhere else (rng_device.hpp): the values are those of covo_randn.
+#pragma once
+#include "rng_device.hpp"
+
+struct EpsGenArgs {
+    float4 *eps_tiled;      // [ceil(N/32)][16][64] float4, null = no generation
+    const uint32_t *dyn;    // {key0, key1} in device memory (step.hip: the act key derived by step_begin_kernel)
+    int64_t sample_offset;  // global id of local sample 0
+    int N;
+};
+
+__device__ __forceinline__ void eps_tiles_generate(const EpsGenArgs &G, int wave_global, int wave_stride, int lane)
+{
+    const uint32_t k0 = G.dyn[0], k1 = G.dyn[1];
+    const int ntiles = (G.N + 31) / 32;
+    const int j = lane & 31, kh = lane >> 5;
+    for (int t = wave_global; t < ntiles; t += wave_stride) {
+        int row = t * 32 + j;
+        row = row < G.N ? row : G.N - 1;
+        const uint64_t id = (uint64_t)(G.sample_offset + row);
+        float4 *out = G.eps_tiled + (size_t)t * 16 * 64 + lane;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) out[q * 64] = rngd::normal4((uint32_t)(2 * q + kh), id, k0, k1);
+    }
+}

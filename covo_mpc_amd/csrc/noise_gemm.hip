@@ -24,9 +24,19 @@
 //     layout a[H][N][4] the rollout kernel reads.
 // fp32 MFMA roofline: 2*128*128 flop per sample (dense-equivalent), 157.3 TFLOP/s peak.
 #include "covo_common.hpp"
-#include "rng_device.hpp"
+#include "eps_tiles.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// scripts/probe/gemm_probe.hip compiles this file with GEMM_PROBE: wave 0 of every workgroup leaves s_memrealtime
+// stamps (100 MHz) at the phase boundaries of its first tile.  Compiled out of the library.
+#ifdef GEMM_PROBE
+__device__ unsigned long long *g_ng_probe;
+#define NG_STAMP(i)                                                                                         \
+    if (threadIdx.x == 0 && g_ng_probe) g_ng_probe[8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + (i)] = wall_clock64();
+#else
+#define NG_STAMP(i)
+#endif
 
 constexpr int NG_BLOCK = 256;
 constexpr int NG_LDA = COVO_NA + 1;  // padded leading dimension of the LDS image of L
@@ -46,6 +56,17 @@ __device__ __forceinline__ BTile load_tile(const float4 *__restrict__ row, int k
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) t.g[g].c[i] = row[2 * (4 * g + i) + kh];
+    return t;
+}
+
+// the same 16 chunks from the tile-ordered image drawn ahead of the GEMM (eps_tiles.hpp): 16 contiguous 1-KiB wave loads
+__device__ __forceinline__ BTile load_tile_tiled(const float4 *__restrict__ tile_base, int lane)
+{
+    BTile t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.g[g].c[i] = tile_base[(4 * g + i) * 64 + lane];
     return t;
 }
 
@@ -126,8 +147,9 @@ __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup 
     }
 }
 
-// PHILOX = false: epsilon is read from `eps`; true: drawn in registers from (k0, k1, sample_offset + n).
-template <bool PHILOX>
+// PHILOX = false: epsilon is read from `eps` (TILED: in the tile order of eps_tiles.hpp, else row-major (N, 128));
+// true: drawn in registers from (k0, k1, sample_offset + n).
+template <bool PHILOX, bool TILED = false>
 __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
                                                               const float *__restrict__ eps, uint32_t k0, uint32_t k1,
                                                               int64_t sample_offset, int N, int ntiles,
@@ -145,6 +167,7 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
         a_out += y * ((size_t)COVO_H * N);
         if (dyn != nullptr) dyn += y * 12;
     }
+    NG_STAMP(0);
     if (dyn != nullptr) { k0 = dyn[0]; k1 = dyn[1]; }
     if (state_for_time != nullptr) {
         int t = __float_as_int(state_for_time[ST_TIME]);
@@ -175,6 +198,7 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
             row = row < N ? row : N - 1;
             return gen_tile((uint64_t)(sample_offset + row), kh, k0, k1);
         }
+        if (TILED) return load_tile_tiled(reinterpret_cast<const float4 *>(eps) + (size_t)t * 16 * 64, lane);
         return load_tile(rowptr(t), kh);
     };
     // PHILOX: only k-group 0 of the first tile is drawn up front; every later group is drawn right behind the MFMAs
@@ -185,25 +209,57 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
         row = row < N ? row : N - 1;
         return (uint64_t)(sample_offset + row);
     };
+    // STREAM (in-kernel Philox, or the tile-ordered image): one k-group is fetched at a time, one group ahead of its MFMAs
+    constexpr bool STREAM = PHILOX || TILED;
+    auto fetch_group = [&](int t, int g) {
+        if (PHILOX) return gen_group(id_of(t), g, kh, k0, k1);
+        BGroup b;
+        const float4 *base = reinterpret_cast<const float4 *>(eps) + ((size_t)t * 16 + 4 * g) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b.c[i] = base[i * 64];
+        return b;
+    };
     BTile cur;
-    if (PHILOX) cur.g[0] = gen_group(id_of(tile < ntiles ? tile : 0), 0, kh, k0, k1);
+    if (STREAM) cur.g[0] = fetch_group(tile < ntiles ? tile : 0, 0);
     else cur = tile_of(tile < ntiles ? tile : 0);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- stage L (masked to its lower triangle) and mu
-    for (int idx = tid; idx < COVO_NA * COVO_NA / 4; idx += NG_BLOCK) {
-        const int i = idx >> 5, k4 = (idx & 31) * 4;
-        const float4 v = reinterpret_cast<const float4 *>(L)[idx];
-        float *d = Ls + i * NG_LDA + k4;
-        d[0] = (k4 + 0 <= i) ? v.x : 0.0f;
-        d[1] = (k4 + 1 <= i) ? v.y : 0.0f;
-        d[2] = (k4 + 2 <= i) ? v.z : 0.0f;
-        d[3] = (k4 + 3 <= i) ? v.w : 0.0f;
+    // ---- stage L (masked to its lower triangle) and mu.  All of a thread's loads are issued before the first LDS
+    // write (a rolled load -> write loop pays one L2 round trip per trip: 3.8 us of a 17 us launch, scripts/probe/
+    // gemm_probe.hip); chunks right of the diagonal block are never read by the MFMA loop (row tile rt stops at
+    // k < 32 (rt + 1)) and are neither loaded nor written, chunks right of the diagonal inside it are written as zeros.
+    {
+        constexpr int TRIPS = COVO_NA * COVO_NA / 4 / NG_BLOCK;  // 16
+        const int k4 = (tid & 31) * 4, i0 = tid >> 5;            // trip `it` handles row i0 + 8 it, columns k4 .. k4 + 3
+        float4 v[TRIPS];
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {
+            const int i = i0 + 8 * it;
+            v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k4 <= i) v[it] = reinterpret_cast<const float4 *>(L)[tid + NG_BLOCK * it];
+        }
+#ifdef GEMM_PROBE
+        NG_STAMP(7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NG_STAMP(6);
+#endif
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {
+            const int i = i0 + 8 * it;
+            if (k4 < 32 * (i / 32 + 1)) {
+                float *d = Ls + i * NG_LDA + k4;
+                d[0] = (k4 + 0 <= i) ? v[it].x : 0.0f;
+                d[1] = (k4 + 1 <= i) ? v[it].y : 0.0f;
+                d[2] = (k4 + 2 <= i) ? v[it].z : 0.0f;
+                d[3] = (k4 + 3 <= i) ? v[it].w : 0.0f;
+            }
+        }
     }
     if (tid < COVO_NA) mus[tid] = mu[tid];
     __syncthreads();
 
     const float *__restrict__ La = Ls + j * NG_LDA + kh;  // this lane's row / k-parity of every A fragment
+    NG_STAMP(1);
 
     if (tile >= ntiles) return;
 
@@ -216,10 +272,9 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
 
         const int next_tile = tile + wave_stride;
         BTile nxt;
-        const uint64_t id = PHILOX ? id_of(tile) : 0;
-        if (!PHILOX) {
+        if (!STREAM) {
             // whole next tile in flight while this one is multiplied (10 240 MFMA cycles of cover)
-            nxt = load_tile(rowptr(next_tile < ntiles ? next_tile : tile), kh);
+            nxt = tile_of(next_tile < ntiles ? next_tile : tile);
             __builtin_amdgcn_sched_barrier(0);
         }
         // L is lower triangular: row tile rt (actions of steps 8 rt .. 8 rt + 7) is complete after k-group rt, so its
@@ -242,19 +297,28 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
                 }
             }
         };
+        if (TILED) cur.g[1] = fetch_group(tile, 1);  // loads: requested BEFORE the MFMAs that hide them
         mfma_group<0>(La, cur.g[0], acc);
+        NG_STAMP(2);
         store_rt(0);
-        if (PHILOX) cur.g[1] = gen_group(id, 1, kh, k0, k1);
+        if (PHILOX) cur.g[1] = fetch_group(tile, 1);  // draws: issued BEHIND the MFMAs they overlap with
+        if (TILED) cur.g[2] = fetch_group(tile, 2);
         mfma_group<1>(La, cur.g[1], acc);
+        NG_STAMP(3);
         store_rt(1);
-        if (PHILOX) cur.g[2] = gen_group(id, 2, kh, k0, k1);
+        if (PHILOX) cur.g[2] = fetch_group(tile, 2);
+        if (TILED) cur.g[3] = fetch_group(tile, 3);
         mfma_group<2>(La, cur.g[2], acc);
+        NG_STAMP(4);
         store_rt(2);
-        if (PHILOX) cur.g[3] = gen_group(id, 3, kh, k0, k1);
+        if (PHILOX) cur.g[3] = fetch_group(tile, 3);
+        if (TILED && next_tile < ntiles) cur.g[0] = fetch_group(next_tile, 0);
         mfma_group<3>(La, cur.g[3], acc);
+        NG_STAMP(5);
         store_rt(3);
-        if (PHILOX && next_tile < ntiles) cur.g[0] = gen_group(id_of(next_tile), 0, kh, k0, k1);
-        if (!PHILOX) cur = nxt;
+        NG_STAMP(6);
+        if (PHILOX && next_tile < ntiles) cur.g[0] = fetch_group(next_tile, 0);
+        if (!STREAM) cur = nxt;
     }
 }
 
@@ -293,7 +357,8 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
 }
 
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
-                      int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table, int batch)
+                      int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table, int batch,
+                      bool eps_tiled)
 {
     const int ntiles = (N + 31) / 32;
     const int waves_per_block = NG_BLOCK / 64;
@@ -306,9 +371,14 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (eps != nullptr)
+    if (eps != nullptr && eps_tiled)
+        hipLaunchKernelGGL((noise_gemm_kernel<false, true>), dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
+                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table);
+    else if (eps != nullptr)
         hipLaunchKernelGGL(noise_gemm_kernel<false>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
                            ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table);
     else

@@ -43,6 +43,7 @@
 #include "covo_common.hpp"
 #include "wave_reduce.hpp"
 #include "chol_lds.hpp"
+#include "eps_tiles.hpp"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -537,10 +538,18 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
 __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restrict__ Z0all, const double *__restrict__ Z1all,
                                                           const double *__restrict__ Zt0all, const double *__restrict__ Zt1all,
                                                           double *__restrict__ scall, float sample_sigma,
-                                                          float *__restrict__ Sigma_out, float *__restrict__ L_out)
+                                                          float *__restrict__ Sigma_out, float *__restrict__ L_out, int batch,
+                                                          const EpsGenArgs gen)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[512];
+    if ((int)blockIdx.x >= batch) {
+        // passenger workgroups (fused step only, eps_tiles.hpp): draw the step's epsilon while workgroups 0..batch-1
+        // factor; the dynamic LDS of this launch keeps them at one workgroup (8 waves) per CU
+        eps_tiles_generate(gen, ((int)blockIdx.x - batch) * 8 + (int)(threadIdx.x >> 6), ((int)gridDim.x - batch) * 8,
+                           (int)(threadIdx.x & 63));
+        return;
+    }
     const int b = blockIdx.x, tid = threadIdx.x;
     double *s = scall + (size_t)b * SC_COUNT;
     const bool z1 = s[SC_ZBUF] != 0.0;
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, hipStream_t, hipEvent_t, hipEvent_t)
+                    hipStream_t s, const EpsGenArgs *gen)
 {
     double *ws = reinterpret_cast<double *>(workspace);
     const size_t M = (size_t)batch * SN * SN;
@@ -643,7 +652,20 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
                            Zt[out], sc, i, out);
     }
     if (g_dbg_sigma_stages < 4) return 0;
-    hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma, Sigma, L);
+    EpsGenArgs g;
+    g.eps_tiled = nullptr;
+    g.dyn = nullptr;
+    g.sample_offset = 0;
+    g.N = 0;
+    int passengers = 0;
+    if (gen != nullptr && gen->eps_tiled != nullptr) {
+        g = *gen;
+        const int ntiles = (g.N + 31) / 32;
+        passengers = (ntiles + 7) / 8;         // 8 waves per workgroup, one tile per wave ...
+        if (passengers > 255) passengers = 255;  // ... at most one workgroup on every other CU, waves stride over tiles
+    }
+    hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch + passengers), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma,
+                       Sigma, L, batch, g);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

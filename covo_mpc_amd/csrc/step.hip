@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include "covo_common.hpp"
+#include "eps_tiles.hpp"
 #include "rng_device.hpp"
 
 __global__ void shift_cov_kernel(const float *__restrict__ in, float *__restrict__ out)
@@ -96,6 +97,7 @@ struct StepState {
     double *R;            // [128][128]
     float *Sigma, *L;     // [128][128]
     float *cov_shift, *Ls;  // [H][4][4]
+    float4 *eps_tiled;    // covo-online: this step's epsilon in tile order, drawn under the Sigma chain (eps_tiles.hpp); or null
     // host (pinned) staging ring for dyn
     uint32_t *dyn_host;
     int ring_pos;
@@ -106,6 +108,9 @@ struct StepState {
     hipGraphExec_t exec;
 };
 constexpr int DYN_RING = 256, DYN_BYTES = 48, DYN_WORDS = DYN_BYTES / 4;
+// up to this many samples per GPU the step's epsilon is drawn by passenger workgroups of the Sigma chain's last launch
+// (~6 us of work per 65 536 samples inside a ~30 us single-workgroup kernel); beyond, the GEMM draws it itself
+constexpr int EPS_AHEAD_MAX_N = 262144;
 
 static int step_state_init(covo_ctx *h)
 {
@@ -120,6 +125,8 @@ static int step_state_init(covo_ctx *h)
     COVO_CHECK_HIP(hipMalloc(&st->cov_shift, COVO_H * 16 * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->Ls, COVO_H * 16 * sizeof(float)));
     COVO_CHECK_HIP(hipHostMalloc((void **)&st->dyn_host, (size_t)DYN_RING * DYN_BYTES, hipHostMallocDefault));
+    if (h->cfg.n_local <= EPS_AHEAD_MAX_N)
+        COVO_CHECK_HIP(hipMalloc(&st->eps_tiled, (size_t)((h->cfg.n_local + 31) / 32) * 16 * 64 * sizeof(float4)));
     h->step = st;
     return 0;
 }
@@ -140,12 +147,17 @@ void step_state_destroy(covo_ctx *h)
     (void)hipFree(st->L);
     (void)hipFree(st->cov_shift);
     (void)hipFree(st->Ls);
+    (void)hipFree(st->eps_tiled);
     (void)hipHostFree(st->dyn_host);
     delete st;
     h->step = nullptr;
 }
 
 int g_dbg_hess_mask = 15, g_dbg_sigma_stages = 4;
+static const int g_dbg_eps_ahead = [] {  // COVO_EPS_AHEAD=0: the GEMM draws epsilon itself (A/B measurements)
+    const char *v = std::getenv("COVO_EPS_AHEAD");
+    return v ? std::atoi(v) : 1;
+}();
 static int g_dbg_step_mask = 63;  // 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
 
 // the launch sequence of one step (everything reads per-step scalars from st->dyn)
@@ -163,8 +175,20 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     if (a.mode == COVO_MODE_COVO_ONLINE) {
         if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
-        if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
-        if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
+        // epsilon needs only the act key: it is drawn under the chain's single-workgroup finalize launch, the GEMM loads it
+        const bool ahead = st->eps_tiled != nullptr && (M & 4) && g_dbg_sigma_stages >= 4 && g_dbg_eps_ahead;
+        EpsGenArgs gen;
+        gen.eps_tiled = ahead ? st->eps_tiled : nullptr;
+        gen.dyn = st->dyn;
+        gen.sample_offset = a.sample_offset;
+        gen.N = N;
+        if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen))) return rc;
+        if (ahead) {
+            if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, reinterpret_cast<const float *>(st->eps_tiled), 0, 0,
+                                                   a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true)))
+                return rc;
+        } else if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn)))
+            return rc;
     } else if (a.mode == COVO_MODE_COVO_OFFLINE) {
         if ((M & 8) && (rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, state,
                                     a.n_table)))
@@ -396,7 +420,7 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
                              b->consts, (size_t)a.T * 3)))
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
-    if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s))) return rc;
     if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E))) return rc;
     if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, true, s))) return rc;
     return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, b->a_mean_shift, a.gamma_mean, a.a_mean, s,
