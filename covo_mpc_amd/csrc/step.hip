@@ -39,25 +39,39 @@ __device__ __forceinline__ float host_normal3(const uint32_t (&key)[2], int i)
     return (float)(sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2));
 }
 
-// first launch of every step: shift the mean (covo.py:201-203), bring this step's state into the fixed-address
-// buffer the captured launches read (its address changes from step to step and travels in the dyn block), and --
-// derive_keys -- turn the controller's raw rng_act into what the host would have computed:
+// the ONE eager launch of every step, ahead of the replayed graph.  What changes per step travels in its kernel
+// arguments (48 bytes; an async H2D copy of the same block runs as a ~5 us copy kernel on this stack): the controller's
+// raw rng_act, the caller's shared disturbance, the address of the state.  It shifts the mean (covo.py:201-203), brings
+// the state into the fixed-address buffer the captured launches read, and fills the device block the captured
+// launches take their per-step scalars from -- with derive_keys, what the host would have computed from rng_act:
 //   rng, act_key = split(rng_act); rng, step_key = split(rng)                (covo.py:212,225 / mppi.py:53,69)
 //   MPPI: f_shared = scale * normal(split(split(split(step_key)[1])[0])[0], (3,))   (quadrotor.py:262, free.py:136,144)
+struct DynBlock {
+    uint32_t w[12];  // {key0, key1, f_shared[3] as float bits, pad[3], state pointer (8 bytes), pad[2]}
+};
 __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
                                   uint32_t *__restrict__ dyn, float *__restrict__ state_buf, int derive_keys,
-                                  float shared_noise_scale)
+                                  float shared_noise_scale, const DynBlock blk)
 {
     const int i = threadIdx.x;  // 128 + 32 + 4 threads
-    const uint32_t raw[2] = {dyn[0], dyn[1]};
-    __syncthreads();
+    const uint32_t raw[2] = {blk.w[0], blk.w[1]};
     if (i < COVO_NA) {
         a_mean_shift[i] = (i < COVO_NA - COVO_DU) ? a_mean[i + COVO_DU] : a_mean[i];
     } else if (i < COVO_NA + COVO_STATE_FLOATS) {
-        const float *src = *reinterpret_cast<const float *const *>(dyn + 8);
+        const float *src;
+        __builtin_memcpy(&src, &blk.w[8], sizeof(src));
         state_buf[i - COVO_NA] = src[i - COVO_NA];
-    } else if (derive_keys) {
+    } else {
         const int q = i - (COVO_NA + COVO_STATE_FLOATS);  // 0: act_key, 1..3: f_shared
+        if (!derive_keys) {
+            if (q == 0) {
+                dyn[0] = raw[0];
+                dyn[1] = raw[1];
+            } else {
+                dyn[2 + (q - 1)] = blk.w[2 + (q - 1)];
+            }
+            return;
+        }
         uint32_t rng1[2], k[2], t[2];
         host_split(raw, 0u, rng1);
         if (q == 0) {
@@ -77,11 +91,6 @@ __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__res
         }
     }
 }
-
-struct DynBlock {
-    uint32_t w[12];
-};
-__global__ void set_dyn_kernel(uint32_t *__restrict__ dyn, const DynBlock b) { dyn[threadIdx.x] = b.w[threadIdx.x]; }
 
 struct StepKey {
     covo_step_args args;
@@ -158,7 +167,7 @@ static const int g_dbg_eps_ahead = [] {  // COVO_EPS_AHEAD=0: the GEMM draws eps
     const char *v = std::getenv("COVO_EPS_AHEAD");
     return v ? std::atoi(v) : 1;
 }();
-static int g_dbg_step_mask = 63;  // 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
+static int g_dbg_step_mask = 63;  // (1: unused, the begin launch is not part of the graph) 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
 
 // the launch sequence of one step (everything reads per-step scalars from st->dyn)
 static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, const covo_step_args &a, hipStream_t s)
@@ -169,9 +178,6 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
     int rc;
     const float *state = st->state_buf;
-    if (M & 1)
-        hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s, a.a_mean, am_shift, st->dyn,
-                           st->state_buf, a.derive_keys, a.shared_noise_scale);
     if (a.mode == COVO_MODE_COVO_ONLINE) {
         if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
@@ -229,11 +235,11 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
         std::memcpy(&slot[2 + i], &f, 4);
     }
     std::memcpy(&slot[8], &args->state, sizeof(const float *));
-    // the 48 bytes travel as kernel arguments of a one-wave launch (1.6 us of GPU time; an async H2D copy of the same
-    // block runs as a ~5 us copy kernel on this stack)
     DynBlock blk;
     std::memcpy(blk.w, slot, DYN_BYTES);
-    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(DYN_WORDS), 0, s, st->dyn, blk);
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s, args->a_mean,
+                       args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
+                       args->shared_noise_scale, blk);
 
     StepKey k;
     std::memset(&k, 0, sizeof(k));
