@@ -87,18 +87,21 @@ int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, u
                            int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr);
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
-                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr);
+                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr,
+                   float *records = nullptr, float lam = 0.0f);  // records: one online-softmax record per workgroup (rollout.hip)
+int rollout_workgroups(int N, bool stats);
 size_t rollout_args_bytes(int n);
 void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
                        const covo_env_params &p, const float *a, int N, float discount, float *cost, float *groupmin,
-                       const float *f_shared_dev);
+                       const float *f_shared_dev, float *records = nullptr, float lam = 0.0f);
 int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, bool trust_clipped, hipStream_t s);
 // a_mean_out != null: finish on this GPU (normalise + blend); else write the merged record to partial_out
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,
                           hipStream_t s, float *partials_ws = nullptr, int batch = 1);  // batch > 1: dense per-instance slices, own partials_ws
+// a_mean_out == null: the merged record goes to partial_out (sample-sharded step); batch > 1: dense per-instance slices
 int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
-                 hipStream_t s);
+                 hipStream_t s, float *partial_out = nullptr, int batch = 1);
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
 size_t hessian_workspace_bytes(int batch);
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,

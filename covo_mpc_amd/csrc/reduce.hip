@@ -213,11 +213,15 @@ int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N,
 }
 
 int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
-                 hipStream_t s)
+                 hipStream_t s, float *partial_out, int batch)
 {
     if (G > MG_MAXG) { covo_set_error("covo_merge: G=%d > %d", G, MG_MAXG); return COVO_E_BADARG; }
-    hipLaunchKernelGGL(merge_kernel<true>, dim3(1), dim3(MG_THREADS), 0, s, partials, G, 1.0f / lam, a_mean_old, gamma_mean,
-                       a_mean_out);
+    if (a_mean_out != nullptr)
+        hipLaunchKernelGGL(merge_kernel<true>, dim3(batch), dim3(MG_THREADS), 0, s, partials, G, 1.0f / lam, a_mean_old, gamma_mean,
+                           a_mean_out);
+    else
+        hipLaunchKernelGGL(merge_kernel<false>, dim3(batch), dim3(MG_THREADS), 0, s, partials, G, 1.0f / lam,
+                           (const float *)nullptr, 1.0f, partial_out);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

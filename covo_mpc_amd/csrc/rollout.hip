@@ -27,6 +27,8 @@ struct RolloutArgs {
     float f_shared[3];
     const float *f_shared_dev;  // nullable: {fx, fy, fz} in device memory (graph replays), overrides f_shared
     int xcd_remap;              // 1: workgroup -> sample chunks follow the noise GEMM's XCD placement (see kernel)
+    float *records;             // nullable: [workgroups][COVO_PARTIAL_FLOATS] online-softmax records (rollout_record below)
+    float inv_lam;
     qm::Consts<float> c;
 };
 
@@ -56,6 +58,72 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // v_readlane_b3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// The softmax update's first stage, done by the workgroup that has just produced the costs (fused step): one
+// online-softmax record {m, s, v[128]} per workgroup -- m = its cost minimum, s = sum_n w_n, v = sum_n w_n a_n with
+// w_n = exp(-(c_n - m)/lam) (covo.py:266-272 with the LOCAL minimum; merge_kernel rescales every record by
+// exp(-(m - min_g m_g)/lam), the same merge that combines the per-GPU records of a sample-sharded step, so the result
+// is the reference's softmax to fp32 rounding).  Saves the launch and the cost re-read of softmax_partial_kernel; the
+// stripes of the few samples with a non-zero weight (at lam = 0.01 a weight underflows once c - m > 1.04) are re-read
+// from the L2 that has just served them.  Called by every wave of the workgroup (waves without costs pass valid = false).
+__device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost, bool valid, int n, int wave, int lane, int wg,
+                                               float *s_m, float *s_s, float (*s_v)[COVO_NA])
+{
+    constexpr int NW = RO_BLOCK / COVO_WAVE;
+    const float wm = wave_min(valid ? cost : __builtin_inff());
+    if (lane == 0) s_m[wave] = wm;
+    __syncthreads();
+    float m = s_m[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) m = fminf(m, s_m[i]);
+    const float w = valid ? expf((m - cost) * A.inv_lam) : 0.0f;
+    const float sw = wave_sum(w);
+    unsigned long long live = __ballot(w > 0.0f);
+    const int t = lane & 31, half = lane >> 5;  // lane -> action stripe t; the two half-waves take alternate live samples
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    while (live != 0ull) {
+        const int l0 = (int)__builtin_ctzll(live);
+        live &= live - 1ull;
+        int l1 = l0;
+        bool two = false;
+        if (live != 0ull) {
+            l1 = (int)__builtin_ctzll(live);
+            live &= live - 1ull;
+            two = true;
+        }
+        const int l = half ? l1 : l0;
+        float wv = __shfl(w, l, COVO_WAVE);
+        const int nl = __shfl(n, l, COVO_WAVE);
+        if (half && !two) wv = 0.0f;
+        const float4 av = A.a[(size_t)t * A.N + nl];
+        acc.x = fmaf(wv, av.x, acc.x);
+        acc.y = fmaf(wv, av.y, acc.y);
+        acc.z = fmaf(wv, av.z, acc.z);
+        acc.w = fmaf(wv, av.w, acc.w);
+    }
+    acc.x += __shfl_xor(acc.x, 32, COVO_WAVE);
+    acc.y += __shfl_xor(acc.y, 32, COVO_WAVE);
+    acc.z += __shfl_xor(acc.z, 32, COVO_WAVE);
+    acc.w += __shfl_xor(acc.w, 32, COVO_WAVE);
+    if (half == 0) *reinterpret_cast<float4 *>(&s_v[wave][4 * t]) = acc;
+    if (lane == 0) s_s[wave] = sw;
+    __syncthreads();
+    float *rec = A.records + (size_t)wg * COVO_PARTIAL_FLOATS;
+    const int tid = wave * COVO_WAVE + lane;
+    if (tid < COVO_NA) {
+        float v = s_v[0][tid];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) v += s_v[i][tid];
+        rec[2 + tid] = v;
+    }
+    if (tid == 0) {
+        float ss = s_s[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) ss += s_s[i];
+        rec[0] = m;
+        rec[1] = ss;
+    }
+}
+
 // STATS: accumulate per-step position sums (covo.py:281).  DISC1: discount == 1 (skip the multiply).
 // CLIP: re-apply step_env's clip (quadrotor.py:223,258); off when the producer guarantees clipped
 // stripes.  PF: how many action stripes are in flight (32 = the whole horizon is issued up front:
@@ -67,6 +135,8 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
 {
     const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
     RO_PROBE_BEGIN();
+    __shared__ float rec_m[RO_BLOCK / COVO_WAVE], rec_s[RO_BLOCK / COVO_WAVE];
+    __shared__ __attribute__((aligned(16))) float rec_v[RO_BLOCK / COVO_WAVE][COVO_NA];
     __shared__ double sacc[STATS ? (RO_BLOCK / COVO_WAVE) * COVO_H * 6 : 1];  // one slot per wave: no atomics, fixed order
     __shared__ float spanel[STATS ? (RO_BLOCK / COVO_WAVE) * 8 * 3 * COVO_WAVE : 1];  // 8 steps x 3 axes x 64 lanes per wave
     const int tid = threadIdx.x, lane = tid & (COVO_WAVE - 1), wave = tid / COVO_WAVE;
@@ -180,6 +250,7 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
         const float wm = wave_min(valid ? cost : __builtin_inff());
         if (lane == 0 && (n_raw & ~(COVO_WAVE - 1)) < A.N) A.groupmin[n_raw >> 6] = wm;
     }
+    if (A.records != nullptr) rollout_record(A, cost, valid, n, wave, lane, blockIdx.x, rec_m, rec_s, rec_v);
     if (STATS) {
         __syncthreads();
         for (int i = tid; i < COVO_H * 6; i += RO_BLOCK)
@@ -215,6 +286,10 @@ __global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel
 {
     const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
     RO_PROBE_BEGIN();
+    __shared__ float rec_m[RO_BLOCK / COVO_WAVE], rec_s[RO_BLOCK / COVO_WAVE];
+    __shared__ __attribute__((aligned(16))) float rec_v[RO_BLOCK / COVO_WAVE][COVO_NA];
+    float rec_cost = 0.0f;
+    bool rec_valid = false;
     __shared__ float4 ring_all[RS_PAIRS][RS_RING][2][COVO_WAVE];
     const int lane = threadIdx.x & (COVO_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -314,6 +389,12 @@ __global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel
             const float wm = wave_min(valid ? cost : __builtin_inff());
             if (lane == 0 && group * COVO_WAVE < A.N) A.groupmin[group] = wm;
         }
+        rec_cost = cost;
+        rec_valid = valid;
+    }
+    if (A.records != nullptr) {  // all four waves: the dynamics waves carry no cost
+        static_assert(2 * RS_PAIRS * COVO_WAVE == RO_BLOCK, "rollout_record assumes RO_BLOCK threads");
+        rollout_record(A, rec_cost, rec_valid, n, wave, lane, blockIdx.x, rec_m, rec_s, rec_v);
     }
     RO_PROBE_END(RS_PAIRS * COVO_WAVE);
 }
@@ -364,6 +445,8 @@ static void fill_rollout_args(RolloutArgs &A, const float *state, const float *p
     for (int i = 0; i < 3; ++i) A.f_shared[i] = f_shared ? f_shared[i] : 0.0f;
     A.f_shared_dev = f_shared_dev;
     A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? 1 : 0;  // the GEMM runs one 32-sample tile per wave up to 512 workgroups
+    A.records = nullptr;
+    A.inv_lam = 0.0f;
     A.c = make_consts<float>(p);
 }
 
@@ -406,11 +489,21 @@ static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int 
 
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
-                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev)
+                   float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev,
+                   float *records, float lam)
 {
     RolloutArgs A;
     fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev);
+    A.records = records;
+    A.inv_lam = records ? 1.0f / lam : 0.0f;
     return dispatch_rollout<false>(A, nullptr, 0, trust_clipped, pos_stats, s);
+}
+
+// workgroups (= softmax records, rollout_record) a rollout over N samples is launched with -- mirrors dispatch_rollout
+int rollout_workgroups(int N, bool stats)
+{
+    if (!stats && 2 * ((N + COVO_WAVE - 1) / COVO_WAVE) <= 1024) return (N + RS_PAIRS * COVO_WAVE - 1) / (RS_PAIRS * COVO_WAVE);
+    return (N + RO_BLOCK - 1) / RO_BLOCK;
 }
 
 // ---- env-batched rollout: one launch, workgroup row y = instance y (step.hip: covo_mpc_step_batched)
@@ -418,10 +511,12 @@ size_t rollout_args_bytes(int n) { return (size_t)n * sizeof(RolloutArgs); }
 
 void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
                        const covo_env_params &p, const float *a, int N, float discount, float *cost, float *groupmin,
-                       const float *f_shared_dev)
+                       const float *f_shared_dev, float *records, float lam)
 {
-    fill_rollout_args(reinterpret_cast<RolloutArgs *>(out)[index], state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost,
-                      groupmin, nullptr, f_shared_dev);
+    RolloutArgs &A = reinterpret_cast<RolloutArgs *>(out)[index];
+    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost, groupmin, nullptr, f_shared_dev);
+    A.records = records;
+    A.inv_lam = records ? 1.0f / lam : 0.0f;
 }
 
 int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, bool trust_clipped, hipStream_t s)

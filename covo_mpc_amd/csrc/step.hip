@@ -206,10 +206,19 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
     }
     const bool clipped = true;  // a comes straight from the noise kernels above
+    // the rollout's workgroups leave the softmax update's stage-1 records themselves when they fit the merge (rollout.hip:
+    // rollout_record); otherwise the stand-alone stage-1 kernel runs over the costs
+    const int G = rollout_workgroups(N, a.pos_stats != nullptr);
+    const bool records = G <= h->max_red_blocks;
     if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
-                                         a.groupmin, a.pos_stats, h->ws_stats, s, fdev)))
+                                         records ? nullptr : a.groupmin, a.pos_stats, h->ws_stats, s, fdev,
+                                         records ? h->ws_partials : nullptr, h->cfg.lam)))
         return rc;
     if (!(M & 32)) return 0;
+    if (records) {
+        if (a.partial_out != nullptr) return launch_merge(h->ws_partials, G, h->cfg.lam, nullptr, 1.0f, nullptr, s, a.partial_out);
+        return launch_merge(h->ws_partials, G, h->cfg.lam, am_shift, a.gamma_mean, a.a_mean, s);
+    }
     // weights + update: finish locally, or leave this shard's record for the all-gather (covo.py:266-275)
     if (a.partial_out != nullptr)
         return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, a.partial_out, nullptr, 1.0f, nullptr, s);
@@ -429,6 +438,9 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
     if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s))) return rc;
     if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E))) return rc;
     if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, true, s))) return rc;
+    const int G = rollout_workgroups(N, false);
+    if (G <= h->max_red_blocks)  // the rollout's workgroups have left the records (rollout_record): instance e's are [e][G]
+        return launch_merge(b->partials, G, h->cfg.lam, b->a_mean_shift, a.gamma_mean, a.a_mean, s, nullptr, E);
     return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, b->a_mean_shift, a.gamma_mean, a.a_mean, s,
                                  b->partials, E);
 }
@@ -472,11 +484,14 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
         COVO_CHECK_HIP(hipMemcpy(b->consts, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
         b->ro_args_host.assign(rollout_args_bytes(E), 0);
         const int N = args->n_samples, ng = (N + 63) / 64;
+        const int bG = rollout_workgroups(N, false);
+        const bool brec = bG <= h->max_red_blocks;
         for (int e = 0; e < E; ++e)
             rollout_fill_args(b->ro_args_host.data(), e, args->states + (size_t)e * COVO_STATE_FLOATS,
                               args->pos_traj + (size_t)e * args->T * 3, args->vel_traj + (size_t)e * args->T * 3, args->T,
                               params[e], args->a + (size_t)e * COVO_H * N * 4, N, h->cfg.discount, args->cost + (size_t)e * N,
-                              args->groupmin + (size_t)e * ng, reinterpret_cast<const float *>(b->dyn + 12 * e + 2));
+                              brec ? nullptr : args->groupmin + (size_t)e * ng, reinterpret_cast<const float *>(b->dyn + 12 * e + 2),
+                              brec ? b->partials + (size_t)e * bG * COVO_PARTIAL_FLOATS : nullptr, h->cfg.lam);
         COVO_CHECK_HIP(hipMemcpy(b->ro_args, b->ro_args_host.data(), b->ro_args_host.size(), hipMemcpyHostToDevice));
         const size_t need_s = sigma_ns_workspace_bytes(E), need_h = hessian_workspace_bytes(E);
         if (need_s > h->ws_sigma_bytes) {

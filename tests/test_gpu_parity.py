@@ -398,8 +398,10 @@ def test_controller_step_teacher_forced(name, task, N):
 @pytest.mark.parametrize("name,task", [("mppi", "hovering"), ("covo-online", "tracking_zigzag"),
                                        ("covo-offline", "tracking_zigzag")])
 def test_fused_step_equals_kernel_by_kernel(name, task):
-    """covo_mpc_step (one C call; eager, captured, then replayed as a hipGraph) must give bit-identical means
-    to the kernel-by-kernel path that materialises epsilon, step after step."""
+    """covo_mpc_step (one C call; eager, captured, then replayed as a hipGraph) against the kernel-by-kernel path that
+    materialises epsilon, step after step: bit-identical actions, costs, Sigma and info; the means agree to fp32
+    rounding (the fused step forms the softmax from per-workgroup records shifted by their LOCAL cost minimum and
+    rescaled in the merge, the stand-alone covo_softmax_reduce shifts by the global minimum like covo.py:266)."""
     import covo_mpc_amd as cm
     from covo_mpc_amd import random as cr
     env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
@@ -417,8 +419,10 @@ def test_fused_step_equals_kernel_by_kernel(name, task):
         key, k_act, k_step = cr.split(key, 3)
         ua, cpa, ia = ca(obs, state, params, k_act, cpa, info)
         ub, cpb, ib = cb(obs, state, params, k_act, cpb, info)
-        assert torch.equal(cpa.a_mean, cpb.a_mean), (name, step, (cpa.a_mean - cpb.a_mean).abs().max())
+        assert (cpa.a_mean - cpb.a_mean).abs().max() <= 2e-6, (name, step, (cpa.a_mean - cpb.a_mean).abs().max())
+        assert torch.equal(ca.core.a, cb.core.a)
         assert torch.equal(ca.core.cost, cb.core.cost)
+        cpb = cpb.replace(a_mean=cpa.a_mean.clone())  # keep the two runs on the same trajectory bit for bit
         assert torch.allclose(cpa.a_cov, cpb.a_cov, rtol=0, atol=0)
         assert torch.equal(ia["pos_mean"], ib["pos_mean"]) and torch.equal(ia["pos_std"], ib["pos_std"])
         obs, state, reward, done, info = env.step(k_step, state, ua.cpu().numpy(), params)
