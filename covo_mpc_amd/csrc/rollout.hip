@@ -81,24 +81,37 @@ __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost,
     const int t = lane & 31, half = lane >> 5;  // lane -> action stripe t; the two half-waves take alternate live samples
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     while (live != 0ull) {
-        const int l0 = (int)__builtin_ctzll(live);
-        live &= live - 1ull;
-        int l1 = l0;
-        bool two = false;
-        if (live != 0ull) {
-            l1 = (int)__builtin_ctzll(live);
-            live &= live - 1ull;
-            two = true;
+        // up to 8 live samples per trip (4 per half-wave): their stripe loads are all issued before the first is used --
+        // one L2 round trip per trip, not per sample
+        float wv[4];
+        float4 av[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int l0 = 0, l1 = 0;
+            bool one = false, two = false;
+            if (live != 0ull) {
+                l0 = (int)__builtin_ctzll(live);
+                live &= live - 1ull;
+                one = true;
+            }
+            if (live != 0ull) {
+                l1 = (int)__builtin_ctzll(live);
+                live &= live - 1ull;
+                two = true;
+            }
+            const int l = half ? l1 : l0;
+            wv[q] = __shfl(w, l, COVO_WAVE);
+            const int nl = __shfl(n, l, COVO_WAVE);
+            if (half ? !two : !one) wv[q] = 0.0f;
+            av[q] = A.a[(size_t)t * A.N + nl];
         }
-        const int l = half ? l1 : l0;
-        float wv = __shfl(w, l, COVO_WAVE);
-        const int nl = __shfl(n, l, COVO_WAVE);
-        if (half && !two) wv = 0.0f;
-        const float4 av = A.a[(size_t)t * A.N + nl];
-        acc.x = fmaf(wv, av.x, acc.x);
-        acc.y = fmaf(wv, av.y, acc.y);
-        acc.z = fmaf(wv, av.z, acc.z);
-        acc.w = fmaf(wv, av.w, acc.w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc.x = fmaf(wv[q], av[q].x, acc.x);
+            acc.y = fmaf(wv[q], av[q].y, acc.y);
+            acc.z = fmaf(wv[q], av[q].z, acc.z);
+            acc.w = fmaf(wv[q], av[q].w, acc.w);
+        }
     }
     acc.x += __shfl_xor(acc.x, 32, COVO_WAVE);
     acc.y += __shfl_xor(acc.y, 32, COVO_WAVE);

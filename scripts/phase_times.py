@@ -27,12 +27,14 @@ for i in range(45):
 torch.cuda.synchronize()
 core = controller.core
 T = core.time_phases
-rows = [("whole step", T()), ("shift_mean", T(1)), ("hessian (4 kernels)", T(2)),
+rows = [("whole step (graph)", T()), ("hessian (4 kernels)", T(2)),
         ("  jac", T(2, 1)), ("  chain", T(2, 2)), ("  hess", T(2, 4)), ("  gemm", T(2, 8)),
         ("sigma (all)", T(4)), ("  prep+squarings", T(4, 15, 1)), ("  +ritz", T(4, 15, 2)), ("  +newton-schulz", T(4, 15, 3)),
-        ("noise gemm", T(8)), ("rollout", T(16)), ("softmax update", T(32)), ("empty graph (floor)", T(0))]
+        ("sigma + gemm (product: eps drawn under finalize, tiled GEMM)", T(12)),
+        ("noise gemm, in-kernel Philox (offline/MPPI path)", T(8)), ("rollout (+ softmax records)", T(16)),
+        ("merge (softmax update)", T(32)), ("empty graph (floor)", T(0))]
 for n, v in rows:
-    print(f"{n:<24} {v:8.2f} us")
+    print(f"{n:<62} {v:8.2f} us")
 print("rollout reps=1", T(16, reps=1), "reps=5", T(16, reps=5), "reps=50", T(16, reps=50))
 print("gemm+rollout", T(24), "gemm+rollout+softmax", T(56), "rollout+softmax", T(48))
 pc = params.to_c()
@@ -58,8 +60,10 @@ for i in [5, 20, 44, 100, 200, 290]:
     ds_i = DeviceState(packed=packed_d[i % 60], pos_traj=dref.pos_traj, vel_traj=dref.vel_traj, time=int(host_states[i % 60].time))
     key, k = cr.split(key)
     u, cp, _ = controller(None, None, params, k, cp, {"noisy_state": ds_i})
-    out_t = torch.zeros(16, dtype=torch.float64).pin_memory()
-    _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out_t), 11 * M, 16, core.stream()))
+    out_t = torch.zeros(24, dtype=torch.float64).pin_memory()
+    _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out_t), 11 * M, 24, core.stream()))
     torch.cuda.synchronize()
     o = out_t.numpy()
-    print(i, "  ".join(f"{n}={o[j]:.5g}" for j, n in enumerate(names)))
+    t = o[16:21]
+    print(i, "  ".join(f"{n}={o[j]:.5g}" for j, n in enumerate(names)),
+          " finalize ticks: load %d chol %d logdet %d outputs %d" % tuple(t[k + 1] - t[k] for k in range(4)))
