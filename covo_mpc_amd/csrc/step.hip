@@ -21,6 +21,45 @@ __global__ void shift_cov_kernel(const float *__restrict__ in, float *__restrict
 }
 __global__ void copy512_kernel(const float *__restrict__ in, float *__restrict__ out) { out[threadIdx.x] = in[threadIdx.x]; }
 
+// MPPI's three tiny launches in one (mppi.py:43-49,59-61): shift the H covariance blocks in place (drop the first, repeat
+// the last) and factor each 4x4 block -- thread t owns block t; same arithmetic as covo_cholesky (sigma.hip:
+// symmetrise, fp64 right-looking Cholesky with sqrt and one division per column, fp32 out)
+__global__ void mppi_prep_kernel(float *__restrict__ a_cov, float *__restrict__ Ls)
+{
+    const int t = threadIdx.x;  // 64 threads, H = 32 active
+    float blk[16];
+    if (t < COVO_H) {
+        const float *src = a_cov + 16 * ((t < COVO_H - 1) ? t + 1 : t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) blk[i] = src[i];
+    }
+    __syncthreads();  // every block is read before any is overwritten
+    if (t >= COVO_H) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a_cov[16 * t + i] = blk[i];
+    double A[4][4];  // lower triangle, A[c][r] for r >= c (column-major like the LDS version)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = c; r < 4; ++r) A[c][r] = 0.5 * ((double)blk[4 * r + c] + (double)blk[4 * c + r]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double djj = sqrt(A[j][j]);
+        const double inv = 1.0 / djj;
+        A[j][j] = djj;
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) A[j][i] = A[j][i] * inv;
+#pragma unroll
+        for (int c = j + 1; c < 4; ++c)
+#pragma unroll
+            for (int i = c; i < 4; ++i) A[c][i] -= A[j][i] * A[j][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Ls[16 * t + 4 * r + c] = (c <= r) ? (float)A[c][r] : 0.0f;
+}
+
 // child i of split(key, 2) / element i of normal(key, (3,)) exactly as covo_mpc_amd/random.py forms them
 __device__ __forceinline__ void host_split(const uint32_t (&key)[2], uint32_t i, uint32_t (&child)[2])
 {
@@ -200,9 +239,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
                                     a.n_table)))
             return rc;
     } else {  // MPPI: shift a_cov, factor the 4x4 blocks, per-step draws (mppi.py:43-66)
-        hipLaunchKernelGGL(shift_cov_kernel, dim3(1), dim3(COVO_H * 16), 0, s, a.a_cov, st->cov_shift);
-        hipLaunchKernelGGL(copy512_kernel, dim3(1), dim3(COVO_H * 16), 0, s, st->cov_shift, a.a_cov);
-        if ((rc = launch_cholesky(st->cov_shift, 4, COVO_H, st->Ls, s))) return rc;
+        hipLaunchKernelGGL(mppi_prep_kernel, dim3(1), dim3(64), 0, s, a.a_cov, st->Ls);
         if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
     }
     const bool clipped = true;  // a comes straight from the noise kernels above
