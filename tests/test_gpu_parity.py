@@ -428,6 +428,37 @@ def test_fused_step_equals_kernel_by_kernel(name, task):
         obs, state, reward, done, info = env.step(k_step, state, ua.cpu().numpy(), params)
 
 
+@pytest.mark.parametrize("name,N,lam", [("covo-online", 1000, "0.01"), ("covo-online", 4096, "1.0"), ("mppi", 100, "0.1"),
+                                        ("covo-online", 65, "0.01")])
+def test_fused_step_ragged_sizes_and_warm_lambda(name, N, lam):
+    """The fused step's own kernels at the edges the stand-alone ones are tested on: sample counts that are not a
+    multiple of the 32-sample MFMA tile / the 64-lane wave / the 256-sample workgroup (epsilon drawn ahead in tile
+    order, softmax records from partial workgroups) and temperatures at which EVERY sample carries weight (the record's
+    live-sample loop runs over whole waves).  Against the kernel-by-kernel path: same actions and costs bit for bit,
+    means to fp32 rounding."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    ca, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=False)
+    cb, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=False)
+    cb.materialize_eps = True
+    params = env.default_params
+    obs, info, state = env.reset(cr.PRNGKey(14), params)
+    cpa = ca.reset(state, params, ca.init_control_params, cr.PRNGKey(5))
+    cpb = cb.reset(state, params, cb.init_control_params, cr.PRNGKey(5))
+    key = cr.PRNGKey(16)
+    for step in range(4):
+        key, k_act, k_step = cr.split(key, 3)
+        ua, cpa, _ = ca(obs, state, params, k_act, cpa, info)
+        ub, cpb, _ = cb(obs, state, params, k_act, cpb, info)
+        assert torch.equal(ca.core.a, cb.core.a), (name, N, step)
+        assert torch.equal(ca.core.cost, cb.core.cost), (name, N, step)
+        assert (cpa.a_mean - cpb.a_mean).abs().max() <= 5e-6, (name, N, step, (cpa.a_mean - cpb.a_mean).abs().max())
+        cpb = cpb.replace(a_mean=cpa.a_mean.clone())
+        obs, state, reward, done, info = env.step(k_step, state, ua.cpu().numpy(), params)
+
+
 def test_env_instances_with_domain_randomisation():
     """BASELINE configs[4] (reduced: 4 of the 256 instances, N = 4096): independent env instances of the lissajous
     `tracking` task, each with its own domain-randomised parameters (quadrotor.py:135-160), each its own complete
@@ -495,6 +526,34 @@ def test_batched_step_equals_replicas():
             assert torch.equal(u_b[e], u), (step, e)
             i["obs"], i["state"], _, _, i["info"] = env.step(i["k_step"], i["state"], u.cpu().numpy(), i["params"])
     assert (batched.a_mean[0] - batched.a_mean[1]).abs().max() > 1e-4  # different plants, different plans
+
+
+def test_batched_step_single_instance_and_errors():
+    """covo_mpc_step_batched at its edges: one instance (no batching to hide behind) equals the plain controller bit for
+    bit; more instances than COVO_MAX_ENVS, and a call before the instances are bound, fail loudly."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    N = 2048
+    env = cm.envs.Quad3D(task="tracking", obs_type="quad_params", enable_randomizer=True, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    params = env.sample_params(cr.PRNGKey(7))
+    controller, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV, compute_info=False)
+    obs, info, state = env.reset(cr.PRNGKey(8), params)
+    cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(2))
+    b = cm.controllers.BatchedCoVOController(env, 1, N, 32, 0.01, discount=cp.discount, gamma_mean=cp.gamma_mean,
+                                             sample_sigma=cp.sample_sigma, a_mean_init=cp.a_mean, device=DEV)
+    with pytest.raises(RuntimeError):
+        b([info["noisy_state"]], np.zeros((1, 2), dtype=np.uint32))
+    b.set_instances([state], [params])
+    key = cr.PRNGKey(9)
+    for step in range(3):
+        key, k_act, k_step = cr.split(key, 3)
+        u_b = b([info["noisy_state"]], np.asarray(k_act)[None]).clone()
+        u, cp, _ = controller(obs, state, params, k_act, cp, info)
+        assert torch.equal(u_b[0], u) and torch.equal(b.a_mean[0].view(32, 4), cp.a_mean) and torch.equal(b.a_cov[0], cp.a_cov)
+        obs, state, _, _, info = env.step(k_step, state, u.cpu().numpy(), params)
+    with pytest.raises(ValueError):
+        cm.controllers.BatchedCoVOController(env, 65, N, 32, 0.01, device=DEV)
 
 
 def test_closed_loop_tracking_sanity():
