@@ -199,12 +199,18 @@ def main():
     controller.alias_outputs = True  # returned tensors alias the controller's buffers: no per-step clones
     core = controller.core
 
-    def step(i, key, cp):
+    # the controller keys of all steps are inputs like the states: the chain rng, rng_act = split(rng) of eval_env's
+    # run_one_step (quadrotor.py:520-524, PRNGKey(1) from :517) is unrolled before the timed region
+    key = cr.PRNGKey(1)
+    act_keys = []
+    for i in range(args.warmup + args.steps):
         key, k_act = cr.split(key)
-        u, cp, _ = controller(None, None, params, k_act, cp, {"noisy_state": dstates[i % n_states]})
+        act_keys.append(k_act)
+
+    def step(i, key, cp):
+        u, cp, _ = controller(None, None, params, act_keys[i], cp, {"noisy_state": dstates[i % n_states]})
         return key, cp
 
-    key = cr.PRNGKey(1)  # mirrors eval_env's PRNGKey(1) (quadrotor.py:517)
     for i in range(args.warmup):
         key, cp = step(i, key, cp)
     torch.cuda.synchronize()
