@@ -146,16 +146,13 @@ struct StepState {
     float *Sigma, *L;     // [128][128]
     float *cov_shift, *Ls;  // [H][4][4]
     float4 *eps_tiled;    // covo-online: this step's epsilon in tile order, drawn under the Sigma chain (eps_tiles.hpp); or null
-    // host (pinned) staging ring for dyn
-    uint32_t *dyn_host;
-    int ring_pos;
     // graph cache
     bool have_key, have_graph;
     StepKey key;
     hipGraph_t graph;
     hipGraphExec_t exec;
 };
-constexpr int DYN_RING = 256, DYN_BYTES = 48, DYN_WORDS = DYN_BYTES / 4;
+constexpr int DYN_BYTES = 48;
 // up to this many samples per GPU the step's epsilon is drawn by passenger workgroups of the Sigma chain's last launch
 // (~6 us of work per 65 536 samples inside a ~30 us single-workgroup kernel); beyond, the GEMM draws it itself
 constexpr int EPS_AHEAD_MAX_N = 262144;
@@ -172,7 +169,6 @@ static int step_state_init(covo_ctx *h)
     COVO_CHECK_HIP(hipMalloc(&st->L, (size_t)COVO_NA * COVO_NA * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->cov_shift, COVO_H * 16 * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->Ls, COVO_H * 16 * sizeof(float)));
-    COVO_CHECK_HIP(hipHostMalloc((void **)&st->dyn_host, (size_t)DYN_RING * DYN_BYTES, hipHostMallocDefault));
     if (h->cfg.n_local <= EPS_AHEAD_MAX_N)
         COVO_CHECK_HIP(hipMalloc(&st->eps_tiled, (size_t)((h->cfg.n_local + 31) / 32) * 16 * 64 * sizeof(float4)));
     h->step = st;
@@ -196,7 +192,6 @@ void step_state_destroy(covo_ctx *h)
     (void)hipFree(st->cov_shift);
     (void)hipFree(st->Ls);
     (void)hipFree(st->eps_tiled);
-    (void)hipHostFree(st->dyn_host);
     delete st;
     h->step = nullptr;
 }
@@ -271,18 +266,16 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
         if (rc) return rc;
     }
     StepState *st = reinterpret_cast<StepState *>(h->step);
-    // per-step scalars -> device block (pinned ring slot so the async copy never races the next call's write)
-    uint32_t *slot = st->dyn_host + (size_t)st->ring_pos * DYN_WORDS;
-    st->ring_pos = (st->ring_pos + 1) % DYN_RING;
-    slot[0] = key0;
-    slot[1] = key1;
+    // per-step scalars: kernel arguments of the begin launch
+    DynBlock blk;
+    std::memset(&blk, 0, sizeof(blk));
+    blk.w[0] = key0;
+    blk.w[1] = key1;
     for (int i = 0; i < 3; ++i) {
         const float f = f_shared ? f_shared[i] : 0.0f;
-        std::memcpy(&slot[2 + i], &f, 4);
+        std::memcpy(&blk.w[2 + i], &f, 4);
     }
-    std::memcpy(&slot[8], &args->state, sizeof(const float *));
-    DynBlock blk;
-    std::memcpy(blk.w, slot, DYN_BYTES);
+    std::memcpy(&blk.w[8], &args->state, sizeof(const float *));
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s, args->a_mean,
                        args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
                        args->shared_noise_scale, blk);
