@@ -32,11 +32,16 @@ __device__ __forceinline__ void eps_tiles_generate(const EpsGenArgs &G, int wave
 #pragma unroll 4
         for (int q = 0; q < 16; ++q) {
             const float4 v = rngd::normal4((uint32_t)(2 * q + kh), id, k0, k1);
-            // write-through stores (sc0 sc1): none of the 33 MB stays dirty in the L2s for the end-of-kernel write-back, which
-            // lands on the one factoring workgroup's critical path (plain stores: +1.4 us per step)
+            // write-through stores (sc0 sc1): none of the 33 MB stays dirty in the L2s for the end-of-kernel write-back behind
+            // the one factoring workgroup (finalize 37 -> 31 us; the GEMM then reads epsilon from HBM instead of L2, so the step
+            // gains only ~0.7 us over plain stores: -DEPS_STORE_PLAIN)
+#ifndef EPS_STORE_PLAIN
             typedef float f4v __attribute__((ext_vector_type(4)));
             const f4v vv = {v.x, v.y, v.z, v.w};
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out + q * 64), "v"(vv) : "memory");
+#else
+            out[q * 64] = v;
+#endif
         }
     }
 }
