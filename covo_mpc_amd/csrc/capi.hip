@@ -210,6 +210,16 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
     return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream);
 }
 
+int covo_debug_set_ns_tail(int n_iters)
+{
+    if (n_iters < 0 || n_iters > 64) {
+        covo_set_error("covo_debug_set_ns_tail: n_iters=%d out of range", n_iters);
+        return COVO_E_BADARG;
+    }
+    g_ns_tail_iters = n_iters;
+    return 0;
+}
+
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)
 {
     REQUIRE(h && out, "covo_debug_sigma_workspace: bad argument");

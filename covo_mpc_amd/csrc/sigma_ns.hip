@@ -65,6 +65,7 @@ constexpr int RITZ = 4;            // Rayleigh-Ritz block: exact lambda_min for 
 enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, SC_XBUF, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
        SC_FRO2, SC_TRACE, SC_GERSH, SC_N0,
        SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug)
+       SC_BAR = 24,            // grid-barrier counter of ns_iter_tail_kernel (an unsigned in the slot; zeroed with the scalars)
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
@@ -474,21 +475,20 @@ __device__ __forceinline__ bool ns_converged(double *__restrict__ s, int iter, i
     return false;
 }
 
-// ---- Newton-Schulz step k >= 1, part 1:  T = a_k I + b_k Z.Y  (64 tiles; T and T^T are stored)
-__global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
-                                                   double *__restrict__ Tall, double *__restrict__ Ttall,
-                                                   double *__restrict__ scall, int iter)
+// ---- Newton-Schulz step k >= 1, part 1:  T = a_k I + b_k Z.Y  (64 tiles; T and T^T are stored).
+// Returns false when the iteration has converged (nothing was written).  Workgroup w of matrix b.
+__device__ __forceinline__ bool ns_T_body(const double *__restrict__ Yall, const double *__restrict__ Ztall,
+                                          double *__restrict__ Tall, double *__restrict__ Ttall, double *__restrict__ scall,
+                                          int iter, int b, int w, double (*red)[4][64], double *part)
 {
-    __shared__ double red[4][4][64];
-    __shared__ double part[4];
-    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
     TileOps ops;
     tile_load(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
     const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
-    if (ns_converged(s, iter, lane, w == 0 && tid == 0)) return;  // Y, Z are final
+    if (ns_converged(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
     const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
@@ -496,28 +496,27 @@ __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Ya
     const double d = p - ((row == col) ? 1.0 : 0.0);
     const double tot = wg_sum4(d * d, part, wv, lane);
     if (tid == 0) s[SC_ERR + iter * 64 + w] = tot;  // |Z Y - I|_F^2 partial
+    return true;
 }
 
-// ---- part 2:  Y' = Y.T (tiles 0..63),  Z' = T.Z (tiles 64..127); each with its transpose
-__global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
-                                                    const double *__restrict__ Tall, const double *__restrict__ Ttall,
-                                                    double *__restrict__ Yout, double *__restrict__ Ytout,
-                                                    double *__restrict__ Zout, double *__restrict__ Ztout,
-                                                    double *__restrict__ scall, int iter, int zbuf_out)
+// ---- part 2:  Y' = Y.T (tiles 0..63),  Z' = T.Z (tiles 64..127); each with its transpose.  Workgroup wx in 0..127.
+__device__ __forceinline__ bool ns_YZ_body(const double *__restrict__ Ytall, const double *__restrict__ Zall,
+                                           const double *__restrict__ Tall, const double *__restrict__ Ttall,
+                                           double *__restrict__ Yout, double *__restrict__ Ytout, double *__restrict__ Zout,
+                                           double *__restrict__ Ztout, double *__restrict__ scall, int iter, int zbuf_out, int b,
+                                           int wx, double (*red)[4][64])
 {
-    __shared__ double red[4][4][64];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
-    int w = blockIdx.x;
-    const bool isZ = w >= 64;
-    w &= 63;
+    const bool isZ = wx >= 64;
+    const int w = wx & 63;
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
     // Y' = Y.T : left factor Y -> pass Y^T;   Z' = T.Z : left factor T -> pass T^T
     TileOps ops;
     tile_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
-    if (ns_converged(s, iter, lane, false)) return;  // the T launch of this iteration raised the flag
-    if (blockIdx.x == 0 && tid == 0) {
+    if (ns_converged(s, iter, lane, false)) return false;  // part 1 of this iteration raised the flag
+    if (wx == 0 && tid == 0) {
         s[SC_ZBUF] = (double)zbuf_out;  // which Z buffer holds the newest iterate
         s[SC_ITERS] = (double)(iter + 1);
     }
@@ -525,6 +524,81 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
     const double v = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
     store_both((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
+                                                   double *__restrict__ Tall, double *__restrict__ Ttall,
+                                                   double *__restrict__ scall, int iter)
+{
+    __shared__ double red[4][4][64];
+    __shared__ double part[4];
+    (void)ns_T_body(Yall, Ztall, Tall, Ttall, scall, iter, blockIdx.y, blockIdx.x, red, part);
+}
+
+__global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
+                                                    const double *__restrict__ Tall, const double *__restrict__ Ttall,
+                                                    double *__restrict__ Yout, double *__restrict__ Ytout,
+                                                    double *__restrict__ Zout, double *__restrict__ Ztout,
+                                                    double *__restrict__ scall, int iter, int zbuf_out)
+{
+    __shared__ double red[4][4][64];
+    (void)ns_YZ_body(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, blockIdx.y, blockIdx.x, red);
+}
+
+// ---- the LAST iterations of the chain in one launch (batch 1 only: its 128 workgroups must be co-resident).
+// A captured graph cannot branch, so every iteration the cap allows costs its two launches (1.6 us each when they
+// find the iteration converged).  Iterations 11 and 12 are live on 3 % / 0 % of closed-loop Hessians: they share ONE
+// launch whose workgroups all take the same converged / not converged decision from the same slots and leave at
+// once in the common case; when an iteration is live its two parts and consecutive iterations are separated by a
+// counter barrier across the grid (release / acquire at agent scope; ~6 us, scripts/probe/chain_probe.hip) -- slower
+// than a launch, which is why only the rarely-live end of the chain is folded.  The spin is bounded (0.2 s): a
+// barrier that cannot complete leaves Z unconverged instead of hanging the GPU.
+__device__ __forceinline__ bool ns_grid_barrier(unsigned *ctr, unsigned target)
+{
+    __shared__ int ok;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        int good = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 20000000LL) {
+                good = 0;
+                break;
+            }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok != 0;
+}
+
+struct NsBufs {
+    double *Y[2], *Yt[2], *Z[2], *Zt[2], *T, *Tt;
+};
+
+__global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, double *__restrict__ scall, int iter_first,
+                                                           int iter_last)
+{
+    __shared__ double red[4][4][64];
+    __shared__ double part[4];
+    const int wx = blockIdx.x, nwg = gridDim.x;  // 128 workgroups, one matrix
+    unsigned *ctr = reinterpret_cast<unsigned *>(scall + SC_BAR);  // zeroed by ns_prep_kernel every run
+    unsigned phase = 0;
+    for (int iter = iter_first; iter <= iter_last; ++iter) {
+        const int in = iter & 1, out = in ^ 1;
+        bool live;
+        if (wx < 64) live = ns_T_body(B.Y[in], B.Zt[in], B.T, B.Tt, scall, iter, 0, wx, red, part);
+        else live = !ns_converged(scall, iter, threadIdx.x & 63, false);
+        if (!live) return;  // every workgroup reads the same slots: all of them leave here together
+        if (!ns_grid_barrier(ctr, (unsigned)nwg * ++phase)) return;
+        (void)ns_YZ_body(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx, red);
+        if (iter < iter_last && !ns_grid_barrier(ctr, (unsigned)nwg * ++phase)) return;
+    }
 }
 
 // ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  ONE Cholesky serves both needs:
@@ -615,6 +689,9 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
         for (int i = 0; i < 5; ++i) s[SC_PROF + i] = (double)(tk[i] - tk[0]);
 }
 
+// how many of the chain's last Newton-Schulz iterations share one launch (ns_iter_tail_kernel); covo_debug_set_ns_tail
+int g_ns_tail_iters = 2;
+
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
@@ -645,11 +722,26 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc);
     if (g_dbg_sigma_stages < 3) return 0;
     hipLaunchKernelGGL(ns_first_kernel, dim3(64, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);
-    for (int i = 1; i < NS_ITERS; ++i) {
+    int n_tail = (batch == 1) ? g_ns_tail_iters : 0;  // the grid barrier needs the launch's workgroups co-resident
+    if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
+    const int n_sep = NS_ITERS - n_tail;
+    for (int i = 1; i < n_sep; ++i) {
         const int in = i & 1, out = in ^ 1;
         hipLaunchKernelGGL(ns_T_kernel, dim3(64, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i);
         hipLaunchKernelGGL(ns_YZ_kernel, dim3(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
                            Zt[out], sc, i, out);
+    }
+    if (n_tail > 0) {
+        NsBufs B;
+        for (int k = 0; k < 2; ++k) {
+            B.Y[k] = Y[k];
+            B.Yt[k] = Yt[k];
+            B.Z[k] = Z[k];
+            B.Zt[k] = Zt[k];
+        }
+        B.T = T;
+        B.Tt = Tt;
+        hipLaunchKernelGGL(ns_iter_tail_kernel, dim3(128), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     EpsGenArgs g;

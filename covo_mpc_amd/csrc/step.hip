@@ -14,13 +14,6 @@
 #include "eps_tiles.hpp"
 #include "rng_device.hpp"
 
-__global__ void shift_cov_kernel(const float *__restrict__ in, float *__restrict__ out)
-{
-    const int i = threadIdx.x;  // 512 threads: (H, 4, 4); mppi.py:43-49
-    out[i] = (i < (COVO_H - 1) * 16) ? in[i + 16] : in[i];
-}
-__global__ void copy512_kernel(const float *__restrict__ in, float *__restrict__ out) { out[threadIdx.x] = in[threadIdx.x]; }
-
 // MPPI's three tiny launches in one (mppi.py:43-49,59-61): shift the H covariance blocks in place (drop the first, repeat
 // the last) and factor each 4x4 block -- thread t owns block t; same arithmetic as covo_cholesky (sigma.hip:
 // symmetrise, fp64 right-looking Cholesky with sqrt and one division per column, fp32 out)
@@ -144,7 +137,7 @@ struct StepState {
     float *a_mean_shift;  // [128]
     double *R;            // [128][128]
     float *Sigma, *L;     // [128][128]
-    float *cov_shift, *Ls;  // [H][4][4]
+    float *Ls;            // [H][4][4] MPPI's block factors
     float4 *eps_tiled;    // covo-online: this step's epsilon in tile order, drawn under the Sigma chain (eps_tiles.hpp); or null
     // graph cache
     bool have_key, have_graph;
@@ -167,7 +160,6 @@ static int step_state_init(covo_ctx *h)
     COVO_CHECK_HIP(hipMalloc(&st->R, (size_t)COVO_NA * COVO_NA * sizeof(double)));
     COVO_CHECK_HIP(hipMalloc(&st->Sigma, (size_t)COVO_NA * COVO_NA * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->L, (size_t)COVO_NA * COVO_NA * sizeof(float)));
-    COVO_CHECK_HIP(hipMalloc(&st->cov_shift, COVO_H * 16 * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->Ls, COVO_H * 16 * sizeof(float)));
     if (h->cfg.n_local <= EPS_AHEAD_MAX_N)
         COVO_CHECK_HIP(hipMalloc(&st->eps_tiled, (size_t)((h->cfg.n_local + 31) / 32) * 16 * 64 * sizeof(float4)));
@@ -189,7 +181,6 @@ void step_state_destroy(covo_ctx *h)
     (void)hipFree(st->R);
     (void)hipFree(st->Sigma);
     (void)hipFree(st->L);
-    (void)hipFree(st->cov_shift);
     (void)hipFree(st->Ls);
     (void)hipFree(st->eps_tiled);
     delete st;

@@ -201,6 +201,10 @@ int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sam
 /* Debug aid: copy `count` doubles from offset `offset_doubles` of the Sigma pipeline's scratch (layout in
  * sigma_ns.hip: 12 matrices [batch][128][128], then 64 scalars per matrix) to `out` (device). */
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
+/* Test hook (process-wide): how many of the eigh-free Sigma chain's last Newton-Schulz iterations run inside ONE launch
+ * separated by grid barriers instead of as two launches each (default 2; 0 = none; >= 11 = all).  The result does not
+ * depend on it bit for bit; graphs captured before the call keep their launch sequence. */
+int covo_debug_set_ns_tail(int n_iters);
 int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 
 /* Profiling aid: covo_sigma for ONE matrix that also stores shader-clock ticks (s_memtime) at the kernel's

@@ -528,6 +528,35 @@ def test_batched_step_equals_replicas():
     assert (batched.a_mean[0] - batched.a_mean[1]).abs().max() > 1e-4  # different plants, different plans
 
 
+def test_sigma_tail_launch_is_bit_identical():
+    """The Sigma chain's last Newton-Schulz iterations share one launch with grid barriers between their parts
+    (sigma_ns.hip: ns_iter_tail_kernel).  Folding none, the default two, or ALL iterations into that launch -- so that up
+    to ten live iterations run through the barrier path -- must not change a single bit of Sigma or L."""
+    from covo_mpc_amd import _lib
+    lib = _lib.load_library()
+    rng = np.random.default_rng(5)
+    n = 128
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    mats = []
+    G = rng.standard_normal((n, n)); mats.append(0.05 * (G + G.T))                                   # ~8 iterations
+    w = np.concatenate([np.abs(rng.standard_normal(20)) * 50, rng.standard_normal(108) * 0.05]); mats.append((Q * w) @ Q.T)
+    w = np.concatenate([[-2.0, -1.1, -0.7], np.geomspace(0.01, 900.0, n - 3)]); mats.append((Q * w) @ Q.T)  # closed-loop-like
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    try:
+        for Rm in mats:
+            R_d = torch.from_numpy(np.ascontiguousarray(Rm)).to(DEV)
+            outs = []
+            for tail in (0, 2, 11):
+                _lib.check(lib.covo_debug_set_ns_tail(tail))
+                Sig, L = core.sigma(R_d[None], 0.5)
+                outs.append((Sig.clone(), L.clone()))
+            assert torch.isfinite(outs[0][0]).all()
+            for Sig, L in outs[1:]:
+                assert torch.equal(Sig, outs[0][0]) and torch.equal(L, outs[0][1])
+    finally:
+        _lib.check(lib.covo_debug_set_ns_tail(2))
+
+
 def test_batched_step_single_instance_and_errors():
     """covo_mpc_step_batched at its edges: one instance (no batching to hide behind) equals the plain controller bit for
     bit; more instances than COVO_MAX_ENVS, and a call before the instances are bound, fail loudly."""
