@@ -210,12 +210,13 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
     return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream);
 }
 
-int covo_debug_set_ns_tail(int n_iters)
+int covo_debug_set_ns_tail(int n_squarings, int n_iters)
 {
-    if (n_iters < 0 || n_iters > 64) {
-        covo_set_error("covo_debug_set_ns_tail: n_iters=%d out of range", n_iters);
+    if (n_squarings < 0 || n_squarings > 64 || n_iters < 0 || n_iters > 64) {
+        covo_set_error("covo_debug_set_ns_tail: (%d, %d) out of range", n_squarings, n_iters);
         return COVO_E_BADARG;
     }
+    g_ns_tail_squarings = n_squarings;
     g_ns_tail_iters = n_iters;
     return 0;
 }

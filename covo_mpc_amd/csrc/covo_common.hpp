@@ -34,7 +34,7 @@ void covo_set_error(const char *fmt, ...);
 // many stages of the Sigma pipeline (1 prep+squarings, 2 +Ritz, 3 +Newton-Schulz, 4 +finalize) are enqueued.
 // Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
-extern int g_ns_tail_iters;  // sigma_ns.hip
+extern int g_ns_tail_iters, g_ns_tail_squarings;  // sigma_ns.hip
 
 #define COVO_CHECK_HIP(expr)                                                         \
     do {                                                                             \

@@ -65,7 +65,7 @@ constexpr int RITZ = 4;            // Rayleigh-Ritz block: exact lambda_min for 
 enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, SC_XBUF, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
        SC_FRO2, SC_TRACE, SC_GERSH, SC_N0,
        SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug)
-       SC_BAR = 24,            // grid-barrier counter of ns_iter_tail_kernel (an unsigned in the slot; zeroed with the scalars)
+       SC_BAR = 24,            // grid-barrier counters of the two persistent launches (unsigned in slots 24, 25; zeroed with the scalars)
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
@@ -93,21 +93,36 @@ struct LoadScaledB {
     __device__ __forceinline__ double operator()(double v, int r, int c) const { return (v + ((r == c) ? delta : 0.0)) * inv; }
 };
 
+// COH: the access is an agent-scope relaxed atomic (sc1): coherent across the XCDs' L2s without cache-wide fences.  Used by
+// the persistent launches below, whose phases exchange tiles and slots across workgroups INSIDE one kernel; the same
+// bodies compiled with COH = false (plain cached accesses) serve the one-launch-per-phase kernels.  Same arithmetic.
+template <bool COH>
+__device__ __forceinline__ double gld(const double *p)
+{
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void gst(double *p, double v)
+{
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 struct TileOps {
     double a[8], b[8];
 };
 // issue the 16 operand loads of this wave's K-quarter (callers issue them BEFORE looking at any flag: every
 // launch of the chain then pays one memory latency, not one per dependent scalar)
-template <class F>
-__device__ __forceinline__ void tile_load(TileOps &o, const double *__restrict__ A, const double *__restrict__ B, int ti, int tj,
-                                          int lane, int kq, F f)
+template <bool COH = false, class F>
+__device__ __forceinline__ void tile_load(TileOps &o, const double *A, const double *B, int ti, int tj, int lane, int kq, F f)
 {
     const int lo = lane & 15, hi = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const int k = 32 * kq + 4 * kk + hi;
-        o.a[kk] = f(A[(size_t)k * SN + 16 * ti + lo], k, 16 * ti + lo);
-        o.b[kk] = f(B[(size_t)k * SN + 16 * tj + lo], k, 16 * tj + lo);
+        o.a[kk] = f(gld<COH>(A + (size_t)k * SN + 16 * ti + lo), k, 16 * ti + lo);
+        o.b[kk] = f(gld<COH>(B + (size_t)k * SN + 16 * tj + lo), k, 16 * tj + lo);
     }
 }
 __device__ __forceinline__ f64x4 tile_mma(const TileOps &o)
@@ -156,16 +171,20 @@ __device__ __forceinline__ void tri_tile(int w, int &ti, int &tj)
     while ((ti + 1) * (ti + 2) / 2 <= w) ++ti;
     tj = w - ti * (ti + 1) / 2;
 }
-__device__ __forceinline__ void store_both(double *__restrict__ O, double *__restrict__ Ot, int row, int col, double v)
+// (staging the transposed copy through LDS so that both orientations leave as 128-byte row segments was measured and
+// changes nothing, neither behind the write-back L2 nor with the write-through stores of the persistent launches)
+template <bool COH = false>
+__device__ __forceinline__ void store_both(double *O, double *Ot, int row, int col, double v)
 {
-    O[(size_t)row * SN + col] = v;
-    Ot[(size_t)col * SN + row] = v;
+    gst<COH>(O + (size_t)row * SN + col, v);
+    gst<COH>(Ot + (size_t)col * SN + row, v);
 }
-__device__ __forceinline__ void store_sym(double *__restrict__ O, int row, int col, double v)
+template <bool COH = false>
+__device__ __forceinline__ void store_sym(double *O, int row, int col, double v)
 {
     if (row >= col) {
-        O[(size_t)row * SN + col] = v;
-        if (row > col) O[(size_t)col * SN + row] = v;
+        gst<COH>(O + (size_t)row * SN + col, v);
+        if (row > col) gst<COH>(O + (size_t)col * SN + row, v);
     }
 }
 
@@ -220,13 +239,12 @@ __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__
 // ---- one doubling of the Chebyshev degree: Xout = Xin^2 / |Xin|_F^2 - I / t_out, t_out = 2 t_in^2 |Xin|_F^2 (36 lower
 // tiles); |Xout|_F^2 partials go to slot row step+1, t_out to slot 63 of that row.
 // FIRST: Xin is A and the operand is Y0 = alpha I - beta A (see the header), t_in = 1.
-template <bool FIRST>
-__global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict__ Xin, double *__restrict__ Xout,
-                                                        double *__restrict__ scall, int step, int xbuf_out)
+// Returns false when the filter is found stationary (nothing was written).  Workgroup w of matrix b.
+template <bool FIRST, bool COH>
+__device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, double *scall, int step, int xbuf_out, int b, int w,
+                                               double (*red)[4][64], double *part)
 {
-    __shared__ double red[4][4][64];
-    __shared__ double part[4];
-    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *X = Xin + (size_t)b * SN * SN;
     double *O = Xout + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -257,38 +275,48 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
     int ti, tj;
     tri_tile(w, ti, tj);
     TileOps ops;
-    if (FIRST) tile_load(ops, X, X, ti, tj, lane, wv, LoadAffine{alpha, beta});
-    else tile_load(ops, X, X, ti, tj, lane, wv, LoadPlain{});
+    if (FIRST) tile_load<COH>(ops, X, X, ti, tj, lane, wv, LoadAffine{alpha, beta});
+    else tile_load<COH>(ops, X, X, ti, tj, lane, wv, LoadPlain{});
     if (!FIRST) {
-        const double done = s[SC_SQ_DONE];
-        const double p1 = (lane < NS_TILES) ? s[SC_SQN + step * 64 + lane] : 0.0;
-        const double p0 = (lane < NS_TILES && step >= 2) ? s[SC_SQN + (step - 1) * 64 + lane] : 0.0;
-        t_in = s[SC_SQN + step * 64 + 63];
-        if (done != 0.0) return;
+        const double done = gld<COH>(s + SC_SQ_DONE);
+        const double p1 = (lane < NS_TILES) ? gld<COH>(s + SC_SQN + step * 64 + lane) : 0.0;
+        const double p0 = (lane < NS_TILES && step >= 2) ? gld<COH>(s + SC_SQN + (step - 1) * 64 + lane) : 0.0;
+        t_in = gld<COH>(s + SC_SQN + step * 64 + 63);
+        if (done != 0.0) return false;
         nrm = wr::wave64_allsum(p1);
         if (step >= 2 && t_in > NS_SQ_TGUARD) {
             // stationary: the bounded part of the spectrum is gone and |X_k|_F^2 stopped moving (X is a projector
             // onto the bottom eigenspace up to scale)
             const double prev = wr::wave64_allsum(p0);
             if (fabs(nrm - prev) <= NS_SQ_TOL * nrm) {
-                if (w == 0 && tid == 0) s[SC_SQ_DONE] = 1.0;
-                return;
+                if (w == 0 && tid == 0) gst<COH>(s + SC_SQ_DONE, 1.0);
+                return false;
             }
         }
     }
     const double t_out = 2.0 * t_in * t_in * nrm;  // overflows to +inf once the filter has separated: 1 / t_out = 0
     const double inv_t = 1.0 / t_out;
     if (w == 0 && tid == 0) {
-        s[SC_XBUF] = (double)xbuf_out;
-        s[SC_SQ] = (double)(step + 1);
-        s[SC_SQN + (step + 1) * 64 + 63] = t_out;
+        gst<COH>(s + SC_XBUF, (double)xbuf_out);
+        gst<COH>(s + SC_SQ, (double)(step + 1));
+        gst<COH>(s + SC_SQN + (step + 1) * 64 + 63, t_out);
     }
     const f64x4 acc = tile_mma(ops);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
     const double v = tile_reduce(acc, red, wv, lane) * (1.0 / nrm) - ((row == col) ? inv_t : 0.0);
-    store_sym(O, row, col, v);
+    store_sym<COH>(O, row, col, v);
     const double tot = wg_sum4((row > col) ? 2.0 * v * v : ((row == col) ? v * v : 0.0), part, wv, lane);
-    if (tid == 0) s[SC_SQN + (step + 1) * 64 + w] = tot;
+    if (tid == 0) gst<COH>(s + SC_SQN + (step + 1) * 64 + w, tot);
+    return true;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict__ Xin, double *__restrict__ Xout,
+                                                        double *__restrict__ scall, int step, int xbuf_out)
+{
+    __shared__ double red[4][4][64];
+    __shared__ double part[4];
+    (void)ns_square_body<FIRST, false>(Xin, Xout, scall, step, xbuf_out, blockIdx.y, blockIdx.x, red, part);
 }
 
 // ---- Rayleigh-Ritz on the RITZ largest-diagonal columns of X: lambda_min(A), delta; then the scale s of
@@ -462,14 +490,15 @@ __global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict_
     store_both(Zout + off, Ztout + off, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
 }
 
-__device__ __forceinline__ bool ns_converged(double *__restrict__ s, int iter, int lane, bool writer)
+template <bool COH>
+__device__ __forceinline__ bool ns_converged(double *s, int iter, int lane, bool writer)
 {
     // both loads are issued before either is looked at
-    const double done = s[SC_NS_DONE];
-    const double e = (iter >= 2) ? s[SC_ERR + (iter - 1) * 64 + lane] : 0.0;
+    const double done = gld<COH>(s + SC_NS_DONE);
+    const double e = (iter >= 2) ? gld<COH>(s + SC_ERR + (iter - 1) * 64 + lane) : 0.0;
     if (done != 0.0) return true;
     if (iter >= 2 && wr::wave64_allsum(e) < NS_TOL2) {
-        if (writer) s[SC_NS_DONE] = 1.0;
+        if (writer) gst<COH>(s + SC_NS_DONE, 1.0);
         return true;
     }
     return false;
@@ -477,8 +506,8 @@ __device__ __forceinline__ bool ns_converged(double *__restrict__ s, int iter, i
 
 // ---- Newton-Schulz step k >= 1, part 1:  T = a_k I + b_k Z.Y  (64 tiles; T and T^T are stored).
 // Returns false when the iteration has converged (nothing was written).  Workgroup w of matrix b.
-__device__ __forceinline__ bool ns_T_body(const double *__restrict__ Yall, const double *__restrict__ Ztall,
-                                          double *__restrict__ Tall, double *__restrict__ Ttall, double *__restrict__ scall,
+template <bool COH>
+__device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztall, double *Tall, double *Ttall, double *scall,
                                           int iter, int b, int w, double (*red)[4][64], double *part)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -486,25 +515,24 @@ __device__ __forceinline__ bool ns_T_body(const double *__restrict__ Yall, const
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
     TileOps ops;
-    tile_load(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
-    if (ns_converged(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
+    tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // written by the Ritz launch
+    if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
     const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-    store_both(Tall + off, Ttall + off, row, col, fma(bq, p, (row == col) ? a : 0.0));
+    store_both<COH>(Tall + off, Ttall + off, row, col, fma(bq, p, (row == col) ? a : 0.0));
     const double d = p - ((row == col) ? 1.0 : 0.0);
     const double tot = wg_sum4(d * d, part, wv, lane);
-    if (tid == 0) s[SC_ERR + iter * 64 + w] = tot;  // |Z Y - I|_F^2 partial
+    if (tid == 0) gst<COH>(s + SC_ERR + iter * 64 + w, tot);  // |Z Y - I|_F^2 partial
     return true;
 }
 
 // ---- part 2:  Y' = Y.T (tiles 0..63),  Z' = T.Z (tiles 64..127); each with its transpose.  Workgroup wx in 0..127.
-__device__ __forceinline__ bool ns_YZ_body(const double *__restrict__ Ytall, const double *__restrict__ Zall,
-                                           const double *__restrict__ Tall, const double *__restrict__ Ttall,
-                                           double *__restrict__ Yout, double *__restrict__ Ytout, double *__restrict__ Zout,
-                                           double *__restrict__ Ztout, double *__restrict__ scall, int iter, int zbuf_out, int b,
-                                           int wx, double (*red)[4][64])
+template <bool COH>
+__device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
+                                           double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
+                                           int zbuf_out, int b, int wx, double (*red)[4][64])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -514,16 +542,16 @@ __device__ __forceinline__ bool ns_YZ_body(const double *__restrict__ Ytall, con
     const int ti = w >> 3, tj = w & 7;
     // Y' = Y.T : left factor Y -> pass Y^T;   Z' = T.Z : left factor T -> pass T^T
     TileOps ops;
-    tile_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
-    if (ns_converged(s, iter, lane, false)) return false;  // part 1 of this iteration raised the flag
+    tile_load<COH>(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
+    if (ns_converged<COH>(s, iter, lane, false)) return false;  // part 1 of this iteration raised the flag
     if (wx == 0 && tid == 0) {
-        s[SC_ZBUF] = (double)zbuf_out;  // which Z buffer holds the newest iterate
-        s[SC_ITERS] = (double)(iter + 1);
+        gst<COH>(s + SC_ZBUF, (double)zbuf_out);  // which Z buffer holds the newest iterate
+        gst<COH>(s + SC_ITERS, (double)(iter + 1));
     }
     const f64x4 acc = tile_mma(ops);
     const double v = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-    store_both((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v);
+    store_both<COH>((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v);
     return true;
 }
 
@@ -533,7 +561,7 @@ __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Ya
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    (void)ns_T_body(Yall, Ztall, Tall, Ttall, scall, iter, blockIdx.y, blockIdx.x, red, part);
+    (void)ns_T_body<false>(Yall, Ztall, Tall, Ttall, scall, iter, blockIdx.y, blockIdx.x, red, part);
 }
 
 __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
@@ -543,28 +571,30 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
                                                     double *__restrict__ scall, int iter, int zbuf_out)
 {
     __shared__ double red[4][4][64];
-    (void)ns_YZ_body(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, blockIdx.y, blockIdx.x, red);
+    (void)ns_YZ_body<false>(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, blockIdx.y, blockIdx.x, red);
 }
 
-// ---- the LAST iterations of the chain in one launch (batch 1 only: its 128 workgroups must be co-resident).
-// A captured graph cannot branch, so every iteration the cap allows costs its two launches (1.6 us each when they
-// find the iteration converged).  Iterations 11 and 12 are live on 3 % / 0 % of closed-loop Hessians: they share ONE
-// launch whose workgroups all take the same converged / not converged decision from the same slots and leave at
-// once in the common case; when an iteration is live its two parts and consecutive iterations are separated by a
-// counter barrier across the grid (release / acquire at agent scope; ~6 us, scripts/probe/chain_probe.hip) -- slower
-// than a launch, which is why only the rarely-live end of the chain is folded.  The spin is bounded (0.2 s): a
-// barrier that cannot complete leaves Z unconverged instead of hanging the GPU.
+// ---- the chain's dependent phases inside ONE persistent launch (batch 1 only: the launch's workgroups must be
+// co-resident).  A captured graph cannot branch, so as separate launches every phase the caps allow costs 1.6 us even
+// after convergence, and a live one ~3.2-3.7 us, most of it launch floor.  Here every workgroup keeps its tile, the phases
+// are separated by a counter barrier across the grid, and all workgroups leave together at the first phase that finds
+// the iteration converged (they all read the same slots).  What makes that barrier affordable is measured in
+// scripts/probe/barrier_probe.hip: with cached accesses + agent-scope release/acquire fences (every fence writes back
+// / invalidates the XCD's whole L2) a phase costs 6-9 us -- 15 us with 128 workgroups polling -- and loses against a
+// launch; with every inter-phase access an agent-scope relaxed atomic (sc1, coherent across the XCDs' L2s; COH = true in
+// the bodies above) the barrier needs no fence, only s_waitcnt + the counter: 2.9 us per phase, GEMM included.
+// The spin is bounded (0.2 s): a barrier that cannot complete leaves the iteration unconverged instead of hanging the GPU.
 __device__ __forceinline__ bool ns_grid_barrier(unsigned *ctr, unsigned target)
 {
     __shared__ int ok;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long t0 = wall_clock64();
         int good = 1;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 20000000LL) {
                 good = 0;
                 break;
@@ -573,31 +603,44 @@ __device__ __forceinline__ bool ns_grid_barrier(unsigned *ctr, unsigned target)
         ok = good;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return ok != 0;
+}
+
+// squarings step_first .. step_last (step >= 1) of the Chebyshev filter: 36 workgroups, X0 <-> X1 by parity
+__global__ __launch_bounds__(256) void ns_square_tail_kernel(double *X0, double *X1, double *scall, int step_first, int step_last)
+{
+    __shared__ double red[4][4][64];
+    __shared__ double part[4];
+    unsigned *ctr = reinterpret_cast<unsigned *>(scall + SC_BAR);  // zeroed by ns_prep_kernel every run
+    unsigned phase = 0;
+    for (int step = step_first; step <= step_last; ++step) {
+        const bool odd = (step & 1) != 0;  // step i reads the buffer step i-1 wrote: X0 after the first squaring
+        if (!ns_square_body<false, true>(odd ? X0 : X1, odd ? X1 : X0, scall, step, odd ? 1 : 0, 0, blockIdx.x, red, part)) return;
+        if (step < step_last && !ns_grid_barrier(ctr, gridDim.x * ++phase)) return;
+    }
 }
 
 struct NsBufs {
     double *Y[2], *Yt[2], *Z[2], *Zt[2], *T, *Tt;
 };
 
-__global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, double *__restrict__ scall, int iter_first,
-                                                           int iter_last)
+// Newton-Schulz iterations iter_first .. iter_last (iter >= 1): 64 workgroups (the barrier's cost grows with the number of
+// pollers: 2.9 us per phase at 64, 5.6 at 128, barrier_probe); workgroup w forms tile w of T, then tile w of Y' and of Z'
+__global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, double *scall, int iter_first, int iter_last)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    const int wx = blockIdx.x, nwg = gridDim.x;  // 128 workgroups, one matrix
-    unsigned *ctr = reinterpret_cast<unsigned *>(scall + SC_BAR);  // zeroed by ns_prep_kernel every run
+    const int wx = blockIdx.x;
+    unsigned *ctr = reinterpret_cast<unsigned *>(scall + SC_BAR + 1);
     unsigned phase = 0;
     for (int iter = iter_first; iter <= iter_last; ++iter) {
         const int in = iter & 1, out = in ^ 1;
-        bool live;
-        if (wx < 64) live = ns_T_body(B.Y[in], B.Zt[in], B.T, B.Tt, scall, iter, 0, wx, red, part);
-        else live = !ns_converged(scall, iter, threadIdx.x & 63, false);
-        if (!live) return;  // every workgroup reads the same slots: all of them leave here together
-        if (!ns_grid_barrier(ctr, (unsigned)nwg * ++phase)) return;
-        (void)ns_YZ_body(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx, red);
-        if (iter < iter_last && !ns_grid_barrier(ctr, (unsigned)nwg * ++phase)) return;
+        if (!ns_T_body<true>(B.Y[in], B.Zt[in], B.T, B.Tt, scall, iter, 0, wx, red, part)) return;  // all leave together
+        if (!ns_grid_barrier(ctr, gridDim.x * ++phase)) return;
+        (void)ns_YZ_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx, red);
+        __syncthreads();
+        (void)ns_YZ_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx + 64, red);
+        if (iter < iter_last && !ns_grid_barrier(ctr, gridDim.x * ++phase)) return;
     }
 }
 
@@ -689,8 +732,12 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
         for (int i = 0; i < 5; ++i) s[SC_PROF + i] = (double)(tk[i] - tk[0]);
 }
 
-// how many of the chain's last Newton-Schulz iterations share one launch (ns_iter_tail_kernel); covo_debug_set_ns_tail
-int g_ns_tail_iters = 2;
+// how many of the chain's last squarings / Newton-Schulz iterations run inside the persistent launches; covo_debug_set_ns_tail.
+// Default: only the two iterations that are almost never live (3 % / 0 % of closed-loop Hessians) -- the launch then costs
+// 1.6 us instead of 4 x 1.6.  Measured with everything folded (scripts/ns_tail_cost.py, 13 squarings + 11 iterations live):
+// +0.4 us per squaring and +3.4 us per iteration over separate launches, so a live phase still loses to a launch here
+// (5.4 us per Newton-Schulz phase against 2.9 in the probe), and only phases that are rarely live are worth folding.
+int g_ns_tail_iters = 2, g_ns_tail_squarings = 0;
 
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
@@ -713,16 +760,21 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     }
     hipLaunchKernelGGL(ns_prep_kernel, dim3(8, batch), dim3(256), 0, s, R, A, sc);
     hipLaunchKernelGGL(ns_square_kernel<true>, dim3(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0);
+    // batch 1: the remaining squarings / iterations run inside persistent launches (co-residency: 36 / 128 workgroups)
+    int sq_tail = (batch == 1) ? g_ns_tail_squarings : 0;
+    if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
+    const int sq_sep = NS_SQUARINGS - sq_tail;
     double *xi = X0, *xo = X1;
-    for (int i = 1; i < NS_SQUARINGS; ++i) {
+    for (int i = 1; i < sq_sep; ++i) {
         hipLaunchKernelGGL(ns_square_kernel<false>, dim3(NS_TILES, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0);
         double *t = xi; xi = xo; xo = t;
     }
+    if (sq_tail > 0) hipLaunchKernelGGL(ns_square_tail_kernel, dim3(NS_TILES), dim3(256), 0, s, X0, X1, sc, sq_sep, NS_SQUARINGS - 1);
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc);
     if (g_dbg_sigma_stages < 3) return 0;
     hipLaunchKernelGGL(ns_first_kernel, dim3(64, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);
-    int n_tail = (batch == 1) ? g_ns_tail_iters : 0;  // the grid barrier needs the launch's workgroups co-resident
+    int n_tail = (batch == 1) ? g_ns_tail_iters : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
     const int n_sep = NS_ITERS - n_tail;
     for (int i = 1; i < n_sep; ++i) {
@@ -741,7 +793,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         }
         B.T = T;
         B.Tt = Tt;
-        hipLaunchKernelGGL(ns_iter_tail_kernel, dim3(128), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1);
+        hipLaunchKernelGGL(ns_iter_tail_kernel, dim3(64), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     EpsGenArgs g;

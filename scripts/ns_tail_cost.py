@@ -13,8 +13,8 @@ n = 128
 Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
 w = np.concatenate([[-2.0, -1.1, -0.7], np.geomspace(0.01, 900.0, n - 3)])
 R = torch.from_numpy(np.ascontiguousarray((Q * w) @ Q.T)).cuda()[None]
-for tail in (0, 2, 11):
-    _lib.check(lib.covo_debug_set_ns_tail(tail))
+for tail in ((0, 0), (0, 2), (0, 64), (64, 0), (64, 64)):
+    _lib.check(lib.covo_debug_set_ns_tail(*tail))
     for _ in range(5): core.sigma(R, 0.5)
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
@@ -32,5 +32,5 @@ for tail in (0, 2, 11):
     out_t = torch.zeros(16, dtype=torch.float64).pin_memory()
     _lib.check(lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out_t), 11 * n * n, 16, core.stream()))
     torch.cuda.synchronize()
-    print(f"tail={tail:2d}: covo_sigma {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us in a graph  (squarings {int(out_t[8])}, NS iterations {int(out_t[6])})")
-_lib.check(lib.covo_debug_set_ns_tail(2))
+    print(f"tail (squarings, iterations) = {tail}: covo_sigma {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us in a graph  (squarings {int(out_t[8])}, NS iterations {int(out_t[6])})")
+_lib.check(lib.covo_debug_set_ns_tail(0, 2))

@@ -529,9 +529,10 @@ def test_batched_step_equals_replicas():
 
 
 def test_sigma_tail_launch_is_bit_identical():
-    """The Sigma chain's last Newton-Schulz iterations share one launch with grid barriers between their parts
-    (sigma_ns.hip: ns_iter_tail_kernel).  Folding none, the default two, or ALL iterations into that launch -- so that up
-    to ten live iterations run through the barrier path -- must not change a single bit of Sigma or L."""
+    """The Sigma chain's squarings and Newton-Schulz iterations run inside two persistent launches whose phases are
+    separated by grid barriers (sigma_ns.hip: ns_square_tail_kernel, ns_iter_tail_kernel; coherent sc1 accesses instead
+    of cached ones).  Every phase its own launch, only some of them folded (the default: the last two iterations), or all of
+    them must give the same Sigma and L bit for bit."""
     from covo_mpc_amd import _lib
     lib = _lib.load_library()
     rng = np.random.default_rng(5)
@@ -546,15 +547,15 @@ def test_sigma_tail_launch_is_bit_identical():
         for Rm in mats:
             R_d = torch.from_numpy(np.ascontiguousarray(Rm)).to(DEV)
             outs = []
-            for tail in (0, 2, 11):
-                _lib.check(lib.covo_debug_set_ns_tail(tail))
+            for tail in ((0, 0), (0, 2), (3, 0), (64, 64)):
+                _lib.check(lib.covo_debug_set_ns_tail(*tail))
                 Sig, L = core.sigma(R_d[None], 0.5)
                 outs.append((Sig.clone(), L.clone()))
             assert torch.isfinite(outs[0][0]).all()
             for Sig, L in outs[1:]:
                 assert torch.equal(Sig, outs[0][0]) and torch.equal(L, outs[0][1])
     finally:
-        _lib.check(lib.covo_debug_set_ns_tail(2))
+        _lib.check(lib.covo_debug_set_ns_tail(0, 2))
 
 
 def test_batched_step_single_instance_and_errors():
