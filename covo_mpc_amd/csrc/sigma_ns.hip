@@ -355,8 +355,12 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
             pick_k[k] = bi;
             if (bi == lane) d0 = -1e300;
             if (bi == lane + 64) d1 = -1e300;
-            v[k][0] = X[(size_t)lane * SN + bi];
-            v[k][1] = X[(size_t)(lane + 64) * SN + bi];
+        }
+        // the four picks need only the diagonal: all eight column loads go out together (one L2 round trip, not four)
+#pragma unroll
+        for (int k = 0; k < RITZ; ++k) {
+            v[k][0] = X[(size_t)lane * SN + pick_k[k]];
+            v[k][1] = X[(size_t)(lane + 64) * SN + pick_k[k]];
         }
 #pragma unroll
         for (int k = 0; k < RITZ; ++k) {
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
             double off = 0.0, dia = 0.0;
             for (int p = 0; p < RITZ; ++p)
                 for (int q2 = 0; q2 < RITZ; ++q2) (p == q2 ? dia : off) += h[p][q2] * h[p][q2];
-            if (off <= 1e-32 * dia) break;
+            if (off <= 1e-26 * dia) break;  // off^2 / gap bounds the eigenvalue error: far below the 1e-13 the chain needs
             for (int p = 0; p < RITZ - 1; ++p)
                 for (int q2 = p + 1; q2 < RITZ; ++q2) {
                     if (h[p][q2] * h[p][q2] <= 1e-34 * fabs(h[p][p] * h[q2][q2])) continue;
