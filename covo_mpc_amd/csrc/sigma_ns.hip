@@ -66,6 +66,7 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_FRO2, SC_TRACE, SC_GERSH, SC_N0,
        SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug)
        SC_BAR = 24,            // grid-barrier counters of the two persistent launches (unsigned in slots 24, 25; zeroed with the scalars)
+       SC_BARFAIL = 26,        // != 0: a grid barrier timed out -> the finalize launch poisons Sigma and L with NaN
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
 // launch; with every inter-phase access an agent-scope relaxed atomic (sc1, coherent across the XCDs' L2s; COH = true in
 // the bodies above) the barrier needs no fence, only s_waitcnt + the counter: 2.9 us per phase, GEMM included.
 // The spin is bounded (0.2 s): a barrier that cannot complete leaves the iteration unconverged instead of hanging the GPU.
-__device__ __forceinline__ bool ns_grid_barrier(unsigned *ctr, unsigned target)
+__device__ __forceinline__ bool ns_grid_barrier(unsigned *ctr, unsigned target, double *fail_flag)
 {
     __shared__ int ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have been acknowledged
@@ -601,6 +602,7 @@ __device__ __forceinline__ bool ns_grid_barrier(unsigned *ctr, unsigned target)
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 20000000LL) {
                 good = 0;
+                gst<true>(fail_flag, 1.0);  // never silently: the finalize launch turns this into NaN outputs
                 break;
             }
         }
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(256) void ns_square_tail_kernel(double *X0, double 
     for (int step = step_first; step <= step_last; ++step) {
         const bool odd = (step & 1) != 0;  // step i reads the buffer step i-1 wrote: X0 after the first squaring
         if (!ns_square_body<false, true>(odd ? X0 : X1, odd ? X1 : X0, scall, step, odd ? 1 : 0, 0, blockIdx.x, red, part)) return;
-        if (step < step_last && !ns_grid_barrier(ctr, gridDim.x * ++phase)) return;
+        if (step < step_last && !ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
     }
 }
 
@@ -640,11 +642,11 @@ __global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, doubl
     for (int iter = iter_first; iter <= iter_last; ++iter) {
         const int in = iter & 1, out = in ^ 1;
         if (!ns_T_body<true>(B.Y[in], B.Zt[in], B.T, B.Tt, scall, iter, 0, wx, red, part)) return;  // all leave together
-        if (!ns_grid_barrier(ctr, gridDim.x * ++phase)) return;
+        if (!ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
         (void)ns_YZ_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx, red);
         __syncthreads();
         (void)ns_YZ_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx + 64, red);
-        if (iter < iter_last && !ns_grid_barrier(ctr, gridDim.x * ++phase)) return;
+        if (iter < iter_last && !ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
     }
 }
 
@@ -711,7 +713,9 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     if (tid == 0) s[SC_LOGDET] = logdetB;
     // log_s = 0.5*log_const - 0.5*log_o with log_const = (2*log_det_a_cov + sum log_o)/n  (covo.py:124-128)
     const double log_c = 0.5 * (2.0 * n * (log((double)sample_sigma) * 2.0) + logdetB) / n;
-    const double cz = exp(log_c) / sqrt(scale), sq = sqrt(cz);
+    // a timed-out grid barrier (ns_grid_barrier) left Z unconverged: fail like the reference's numerical failures do, in NaNs
+    const double poison = (s[SC_BARFAIL] != 0.0) ? __builtin_nan("") : 1.0;
+    const double cz = poison * exp(log_c) / sqrt(scale), sq = sqrt(cz);
     tk[3] = clock64();
     if (Sigma_out) {
         float2 *So = reinterpret_cast<float2 *>(Sigma_out + (size_t)b * SN * SN);
