@@ -429,7 +429,8 @@ def test_fused_step_equals_kernel_by_kernel(name, task):
 
 
 @pytest.mark.parametrize("name,N,lam", [("covo-online", 1000, "0.01"), ("covo-online", 4096, "1.0"), ("mppi", 100, "0.1"),
-                                        ("covo-online", 65, "0.01")])
+                                        ("covo-online", 65, "0.01"),
+                                        ("covo-online", 131072, "0.01")])  # > 256 rollout workgroups: stand-alone softmax stage 1
 def test_fused_step_ragged_sizes_and_warm_lambda(name, N, lam):
     """The fused step's own kernels at the edges the stand-alone ones are tested on: sample counts that are not a
     multiple of the 32-sample MFMA tile / the 64-lane wave / the 256-sample workgroup (epsilon drawn ahead in tile
