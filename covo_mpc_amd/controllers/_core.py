@@ -44,7 +44,7 @@ def exchange_records(record, gathered_flat, process_group=None):
 
 class SamplingCore:
     def __init__(self, N: int, H: int, lam: float, discount: float, device=None, process_group=None,
-                 compute_info: bool = True, trust_clipped: bool = False):
+                 compute_info: bool = True, trust_clipped: bool = False, use_graph=None):
         import torch
         if H != COVO_H:
             raise NotImplementedError(f"the fused kernels are built for H={COVO_H}, got H={H}")
@@ -66,7 +66,22 @@ class SamplingCore:
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.offset, self.n_local = shard_range(self.N, self.rank, self.world)
         # the action stripes this core rolls out always come from covo_noise_* (already clipped)
-        cfg = _lib.ConfigC(self.n_local, self.H, 4, self.lam, self.discount, _lib.COVO_FLAG_ACTIONS_CLIPPED if trust_clipped else 0)
+        # covo_mpc_step replays a captured hipGraph or issues its launches one by one (COVO_FLAG_NO_GRAPH).  Measured on the
+        # MI355X box: every graph replay costs a ~8 us bubble on the GPU, an eager launch ~3.5 us of host
+        # time; with one rank per node the host keeps ahead and eager is faster on every config (covo-online +3.4 %,
+        # covo-offline / MPPI +18..25 %); a sample-sharded rank has less GPU work per step plus a collective to issue and is
+        # better off with the graph's 40 us of host time.  COVO_GRAPH=1 / COVO_NO_GRAPH=1 force either.
+        import os
+        eager = self.world == 1
+        if use_graph is not None:
+            eager = not use_graph
+        if os.environ.get("COVO_GRAPH") == "1":
+            eager = False
+        if os.environ.get("COVO_NO_GRAPH") == "1":
+            eager = True
+        self.uses_graph = not eager
+        flags = (_lib.COVO_FLAG_ACTIONS_CLIPPED if trust_clipped else 0) | (_lib.COVO_FLAG_NO_GRAPH if eager else 0)
+        cfg = _lib.ConfigC(self.n_local, self.H, 4, self.lam, self.discount, flags)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.covo_create(C.byref(cfg), C.byref(h)), "covo_create")

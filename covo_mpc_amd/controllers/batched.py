@@ -27,7 +27,9 @@ class BatchedCoVOController:
             raise ValueError(f"n_envs={n_envs} outside (0, {_lib.COVO_MAX_ENVS}]")
         self.env, self.E, self.N, self.H = env, int(n_envs), int(N), int(H)
         self.gamma_mean, self.sample_sigma = float(gamma_mean), float(sample_sigma)
-        self.core = SamplingCore(N, H, lam, discount, device=device, compute_info=False, trust_clipped=True)
+        # one call advances all instances: the ~56 launches are worth a graph (same GPU time as eager, 40 us instead of
+        # 150-270 us of host time per call)
+        self.core = SamplingCore(N, H, lam, discount, device=device, compute_info=False, trust_clipped=True, use_graph=True)
         torch = self.core.torch
         f32 = dict(dtype=torch.float32, device=self.core.device)
         E, n = self.E, self.N

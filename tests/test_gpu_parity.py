@@ -395,10 +395,11 @@ def test_controller_step_teacher_forced(name, task, N):
         obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
 
 
+@pytest.mark.parametrize("graph", ["graph", "eager"])
 @pytest.mark.parametrize("name,task", [("mppi", "hovering"), ("covo-online", "tracking_zigzag"),
                                        ("covo-offline", "tracking_zigzag")])
-def test_fused_step_equals_kernel_by_kernel(name, task):
-    """covo_mpc_step (one C call; eager, captured, then replayed as a hipGraph) against the kernel-by-kernel path that
+def test_fused_step_equals_kernel_by_kernel(name, task, graph, monkeypatch):
+    """covo_mpc_step (one C call; eager, or eager once, captured, then replayed as a hipGraph) against the kernel-by-kernel path that
     materialises epsilon, step after step: bit-identical actions, costs, Sigma and info; the means agree to fp32
     rounding (the fused step forms the softmax from per-workgroup records shifted by their LOCAL cost minimum and
     rescaled in the merge, the stand-alone covo_softmax_reduce shifts by the global minimum like covo.py:266)."""
@@ -407,7 +408,9 @@ def test_fused_step_equals_kernel_by_kernel(name, task):
     env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
                          generate_noisy_state=True, device=DEV)
     N = 4096
+    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
     ca, cpa = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
+    assert ca.core.uses_graph == (graph == "graph")
     cb, cpb = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
     cb.materialize_eps = True
     params = env.default_params
@@ -431,7 +434,8 @@ def test_fused_step_equals_kernel_by_kernel(name, task):
 @pytest.mark.parametrize("name,N,lam", [("covo-online", 1000, "0.01"), ("covo-online", 4096, "1.0"), ("mppi", 100, "0.1"),
                                         ("covo-online", 65, "0.01"),
                                         ("covo-online", 131072, "0.01")])  # > 256 rollout workgroups: stand-alone softmax stage 1
-def test_fused_step_ragged_sizes_and_warm_lambda(name, N, lam):
+@pytest.mark.parametrize("graph", ["graph", "eager"])
+def test_fused_step_ragged_sizes_and_warm_lambda(name, N, lam, graph, monkeypatch):
     """The fused step's own kernels at the edges the stand-alone ones are tested on: sample counts that are not a
     multiple of the 32-sample MFMA tile / the 64-lane wave / the 256-sample workgroup (epsilon drawn ahead in tile
     order, softmax records from partial workgroups) and temperatures at which EVERY sample carries weight (the record's
@@ -441,6 +445,7 @@ def test_fused_step_ragged_sizes_and_warm_lambda(name, N, lam):
     from covo_mpc_amd import random as cr
     env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian",
                          disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
     ca, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=False)
     cb, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=False)
     cb.materialize_eps = True
