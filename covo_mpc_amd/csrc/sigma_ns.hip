@@ -741,11 +741,13 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 }
 
 // how many of the chain's last squarings / Newton-Schulz iterations run inside the persistent launches; covo_debug_set_ns_tail.
-// Default: only the two iterations that are almost never live (3 % / 0 % of closed-loop Hessians) -- the launch then costs
-// 1.6 us instead of 4 x 1.6.  Measured with everything folded (scripts/ns_tail_cost.py, 13 squarings + 11 iterations live):
-// +0.4 us per squaring and +3.4 us per iteration over separate launches, so a live phase still loses to a launch here
-// (5.4 us per Newton-Schulz phase against 2.9 in the probe), and only phases that are rarely live are worth folding.
-int g_ns_tail_iters = 2, g_ns_tail_squarings = 0;
+// A folded phase costs nothing once the chain has converged (a separate launch: 1.6 us) and, while live, +0.4 us per
+// squaring / +2.2 us per iteration over its separate launch(es) (scripts/ns_tail_cost.py: a phase is coherent loads from the
+// Infinity Cache + write-through stores + the barrier -- no cheaper than a launch).  So the phases that are often idle are
+// folded: squarings 8..13 (live on 98 .. 17 % of closed-loop Hessians, on almost none of the bench's teacher-forced ones)
+// and iterations 10..12 (68 / 4 / 0 %).  Measured (scripts/tail_bench.py, N = 65 536): bench 4 411 -> 4 615 steps/s,
+// closed loop unchanged (4 126 -> 4 120); folding everything: 4 550 / 4 078.
+int g_ns_tail_iters = 3, g_ns_tail_squarings = 6;
 
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 

@@ -33,4 +33,4 @@ for tail in ((0, 0), (0, 2), (0, 64), (64, 0), (64, 64)):
     _lib.check(lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out_t), 11 * n * n, 16, core.stream()))
     torch.cuda.synchronize()
     print(f"tail (squarings, iterations) = {tail}: covo_sigma {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us in a graph  (squarings {int(out_t[8])}, NS iterations {int(out_t[6])})")
-_lib.check(lib.covo_debug_set_ns_tail(0, 2))
+_lib.check(lib.covo_debug_set_ns_tail(6, 3))

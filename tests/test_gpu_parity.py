@@ -537,8 +537,8 @@ def test_batched_step_equals_replicas():
 def test_sigma_tail_launch_is_bit_identical():
     """The Sigma chain's squarings and Newton-Schulz iterations run inside two persistent launches whose phases are
     separated by grid barriers (sigma_ns.hip: ns_square_tail_kernel, ns_iter_tail_kernel; coherent sc1 accesses instead
-    of cached ones).  Every phase its own launch, only some of them folded (the default: the last two iterations), or all of
-    them must give the same Sigma and L bit for bit."""
+    of cached ones).  Every phase its own launch, only some of them folded (the default: the last six squarings and three
+    iterations), or all of them must give the same Sigma and L bit for bit."""
     from covo_mpc_amd import _lib
     lib = _lib.load_library()
     rng = np.random.default_rng(5)
@@ -553,7 +553,7 @@ def test_sigma_tail_launch_is_bit_identical():
         for Rm in mats:
             R_d = torch.from_numpy(np.ascontiguousarray(Rm)).to(DEV)
             outs = []
-            for tail in ((0, 0), (0, 2), (3, 0), (64, 64)):
+            for tail in ((0, 0), (0, 2), (6, 3), (64, 64)):
                 _lib.check(lib.covo_debug_set_ns_tail(*tail))
                 Sig, L = core.sigma(R_d[None], 0.5)
                 outs.append((Sig.clone(), L.clone()))
@@ -561,7 +561,7 @@ def test_sigma_tail_launch_is_bit_identical():
             for Sig, L in outs[1:]:
                 assert torch.equal(Sig, outs[0][0]) and torch.equal(L, outs[0][1])
     finally:
-        _lib.check(lib.covo_debug_set_ns_tail(0, 2))
+        _lib.check(lib.covo_debug_set_ns_tail(6, 3))
 
 
 def test_batched_step_single_instance_and_errors():
