@@ -560,6 +560,35 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Za
     return true;
 }
 
+// both part-2 tiles of one workgroup (tile w of Y' and tile w of Z') with all 32 operand loads in flight together: the
+// persistent launch runs part 2 on 64 workgroups, and two dependent coherent-load round trips per phase would cost 1.5 us
+template <bool COH>
+__device__ __forceinline__ bool ns_YZ2_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
+                                            double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
+                                            int zbuf_out, int w, double (*red)[4][64])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *s = scall;
+    const int ti = w >> 3, tj = w & 7;
+    TileOps oy, oz;
+    tile_load<COH>(oy, Ytall, Tall, ti, tj, lane, wv, LoadPlain{});  // Y' = Y.T
+    tile_load<COH>(oz, Ttall, Zall, ti, tj, lane, wv, LoadPlain{});  // Z' = T.Z
+    if (ns_converged<COH>(s, iter, lane, false)) return false;
+    if (w == 0 && tid == 0) {
+        gst<COH>(s + SC_ZBUF, (double)zbuf_out);
+        gst<COH>(s + SC_ITERS, (double)(iter + 1));
+    }
+    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+    const f64x4 ay = tile_mma(oy);
+    const double vy = tile_reduce(ay, red, wv, lane);
+    store_both<COH>(Yout, Ytout, row, col, vy);
+    const f64x4 az = tile_mma(oz);
+    __syncthreads();  // red is reused
+    const double vz = tile_reduce(az, red, wv, lane);
+    store_both<COH>(Zout, Ztout, row, col, vz);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
                                                    double *__restrict__ Tall, double *__restrict__ Ttall,
                                                    double *__restrict__ scall, int iter)
@@ -643,9 +672,7 @@ __global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, doubl
         const int in = iter & 1, out = in ^ 1;
         if (!ns_T_body<true>(B.Y[in], B.Zt[in], B.T, B.Tt, scall, iter, 0, wx, red, part)) return;  // all leave together
         if (!ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
-        (void)ns_YZ_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx, red);
-        __syncthreads();
-        (void)ns_YZ_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, 0, wx + 64, red);
+        (void)ns_YZ2_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, wx, red);
         if (iter < iter_last && !ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
     }
 }
