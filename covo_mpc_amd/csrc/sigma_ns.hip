@@ -769,7 +769,7 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 
 // how many of the chain's last squarings / Newton-Schulz iterations run inside the persistent launches; covo_debug_set_ns_tail.
 // A folded phase costs nothing once the chain has converged (a separate launch: 1.6 us) and, while live, +0.4 us per
-// squaring / +2.2 us per iteration over its separate launch(es) (scripts/ns_tail_cost.py: a phase is coherent loads from the
+// squaring / +1.4 us per iteration over its separate launch(es) (scripts/ns_tail_cost.py: a phase is coherent loads from the
 // Infinity Cache + write-through stores + the barrier -- no cheaper than a launch).  So the phases that are often idle are
 // folded: squarings 8..13 (live on 98 .. 17 % of closed-loop Hessians, on almost none of the bench's teacher-forced ones)
 // and iterations 10..12 (68 / 4 / 0 %).  Measured (scripts/tail_bench.py, N = 65 536): bench 4 411 -> 4 615 steps/s,
