@@ -744,23 +744,27 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     const double poison = (s[SC_BARFAIL] != 0.0) ? __builtin_nan("") : 1.0;
     const double cz = poison * exp(log_c) / sqrt(scale), sq = sqrt(cz);
     tk[3] = clock64();
+    // a_cov = cz sym(Z) needs Z once more: its 32 loads go out first and land while L is written from LDS
+    constexpr int TRS = SN * SN / 2 / 512;
+    double2 za[TRS], zt[TRS];
     if (Sigma_out) {
-        float2 *So = reinterpret_cast<float2 *>(Sigma_out + (size_t)b * SN * SN);
-        constexpr int TR = SN * SN / 2 / 512;
-        double2 za[TR], zt[TR];
 #pragma unroll
-        for (int t = 0; t < TR; ++t) {
+        for (int t = 0; t < TRS; ++t) {
             za[t] = Z[tid + 512 * t];
             zt[t] = Zt[tid + 512 * t];
         }
-#pragma unroll
-        for (int t = 0; t < TR; ++t)  // a_cov is fp32
-            So[tid + 512 * t] = make_float2((float)(cz * 0.5 * (za[t].x + zt[t].x)), (float)(cz * 0.5 * (za[t].y + zt[t].y)));
     }
     float *Lo = L_out + (size_t)b * SN * SN;
+#pragma unroll 4
     for (int e = tid; e < SN * SN; e += 512) {
         const int r = e / SN, c = e % SN;
         Lo[e] = (c <= r) ? (float)(sq * sm[c * LD + r]) : 0.0f;
+    }
+    if (Sigma_out) {
+        float2 *So = reinterpret_cast<float2 *>(Sigma_out + (size_t)b * SN * SN);
+#pragma unroll
+        for (int t = 0; t < TRS; ++t)  // a_cov is fp32
+            So[tid + 512 * t] = make_float2((float)(cz * 0.5 * (za[t].x + zt[t].x)), (float)(cz * 0.5 * (za[t].y + zt[t].y)));
     }
     tk[4] = clock64();
     if (tid == 0)
