@@ -18,7 +18,7 @@ COVO_NA = COVO_H * COVO_DU
 COVO_STATE_FLOATS = 32
 COVO_PARTIAL_FLOATS = 132
 COVO_POS_STATS_DOUBLES = COVO_H * 6
-ABI_VERSION = 1
+ABI_VERSION = 2
 COVO_FLAG_ACTIONS_CLIPPED = 1
 
 
@@ -32,6 +32,7 @@ class EnvParamsC(C.Structure):
         ("max_thrust", C.c_float), ("max_torque", C.c_float * 3), ("max_omega", C.c_float * 3),
         ("dt", C.c_float), ("g", C.c_float), ("m", C.c_float), ("action_scale", C.c_float),
         ("alpha_bodyrate", C.c_float), ("max_steps_in_episode", C.c_int32), ("pos_limit", C.c_float),
+        ("rollover_terminate", C.c_int32),
     ]
 
 

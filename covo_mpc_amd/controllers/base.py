@@ -10,10 +10,12 @@ class BaseController:
         return control_params
 
     def _params_c(self, env_params):
-        """struct covo_env_params of `env_params`, cached on object identity (frozen dataclass: never mutated)."""
+        """struct covo_env_params of `env_params` (+ the env's rollover-termination switch, quadrotor.py:486), cached on
+        object identity (frozen dataclass: never mutated)."""
         cache = getattr(self, "_params_c_cache", None)
         if cache is None or cache[0] is not env_params:
-            cache = (env_params, env_params.to_c())
+            roll = not getattr(self.env, "disable_rollover_terminate", True)
+            cache = (env_params, env_params.to_c(rollover_terminate=roll))
             self._params_c_cache = cache
         return cache[1]
 

@@ -27,6 +27,9 @@ class BatchedCoVOController:
             raise ValueError(f"n_envs={n_envs} outside (0, {_lib.COVO_MAX_ENVS}]")
         self.env, self.E, self.N, self.H = env, int(n_envs), int(N), int(H)
         self.gamma_mean, self.sample_sigma = float(gamma_mean), float(sample_sigma)
+        self.rollover_terminate = not getattr(env, "disable_rollover_terminate", True)  # quadrotor.py:486
+        if getattr(env, "disturb_type", "none") not in ("gaussian", "none"):
+            raise NotImplementedError(f"disturb_type={env.disturb_type!r} inside the fused rollout")
         # one call advances all instances: the ~56 launches are worth a graph (same GPU time as eager, 40 us instead of
         # 150-270 us of host time per call)
         self.core = SamplingCore(N, H, lam, discount, device=device, compute_info=False, trust_clipped=True, use_graph=True)
@@ -55,7 +58,7 @@ class BatchedCoVOController:
         pos = torch.stack([d.pos_traj.reshape(T, 3) for d in ds]).contiguous()
         vel = torch.stack([d.vel_traj.reshape(T, 3) for d in ds]).contiguous()
         self._traj = (pos, vel, T)
-        self._params = (_lib.EnvParamsC * self.E)(*[p.to_c() for p in env_params])
+        self._params = (_lib.EnvParamsC * self.E)(*[p.to_c(rollover_terminate=self.rollover_terminate) for p in env_params])
         a = _lib.BatchArgsC()
         a.n_envs, a.n_samples, a.T = self.E, self.N, T
         a.states, a.pos_traj, a.vel_traj = self._states.data_ptr(), pos.data_ptr(), vel.data_ptr()

@@ -49,6 +49,7 @@ class CoVOController(BaseController):
         self.action_dim = self.env.action_dim
         if mode not in ("online", "offline"):
             raise NotImplementedError(mode)  # covo.py:113-114
+        self._check_disturb_type()
         if mode == "offline":
             assert env.action_dim == 4, "only support 4D action space Quadrotor environment for now"  # covo.py:45-47
             self.expansion_control_params = PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0)  # covo.py:48-53
@@ -58,9 +59,20 @@ class CoVOController(BaseController):
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
 
+    def _check_disturb_type(self):
+        """The fused rollout and the Hessian take f_disturb = 0 for every step k >= 1: what the reference's
+        deterministic=True gives for 'gaussian' (dyn_noise_scale zeroed, quadrotor.py:234-235) and 'none'.  The other
+        models (periodic, sin, drag, mixed: free.py:10-58) keep or recompute a state/time-dependent force that
+        deterministic=True does not switch off -- not built, so refuse instead of diverging silently."""
+        dt = getattr(self.env, "disturb_type", "none")
+        if dt not in ("gaussian", "none"):
+            raise NotImplementedError(f"disturb_type={dt!r} inside the fused rollout / Hessian (only 'gaussian' and 'none': "
+                                      "state- and time-dependent disturbance models are outside the kernels' scope)")
+
     # ---- Sigma selection (covo.py:36-41 / 107-108) ----------------------------------------------
     def get_hessian(self, env_state, env_params, control_params, a_mean, rng_act=None):
         """covo.py:134-185 -> (128,128) fp64 tensor."""
+        self._check_disturb_type()
         dstate = as_device_state(env_state, self.core.device)
         return self.core.hessian(dstate.packed, dstate, env_params.to_c(), a_mean.reshape(-1))[0]
 
@@ -135,6 +147,7 @@ class CoVOController(BaseController):
         """n_steps closed-loop steps (this controller + the device env step) enqueued by one C call; keys threaded like
         eval_env's run_one_step.  -> (control_params with the final mean / Sigma, rng).  See SamplingCore.run_episode."""
         from .. import _lib
+        self._check_disturb_type()
         if self.mode == "offline" and control_params.a_chol_offline is None:
             raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
         mode = _lib.MODE_COVO_ONLINE if self.mode == "online" else _lib.MODE_COVO_OFFLINE
@@ -153,6 +166,7 @@ class CoVOController(BaseController):
         from .. import random as crandom
         from .. import _lib
         core = self.core
+        self._check_disturb_type()
         dstate = as_device_state(info["noisy_state"], core.device)  # covo.py:198
         params_c = self._params_c(env_params)
         if self.mode == "offline" and control_params.a_chol_offline is None:

@@ -100,7 +100,7 @@ class MPPIController(BaseController):
         core.noise_blockdiag(Ls, a_mean)
         rng_act, step_key = crandom.split(rng_act)  # mppi.py:69-106
         f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)
-        core.rollout(dstate, env_params.to_c(), f_shared, core.compute_info)
+        core.rollout(dstate, self._params_c(env_params), f_shared, core.compute_info)
         a_mean_new = core.update(a_mean.reshape(-1), control_params.gamma_mean).view(self.H, 4)  # mppi.py:109-125
         control_params = control_params.replace(a_mean=a_mean_new)
         out_info = core.info(dstate) if core.compute_info else {}

@@ -90,12 +90,12 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr,
                    float *records = nullptr, float lam = 0.0f);  // records: one online-softmax record per workgroup (rollout.hip)
-int rollout_workgroups(int N, bool stats);
+int rollout_workgroups(int N, bool stats, int nbatch = 1);
 size_t rollout_args_bytes(int n);
 void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
                        const covo_env_params &p, const float *a, int N, float discount, float *cost, float *groupmin,
-                       const float *f_shared_dev, float *records = nullptr, float lam = 0.0f);
-int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, bool trust_clipped, hipStream_t s);
+                       const float *f_shared_dev, float *records = nullptr, float lam = 0.0f, bool trust_clipped = true);
+int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, hipStream_t s);
 // a_mean_out != null: finish on this GPU (normalise + blend); else write the merged record to partial_out
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,

@@ -27,6 +27,7 @@ struct EnvStepArgs {
     uint32_t step_key[2];  // the key Quad3D.step receives; the five noise keys are derived from it on the device
     qm::Consts<float> c;
     int max_steps;
+    int rollover;  // is_terminal's rollover test (quadrotor.py:486-490)
 };
 
 // element i of normal(key, (n,)) -- host formula (random.py) in fp64
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
         const float r = qm::reward<float, float>(s, tx, ty, tz, tvx, tvy, tvz);
         const float ex = tx - s.px, ey = ty - s.py, ez = tz - s.pz;
         const float wx = tvx - s.vx, wy = tvy - s.vy, wz = tvz - s.vz;
-        const bool done = (time >= A.max_steps) || fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz)) > A.c.pos_limit;
+        bool done = (time >= A.max_steps) || fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz)) > A.c.pos_limit;
+        if (A.rollover)  // quadrotor.py:486-490
+            done = done || s.qw < 0.70710678118654752f || fmaxf(fmaxf(fabsf(s.ox), fabsf(s.oy)), fabsf(s.oz)) > 100.0f;
         float *__restrict__ lg = A.log + 4 * A.log_index;
         lg[0] = r;
         lg[1] = sqrtf(ex * ex + ey * ey + ez * ez);
@@ -156,6 +159,7 @@ int launch_env_step(float *state, float *noisy, const float *pos_traj, const flo
     A.step_key[1] = step_key[1];
     A.c = make_consts<float>(p);
     A.max_steps = p.max_steps_in_episode;
+    A.rollover = p.rollover_terminate != 0;
     hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;

@@ -5,13 +5,13 @@
 //   quadjax/envs/quadrotor.py:215-263, 479-490           (step_env, raw_step, is_terminal)
 //   quadjax/dynamics/free.py:74-155, utils.py:266-294    (dynamics, reward)  -> quad_model.hpp
 //
-// One lane = one sample.  The 13-float state, the frozen reward and the running cost stay in
-// VGPRs for the whole horizon; wave-uniform data (per-step targets, discount) are spread over
-// the lanes of the wave and fetched with v_readlane (no LDS, no barrier); the only per-sample HBM
-// traffic is the stripe-ordered
-// action read (32 x 16 B, each wave-load one contiguous 1 KiB) and the 4-byte cost write:
-// 516 B / sample.  HBM-roofline kernel; ~165 VALU slots per step put it on the
-// fp32 ridge, so instruction count matters as much as bytes.
+// The only per-sample HBM traffic is the stripe-ordered action read (32 x 16 B, each wave-load one contiguous 1 KiB)
+// and the 4-byte cost write: 516 B / sample.  HBM-roofline kernel by bytes, VALU-issue bound in fact
+// (~100-135 instructions per sample-step), so instruction count and waves per SIMD matter as much as bytes.
+//   rollout_pipe3_kernel (rollout_pipe.hpp): the product kernel -- three waves per 64 samples (attitude / translation /
+//     reward) pipelined through LDS rings;
+//   rollout_kernel (below): one lane = one sample, everything in VGPRs, targets by v_readlane; kept for the position
+//     statistics of --info (covo.py:281).
 #include "covo_common.hpp"
 
 struct RolloutArgs {
@@ -29,6 +29,8 @@ struct RolloutArgs {
     int xcd_remap;              // 1: workgroup -> sample chunks follow the noise GEMM's XCD placement (see kernel)
     float *records;             // nullable: [workgroups][COVO_PARTIAL_FLOATS] online-softmax records (rollout_record below)
     float inv_lam;
+    int clip;      // 1: re-apply step_env's clip to the stripes (quadrotor.py:223,258); 0: the producer guarantees clipped stripes
+    int rollover;  // 1: is_terminal's rollover test is on (quadrotor.py:486-490)
     qm::Consts<float> c;
 };
 
@@ -64,13 +66,14 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // v_readlane_b3
 // exp(-(m - min_g m_g)/lam), the same merge that combines the per-GPU records of a sample-sharded step, so the result
 // is the reference's softmax to fp32 rounding).  Saves the launch and the cost re-read of softmax_partial_kernel; the
 // stripes of the few samples with a non-zero weight (at lam = 0.01 a weight underflows once c - m > 1.04) are re-read
-// from the L2 that has just served them.  Called by every wave of the workgroup (waves without costs pass valid = false).
-__device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost, bool valid, int n, int wave, int lane, int wg,
-                                               float *s_m, float *s_s, float (*s_v)[COVO_NA])
+// from the L2 that has just served them.  Called by every wave of the workgroup: NWAVES waves in all, NW of them carry
+// costs (`carrier`, slot `wave` < NW); the others pass valid = false and only take part in the barriers and the final sums.
+template <int NWAVES, int NW>
+__device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost, bool valid, int n, int wave, bool carrier, int lane,
+                                               int wg, float *s_m, float *s_s, float (*s_v)[COVO_NA])
 {
-    constexpr int NW = RO_BLOCK / COVO_WAVE;
     const float wm = wave_min(valid ? cost : __builtin_inff());
-    if (lane == 0) s_m[wave] = wm;
+    if (carrier && lane == 0) s_m[wave] = wm;
     __syncthreads();
     float m = s_m[0];
 #pragma unroll
@@ -117,11 +120,11 @@ __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost,
     acc.y += __shfl_xor(acc.y, 32, COVO_WAVE);
     acc.z += __shfl_xor(acc.z, 32, COVO_WAVE);
     acc.w += __shfl_xor(acc.w, 32, COVO_WAVE);
-    if (half == 0) *reinterpret_cast<float4 *>(&s_v[wave][4 * t]) = acc;
-    if (lane == 0) s_s[wave] = sw;
+    if (carrier && half == 0) *reinterpret_cast<float4 *>(&s_v[wave][4 * t]) = acc;
+    if (carrier && lane == 0) s_s[wave] = sw;
     __syncthreads();
     float *rec = A.records + (size_t)wg * COVO_PARTIAL_FLOATS;
-    const int tid = wave * COVO_WAVE + lane;
+    const int tid = threadIdx.x;
     if (tid < COVO_NA) {
         float v = s_v[0][tid];
 #pragma unroll
@@ -215,7 +218,9 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
         // reward / termination of the PRE-step state (quadrotor.py:243-244)
         float r = qm::reward<float, float>(s, tx, ty, tz, tvx, tvy, tvz);
         const float pmax = fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz));
-        const bool done = (k >= kdone) | (pmax > c.pos_limit);
+        bool done = (k >= kdone) | (pmax > c.pos_limit);
+        if (A.rollover)  // quadrotor.py:486-490
+            done = done | (s.qw < 0.70710678118654752f) | (fmaxf(fmaxf(fabsf(s.ox), fabsf(s.oy)), fabsf(s.oz)) > 100.0f);
         r = done_before ? r_before : r;  // covo.py:233
         done_before = done_before | done;
         r_before = r;
@@ -263,7 +268,8 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
         const float wm = wave_min(valid ? cost : __builtin_inff());
         if (lane == 0 && (n_raw & ~(COVO_WAVE - 1)) < A.N) A.groupmin[n_raw >> 6] = wm;
     }
-    if (A.records != nullptr) rollout_record(A, cost, valid, n, wave, lane, blockIdx.x, rec_m, rec_s, rec_v);
+    if (A.records != nullptr)
+        rollout_record<RO_BLOCK / COVO_WAVE, RO_BLOCK / COVO_WAVE>(A, cost, valid, n, wave, true, lane, blockIdx.x, rec_m, rec_s, rec_v);
     if (STATS) {
         __syncthreads();
         for (int i = tid; i < COVO_H * 6; i += RO_BLOCK)
@@ -273,144 +279,7 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
     RO_PROBE_END(0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Split variant for small grids (N <= 32 768 on one MI355X: the per-GPU shard of a sample-sharded
-// step).  Measured on gfx950 (scripts/probe/issue_probe.hip): ONE wave issues at most one VALU
-// instruction per ~5 cycles, so when there are fewer waves than SIMDs the kernel time is one wave's
-// instruction count x 5 cycles.  Here every 64 samples get a 2-wave workgroup, halving that count: the DYNAMICS wave integrates the state and publishes what the reward needs
-// (pos, vel, yaw numerator/denominator = 2 x float4 per lane) into a 3-slot LDS ring; the REWARD
-// wave, one phase behind, turns them into reward / termination / frozen-reward / running cost.
-// One raw s_barrier per step (lgkmcnt only -- a __syncthreads() would also drain vmcnt and stall on
-// the whole prefetched action stream).  Same arithmetic as rollout_kernel (quad_model.hpp).
-constexpr int RS_RING = 3;
-constexpr int RS_PAIRS = 2;  // sample groups per workgroup: 256 threads = 2 dynamics waves + 2 reward waves, one per SIMD.
-                             // Measured (scripts/kbench.py, N = 8 192 .. 32 768): 8.7-9.2 us (RS_PAIRS = 1: 8.4-9.8;
-                             // RS_PAIRS = 4, both kinds sharing a SIMD: 12 us).  At N = 65 536 (2 waves per SIMD in either
-                             // scheme) the split is slower than the plain kernel (13.0 vs 11.5 us).
-
-__device__ __forceinline__ void lds_phase_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <bool DISC1, bool CLIP, bool BATCHED = false>
-__global__ __launch_bounds__(2 * RS_PAIRS * COVO_WAVE) void rollout_split_kernel(const RolloutArgs A_,
-                                                                                 const RolloutArgs *__restrict__ batch)
-{
-    const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
-    RO_PROBE_BEGIN();
-    __shared__ float rec_m[RO_BLOCK / COVO_WAVE], rec_s[RO_BLOCK / COVO_WAVE];
-    __shared__ __attribute__((aligned(16))) float rec_v[RO_BLOCK / COVO_WAVE][COVO_NA];
-    float rec_cost = 0.0f;
-    bool rec_valid = false;
-    __shared__ float4 ring_all[RS_PAIRS][RS_RING][2][COVO_WAVE];
-    const int lane = threadIdx.x & (COVO_WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wave & (RS_PAIRS - 1);
-    float4 (*ring_s)[2][COVO_WAVE] = ring_all[pair];
-    const float *__restrict__ st = A.state;
-    const int group = blockIdx.x * RS_PAIRS + pair;  // 64-sample group
-    const int n_raw = group * COVO_WAVE + lane;
-    const bool valid = n_raw < A.N;
-    const int n = valid ? n_raw : A.N - 1;
-
-    if (wave < RS_PAIRS) {
-        // ================= dynamics wave
-        const float4 *__restrict__ ap = A.a + n;
-        const size_t stride = (size_t)A.N;
-        float4 av[COVO_H];
-#pragma unroll
-        for (int i = 0; i < COVO_H - 1; ++i) av[i] = ap[(size_t)i * stride];  // a_{H-1} never reaches a reward
-        __builtin_amdgcn_sched_barrier(0);
-        qm::State<float> s;
-        s.px = st[ST_POS + 0]; s.py = st[ST_POS + 1]; s.pz = st[ST_POS + 2];
-        s.vx = st[ST_VEL + 0]; s.vy = st[ST_VEL + 1]; s.vz = st[ST_VEL + 2];
-        s.qx = st[ST_QUAT + 0]; s.qy = st[ST_QUAT + 1]; s.qz = st[ST_QUAT + 2]; s.qw = st[ST_QUAT + 3];
-        s.ox = st[ST_OMEGA + 0]; s.oy = st[ST_OMEGA + 1]; s.oz = st[ST_OMEGA + 2];
-        const float f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
-        const float fsx = A.f_shared_dev ? A.f_shared_dev[0] : A.f_shared[0];
-        const float fsy = A.f_shared_dev ? A.f_shared_dev[1] : A.f_shared[1];
-        const float fsz = A.f_shared_dev ? A.f_shared_dev[2] : A.f_shared[2];
-        const qm::Consts<float> c = A.c;
-#pragma unroll
-        for (int k = 0; k < COVO_H; ++k) {
-            float yn, yd;
-            qm::yaw_terms<float, float>(s, yn, yd);
-            ring_s[k % RS_RING][0][lane] = make_float4(s.px, s.py, s.pz, s.vx);
-            ring_s[k % RS_RING][1][lane] = make_float4(s.vy, s.vz, yn, yd);
-            lds_phase_barrier();  // B_k: state k is visible to the reward wave
-            if (k < COVO_H - 1) {
-                float4 a4 = av[k];
-                if (CLIP) { a4.x = qm::clip11_(a4.x); a4.y = qm::clip11_(a4.y); a4.z = qm::clip11_(a4.z); a4.w = qm::clip11_(a4.w); }
-                const float fx = (k == 0) ? f0x : fsx;
-                const float fy = (k == 0) ? f0y : fsy;
-                const float fz = (k == 0) ? f0z : fsz;
-                qm::dyn_step<float, float>(s, a4.x, a4.y, a4.z, a4.w, c, fx, fy, fz);
-            }
-        }
-    } else {
-        // ================= reward wave
-        const int time0 = __float_as_int(st[ST_TIME]);
-        float wpx, wpy, wpz, wvx, wvy, wvz, wdisc = 1.0f;
-        {
-            const int k = lane & (COVO_H - 1);
-            int idx = time0 + k;
-            idx = idx < 0 ? 0 : (idx > A.T - 1 ? A.T - 1 : idx);
-            const bool own = (k == 0);
-            wpx = own ? st[ST_POSTAR + 0] : A.pos_traj[3 * idx + 0];
-            wpy = own ? st[ST_POSTAR + 1] : A.pos_traj[3 * idx + 1];
-            wpz = own ? st[ST_POSTAR + 2] : A.pos_traj[3 * idx + 2];
-            wvx = own ? st[ST_VELTAR + 0] : A.vel_traj[3 * idx + 0];
-            wvy = own ? st[ST_VELTAR + 1] : A.vel_traj[3 * idx + 1];
-            wvz = own ? st[ST_VELTAR + 2] : A.vel_traj[3 * idx + 2];
-            if (!DISC1) {
-                for (int i = 0; i < k; ++i) wdisc *= A.discount;
-            }
-        }
-        const int kdone = A.max_steps - time0;
-        const float pos_limit = A.c.pos_limit;
-        // the window loads above are ordinary VMEM loads: make sure they have landed before the first
-        // raw barrier sequence (which only waits on lgkmcnt)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float acc = 0.0f, r_before = 0.0f;
-        bool done_before = false;
-        lds_phase_barrier();  // B_0
-        float4 c0 = ring_s[0][0][lane], c1 = ring_s[0][1][lane];
-#pragma unroll
-        for (int k = 0; k < COVO_H; ++k) {
-            float4 n0 = c0, n1 = c1;
-            if (k + 1 < COVO_H) {
-                lds_phase_barrier();  // B_{k+1}
-                n0 = ring_s[(k + 1) % RS_RING][0][lane];
-                n1 = ring_s[(k + 1) % RS_RING][1][lane];
-            }
-            const float tx = lane_bcast(wpx, k), ty = lane_bcast(wpy, k), tz = lane_bcast(wpz, k);
-            const float tvx = lane_bcast(wvx, k), tvy = lane_bcast(wvy, k), tvz = lane_bcast(wvz, k);
-            float r = qm::reward_parts<float, float>(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, tx, ty, tz, tvx, tvy, tvz);
-            const float pmax = fmaxf(fmaxf(fabsf(c0.x), fabsf(c0.y)), fabsf(c0.z));
-            const bool done = (k >= kdone) | (pmax > pos_limit);
-            r = done_before ? r_before : r;  // covo.py:233
-            done_before = done_before | done;
-            r_before = r;
-            acc = DISC1 ? acc + r : fmaf(lane_bcast(wdisc, k), r, acc);
-            c0 = n0;
-            c1 = n1;
-        }
-        const float cost = -acc;
-        if (valid) A.cost[n] = cost;
-        if (A.groupmin != nullptr) {
-            const float wm = wave_min(valid ? cost : __builtin_inff());
-            if (lane == 0 && group * COVO_WAVE < A.N) A.groupmin[group] = wm;
-        }
-        rec_cost = cost;
-        rec_valid = valid;
-    }
-    if (A.records != nullptr) {  // all four waves: the dynamics waves carry no cost
-        static_assert(2 * RS_PAIRS * COVO_WAVE == RO_BLOCK, "rollout_record assumes RO_BLOCK threads");
-        rollout_record(A, rec_cost, rec_valid, n, wave, lane, blockIdx.x, rec_m, rec_s, rec_v);
-    }
-    RO_PROBE_END(RS_PAIRS * COVO_WAVE);
-}
+#include "rollout_pipe.hpp"
 
 // sums the per-block position statistics in fp64: out[k*6+i]
 // one workgroup per (step, statistic) column: 256 threads stride over the per-block partials, fixed-order tree
@@ -460,42 +329,59 @@ static void fill_rollout_args(RolloutArgs &A, const float *state, const float *p
     A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? 1 : 0;  // the GEMM runs one 32-sample tile per wave up to 512 workgroups
     A.records = nullptr;
     A.inv_lam = 0.0f;
+    A.clip = 1;
+    A.rollover = p.rollover_terminate != 0;
     A.c = make_consts<float>(p);
 }
 
+// 64-sample groups per workgroup of the pipelined kernel: as few as keep the workgroup count within the 256 records the
+// merge takes in one pass, four (one wave of each stage on every SIMD) once the launch has >= 1024 groups to spread
+static int pipe_groups(int N, int nbatch)
+{
+    const int ng = (N + COVO_WAVE - 1) / COVO_WAVE;
+    if ((long long)ng * nbatch >= 1024 || ng > 512) return 4;
+    return ng > 256 ? 2 : 1;
+}
+
+template <bool DISC1, bool ROLL, bool BATCHED>
+static void launch_pipe3(const RolloutArgs &A, const RolloutArgs *batch, int nb, int groups, hipStream_t s)
+{
+    const int ng = (A.N + COVO_WAVE - 1) / COVO_WAVE;
+    const dim3 grid((ng + groups - 1) / groups, nb);
+    if (groups == 4)
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 1, 4, BATCHED>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
+    else if (groups == 2)
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 1, 2, BATCHED>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
+    else
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 1, 1, BATCHED>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
+}
+
 // nbatch == 0: one rollout described by A; else nbatch instances described by the device array `batch` (all with A's
-// N, discount and clip contract -- A is only used to pick the kernel variant, the same one a single launch would get)
+// N, discount, clip and rollover contract -- A is only used to pick the kernel variant, the same one a single launch would get)
 template <bool BATCHED>
-static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int nbatch, bool trust_clipped, double *pos_stats,
-                            hipStream_t s)
+static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int nbatch, double *pos_stats, hipStream_t s)
 {
     const int N = A.N;
     const int nb = BATCHED ? nbatch : 1;
-    const int grid = (N + RO_BLOCK - 1) / RO_BLOCK;
-    const bool deep = grid * nb <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
     const bool d1 = (A.discount == 1.0f);
     const bool stats = !BATCHED && pos_stats != nullptr;
-    if (!stats && 2 * ((N + COVO_WAVE - 1) / COVO_WAVE) <= 1024) {  // both waves of every pair get their own SIMD
-        const dim3 g2((N + RS_PAIRS * COVO_WAVE - 1) / (RS_PAIRS * COVO_WAVE), nb), blk(2 * RS_PAIRS * COVO_WAVE);
-        if (d1) { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<true, false, BATCHED>), g2, blk, 0, s, A, batch);
-                  else hipLaunchKernelGGL((rollout_split_kernel<true, true, BATCHED>), g2, blk, 0, s, A, batch); }
-        else    { if (trust_clipped) hipLaunchKernelGGL((rollout_split_kernel<false, false, BATCHED>), g2, blk, 0, s, A, batch);
-                  else hipLaunchKernelGGL((rollout_split_kernel<false, true, BATCHED>), g2, blk, 0, s, A, batch); }
+    if (!stats) {
+        const int groups = pipe_groups(N, nb);
+        if (d1) { if (A.rollover) launch_pipe3<true, true, BATCHED>(A, batch, nb, groups, s); else launch_pipe3<true, false, BATCHED>(A, batch, nb, groups, s); }
+        else    { if (A.rollover) launch_pipe3<false, true, BATCHED>(A, batch, nb, groups, s); else launch_pipe3<false, false, BATCHED>(A, batch, nb, groups, s); }
         COVO_CHECK_HIP(hipGetLastError());
         return 0;
     }
-#define RO_DISPATCH(ST, D1, CL) launch_rollout_pf<ST, D1, CL, BATCHED>(A, batch, nb, grid, deep, s)
-    if (stats) {
-        if constexpr (!BATCHED) {
-            if (d1) { if (trust_clipped) RO_DISPATCH(true, true, false); else RO_DISPATCH(true, true, true); }
-            else    { if (trust_clipped) RO_DISPATCH(true, false, false); else RO_DISPATCH(true, false, true); }
-            hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(COVO_H * 6), dim3(256), 0, s, A.stats_ws, grid, pos_stats);
-        }
-    } else {
-        if (d1) { if (trust_clipped) RO_DISPATCH(false, true, false); else RO_DISPATCH(false, true, true); }
-        else    { if (trust_clipped) RO_DISPATCH(false, false, false); else RO_DISPATCH(false, false, true); }
-    }
+    if constexpr (!BATCHED) {
+        const int grid = (N + RO_BLOCK - 1) / RO_BLOCK;
+        const bool deep = grid <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
+        const bool clip = A.clip != 0;
+#define RO_DISPATCH(D1, CL) launch_rollout_pf<true, D1, CL, false>(A, batch, nb, grid, deep, s)
+        if (d1) { if (!clip) RO_DISPATCH(true, false); else RO_DISPATCH(true, true); }
+        else    { if (!clip) RO_DISPATCH(false, false); else RO_DISPATCH(false, true); }
 #undef RO_DISPATCH
+        hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(COVO_H * 6), dim3(256), 0, s, A.stats_ws, grid, pos_stats);
+    }
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -507,16 +393,19 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
 {
     RolloutArgs A;
     fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev);
+    A.clip = trust_clipped ? 0 : 1;
     A.records = records;
     A.inv_lam = records ? 1.0f / lam : 0.0f;
-    return dispatch_rollout<false>(A, nullptr, 0, trust_clipped, pos_stats, s);
+    return dispatch_rollout<false>(A, nullptr, 0, pos_stats, s);
 }
 
-// workgroups (= softmax records, rollout_record) a rollout over N samples is launched with -- mirrors dispatch_rollout
-int rollout_workgroups(int N, bool stats)
+// workgroups (= softmax records, rollout_record) a rollout over N samples (x nbatch instances) is launched with, per
+// instance -- mirrors dispatch_rollout
+int rollout_workgroups(int N, bool stats, int nbatch)
 {
-    if (!stats && 2 * ((N + COVO_WAVE - 1) / COVO_WAVE) <= 1024) return (N + RS_PAIRS * COVO_WAVE - 1) / (RS_PAIRS * COVO_WAVE);
-    return (N + RO_BLOCK - 1) / RO_BLOCK;
+    if (stats) return (N + RO_BLOCK - 1) / RO_BLOCK;
+    const int ng = (N + COVO_WAVE - 1) / COVO_WAVE, groups = pipe_groups(N, nbatch);
+    return (ng + groups - 1) / groups;
 }
 
 // ---- env-batched rollout: one launch, workgroup row y = instance y (step.hip: covo_mpc_step_batched)
@@ -524,16 +413,18 @@ size_t rollout_args_bytes(int n) { return (size_t)n * sizeof(RolloutArgs); }
 
 void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
                        const covo_env_params &p, const float *a, int N, float discount, float *cost, float *groupmin,
-                       const float *f_shared_dev, float *records, float lam)
+                       const float *f_shared_dev, float *records, float lam, bool trust_clipped)
 {
     RolloutArgs &A = reinterpret_cast<RolloutArgs *>(out)[index];
     fill_rollout_args(A, state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost, groupmin, nullptr, f_shared_dev);
+    A.clip = trust_clipped ? 0 : 1;
     A.records = records;
     A.inv_lam = records ? 1.0f / lam : 0.0f;
 }
 
-int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, bool trust_clipped, hipStream_t s)
+// every instance must share instance 0's N, discount, clip and rollover settings (checked by the caller)
+int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, hipStream_t s)
 {
     return dispatch_rollout<true>(reinterpret_cast<const RolloutArgs *>(args_host)[0],
-                                  reinterpret_cast<const RolloutArgs *>(args_dev), nbatch, trust_clipped, nullptr, s);
+                                  reinterpret_cast<const RolloutArgs *>(args_dev), nbatch, nullptr, s);
 }

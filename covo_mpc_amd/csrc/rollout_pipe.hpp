@@ -1,0 +1,317 @@
+// rollout_pipe.hpp -- the N-sample x H-step rollout as a three-stage wave pipeline (gfx950).  Included by rollout.hip.
+#pragma once
+
+constexpr float RP_COS_PI_4 = 0.70710678118654752f;  // quadrotor.py:487
+
+// Empty asm with the live state as in/out operands: volatile asms keep their order, so the arithmetic of a chunk can
+// neither sink below the next barrier nor be hoisted above the previous one (LLVM's IR passes move pure arithmetic
+// freely across the barrier asm otherwise -- observed: all barriers and ring reads first, 400 VGPRs).
+__device__ __forceinline__ void rp_pin(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &h)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+
+// Three-stage pipeline (the product kernel; the one-lane-per-sample kernel of rollout.hip remains for the position
+// statistics of --info).  Measured on gfx950 (scripts/probe/valu_probe.hip, rollout_lab.hip): one wave
+// retires a dependent VALU instruction per ~4 ns, a SIMD with three such waves one per ~1.2-1.5 ns, and every LDS
+// instruction costs about as much SIMD time as 6-8 VALU instructions.  So a launch wants >= 3 waves per SIMD, as few VALU
+// instructions as the arithmetic allows, and as few dwords through LDS as the stages can do with.  Every 64 samples get
+// three waves that run the horizon one chunk of CH steps apart:
+//
+//   A (attitude)     stripes a[k][n] -> g = dt/2 omega (body-rate lag, free.py:105-107), quaternion step + re-normalise
+//                    (free.py:96,104,139)                         -> ring A slot k: {x, y, z, w}, {tau = thrust dt / m}
+//   T (translation)  ring A + per-step targets (v_readlane) -> squared position / velocity errors, termination flag and yaw
+//                    terms of the PRE-step state (quadrotor.py:243-244, 479-490; utils.py:286-290)
+//                                                                 -> ring T slot k: {err_pos^2, err_vel^2 | flag, yn, yd}
+//                    then velocity and position (free.py:92,97-103)
+//   R (reward)       ring T -> reward (utils.py:266-294), frozen reward, running cost (covo.py:233-263)
+//
+// ~28 + 41 + 34 VALU instructions per sample-step (the one-lane-per-sample kernel: 135), one s_barrier per CH steps.
+// Differences to quad_model.hpp's operation order, all at the 1-ulp level (tests: <= 1e-5 relative on the cost against the
+// fp64 oracle, as before): the stored quaternion of steps k >= 1 was normalised by the previous step (free.py:139), so
+// free.py:88's re-normalisation is applied at step 0 only (it changes a unit quaternion by <= 1 ulp) and Q[2,2] is formed as
+// 1 - 2(x^2 + y^2); dt/2, dt/m and (1 - alpha) are folded into the constants of their products; atan2's arguments are
+// halved (exact); |atan| is a 6-term odd minimax polynomial (3.9e-7 abs).
+#ifdef RP_TIMELINE
+__device__ unsigned long long *g_rp_tl;  // scripts/probe/pipe_timeline.hip: [workgroup][3 stages][8] stamps
+#define RP3_DECL() unsigned long long rp3_t_[4] = {0, 0, 0, 0}, rp3_c_[4] = {0, 0, 0, 0}
+#define RP3_STAMP(I) do { rp3_t_[I] = wall_clock64(); rp3_c_[I] = __builtin_readcyclecounter(); } while (0)
+#define RP3_FLUSH(ROLE) do { if (lane == 0 && g_rp_tl) { unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); \
+    unsigned long long *o_ = g_rp_tl + ((size_t)blockIdx.x * 3 + (ROLE)) * 8; o_[0] = rp3_t_[0]; o_[1] = rp3_t_[1]; o_[2] = rp3_t_[2]; o_[3] = rp3_t_[3]; o_[4] = hw_; o_[5] = rp3_c_[3] - rp3_c_[1]; } } while (0)
+#else
+#define RP3_DECL()
+#define RP3_STAMP(I)
+#define RP3_FLUSH(ROLE)
+#endif
+
+template <int CH>
+struct Rp3Lds {
+    float4 q[2 * CH][COVO_WAVE];   // ring A: x, y, z, w (unit)
+    float tau[2 * CH][COVO_WAVE];  // ring A: thrust dt / m (sign bit: rollover flag of the stored state)
+    float4 t[2 * CH][COVO_WAVE];   // ring T: err_pos^2, err_vel^2 (sign bit: terminated), yn/2, yd/2 of the stored quaternion
+};
+
+template <int ONLY>
+__device__ __forceinline__ void rp3_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    if (ONLY == -1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// |atan2(y, x)|: odd minimax polynomial of atan on [0,1] (6 terms, 3.9e-7 abs) + octant fix-up; atan2(0, 0) = 0 through the
+// floor on the larger magnitude.  17 VALU.
+__device__ __forceinline__ float rp3_atan2abs(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-30f), mn = __builtin_fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = t * t;
+    float r = 0.007374854292720556f;
+    r = __builtin_fmaf(r, s, -0.03552231565117836f);
+    r = __builtin_fmaf(r, s, 0.08217037469148636f);
+    r = __builtin_fmaf(r, s, -0.13398927450180054f);
+    r = __builtin_fmaf(r, s, 0.1986188441514969f);
+    r = __builtin_fmaf(r, s, -0.33325397968292236f);
+    r = r * s;
+    r = __builtin_fmaf(r, t, t);
+    r = (ay > ax) ? (1.57079637f - r) : r;
+    r = (x < 0.0f) ? (3.14159274f - r) : r;
+    return r;
+}
+
+// ROLL: the rollover termination of is_terminal (quadrotor.py:486-490) is on (Quad3D(disable_rollover_terminate=False)).
+// GROUPS: 64-sample groups per workgroup (3 GROUPS waves, stage-major: waves [0, GROUPS) are the A waves, ... -- with four
+//   groups every SIMD of the CU hosts one wave of each stage); CH: steps per barrier.
+// ONLY >= 0 (scripts/probe/rollout_lab.hip): every wave runs stage ONLY on its own LDS copy, no barriers -- the stage's
+//   instruction stream in isolation; ONLY == -2: all three stages without barriers (timing bound, garbage results).
+template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3>
+__global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) void rollout_pipe3_kernel(
+    const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
+{
+    static_assert(COVO_H % CH == 0, "CH must divide the horizon");
+    const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
+    __shared__ Rp3Lds<CH> lds_all[ONLY >= 0 ? ONLY_WAVES : GROUPS];
+    RP3_DECL();
+    const int lane = threadIdx.x & (COVO_WAVE - 1);
+    const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = ONLY >= 0 ? ONLY : wave_ / GROUPS;  // role-major: the GROUPS waves of one stage are neighbours
+    const int gsub = ONLY >= 0 ? 0 : wave_ % GROUPS;
+    Rp3Lds<CH> &lds = lds_all[ONLY >= 0 ? wave_ : gsub];
+    const float *__restrict__ st = A.state;
+
+    int group = blockIdx.x * GROUPS + gsub;  // XCD affinity as in the two-stage kernel (speed only)
+    if (A.xcd_remap) {
+        const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + gsub;
+        group = 2 * (x + 8 * (m >> 1)) + (m & 1);
+    }
+    const int n_raw = group * COVO_WAVE + lane;
+    const bool valid = n_raw < A.N;
+    const int n = valid ? n_raw : A.N - 1;
+    const qm::Consts<float> c = A.c;
+
+    if (role == 0) {
+        // ============================================================ A: attitude (the serial chain: runs at high priority)
+        const float4 *__restrict__ ap = A.a + n;
+        const size_t stride = (size_t)A.N;
+        constexpr int PF = 12 < COVO_H ? 12 : COVO_H;  // stripes in flight
+        float4 ring[PF];
+        RP3_STAMP(0);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ring[i] = ap[(size_t)(i < COVO_H - 1 ? i : 0) * stride];
+        const float ctau = c.thrust_half * c.inv_m * c.dt;                     // tau = (a0 + 1) ctau = thrust dt / m
+        const float kg0 = c.komega[0] * c.one_m_alpha * c.half_dt, kg1 = c.komega[1] * c.one_m_alpha * c.half_dt,
+                    kg2 = c.komega[2] * c.one_m_alpha * c.half_dt;            // g' = alpha g + a kg,  g = dt/2 omega
+        float x, y, z, w;
+        {
+            const float qx = st[ST_QUAT + 0], qy = st[ST_QUAT + 1], qz = st[ST_QUAT + 2], qw = st[ST_QUAT + 3];
+            const float rn = qm::rsqrt_(qx * qx + qy * qy + qz * qz + qw * qw);  // free.py:88 (the noisy state is not unit)
+            x = qx * rn; y = qy * rn; z = qz * rn; w = qw * rn;
+        }
+        float gx = st[ST_OMEGA + 0] * c.half_dt, gy = st[ST_OMEGA + 1] * c.half_dt, gz = st[ST_OMEGA + 2] * c.half_dt;
+        const float groll = 100.0f * c.half_dt;
+#pragma unroll
+        for (int k = 0; k < COVO_H; ++k) {
+            float4 a4 = ring[k % PF];
+            if (k + PF < COVO_H - 1) ring[k % PF] = ap[(size_t)(k + PF) * stride];
+            if (A.clip) { a4.x = qm::clip11_(a4.x); a4.y = qm::clip11_(a4.y); a4.z = qm::clip11_(a4.z); a4.w = qm::clip11_(a4.w); }
+            float tau = __builtin_fmaf(a4.x, ctau, ctau);  // quadrotor.py:259, free.py:82,98,103
+            if (ROLL && k > 0) {  // quadrotor.py:486-490 on the stored state (step 0: wave T, from the state itself)
+                const bool roll = (w < RP_COS_PI_4) | (fmaxf(fmaxf(fabsf(gx), fabsf(gy)), fabsf(gz)) > groll);
+                tau = roll ? __int_as_float(__float_as_int(tau) | 0x80000000) : tau;
+            }
+            lds.q[k % (2 * CH)][lane] = make_float4(x, y, z, w);
+            lds.tau[k % (2 * CH)][lane] = tau;
+            if (k < COVO_H - 1) {
+                // q + dt/2 L(q) H omega (free.py:96,104) = q (x) (1, g)
+                const float nx = __builtin_fmaf(-z, gy, __builtin_fmaf(y, gz, __builtin_fmaf(w, gx, x)));
+                const float ny = __builtin_fmaf(-x, gz, __builtin_fmaf(z, gx, __builtin_fmaf(w, gy, y)));
+                const float nz = __builtin_fmaf(-y, gx, __builtin_fmaf(x, gy, __builtin_fmaf(w, gz, z)));
+                const float nw = __builtin_fmaf(-z, gz, __builtin_fmaf(-y, gy, __builtin_fmaf(-x, gx, w)));
+                gx = __builtin_fmaf(gx, c.alpha, a4.y * kg0);  // free.py:105-107, 122
+                gy = __builtin_fmaf(gy, c.alpha, a4.z * kg1);
+                gz = __builtin_fmaf(gz, c.alpha, a4.w * kg2);
+                const float rn = qm::rsqrt_(__builtin_fmaf(nw, nw, __builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx))));  // free.py:139
+                x = nx * rn; y = ny * rn; z = nz * rn; w = nw * rn;
+            }
+            if ((k + 1) % CH == 0) {
+                if (k + 1 == CH) RP3_STAMP(1);
+                if (k + 1 == COVO_H / 2) RP3_STAMP(2);
+                if (k + 1 == COVO_H) RP3_STAMP(3);
+                rp3_barrier<ONLY>();
+                float pin_ = 0.0f;
+                rp_pin(x, y, z, w, gx, gy, gz, pin_);
+            }
+        }
+        RP3_FLUSH(0);
+        rp3_barrier<ONLY>();
+        rp3_barrier<ONLY>();
+        if (A.records == nullptr) return;
+    }
+
+    if (role == 1) {
+        // ============================================================ T: translation
+        const int time0 = __float_as_int(st[ST_TIME]);
+        // wave-uniform horizon window held across lanes: lane k carries step k's targets
+        // (free.py:150-155: targets = traj[time+1] after each step, gather clamps; step 0 = the state's own)
+        float wpx, wpy, wpz, wvx, wvy, wvz;
+        {
+            const int k = lane & (COVO_H - 1);
+            int idx = time0 + k;
+            idx = idx < 0 ? 0 : (idx > A.T - 1 ? A.T - 1 : idx);
+            const bool own = (k == 0);
+            wpx = own ? st[ST_POSTAR + 0] : A.pos_traj[3 * idx + 0];
+            wpy = own ? st[ST_POSTAR + 1] : A.pos_traj[3 * idx + 1];
+            wpz = own ? st[ST_POSTAR + 2] : A.pos_traj[3 * idx + 2];
+            wvx = own ? st[ST_VELTAR + 0] : A.vel_traj[3 * idx + 0];
+            wvy = own ? st[ST_VELTAR + 1] : A.vel_traj[3 * idx + 1];
+            wvz = own ? st[ST_VELTAR + 2] : A.vel_traj[3 * idx + 2];
+        }
+        const int kdone = A.max_steps - time0;  // steps k >= kdone see time >= max_steps (quadrotor.py:483)
+        float px = st[ST_POS + 0], py = st[ST_POS + 1], pz = st[ST_POS + 2];
+        float vx = st[ST_VEL + 0], vy = st[ST_VEL + 1], vz = st[ST_VEL + 2];
+        const float kf = c.inv_m * c.dt;  // v += dt/m f (free.py:98,103)
+        const float c0x = st[ST_FDIST + 0] * kf, c0y = st[ST_FDIST + 1] * kf, c0z = __builtin_fmaf(st[ST_FDIST + 2], kf, c.neg_g * c.dt);
+        const float fsx = A.f_shared_dev ? A.f_shared_dev[0] : A.f_shared[0];
+        const float fsy = A.f_shared_dev ? A.f_shared_dev[1] : A.f_shared[1];
+        const float fsz = A.f_shared_dev ? A.f_shared_dev[2] : A.f_shared[2];
+        const float csx = fsx * kf, csy = fsy * kf, csz = __builtin_fmaf(fsz, kf, c.neg_g * c.dt);
+        float yn0, yd0;  // step 0: yaw terms of the un-normalised stored quaternion (utils.py:289-290)
+        bool roll0 = false;
+        {
+            const float qx = st[ST_QUAT + 0], qy = st[ST_QUAT + 1], qz = st[ST_QUAT + 2], qw = st[ST_QUAT + 3];
+            yn0 = __builtin_fmaf(qw, qz, qx * qy);
+            yd0 = __builtin_fmaf(-qz, qz, __builtin_fmaf(-qy, qy, 0.5f));
+            if (ROLL) roll0 = (qw < RP_COS_PI_4) |
+                              (fmaxf(fmaxf(fabsf(st[ST_OMEGA + 0]), fabsf(st[ST_OMEGA + 1])), fabsf(st[ST_OMEGA + 2])) > 100.0f);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the window loads: rp3_barrier only waits on lgkmcnt
+        RP3_STAMP(0);
+        rp3_barrier<ONLY>();  // interval 0: chunk 0 of ring A is being written
+#pragma unroll
+        for (int k = 0; k < COVO_H; ++k) {
+            if (k % CH == 0) {
+                float pin0_ = 0.0f, pin1_ = 0.0f;
+                rp_pin(px, py, pz, vx, vy, vz, pin0_, pin1_);
+            }
+            const float4 q4 = lds.q[k % (2 * CH)][lane];
+            const float tau_raw = lds.tau[k % (2 * CH)][lane];
+            const float tx = lane_bcast(wpx, k), ty = lane_bcast(wpy, k), tz = lane_bcast(wpz, k);
+            const float tvx = lane_bcast(wvx, k), tvy = lane_bcast(wvy, k), tvz = lane_bcast(wvz, k);
+            const float x = q4.x, y = q4.y, z = q4.z, w = q4.w;
+            // squared errors, termination and yaw terms of the PRE-step state (quadrotor.py:243-244, 479-490; utils.py:286-290)
+            const float dx = tx - px, dy = ty - py, dz = tz - pz;
+            const float ex = tvx - vx, ey = tvy - vy, ez = tvz - vz;
+            const float ep2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            float ev2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+            const float pmax = fmaxf(fmaxf(fabsf(px), fabsf(py)), fabsf(pz));
+            bool done = (k >= kdone) | (pmax > c.pos_limit);
+            float tau = tau_raw;
+            if (ROLL) {
+                done = done | ((k == 0) ? roll0 : (__float_as_int(tau_raw) < 0));
+                tau = fabsf(tau_raw);
+            }
+            ev2 = done ? -ev2 : ev2;
+            const float yn = (k == 0) ? yn0 : __builtin_fmaf(w, z, x * y);
+            const float yd = (k == 0) ? yd0 : __builtin_fmaf(-z, z, __builtin_fmaf(-y, y, 0.5f));
+            lds.t[k % (2 * CH)][lane] = make_float4(ep2, ev2, yn, yd);
+            if (k < COVO_H - 1) {
+                // Q[:,2] of qtoQ(q) (geom.py:68-77) for a unit quaternion: 2 (xz + yw), 2 (yz - xw), 1 - 2 (x^2 + y^2);
+                // v += dt (Q [0,0,T] + f)/m + dt [0,0,-g] (free.py:97-99,103); position with the OLD velocity (free.py:102)
+                const float tau2 = tau + tau;
+                const float u0 = __builtin_fmaf(x, z, y * w), u1 = __builtin_fmaf(y, z, -(x * w));
+                const float s2 = __builtin_fmaf(y, y, x * x);
+                px = __builtin_fmaf(vx, c.dt, px);
+                py = __builtin_fmaf(vy, c.dt, py);
+                pz = __builtin_fmaf(vz, c.dt, pz);
+                vx = __builtin_fmaf(u0, tau2, vx);
+                vy = __builtin_fmaf(u1, tau2, vy);
+                vz = __builtin_fmaf(-tau2, s2, vz + tau);
+                if (k == 0) { vx += c0x; vy += c0y; vz += c0z; }
+                else { vx += csx; vy += csy; vz += csz; }
+            }
+            if ((k + 1) % CH == 0) {
+                if (k + 1 == CH) RP3_STAMP(1);
+                if (k + 1 == COVO_H / 2) RP3_STAMP(2);
+                if (k + 1 == COVO_H) RP3_STAMP(3);
+                rp3_barrier<ONLY>();
+            }
+        }
+        RP3_FLUSH(1);
+        rp3_barrier<ONLY>();
+        if (A.records == nullptr) return;
+    }
+
+    float cost = 0.0f;
+    if (role == 2) {
+    // ================================================================ R: reward
+    constexpr float LN2 = 0.69314718056f;
+    float acc = 0.0f, r_before = 0.0f, dk = 1.0f;  // covo.py:246-247
+    bool done_before = false;
+    RP3_STAMP(0);
+    rp3_barrier<ONLY>();
+    rp3_barrier<ONLY>();
+#pragma unroll
+    for (int k = 0; k < COVO_H; ++k) {
+        if (k % CH == 0) {
+            float p0_ = 0.0f, p1_ = 0.0f, p2_ = 0.0f, p3_ = 0.0f, p4_ = 0.0f, p5_ = 0.0f;
+            rp_pin(acc, r_before, p0_, p1_, p2_, p3_, p4_, p5_);
+        }
+        const float4 e4 = lds.t[k % (2 * CH)][lane];
+        const float err_pos = qm::sqrt_(e4.x), err_vel = qm::sqrt_(fabsf(e4.y));
+        const float yaw = rp3_atan2abs(e4.z, e4.w);
+        const float l2 = __builtin_amdgcn_logf(err_pos + 1.0f);  // log2
+        // utils.py:266-274, 285-294: r = 1.3 - 0.05 err_vel - (0.4 e + 0.4 sat(4 l) + 0.2 sat(8 l) + 0.1 sat(16 l) + 0.1 sat(32 l)) - 0.2 |yaw|
+        float r = __builtin_fmaf(err_vel, -0.05f, 1.3f);
+        r = __builtin_fmaf(err_pos, -0.4f, r);
+        r = __builtin_fmaf(qm::sat01_(l2 * (4.0f * LN2)), -0.4f, r);
+        r = __builtin_fmaf(qm::sat01_(l2 * (8.0f * LN2)), -0.2f, r);
+        r = __builtin_fmaf(qm::sat01_(l2 * (16.0f * LN2)) + qm::sat01_(l2 * (32.0f * LN2)), -0.1f, r);
+        r = __builtin_fmaf(yaw, -0.2f, r);
+        const bool done = __float_as_int(e4.y) < 0;
+        r = done_before ? r_before : r;  // covo.py:233
+        done_before = done_before | done;
+        r_before = r;
+        if (DISC1) acc += r;
+        else { acc = __builtin_fmaf(dk, r, acc); dk *= A.discount; }  // covo.py:257-261
+        if (k + 1 == CH) RP3_STAMP(1);
+        if (k + 1 == COVO_H / 2) RP3_STAMP(2);
+        if (k + 1 == COVO_H) RP3_STAMP(3);
+        if ((k + 1) % CH == 0) rp3_barrier<ONLY>();  // (the last one only keeps the three stages' barrier counts equal)
+    }
+    RP3_FLUSH(2);
+    cost = -acc;  // covo.py:263
+    if (valid) A.cost[n] = cost;
+    if (A.groupmin != nullptr) {
+        const float wm = wave_min(valid ? cost : __builtin_inff());
+        if (lane == 0 && group * COVO_WAVE < A.N) A.groupmin[group] = wm;
+    }
+    }
+    if (ONLY == -1 && A.records != nullptr) {  // every wave of the workgroup (the A and T waves carry no cost)
+        __shared__ float rec_m[GROUPS], rec_s[GROUPS];
+        __shared__ __attribute__((aligned(16))) float rec_v[GROUPS][COVO_NA];
+        rollout_record<3 * GROUPS, GROUPS>(A, cost, valid && role == 2, n, role == 2 ? gsub : 0, role == 2, lane, blockIdx.x, rec_m,
+                                           rec_s, rec_v);
+    }
+}

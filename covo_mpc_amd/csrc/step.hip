@@ -458,8 +458,8 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
     if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s))) return rc;
     if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E))) return rc;
-    if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, true, s))) return rc;
-    const int G = rollout_workgroups(N, false);
+    if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, s))) return rc;
+    const int G = rollout_workgroups(N, false, E);
     if (G <= h->max_red_blocks)  // the rollout's workgroups have left the records (rollout_record): instance e's are [e][G]
         return launch_merge(b->partials, G, h->cfg.lam, b->a_mean_shift, a.gamma_mean, a.a_mean, s, nullptr, E);
     return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, b->a_mean_shift, a.gamma_mean, a.a_mean, s,
@@ -505,7 +505,7 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
         COVO_CHECK_HIP(hipMemcpy(b->consts, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
         b->ro_args_host.assign(rollout_args_bytes(E), 0);
         const int N = args->n_samples, ng = (N + 63) / 64;
-        const int bG = rollout_workgroups(N, false);
+        const int bG = rollout_workgroups(N, false, E);
         const bool brec = bG <= h->max_red_blocks;
         for (int e = 0; e < E; ++e)
             rollout_fill_args(b->ro_args_host.data(), e, args->states + (size_t)e * COVO_STATE_FLOATS,

@@ -66,8 +66,9 @@ class EnvParams3D:
     def replace(self, **kw) -> "EnvParams3D":
         return dataclasses.replace(self, **kw)
 
-    def to_c(self) -> EnvParamsC:
-        """The rollout-relevant subset as struct covo_env_params."""
+    def to_c(self, rollover_terminate: bool = False) -> EnvParamsC:
+        """The rollout-relevant subset as struct covo_env_params.  `rollover_terminate` is the env's
+        `not disable_rollover_terminate` (envs/quadrotor.py:486-490): an attribute of Quad3D, not of the parameters."""
         c = EnvParamsC()
         c.max_thrust = float(self.max_thrust)
         for i in range(3):
@@ -77,6 +78,7 @@ class EnvParams3D:
         c.action_scale, c.alpha_bodyrate = float(self.action_scale), float(self.alpha_bodyrate)
         c.max_steps_in_episode = int(self.max_steps_in_episode)
         c.pos_limit = 3.0  # envs/quadrotor.py:484
+        c.rollover_terminate = 1 if rollover_terminate else 0
         return c
 
 

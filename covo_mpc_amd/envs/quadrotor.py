@@ -222,7 +222,7 @@ class DeviceEpisode:
         self.pos_traj, self.vel_traj, self.acc_traj = up(state.pos_traj), up(state.vel_traj), up(state.acc_traj)
         self.T = int(state.pos_traj.shape[0])
         self.log = torch.zeros((params.max_steps_in_episode + 1, 4), dtype=torch.float32, device=device)
-        self.params_c = params.to_c()
+        self.params_c = params.to_c(rollover_terminate=not env.disable_rollover_terminate)
         self.n_steps = 0
         if env.disturb_type not in ("gaussian", "none"):
             raise NotImplementedError(f"disturb_type={env.disturb_type!r} in the device env step")

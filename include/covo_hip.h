@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define COVO_ABI_VERSION 1
+#define COVO_ABI_VERSION 2
 
 #define COVO_H 32            /* horizon (compile-time in the fused kernels)          */
 #define COVO_DU 4            /* action dim, quadjax/envs/quadrotor.py:198            */
@@ -77,6 +77,9 @@ typedef struct covo_env_params {
     float alpha_bodyrate;   /* .5   */
     int32_t max_steps_in_episode; /* 300 */
     float pos_limit;        /* 3.0, quadrotor.py:484 */
+    int32_t rollover_terminate; /* 1: is_terminal also fires on quat[3] < cos(pi/4) or any |omega| > 100 (quadrotor.py:486-490),
+                                 *    i.e. Quad3D(disable_rollover_terminate=False), the constructor's default; quadjax's main()
+                                 *    builds its env with disable_rollover_terminate=True (quadrotor.py:779) -> 0 */
 } covo_env_params;
 
 typedef struct covo_config {
@@ -129,8 +132,9 @@ int covo_noise_blockdiag_philox(covo_handle_t h, const float *Ls, const float *m
 /* The fused N x H rollout: lax.scan(H) of vmap(N) Quad3D.step_env + done-freeze +
  * discounted cost (controllers/covo.py:227-263, mppi.py:71-106; envs/quadrotor.py:215-263,
  * 479-490; dynamics/free.py:74-155; dynamics/utils.py:266-294).  Per-sample state lives in
- * registers; only cost[N] (+ one min per 64-sample wave) is written.  Actions are re-clipped like
- * step_env does unless the handle was created with COVO_FLAG_ACTIONS_CLIPPED.
+ * registers / LDS; only cost[N] (+ one min per 64-sample wave) is written.  Actions are re-clipped like
+ * step_env does unless the handle was created with COVO_FLAG_ACTIONS_CLIPPED.  Termination follows
+ * params->rollover_terminate (quadrotor.py:479-490).
  * f_disturb_shared [host float[3]]: the single disturbance vector every sample receives
  *   for rollout steps >= 1 from the shared step_key (0 for CoVO's deterministic=True).
  * pos_stats (nullable): double[COVO_H*6] accumulators, zeroed by the call, receiving

@@ -44,8 +44,10 @@ def _p(a, ct):
     return a.ctypes.data_as(C.POINTER(ct)) if a is not None else None
 
 
-def rollout(s, p, a_sampled, discount=1.0, f_shared=None, dtype=np.float32, want_rewards=False, want_poses=False):
-    """a_sampled (N,H,4).  Returns cost[, rewards (N,H)][, poses (H,N,3)]."""
+def rollout(s, p, a_sampled, discount=1.0, f_shared=None, dtype=np.float32, want_rewards=False, want_poses=False,
+            rollover=False):
+    """a_sampled (N,H,4).  Returns cost[, rewards (N,H)][, poses (H,N,3)].  rollover: is_terminal's rollover test
+    (envs/quadrotor.py:486-490, Quad3D(disable_rollover_terminate=False))."""
     ct = C.c_float if dtype == np.float32 else C.c_double
     fn = lib().oracle_rollout_f32 if dtype == np.float32 else lib().oracle_rollout_f64
     a = np.ascontiguousarray(a_sampled, dtype=dtype)
@@ -61,7 +63,7 @@ def rollout(s, p, a_sampled, discount=1.0, f_shared=None, dtype=np.float32, want
     fn.restype = None
     fn(_p(prm, C.c_double), C.c_int(p.max_steps_in_episode), _p(st, ct), C.c_int(int(s.time)), _p(pt, ct), _p(vt, ct),
        C.c_int(pt.shape[0]), _p(a, ct), C.c_long(N), C.c_int(H), ct(discount), _p(fs, ct), _p(cost, ct), _p(rew, ct),
-       _p(pos, ct))
+       _p(pos, ct), C.c_int(1 if rollover else 0))
     out = [cost]
     if want_rewards:
         out.append(rew)

@@ -87,7 +87,7 @@ void oracle_sampling_step_f32(const double *prm, int max_steps, const float *sta
     const float zero3[3] = {0, 0, 0};
     oracle_noise_gemm_f32(L, a_mean, eps, N, n, a_work);
     oracle_rollout_f32(prm, max_steps, state22, time, pos_traj, vel_traj, T, a_work, N, H, discount, zero3, cost_work, NULL,
-                       NULL);
+                       NULL, 0);
     float m, s;
     float v[512];
     oracle_softmax_partial_f32(cost_work, a_work, N, n, lam, &m, &s, v);

@@ -36,10 +36,14 @@ static inline REAL SUF(reward)(const SUF(ostate) * s)
     return (REAL)1.3 - (REAL)0.05 * err_vel - SUF(log_pos)(err_pos) - FABS(yaw) * (REAL)0.2;
 }
 
-/* envs/quadrotor.py:479-490, disable_rollover_terminate=True */
-static inline int SUF(terminal)(const SUF(ostate) * s, int max_steps)
+/* envs/quadrotor.py:479-490; rollover = !disable_rollover_terminate (:486-490) */
+static inline int SUF(terminal)(const SUF(ostate) * s, int max_steps, int rollover)
 {
-    return (s->time >= max_steps) || FABS(s->pos[0]) > 3 || FABS(s->pos[1]) > 3 || FABS(s->pos[2]) > 3;
+    int done = (s->time >= max_steps) || FABS(s->pos[0]) > 3 || FABS(s->pos[1]) > 3 || FABS(s->pos[2]) > 3;
+    if (rollover)
+        done = done || s->quat[3] < (REAL)0.70710678118654752440 /* cos(pi/4) */ || FABS(s->omega[0]) > 100 ||
+               FABS(s->omega[1]) > 100 || FABS(s->omega[2]) > 100;
+    return done;
 }
 
 /* envs/quadrotor.py:250-263 + dynamics/free.py:114-155 + free.py:74-112.
@@ -87,7 +91,7 @@ static inline void SUF(dyn_step)(SUF(ostate) * s, const REAL *act, const double 
  * rewards (N,H) and poses (H,N,3) may be NULL. */
 void SUF(oracle_rollout)(const double *prm, int max_steps, const REAL *state22, int time, const REAL *pos_traj,
                          const REAL *vel_traj, int T, const REAL *a, long N, int H, REAL discount,
-                         const REAL *f_shared, REAL *cost, REAL *rewards, REAL *poses)
+                         const REAL *f_shared, REAL *cost, REAL *rewards, REAL *poses, int rollover)
 {
 #pragma omp parallel for schedule(static)
     for (long n = 0; n < N; ++n) {
@@ -104,7 +108,7 @@ void SUF(oracle_rollout)(const double *prm, int max_steps, const REAL *state22, 
         int done_before = 0;
         for (int k = 0; k < H; ++k) {
             REAL r = SUF(reward)(&s);               /* quadrotor.py:243 (pre-step) */
-            int done = SUF(terminal)(&s, max_steps); /* quadrotor.py:244 */
+            int done = SUF(terminal)(&s, max_steps, rollover); /* quadrotor.py:244 */
             SUF(dyn_step)(&s, a + ((size_t)n * H + k) * 4, prm, f_shared, pos_traj, vel_traj, T);
             if (done_before) r = reward_before; /* covo.py:233 */
             done_before |= done;

@@ -196,9 +196,12 @@ def tracking_penyaw_reward_fn(state: State):
     return dt(1.3) - dt(0.05) * err_vel - log_pos_fn(err_pos) - np.abs(yaw) * dt(0.2)
 
 
-def is_terminal(state: State, p: Params):
-    """envs/quadrotor.py:479-490 with disable_rollover_terminate=True (main, :779)."""
-    return (state.time >= p.max_steps_in_episode) | np.any(np.abs(state.pos) > 3.0, axis=-1)
+def is_terminal(state: State, p: Params, rollover: bool = False):
+    """envs/quadrotor.py:479-490; rollover = not disable_rollover_terminate (main() passes True, :779 -> rollover False)."""
+    done = (state.time >= p.max_steps_in_episode) | np.any(np.abs(state.pos) > 3.0, axis=-1)
+    if rollover:  # :486-490
+        done = done | (state.quat[..., 3] < np.cos(np.pi / 4.0)) | np.any(np.abs(state.omega) > 100.0, axis=-1)
+    return done
 
 
 # ----------------------------------------------------------------------------
@@ -266,7 +269,7 @@ def raw_step(s: State, sub_action, p: Params, f_disturb_next):
     return free_dynamics_3d_bodyrate(p, s, thrust, torque, f_disturb_next, p.dt)
 
 
-def step_env(s: State, action, p: Params, f_disturb_next):
+def step_env(s: State, action, p: Params, f_disturb_next, rollover: bool = False):
     """envs/quadrotor.py:215-248 (lower_controller='base', substeps=1).
 
     Reward and termination are evaluated on the PRE-step state (:243-244).
@@ -276,7 +279,7 @@ def step_env(s: State, action, p: Params, f_disturb_next):
     t = s.pos.dtype.type
     action = np.clip(action, t(-1.0), t(1.0))
     nxt = raw_step(s, action, p, f_disturb_next)
-    return nxt, tracking_penyaw_reward_fn(s), is_terminal(s, p)
+    return nxt, tracking_penyaw_reward_fn(s), is_terminal(s, p, rollover)
 
 
 # ----------------------------------------------------------------------------
@@ -303,7 +306,7 @@ def sample_actions_blockdiag(a_mean, a_cov, eps):
     return np.clip(a, -1.0, 1.0).astype(a_mean.dtype), Ls
 
 
-def rollout(s0: State, p: Params, a_sampled, discount, f_disturb_shared):
+def rollout(s0: State, p: Params, a_sampled, discount, f_disturb_shared, rollover: bool = False):
     """covo.py:227-263 / mppi.py:71-106.
 
     a_sampled (N,H,du) already clipped.  ``f_disturb_shared`` (3,) is the single
@@ -319,7 +322,7 @@ def rollout(s0: State, p: Params, a_sampled, discount, f_disturb_shared):
     rewards = np.zeros((N, H), dtype=dtype)
     poses = np.zeros((H, N, 3), dtype=dtype)
     for k in range(H):
-        s, reward, done = step_env(s, a_sampled[:, k], p, f_disturb_shared)
+        s, reward, done = step_env(s, a_sampled[:, k], p, f_disturb_shared, rollover)
         reward = np.where(done_before, reward_before, reward)  # covo.py:233
         done_before = done | done_before
         reward_before = reward

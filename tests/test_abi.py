@@ -33,7 +33,7 @@ def test_load_and_abi_version(built):
 
 
 def test_struct_layouts_match_header(built):
-    assert ctypes.sizeof(built.EnvParamsC) == 4 * (1 + 3 + 3 + 5 + 1 + 1)
+    assert ctypes.sizeof(built.EnvParamsC) == 4 * (1 + 3 + 3 + 5 + 1 + 1 + 1)  # + rollover_terminate (ABI 2)
     assert ctypes.sizeof(built.ConfigC) == 24
 
 
