@@ -237,17 +237,20 @@ def main():
     # SAME buffers; `in_step_us` is the graph-replay time of the (noise GEMM -> rollout) pair minus the GEMM
     # alone (covo_debug_time_step: 20 copies in one graph), i.e. the rollout reading stripes the GEMM has
     # just written.  The rocprofv3 kernel-trace of this command (profiles/) gives the same kernel's average.
-    reps = 50
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     pc = params.to_c()
-    for _ in range(3):
-        core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), args.info)
-    e0.record()
-    for _ in range(reps):
-        core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), args.info)
-    e1.record()
-    torch.cuda.synchronize()
-    rollout_b2b_ms = e0.elapsed_time(e1) / reps
+    if args.info:  # the position statistics take the one-lane-per-sample kernel + a finalize launch: timed from Python
+        reps = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), True)
+        e0.record()
+        for _ in range(reps):
+            core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), True)
+        e1.record()
+        torch.cuda.synchronize()
+        rollout_b2b_ms = e0.elapsed_time(e1) / reps
+    else:  # launches issued from C (a Python loop of ctypes calls is host-bound below ~10 us per launch)
+        rollout_b2b_ms = 1e-3 * core.time_rollout(dstates[40], pc, reps=100)
     in_step_us = None
     if world == 1:
         try:

@@ -165,6 +165,16 @@ class SamplingCore:
               "covo_rollout_cost")
         return self.cost
 
+    def time_rollout(self, dstate, params_c, f_shared=(0.0, 0.0, 0.0), reps=100):
+        """GPU microseconds per covo_rollout_cost launch, `reps` launches issued back to back from C between two events."""
+        fs = (C.c_float * 3)(*[float(x) for x in f_shared])
+        us = C.c_float(0.0)
+        check(self.lib.covo_debug_time_rollout(self.h, ptr(dstate.packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj), dstate.T,
+                                               C.byref(params_c), fs, ptr(self.a), self.n_local, ptr(self.cost),
+                                               ptr(self.blockmin), int(reps), C.byref(us), self.stream()),
+              "covo_debug_time_rollout")
+        return float(us.value)
+
     def hessian(self, packed, dstate, params_c, a_mean, batch=1, method="adjoint"):
         """d^2 C / da^2 (covo.py:134-185); method "adjoint" (default, hessian_adj.hip) or "pairs" (hessian.hip)."""
         R = self.torch.empty((batch, COVO_NA, COVO_NA), dtype=self.torch.float64, device=self.device)

@@ -133,6 +133,41 @@ int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj
                           (hipStream_t)stream);
 }
 
+int covo_debug_time_rollout(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                            const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
+                            float *cost_out, float *groupmin, int32_t reps, float *us_out, void *stream)
+{
+    REQUIRE(h, "covo_debug_time_rollout: null handle");
+    REQUIRE(state && pos_traj && vel_traj && params && a && cost_out && us_out && T > 0 && reps > 0, "covo_debug_time_rollout: bad argument");
+    REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_debug_time_rollout: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    hipStream_t s = (hipStream_t)stream;
+    const bool clipped = (h->cfg.flags & COVO_FLAG_ACTIONS_CLIPPED) != 0;
+    hipEvent_t e0, e1;
+    COVO_CHECK_HIP(hipEventCreate(&e0));
+    COVO_CHECK_HIP(hipEventCreate(&e1));
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i)
+        rc = launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount, clipped, cost_out,
+                            groupmin, nullptr, h->ws_stats, s);
+    float best = 1e30f;
+    for (int it = 0; it < 3 && !rc; ++it) {
+        COVO_CHECK_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < reps && !rc; ++i)
+            rc = launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount, clipped, cost_out,
+                                groupmin, nullptr, h->ws_stats, s);
+        COVO_CHECK_HIP(hipEventRecord(e1, s));
+        COVO_CHECK_HIP(hipStreamSynchronize(s));
+        float ms = 0.0f;
+        COVO_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *us_out = best * 1e3f / (float)reps;
+    return 0;
+}
+
 int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
                         float *partial_out, void *stream)
 {

@@ -349,11 +349,11 @@ static void launch_pipe3(const RolloutArgs &A, const RolloutArgs *batch, int nb,
     const int ng = (A.N + COVO_WAVE - 1) / COVO_WAVE;
     const dim3 grid((ng + groups - 1) / groups, nb);
     if (groups == 4)
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 1, 4, BATCHED>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 4, BATCHED>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
     else if (groups == 2)
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 1, 2, BATCHED>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 2, BATCHED>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
     else
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 1, 1, BATCHED>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 1, BATCHED>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
 }
 
 // nbatch == 0: one rollout described by A; else nbatch instances described by the device array `batch` (all with A's

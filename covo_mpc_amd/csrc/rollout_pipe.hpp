@@ -6,10 +6,15 @@ constexpr float RP_COS_PI_4 = 0.70710678118654752f;  // quadrotor.py:487
 // Empty asm with the live state as in/out operands: volatile asms keep their order, so the arithmetic of a chunk can
 // neither sink below the next barrier nor be hoisted above the previous one (LLVM's IR passes move pure arithmetic
 // freely across the barrier asm otherwise -- observed: all barriers and ring reads first, 400 VGPRs).
-__device__ __forceinline__ void rp_pin(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &h)
+__device__ __forceinline__ void rp_pin(float &a, float &b, float &c, float &d, float &e, float &f, float &g)
 {
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g));
 }
+__device__ __forceinline__ void rp_pin(float &a, float &b, float &c, float &d, float &e, float &f)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+__device__ __forceinline__ void rp_pin(float &a, float &b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
 // Three-stage pipeline (the product kernel; the one-lane-per-sample kernel of rollout.hip remains for the position
 // statistics of --info).  Measured on gfx950 (scripts/probe/valu_probe.hip, rollout_lab.hip): one wave
@@ -65,7 +70,8 @@ __device__ __forceinline__ void rp3_barrier()
 __device__ __forceinline__ float rp3_atan2abs(float y, float x)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-30f), mn = __builtin_fminf(ax, ay);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-30f);
+    const float mn = __builtin_amdgcn_fmed3f(ax, ay, 0.0f);  // min of two non-negative numbers as ONE v_med3 with |.| modifiers
     const float t = mn * __builtin_amdgcn_rcpf(mx);
     const float s = t * t;
     float r = 0.007374854292720556f;
@@ -160,8 +166,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
                 if (k + 1 == COVO_H / 2) RP3_STAMP(2);
                 if (k + 1 == COVO_H) RP3_STAMP(3);
                 rp3_barrier<ONLY>();
-                float pin_ = 0.0f;
-                rp_pin(x, y, z, w, gx, gy, gz, pin_);
+                rp_pin(x, y, z, w, gx, gy, gz);
             }
         }
         RP3_FLUSH(0);
@@ -212,8 +217,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
 #pragma unroll
         for (int k = 0; k < COVO_H; ++k) {
             if (k % CH == 0) {
-                float pin0_ = 0.0f, pin1_ = 0.0f;
-                rp_pin(px, py, pz, vx, vy, vz, pin0_, pin1_);
+                rp_pin(px, py, pz, vx, vy, vz);
             }
             const float4 q4 = lds.q[k % (2 * CH)][lane];
             const float tau_raw = lds.tau[k % (2 * CH)][lane];
@@ -275,8 +279,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
 #pragma unroll
     for (int k = 0; k < COVO_H; ++k) {
         if (k % CH == 0) {
-            float p0_ = 0.0f, p1_ = 0.0f, p2_ = 0.0f, p3_ = 0.0f, p4_ = 0.0f, p5_ = 0.0f;
-            rp_pin(acc, r_before, p0_, p1_, p2_, p3_, p4_, p5_);
+            rp_pin(acc, r_before);
         }
         const float4 e4 = lds.t[k % (2 * CH)][lane];
         const float err_pos = qm::sqrt_(e4.x), err_vel = qm::sqrt_(fabsf(e4.y));

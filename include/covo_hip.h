@@ -325,6 +325,13 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
                          int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream);
 
+/* Profiling aid: covo_rollout_cost `reps` times back to back on `stream` between two events; *us_out = GPU microseconds
+ * per launch (what bench.py reports as roofline.launch_us: a Python loop of single calls is host-bound below ~10 us per
+ * launch).  Synchronises the stream.  Arguments as covo_rollout_cost (no position statistics). */
+int covo_debug_time_rollout(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
+                            const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
+                            float *cost_out, float *groupmin, int32_t reps, float *us_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,9 +119,9 @@ def test_noise_blockdiag_bit_exact_and_cholesky4():
 
 
 # ------------------------------------------------------------------------------------------ rollout
-def _run_rollout(core, s, p, a_nh4, f_shared, want_stats=False):
+def _run_rollout(core, s, p, a_nh4, f_shared, want_stats=False, rollover=False):
     core.a.copy_(to_stripes(a_nh4))
-    cost = core.rollout(dev_state(s), EnvParams3D().to_c(), f_shared, want_stats).cpu().numpy()
+    cost = core.rollout(dev_state(s), EnvParams3D().to_c(rollover_terminate=rollover), f_shared, want_stats).cpu().numpy()
     return cost
 
 
@@ -167,6 +167,30 @@ def test_rollout_freeze_and_box_exit():
     assert rel_err(cost, ref).max() < 1e-5
 
 
+@pytest.mark.parametrize("want_stats", [False, True])
+def test_rollout_rollover_termination(want_stats):
+    """Quad3D(disable_rollover_terminate=False), the constructor's default: is_terminal also fires on quat[3] < cos(pi/4)
+    or |omega| > 100 (quadrotor.py:486-490).  Large body-rate commands tip a good share of the samples over within the
+    horizon; both rollout kernels (pipelined / one-lane-per-sample with position statistics) against the oracle."""
+    s, p, rng = make_problem(seed=31, time=60)
+    N = 3000
+    a = np.clip(R.hover_action(p, 32, np.float64)[None] + np.array([0.3, 1.5, 1.5, 0.5]) * rng.normal(size=(N, 32, 4)), -1, 1)
+    a = a.astype(np.float32)
+    core = SamplingCore(N, 32, 0.01, 0.97, device=DEV)
+    cost = _run_rollout(core, s, p, a, np.zeros(3), want_stats=want_stats, rollover=True)
+    ref, rew = CO.rollout(s, p, a.astype(np.float64), 0.97, np.zeros(3), dtype=np.float64, want_rewards=True, rollover=True)
+    ref_off = CO.rollout(s, p, a.astype(np.float64), 0.97, np.zeros(3), dtype=np.float64)
+    tipped = np.abs(ref - ref_off) > 1e-3
+    assert 0.1 < tipped.mean() < 0.999, tipped.mean()  # the flag matters for many samples, not for all
+    # a sample whose quat[3] passes within rounding of cos(pi/4) may freeze one step apart in fp32 and fp64: those few are
+    # compared against the neighbouring decisions instead (the oracle run in fp32 takes the fp32 side of the coin)
+    ref32 = CO.rollout(s.astype(np.float32), p, a, 0.97, np.zeros(3, np.float32), dtype=np.float32, rollover=True)
+    err = np.minimum(rel_err(cost, ref), rel_err(cost, ref32.astype(np.float64)))
+    assert (err < 1e-5).mean() > 0.995 and np.median(err) < 2e-6
+    off = _run_rollout(core, s, p, a, np.zeros(3), want_stats=want_stats, rollover=False)
+    assert rel_err(off, ref_off).max() < 1e-5
+
+
 def test_rollout_full_size_properties():
     """N = 65536 (BASELINE full size): duplicate / permutation invariance and a sub-sampled oracle check."""
     N = 65536
@@ -181,11 +205,10 @@ def test_rollout_full_size_properties():
     assert rel_err(cost[idx], ref).max() < 1e-5
 
 
-@pytest.mark.parametrize("N", [70016, 600000])
-def test_rollout_plain_kernel_paths(N):
-    """N > 32 768 uses the one-wave-per-64-samples kernel (whole-horizon prefetch up to 2 waves/SIMD, 8-deep
-    ring beyond; XCD-affine chunks at N = 65 536, test_rollout_full_size_properties); N <= 32 768 without pos_stats
-    uses the dynamics/reward split kernel (other tests)."""
+@pytest.mark.parametrize("N", [16448, 20000, 40001, 70016, 600000])
+def test_rollout_workgroup_shapes(N):
+    """The pipelined kernel runs 1, 2 or 4 sample groups per workgroup (rollout.hip: pipe_groups): <= 256 groups -> 1,
+    <= 512 -> 2, beyond -> 4 (XCD-affine chunks at N = 65 536: test_rollout_full_size_properties); ragged tails in each."""
     s, p, rng = make_problem(seed=21, time=200)
     a = sample_actions(p, rng, N)
     core = SamplingCore(N, 32, 0.01, 0.99, device=DEV)

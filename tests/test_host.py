@@ -99,3 +99,27 @@ def test_world_size_2_gloo_exchange():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_OK" in r.stdout
+
+
+def test_covo_refuses_state_dependent_disturbance_models():
+    """quadjax's deterministic=True only zeroes dyn_noise_scale (quadrotor.py:234-235): under 'periodic' (Quad3D's own
+    default), 'sin', 'drag' and 'mixed' the reference rollout keeps a state/time-dependent force (free.py:10-58) that the
+    fused rollout and the Hessian do not model -- the controllers must refuse instead of diverging silently."""
+    import covo_mpc_amd as cm
+    for dt in ("periodic", "sin", "drag", "mixed"):
+        env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type=dt, disable_rollover_terminate=True)
+        import types
+        cp = types.SimpleNamespace(discount=1.0)
+        for mode in ("online", "offline"):  # refused before any device work: holds on a box without a GPU too
+            with pytest.raises(NotImplementedError, match="disturb_type"):
+                cm.controllers.CoVOController(env, cp, 1024, 32, 0.01, mode=mode)
+
+
+def test_rollover_flag_reaches_the_c_params():
+    import covo_mpc_amd as cm
+    p = cm.dynamics.EnvParams3D()
+    assert p.to_c().rollover_terminate == 0 and p.to_c(rollover_terminate=True).rollover_terminate == 1
+    from covo_mpc_amd.controllers.base import BaseController
+    for off in (True, False):
+        env = cm.envs.Quad3D(task="hovering", enable_randomizer=False, disturb_type="none", disable_rollover_terminate=off)
+        assert BaseController(env, None)._params_c(p).rollover_terminate == (0 if off else 1)

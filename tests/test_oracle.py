@@ -163,3 +163,27 @@ def test_c_hessian_matches_torch_ad():
     Rt = RT.hessian(s, p, a.reshape(-1).astype(np.float64), 32)
     assert np.abs(Rc - Rt).max() < 1e-12 and np.abs(Rc - Rc.T).max() == 0.0 and np.abs(Rc[124:]).max() == 0.0
     assert np.abs(Rt[13]).max() > 0
+
+
+def test_rollover_termination_oracle():
+    """envs/quadrotor.py:486-490: with the rollover test on, a state tipped past 90 degrees (quat[3] < cos(pi/4)) or spinning
+    faster than 100 rad/s is terminal; numpy and C restatements agree, and the flag changes nothing for upright samples."""
+    from oracle import c_oracle as CO
+    s, p, rng = make_problem(seed=5, time=20)
+    assert not R.is_terminal(s, p, rollover=True)
+    tipped = s.replace(quat=np.array([0.8, 0.0, 0.0, 0.6]))
+    assert R.is_terminal(tipped, p, rollover=True) and not R.is_terminal(tipped, p, rollover=False)
+    spinning = s.replace(omega=np.array([0.0, -100.5, 0.0]))
+    assert R.is_terminal(spinning, p, rollover=True) and not R.is_terminal(spinning, p)
+    edge = s.replace(quat=np.array([0.0, 0.0, np.sqrt(0.5), np.cos(np.pi / 4)]))
+    assert not R.is_terminal(edge, p, rollover=True)  # strict <
+    N = 64
+    a = np.clip(R.hover_action(p, 32, np.float64)[None] + np.array([0.3, 1.5, 1.5, 0.5]) * rng.normal(size=(N, 32, 4)), -1, 1)
+    c_np, rew_np, _ = R.rollout(s, p, a, 0.97, np.zeros(3), rollover=True)
+    c_c = CO.rollout(s, p, a, 0.97, np.zeros(3), dtype=np.float64, rollover=True)
+    assert np.abs(c_np - c_c).max() < 1e-9
+    c_off = CO.rollout(s, p, a, 0.97, np.zeros(3), dtype=np.float64)
+    assert np.any(np.abs(c_c - c_off) > 1e-3)
+    calm = np.clip(R.hover_action(p, 32, np.float64)[None] + 0.05 * rng.normal(size=(N, 32, 4)), -1, 1)
+    assert np.array_equal(CO.rollout(s, p, calm, 1.0, np.zeros(3), dtype=np.float64, rollover=True),
+                          CO.rollout(s, p, calm, 1.0, np.zeros(3), dtype=np.float64))
