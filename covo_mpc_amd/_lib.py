@@ -64,11 +64,16 @@ class BatchArgsC(C.Structure):
 COVO_MAX_ENVS = 64
 MODE_MPPI, MODE_COVO_ONLINE, MODE_COVO_OFFLINE = 0, 1, 2
 COVO_FLAG_NO_GRAPH = 2
+COVO_FLAG_SHARED_DEVICE = 4
+COVO_E_DEVICE = -4
+COVO_DEVSTAT_GRID_BARRIER = 1
 _SIGS = {
     "covo_last_error": (C.c_char_p, []),
     "covo_abi_version": (C.c_int, []),
     "covo_create": (C.c_int, [C.POINTER(ConfigC), C.POINTER(_P)]),
     "covo_destroy": (C.c_int, [_P]),
+    "covo_device_status": (C.c_int, [_P, C.c_int32]),
+    "covo_debug_raise_device_status": (C.c_int, [_P, C.c_int32, _P]),
     "covo_randn": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "covo_noise_gemm": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
     "covo_noise_blockdiag": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),

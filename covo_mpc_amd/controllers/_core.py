@@ -44,7 +44,7 @@ def exchange_records(record, gathered_flat, process_group=None):
 
 class SamplingCore:
     def __init__(self, N: int, H: int, lam: float, discount: float, device=None, process_group=None,
-                 compute_info: bool = True, trust_clipped: bool = False, use_graph=None):
+                 compute_info: bool = True, trust_clipped: bool = False, use_graph=None, shared_device=None):
         import torch
         if H != COVO_H:
             raise NotImplementedError(f"the fused kernels are built for H={COVO_H}, got H={H}")
@@ -80,7 +80,15 @@ class SamplingCore:
         if os.environ.get("COVO_NO_GRAPH") == "1":
             eager = True
         self.uses_graph = not eager
-        flags = (_lib.COVO_FLAG_ACTIONS_CLIPPED if trust_clipped else 0) | (_lib.COVO_FLAG_NO_GRAPH if eager else 0)
+        # shared_device (or COVO_SHARED_DEVICE=1): other processes / streams compete for this GPU, so no launch may rely on
+        # its workgroups being co-resident -- the Sigma chain's two persistent launches (grid barriers) are replaced by one
+        # launch per phase.  Without it a starved barrier times out after 0.2 s, that step's Sigma is NaN and the NEXT call
+        # on the handle fails with COVO_E_DEVICE (covo_device_status).
+        if shared_device is None:
+            shared_device = os.environ.get("COVO_SHARED_DEVICE") == "1"
+        self.shared_device = bool(shared_device)
+        flags = ((_lib.COVO_FLAG_ACTIONS_CLIPPED if trust_clipped else 0) | (_lib.COVO_FLAG_NO_GRAPH if eager else 0) |
+                 (_lib.COVO_FLAG_SHARED_DEVICE if self.shared_device else 0))
         cfg = _lib.ConfigC(self.n_local, self.H, 4, self.lam, self.discount, flags)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -105,6 +113,10 @@ class SamplingCore:
                 self.h = None
         except Exception:
             pass
+
+    def device_status(self, clear: bool = False) -> int:
+        """Sticky COVO_DEVSTAT_* bits raised by kernels of earlier calls (0 = fine); no synchronisation."""
+        return int(self.lib.covo_device_status(self.h, 1 if clear else 0))
 
     # -- individual kernels -------------------------------------------------------------------
     def stream(self):

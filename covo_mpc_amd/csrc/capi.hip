@@ -22,6 +22,25 @@ void covo_set_error(const char *fmt, ...)
         }                             \
     } while (0)
 
+// a kernel of an earlier call raised a sticky status bit (covo_device_status): refuse to pile more work on poisoned data
+#define CHECK_DEVICE(h, what)                                                                                                \
+    do {                                                                                                                     \
+        const int st_ = *(volatile int *)(h)->status_host;                                                                   \
+        if (st_ != 0) {                                                                                                      \
+            covo_set_error("%s: device status 0x%x from an earlier call%s (covo_device_status)", what, st_,                 \
+                           (st_ & COVO_DEVSTAT_GRID_BARRIER)                                                                 \
+                               ? ": a grid barrier of the Sigma chain timed out -- the GPU is shared with other work; that " \
+                                 "call's Sigma / L / mean are NaN.  Create the handle with COVO_FLAG_SHARED_DEVICE"        \
+                               : "");                                                                                        \
+            return COVO_E_DEVICE;                                                                                            \
+        }                                                                                                                    \
+    } while (0)
+
+__global__ void raise_status_kernel(int *status, int bits)
+{
+    __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 extern "C" {
 
 const char *covo_last_error(void) { return g_err; }
@@ -49,6 +68,9 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     COVO_CHECK_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     COVO_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     COVO_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    COVO_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->status_host), sizeof(int), hipHostMallocMapped));
+    *h->status_host = 0;
+    COVO_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->status_dev), h->status_host, 0));
     *out = h;
     return 0;
 }
@@ -75,10 +97,27 @@ int covo_destroy(covo_handle_t h)
     DESTROY(hipEventDestroy(h->ev_fork));
     DESTROY(hipEventDestroy(h->ev_join));
     DESTROY(hipStreamDestroy(h->side_stream));
+    DESTROY(hipHostFree(h->status_host));
 #undef DESTROY
     (void)hipGetLastError();  // never leave a sticky error behind for the caller's runtime (torch checks it)
     delete h;
     return rc;
+}
+
+int covo_device_status(covo_handle_t h, int32_t clear)
+{
+    if (!h) return COVO_E_NOHANDLE;
+    const int st = *(volatile int *)h->status_host;
+    if (clear) *(volatile int *)h->status_host = 0;
+    return st;
+}
+
+int covo_debug_raise_device_status(covo_handle_t h, int32_t bits, void *stream)
+{
+    REQUIRE(h, "covo_debug_raise_device_status: null handle");
+    hipLaunchKernelGGL(raise_status_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->status_dev, (int)bits);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int covo_randn(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t sample_offset, int32_t n_samples, int32_t n_cols,
@@ -93,6 +132,7 @@ int covo_noise_gemm(covo_handle_t h, const float *L, const float *mu, const floa
                     void *stream)
 {
     REQUIRE(h, "covo_noise_gemm: null handle");
+    CHECK_DEVICE(h, "covo_noise_gemm");
     REQUIRE(L && mu && eps && a_out && N > 0, "covo_noise_gemm: bad argument");
     return launch_noise_gemm(L, mu, eps, 0u, 0u, 0, N, a_out, (hipStream_t)stream);
 }
@@ -101,6 +141,7 @@ int covo_noise_gemm_philox(covo_handle_t h, const float *L, const float *mu, uin
                            int64_t sample_offset, int32_t N, float *a_out, void *stream)
 {
     REQUIRE(h, "covo_noise_gemm_philox: null handle");
+    CHECK_DEVICE(h, "covo_noise_gemm_philox");
     REQUIRE(L && mu && a_out && N > 0, "covo_noise_gemm_philox: bad argument");
     return launch_noise_gemm(L, mu, nullptr, key0, key1, sample_offset, N, a_out, (hipStream_t)stream);
 }
@@ -126,6 +167,7 @@ int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj
                       float *cost_out, float *groupmin, double *pos_stats, void *stream)
 {
     REQUIRE(h, "covo_rollout_cost: null handle");
+    CHECK_DEVICE(h, "covo_rollout_cost");
     REQUIRE(state && pos_traj && vel_traj && params && a && cost_out && T > 0, "covo_rollout_cost: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_rollout_cost: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
     return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount,
@@ -172,6 +214,7 @@ int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int3
                         float *partial_out, void *stream)
 {
     REQUIRE(h, "covo_softmax_reduce: null handle");
+    CHECK_DEVICE(h, "covo_softmax_reduce");
     REQUIRE(cost && a && partial_out, "covo_softmax_reduce: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_reduce: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
     return launch_softmax_reduce(h, cost, a, N, groupmin, (N + 63) / 64, partial_out, nullptr, 1.0f, nullptr,
@@ -182,6 +225,7 @@ int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int3
                         const float *a_mean_old, float gamma_mean, float *a_mean_out, void *stream)
 {
     REQUIRE(h, "covo_softmax_update: null handle");
+    CHECK_DEVICE(h, "covo_softmax_update");
     REQUIRE(cost && a && a_mean_old && a_mean_out, "covo_softmax_update: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_update: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
     return launch_softmax_reduce(h, cost, a, N, groupmin, (N + 63) / 64, nullptr, a_mean_old, gamma_mean, a_mean_out,
@@ -192,6 +236,7 @@ int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a
                float *a_mean_out, void *stream)
 {
     REQUIRE(h, "covo_merge: null handle");
+    CHECK_DEVICE(h, "covo_merge");
     REQUIRE(partials && a_mean_old && a_mean_out && G > 0, "covo_merge: bad argument");
     return launch_merge(partials, G, h->cfg.lam, a_mean_old, gamma_mean, a_mean_out, (hipStream_t)stream);
 }
@@ -207,10 +252,12 @@ int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, con
                  const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream)
 {
     REQUIRE(h, "covo_hessian: null handle");
+    CHECK_DEVICE(h, "covo_hessian");
     REQUIRE(state && pos_traj && vel_traj && params && a_mean && R_out && T > 0 && batch > 0, "covo_hessian: bad argument");
     const size_t need = hessian_workspace_bytes(batch);
     if (need > h->ws_hess_bytes) {  // only for batch sizes not seen before (never inside the steady-state step)
         COVO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        step_graphs_drop(h);  // captured step graphs hold the old address
         (void)hipFree(h->ws_hess);
         h->ws_hess = nullptr;
         h->ws_hess_bytes = 0;
@@ -232,17 +279,20 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
                void *stream)
 {
     REQUIRE(h, "covo_sigma: null handle");
+    CHECK_DEVICE(h, "covo_sigma");
     REQUIRE(R && L_out && batch > 0 && sample_sigma > 0.0f, "covo_sigma: bad argument");
     const size_t need = sigma_ns_workspace_bytes(batch);
     if (need > h->ws_sigma_bytes) {  // only for batch sizes not seen before (never inside the steady-state step)
         COVO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        step_graphs_drop(h);  // captured step graphs hold the old address
         (void)hipFree(h->ws_sigma);
         h->ws_sigma = nullptr;
         h->ws_sigma_bytes = 0;
         COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, need));
         h->ws_sigma_bytes = need;
     }
-    return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream);
+    return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream, nullptr, h->status_dev,
+                           (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0);
 }
 
 int covo_debug_set_ns_tail(int n_squarings, int n_iters)
@@ -311,6 +361,7 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
                      float obs_noise_scale, float *log, uint32_t *rng, int32_t n_steps, void *stream)
 {
     REQUIRE(h, "covo_run_episode: null handle");
+    CHECK_DEVICE(h, "covo_run_episode");
     REQUIRE(params && args && state_true && acc_traj && rng && n_steps > 0, "covo_run_episode: bad argument");
     REQUIRE(args->derive_keys == 1, "covo_run_episode: args->derive_keys must be 1 (the controller key is the raw rng_act)");
     REQUIRE(args->partial_out == nullptr, "covo_run_episode: a sample-sharded step needs its all-gather between the calls");
@@ -342,6 +393,7 @@ int covo_mpc_step_batched(covo_handle_t h, const covo_batch_args *args, const co
                           void *stream)
 {
     REQUIRE(h, "covo_mpc_step_batched: null handle");
+    CHECK_DEVICE(h, "covo_mpc_step_batched");
     REQUIRE(args && params && keys, "covo_mpc_step_batched: null argument");
     REQUIRE(args->n_envs > 0 && args->n_envs <= COVO_MAX_ENVS, "covo_mpc_step_batched: n_envs=%d outside (0, %d]", args->n_envs,
             COVO_MAX_ENVS);
@@ -389,6 +441,7 @@ int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_ste
                   const float *f_disturb_shared, void *stream)
 {
     REQUIRE(h, "covo_mpc_step: null handle");
+    CHECK_DEVICE(h, "covo_mpc_step");
     REQUIRE(params && args, "covo_mpc_step: null argument");
     REQUIRE(args->mode >= 0 && args->mode <= 2, "covo_mpc_step: mode=%d", args->mode);
     REQUIRE(args->n_samples > 0 && args->n_samples <= h->cfg.n_local, "covo_mpc_step: n_samples=%d outside (0, %d]",

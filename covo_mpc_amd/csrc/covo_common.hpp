@@ -26,6 +26,8 @@ struct covo_ctx {
     hipStream_t side_stream;  // forked work inside one call (joined before the call's last kernel)
     hipEvent_t ev_fork, ev_join;
     int max_red_blocks;
+    int *status_host;         // host-mapped sticky status word (COVO_DEVSTAT_* bits written by kernels), see covo_device_status
+    int *status_dev;          // its device address
 };
 
 void covo_set_error(const char *fmt, ...);
@@ -118,9 +120,12 @@ int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, f
 size_t sigma_ns_workspace_bytes(int batch);
 struct EpsGenArgs;  // eps_tiles.hpp
 // gen != null (fused step): the finalize launch also draws the step's epsilon in tile order (eps_tiles.hpp)
+// status: the handle's sticky status word (a timed-out grid barrier raises COVO_DEVSTAT_GRID_BARRIER there, next to the NaN
+// outputs); persistent_ok = false (COVO_FLAG_SHARED_DEVICE): every phase its own launch
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, const EpsGenArgs *gen = nullptr);
+                    hipStream_t s, const EpsGenArgs *gen = nullptr, int *status = nullptr, bool persistent_ok = true);
 void step_state_destroy(covo_ctx *h);
+void step_graphs_drop(covo_ctx *h);  // before re-allocating h->ws_sigma / h->ws_hess: captured graphs hold their addresses
 void batch_state_destroy(covo_ctx *h);
 int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,
                            hipStream_t s);

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
                                                           const double *__restrict__ Zt0all, const double *__restrict__ Zt1all,
                                                           double *__restrict__ scall, float sample_sigma,
                                                           float *__restrict__ Sigma_out, float *__restrict__ L_out, int batch,
-                                                          const EpsGenArgs gen)
+                                                          const EpsGenArgs gen, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[512];
@@ -742,6 +742,8 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     const double log_c = 0.5 * (2.0 * n * (log((double)sample_sigma) * 2.0) + logdetB) / n;
     // a timed-out grid barrier (ns_grid_barrier) left Z unconverged: fail like the reference's numerical failures do, in NaNs
     const double poison = (s[SC_BARFAIL] != 0.0) ? __builtin_nan("") : 1.0;
+    if (tid == 0 && s[SC_BARFAIL] != 0.0 && status != nullptr)  // ... and loudly: the next C call on this handle fails (capi.hip)
+        __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const double cz = poison * exp(log_c) / sqrt(scale), sq = sqrt(cz);
     tk[3] = clock64();
     // a_cov = cz sym(Z) needs Z once more: its 32 loads go out first and land while L is written from LDS
@@ -783,7 +785,7 @@ int g_ns_tail_iters = 3, g_ns_tail_squarings = 6;
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, const EpsGenArgs *gen)
+                    hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok)
 {
     double *ws = reinterpret_cast<double *>(workspace);
     const size_t M = (size_t)batch * SN * SN;
@@ -802,7 +804,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     hipLaunchKernelGGL(ns_prep_kernel, dim3(8, batch), dim3(256), 0, s, R, A, sc);
     hipLaunchKernelGGL(ns_square_kernel<true>, dim3(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0);
     // batch 1: the remaining squarings / iterations run inside persistent launches (co-residency: 36 / 128 workgroups)
-    int sq_tail = (batch == 1) ? g_ns_tail_squarings : 0;
+    int sq_tail = (batch == 1 && persistent_ok) ? g_ns_tail_squarings : 0;
     if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
     const int sq_sep = NS_SQUARINGS - sq_tail;
     double *xi = X0, *xo = X1;
@@ -815,7 +817,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc);
     if (g_dbg_sigma_stages < 3) return 0;
     hipLaunchKernelGGL(ns_first_kernel, dim3(64, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);
-    int n_tail = (batch == 1) ? g_ns_tail_iters : 0;
+    int n_tail = (batch == 1 && persistent_ok) ? g_ns_tail_iters : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
     const int n_sep = NS_ITERS - n_tail;
     for (int i = 1; i < n_sep; ++i) {
@@ -850,7 +852,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         if (passengers > 255) passengers = 255;  // ... at most one workgroup on every other CU, waves stride over tiles
     }
     hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch + passengers), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma,
-                       Sigma, L, batch, g);
+                       Sigma, L, batch, g, status);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -213,7 +213,8 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         gen.dyn = st->dyn;
         gen.sample_offset = a.sample_offset;
         gen.N = N;
-        if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen))) return rc;
+        if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen, h->status_dev,
+                                             (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0))) return rc;
         if (ahead) {
             if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, reinterpret_cast<const float *>(st->eps_tiled), 0, 0,
                                                    a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true)))
@@ -434,6 +435,27 @@ static void batch_state_free(BatchState *b)
     b->dyn = nullptr; b->a_mean_shift = nullptr; b->R = nullptr; b->Sigma = b->L = nullptr; b->consts = nullptr;
     b->ro_args = nullptr; b->partials = nullptr;
 }
+// The captured graphs (fused step, env-batched step) hold the addresses of h->ws_sigma / h->ws_hess in their kernel nodes:
+// whoever re-allocates a workspace (a larger batch through covo_sigma / covo_hessian / covo_mpc_step_batched) calls this
+// first, so that a later covo_mpc_step re-captures instead of replaying launches that point into freed memory.
+void step_graphs_drop(covo_ctx *h)
+{
+    StepState *st = reinterpret_cast<StepState *>(h->step);
+    if (st && st->have_graph) {
+        (void)hipGraphExecDestroy(st->exec);
+        (void)hipGraphDestroy(st->graph);
+        st->have_graph = false;
+    }
+    if (st) st->have_key = false;  // the next call runs eagerly, the one after captures again
+    BatchState *b = reinterpret_cast<BatchState *>(h->batch);
+    if (b && b->have_graph) {
+        (void)hipGraphExecDestroy(b->exec);
+        (void)hipGraphDestroy(b->graph);
+        b->have_graph = false;
+    }
+    if (b) b->have_key = false;
+}
+
 void batch_state_destroy(covo_ctx *h)
 {
     BatchState *b = reinterpret_cast<BatchState *>(h->batch);
@@ -456,7 +478,8 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
                              b->consts, (size_t)a.T * 3)))
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
-    if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s))) return rc;
+    if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
+                              (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0))) return rc;
     if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E))) return rc;
     if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, s))) return rc;
     const int G = rollout_workgroups(N, false, E);
@@ -515,6 +538,7 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
                               brec ? b->partials + (size_t)e * bG * COVO_PARTIAL_FLOATS : nullptr, h->cfg.lam);
         COVO_CHECK_HIP(hipMemcpy(b->ro_args, b->ro_args_host.data(), b->ro_args_host.size(), hipMemcpyHostToDevice));
         const size_t need_s = sigma_ns_workspace_bytes(E), need_h = hessian_workspace_bytes(E);
+        if (need_s > h->ws_sigma_bytes || need_h > h->ws_hess_bytes) step_graphs_drop(h);  // captured launches point into them
         if (need_s > h->ws_sigma_bytes) {
             (void)hipFree(h->ws_sigma);
             h->ws_sigma = nullptr;

@@ -54,6 +54,9 @@ extern "C" {
                                        clipped to [-1,1] (true for covo_noise_* outputs): skip step_env's re-clip */
 
 #define COVO_FLAG_NO_GRAPH 2         /* covo_config.flags: covo_mpc_step always launches eagerly (no hipGraph) */
+#define COVO_FLAG_SHARED_DEVICE 4    /* covo_config.flags: other processes / streams compete for this GPU: no launch may depend on
+                                        its workgroups being co-resident (the Sigma chain then runs every phase as its own
+                                        launch instead of folding the often-idle ones into two persistent launches) */
 
 #define COVO_MODE_MPPI 0
 #define COVO_MODE_COVO_ONLINE 1
@@ -62,6 +65,10 @@ extern "C" {
 #define COVO_E_BADARG (-1)
 #define COVO_E_NOHANDLE (-2)
 #define COVO_E_UNSUPPORTED (-3)
+#define COVO_E_DEVICE (-4)           /* a kernel of an EARLIER call on this handle reported a failure (covo_device_status) */
+
+#define COVO_DEVSTAT_GRID_BARRIER 1  /* a grid barrier of the Sigma chain's persistent launches timed out (its workgroups were not
+                                        co-resident within 0.2 s: GPU shared with other work); that call's Sigma / L are NaN */
 
 typedef struct covo_ctx *covo_handle_t;
 
@@ -97,6 +104,12 @@ int covo_abi_version(void);
 /* Replaces nothing in the reference: lifetime of the opaque handle + workspace. */
 int covo_create(const covo_config *cfg, covo_handle_t *out);
 int covo_destroy(covo_handle_t h);
+
+/* Sticky device-side status of the handle: COVO_DEVSTAT_* bits raised by kernels of earlier (asynchronous) calls, read from
+ * host-mapped memory without synchronising.  While it is non-zero every compute entry point returns COVO_E_DEVICE instead of
+ * enqueueing more work on poisoned data; clear != 0 resets it (after the caller has dealt with the failed step, e.g. by
+ * re-creating the handle with COVO_FLAG_SHARED_DEVICE).  Returns the status before clearing, or COVO_E_NOHANDLE. */
+int covo_device_status(covo_handle_t h, int32_t clear);
 
 /* Counter-based N(0,1) fill (Philox4x32-10 + Box-Muller) keyed by
  * (key0, key1, global sample id, column): results do not depend on how samples are
@@ -324,6 +337,10 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
  * prep+squarings, +Ritz, +Newton-Schulz, +finalize.  Uses the buffers in `args` exactly like covo_mpc_step. */
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
                          int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream);
+
+/* Test hook: a one-thread kernel on `stream` ORs `bits` into the handle's status word the way a failing kernel would
+ * (device store to host-mapped memory); covo_device_status / COVO_E_DEVICE can then be exercised without starving a barrier. */
+int covo_debug_raise_device_status(covo_handle_t h, int32_t bits, void *stream);
 
 /* Profiling aid: covo_rollout_cost `reps` times back to back on `stream` between two events; *us_out = GPU microseconds
  * per launch (what bench.py reports as roofline.launch_us: a Python loop of single calls is host-bound below ~10 us per

@@ -1,7 +1,10 @@
 """world_size-2 worker for tests/test_gpu_parity.py::test_two_ranks_one_gpu: two processes share cuda:0 and run the
 sample-sharded controller (covo_mpc_step with partial_out -> all-gather of the 132-float records -> covo_merge) over
 gloo; every rank checks the sharded result against an unsharded controller fed the same keys."""
+import os
 import sys
+
+os.environ["COVO_SHARED_DEVICE"] = "1"  # two ranks share cuda:0: no launch may rely on co-resident workgroups (_core.py)
 
 import numpy as np
 import torch

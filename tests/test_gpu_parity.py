@@ -738,6 +738,71 @@ def test_two_ranks_one_gpu(name):
     assert "DIST_GPU_OK" in r.stdout
 
 
+def test_device_status_is_sticky_and_refuses_further_work():
+    """A kernel-side failure (the Sigma chain's grid barrier timing out on a shared GPU) must not stay silent: it raises a
+    bit in host-mapped memory, the next compute call on the handle returns COVO_E_DEVICE, clearing re-arms the handle."""
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    assert core.device_status() == 0
+    A = np.random.default_rng(0).normal(size=(128, 128))
+    Rm = torch.from_numpy(0.05 * (A + A.T)).to(DEV).reshape(1, 128, 128)
+    core.sigma(Rm, 0.5)
+    _lib.check(core.lib.covo_debug_raise_device_status(core.h, _lib.COVO_DEVSTAT_GRID_BARRIER, core.stream()), "raise")
+    torch.cuda.synchronize()
+    assert core.device_status() == _lib.COVO_DEVSTAT_GRID_BARRIER
+    with pytest.raises(_lib.CovoError, match="grid barrier"):
+        core.sigma(Rm, 0.5)
+    with pytest.raises(_lib.CovoError, match="device status"):
+        core.noise_gemm_philox(torch.eye(128, device=DEV), torch.zeros(128, device=DEV), (1, 2))
+    assert core.device_status(clear=True) == _lib.COVO_DEVSTAT_GRID_BARRIER and core.device_status() == 0
+    S2, L2 = core.sigma(Rm, 0.5)
+    assert torch.isfinite(S2).all() and torch.isfinite(L2).all()
+
+
+def test_shared_device_flag_runs_the_chain_phase_by_phase_with_identical_results():
+    """COVO_FLAG_SHARED_DEVICE: no persistent launches (grid barriers) in the Sigma chain; same Sigma and L bit for bit."""
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(128, 128))
+    Rm = torch.from_numpy(0.5 * (A + A.T) + np.diag(rng.uniform(0, 30, 128))).to(DEV).reshape(1, 128, 128)
+    c0 = SamplingCore(64, 32, 0.01, 1.0, device=DEV)
+    c1 = SamplingCore(64, 32, 0.01, 1.0, device=DEV, shared_device=True)
+    S0, L0 = c0.sigma(Rm, 0.5)
+    S1, L1 = c1.sigma(Rm, 0.5)
+    assert torch.equal(S0, S1) and torch.equal(L0, L1) and torch.isfinite(S0).all()
+
+
+def test_workspace_growth_drops_the_captured_step_graph(monkeypatch):
+    """A captured covo_mpc_step graph holds the Sigma / Hessian workspace addresses; a later larger-batch covo_sigma /
+    covo_hessian re-allocates them.  The handle must re-capture instead of replaying launches into freed memory."""
+    monkeypatch.setenv("COVO_GRAPH", "1")
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params
+    cg, cpg = cm.envs.get_controller(env, "covo-online", "N1024_H32_lam0.01", device=DEV)
+    monkeypatch.setenv("COVO_GRAPH", "0")
+    monkeypatch.setenv("COVO_NO_GRAPH", "1")
+    ce, cpe = cm.envs.get_controller(env, "covo-online", "N1024_H32_lam0.01", device=DEV)
+    assert cg.core.uses_graph and not ce.core.uses_graph
+    obs, info, state = env.reset(cr.PRNGKey(2), params)
+    key = cr.PRNGKey(9)
+    rng = np.random.default_rng(1)
+    for step in range(7):
+        key, k_act, k_step = cr.split(key, 3)
+        ug, cpg, _ = cg(obs, state, params, k_act, cpg, info)
+        ue, cpe, _ = ce(obs, state, params, k_act, cpe, info)
+        assert torch.equal(cpg.a_mean, cpe.a_mean) and torch.equal(cpg.a_cov, cpe.a_cov), step
+        if step == 3:  # graph captured at step 1, replayed since: now grow both workspaces under it
+            A = rng.normal(size=(5, 128, 128))
+            Rb = torch.from_numpy(0.05 * (A + np.transpose(A, (0, 2, 1)))).to(DEV)
+            S, L = cg.core.sigma(Rb, 0.5, batch=5)
+            assert torch.isfinite(S).all()
+            ds = info["noisy_state"].to_device(DEV)
+            Hs = cg.core.hessian(ds.packed.repeat(5), ds, params.to_c(), cpg.a_mean.reshape(-1).repeat(5), batch=5)
+            assert torch.isfinite(Hs).all()
+        obs, state, reward, done, info = env.step(k_step, state, ue.cpu().numpy(), params)
+
+
 def test_errors_are_reported_through_the_abi():
     core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
     with pytest.raises(_lib.CovoError):
