@@ -128,15 +128,24 @@ def closed_loop(env, controller, params, T):
     return res
 
 
-def pmc_traffic(n_local):
-    """HBM-side bytes per rollout launch from the committed rocprofv3 --pmc passes of this command
-    (profiles/r01_bench_pmc_summary.json, scripts/pmc_summary.py); null when the shard size differs."""
+PMC_SUMMARY = os.path.join("profiles", "r02_bench_pmc_summary.json")
+
+
+def pmc_traffic(args, n_local):
+    """HBM-side bytes per rollout launch.  PMC counters cannot be read inside this process; the number comes from the two
+    separate `rocprofv3 --pmc` passes over THIS command that scripts/profile_bench.sh committed (profiles/, with the
+    commit they were taken at), and is only attached when the run is that command's workload: default controller,
+    N_local = 65 536, no --info.  -> (bytes or None, provenance or None)."""
+    if args.controller != "covo-online" or args.info or n_local != 65536:
+        return None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             d = json.load(f)
-        return d["traffic_bytes_per_launch"] if n_local == 65536 else None
+        src = {"kind": "committed_profile", "file": PMC_SUMMARY, "command": d.get("command"), "commit": d.get("commit"),
+               "kernel": d.get("kernel")}
+        return d["traffic_bytes_per_launch"], src
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -262,6 +271,7 @@ def main():
         n_local = core.n_local
         alg_bytes = n_local * ROLLOUT_BYTES_PER_SAMPLE
         achieved = alg_bytes / (rollout_b2b_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args, n_local)
         out = {
             "metric": "mpc_control_steps_per_sec", "value": args.steps / elapsed, "unit": "control-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -271,8 +281,9 @@ def main():
                                    f"{n_local}, one 132-float all-gather per step)",
                        "controller": args.controller, "N_global": args.N, "N_local": n_local, "H": H,
                        "pos_stats_info": bool(args.info)},
-            "roofline": {"bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_local),
+            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.info else "rollout_pipe3_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_us": 1e3 * rollout_b2b_ms,
                          "in_step_us": in_step_us},
         }

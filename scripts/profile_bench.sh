@@ -16,5 +16,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -o b
 cd "$R"
 python3 scripts/phase_times.py > gpurun_out/phase_times.log 2>/dev/null
 python3 scripts/kbench.py > gpurun_out/kbench.log 2>/dev/null
+python3 scripts/pmc_summary.py gpurun_out r02 > gpurun_out/pmc_summary.log 2>&1
 find gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" | head -20
 tail -c 600 gpurun_out/bench_line.json
