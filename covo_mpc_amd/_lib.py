@@ -75,6 +75,7 @@ _SIGS = {
     "covo_device_status": (C.c_int, [_P, C.c_int32]),
     "covo_debug_raise_device_status": (C.c_int, [_P, C.c_int32, _P]),
     "covo_randn": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    "covo_randn_jax": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "covo_noise_gemm": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
     "covo_noise_blockdiag": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
     "covo_noise_gemm_philox": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, _P, _P]),

@@ -140,6 +140,13 @@ class SamplingCore:
                                   self.stream()), "covo_randn")
         return self.eps
 
+    def randn_jax(self, act_key, mppi=False):
+        """epsilon of this shard from jax.random's bitstream (random_jax.py / csrc/rng_jax.hip): what quadjax's
+        split(act_key, N) + normal draws would be for the same key."""
+        check(self.lib.covo_randn_jax(self.h, int(act_key[0]), int(act_key[1]), self.N, self.offset, self.n_local,
+                                      1 if mppi else 0, ptr(self.eps), self.stream()), "covo_randn_jax")
+        return self.eps
+
     def noise_gemm(self, L, mu, eps=None):
         eps = self.eps if eps is None else eps
         check(self.lib.covo_noise_gemm(self.h, ptr(L), ptr(mu), ptr(eps), self.n_local, ptr(self.a), self.stream()),

@@ -45,6 +45,8 @@ class CoVOController(BaseController):
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
         self.materialize_eps = False  # True: epsilon is written to HBM and the kernels are called one by one (parity)
+        self.noise_stream = "philox"  # "jax": keys split and epsilon drawn from jax.random's own bitstream (random_jax.py,
+                                      # csrc/rng_jax.hip; kernel-by-kernel path) -- replayable on a JAX-equipped machine
         self.alias_outputs = False    # True: returned a_mean / a_cov alias the controller's buffers (no clones)
         self.action_dim = self.env.action_dim
         if mode not in ("online", "offline"):
@@ -171,7 +173,9 @@ class CoVOController(BaseController):
         params_c = self._params_c(env_params)
         if self.mode == "offline" and control_params.a_chol_offline is None:
             raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
-        if not self.materialize_eps:
+        if self.noise_stream not in ("philox", "jax"):
+            raise ValueError(f"noise_stream={self.noise_stream!r}")
+        if not self.materialize_eps and self.noise_stream == "philox":
             # ---- production path: the whole step is one C call / one hipGraph replay (csrc/step.hip)
             # rng_act, act_key = split(rng_act) (covo.py:212) and the unused step_key (covo.py:225: deterministic
             # rollouts draw nothing) are derived on the device from the raw key (step.hip: step_begin_kernel)
@@ -208,8 +212,13 @@ class CoVOController(BaseController):
             a_cov = control_params.a_cov_offline.index_select(0, t_idx)[0]
             L = control_params.a_chol_offline.index_select(0, t_idx)[0]
         control_params = control_params.replace(a_cov=a_cov)
-        rng_act, act_key = crandom.split(rng_act)  # covo.py:212-224
-        core.randn(act_key)
+        if self.noise_stream == "jax":  # covo.py:212-220 on jax's own threefry stream
+            from .. import random_jax
+            rng_act, act_key = random_jax.split(rng_act)
+            core.randn_jax(act_key)
+        else:
+            rng_act, act_key = crandom.split(rng_act)  # covo.py:212-224
+            core.randn(act_key)
         core.noise_gemm(L, a_mean)
         rng_act, step_key = crandom.split(rng_act)  # covo.py:225-263: deterministic=True -> no disturbance draw
         core.rollout(dstate, params_c, (0.0, 0.0, 0.0), core.compute_info)

@@ -34,6 +34,7 @@ class MPPIController(BaseController):
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
         self.materialize_eps = False  # True: epsilon is written to HBM and the kernels are called one by one (parity)
+        self.noise_stream = "philox"  # "jax": sampling keys / epsilon from jax.random's own bitstream (random_jax.py)
         self.alias_outputs = False    # True: returned a_mean / a_cov alias the controller's buffers (no clones)
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
@@ -66,7 +67,9 @@ class MPPIController(BaseController):
             raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0, mppi.py:119-125) is not built; "
                                       "quadjax's own factory fixes gamma_sigma = 0 (envs/quadrotor.py:715)")
         dstate = as_device_state(info["noisy_state"], core.device)  # mppi.py:40
-        if not self.materialize_eps:
+        if self.noise_stream not in ("philox", "jax"):
+            raise ValueError(f"noise_stream={self.noise_stream!r}")
+        if not self.materialize_eps and self.noise_stream == "philox":
             # ---- production path: one C call / one hipGraph replay (csrc/step.hip)
             from .. import _lib
             # rng_act, act_key = split(rng_act) (mppi.py:53); rng_act, step_key = split(rng_act) and the ONE shared
@@ -94,9 +97,14 @@ class MPPIController(BaseController):
         a_mean = core.shift_mean(control_params.a_mean.reshape(-1)).view(self.H, 4)  # mppi.py:43-49
         a_cov = torch.cat([control_params.a_cov[1:], control_params.a_cov[-1:]], dim=0).contiguous()
         control_params = control_params.replace(a_mean=a_mean, a_cov=a_cov)
-        rng_act, act_key = crandom.split(rng_act)  # mppi.py:53-66
         Ls = core.cholesky(a_cov, 4, self.H)
-        core.randn(act_key)
+        if self.noise_stream == "jax":  # mppi.py:53-60 on jax's own threefry stream
+            from .. import random_jax
+            rng_act, act_key = random_jax.split(rng_act)
+            core.randn_jax(act_key, mppi=True)
+        else:
+            rng_act, act_key = crandom.split(rng_act)  # mppi.py:53-66
+            core.randn(act_key)
         core.noise_blockdiag(Ls, a_mean)
         rng_act, step_key = crandom.split(rng_act)  # mppi.py:69-106
         f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)

@@ -128,6 +128,15 @@ int covo_randn(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t sample_off
     return launch_randn(key0, key1, sample_offset, n_samples, n_cols, eps_out, (hipStream_t)stream);
 }
 
+int covo_randn_jax(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t n_total, int64_t sample_offset, int32_t n_samples,
+                   int32_t mppi, float *eps_out, void *stream)
+{
+    REQUIRE(h, "covo_randn_jax: null handle");
+    REQUIRE(eps_out && n_samples > 0 && sample_offset >= 0 && n_total >= sample_offset + n_samples, "covo_randn_jax: bad argument");
+    REQUIRE(n_total < (1ll << 31), "covo_randn_jax: n_total=%lld: jax's iota(2 N) counters are 32-bit", (long long)n_total);
+    return launch_randn_jax(key0, key1, n_total, sample_offset, n_samples, mppi, eps_out, (hipStream_t)stream);
+}
+
 int covo_noise_gemm(covo_handle_t h, const float *L, const float *mu, const float *eps, int32_t N, float *a_out,
                     void *stream)
 {

@@ -81,6 +81,7 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // launch entry points implemented in the .hip files (host functions)
 int launch_randn(uint32_t k0, uint32_t k1, int64_t off, int n_samples, int n_cols, float *out, hipStream_t s);
+int launch_randn_jax(uint32_t k0, uint32_t k1, int64_t n_total, int64_t off, int n_samples, int mppi, float *out, hipStream_t s);
 // eps == null: epsilon is drawn in-kernel from (k0, k1, sample_offset + n) (rng_device.hpp)
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr, const float *state_for_time = nullptr,

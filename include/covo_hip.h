@@ -120,6 +120,16 @@ int covo_device_status(covo_handle_t h, int32_t clear);
 int covo_randn(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t sample_offset, int32_t n_samples,
                int32_t n_cols, float *eps_out, void *stream);
 
+/* The same draws from jax.random's OWN bitstream (threefry2x32-20, jax 0.4.x default layout), so that a
+ * JAX-equipped machine can replay a run without shipping epsilon:  row n of eps_out (float[n_samples][128]) is
+ *   mppi == 0:  jax.random.normal(jax.random.split(act_key, n_total)[sample_offset + n], (128,))        (covo.py:213-220)
+ *   mppi != 0:  concat_t jax.random.normal(jax.random.split(jax.random.split(act_key, n_total)[..], H)[t], (4,))  (mppi.py:53-60)
+ * with act_key = (key0, key1).  Twin of covo_mpc_amd/random_jax.py, which is pinned to the Random123 threefry vectors and to
+ * the values jax's documentation prints; ~2x the cost of covo_randn, meant for replay / parity runs (the kernel-by-kernel
+ * path), not for the fused step. */
+int covo_randn_jax(covo_handle_t h, uint32_t key0, uint32_t key1, int64_t n_total, int64_t sample_offset, int32_t n_samples,
+                   int32_t mppi, float *eps_out, void *stream);
+
 /* a = clip(mu + L eps, -1, 1): jax.random.multivariate_normal's `mean + factor @ eps`
  * followed by jnp.clip (controllers/covo.py:215-224).  fp32 MFMA GEMM
  * (v_mfma_f32_32x32x2_f32; each dot product is an ascending-k fmaf chain, bit-exact).

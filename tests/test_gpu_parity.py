@@ -65,6 +65,28 @@ def test_randn_matches_philox_oracle_and_is_shard_invariant():
     assert np.abs(z2 - rng_np.randn(123, 456, 1 << 33, 64, 128)).max() < 2e-5
 
 
+def test_randn_jax_equals_the_numpy_twin_and_is_shard_invariant():
+    """covo_randn_jax (csrc/rng_jax.hip) against covo_mpc_amd/random_jax.py, which is pinned to jax's published outputs
+    (tests/test_host.py): the threefry integers are exact, the normals agree to the last ulp of log1p / sqrt."""
+    from covo_mpc_amd import random_jax as rj
+    N = 1000
+    key = rj.split(rj.PRNGKey(1))[1]
+    core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
+    z = core.randn_jax(key).cpu().numpy().copy()
+    ref = rj.controller_epsilon(key, N)
+    assert np.abs(z - ref).max() < 2e-6 and np.mean(z == ref) > 0.9  # bit-equal except where log1p rounds the other way
+    assert abs(z.mean()) < 1e-2 and abs(z.std() - 1) < 1e-2
+    zm = core.randn_jax(key, mppi=True).cpu().numpy().copy()
+    refm = rj.controller_epsilon_mppi(key, N, n_samples=64)
+    assert np.abs(zm[:64] - refm).max() < 2e-6
+    assert np.abs(zm - z).max() > 0.1  # the two key trees differ
+    # a shard draws exactly its rows of the global matrix (split(act_key, N_global) indexed by global id)
+    core.N, core.offset, core.n_local = 4 * N, 3 * N, N
+    zs = core.randn_jax(key).cpu().numpy()
+    refs = rj.controller_epsilon(key, 4 * N, sample_offset=3 * N, n_samples=32)
+    assert np.abs(zs[:32] - refs).max() < 2e-6
+
+
 # ------------------------------------------------------------------------------------------ noise
 @pytest.mark.parametrize("N", [32, 1000, 8192])
 def test_noise_gemm_bit_exact(N):
@@ -801,6 +823,40 @@ def test_workspace_growth_drops_the_captured_step_graph(monkeypatch):
             Hs = cg.core.hessian(ds.packed.repeat(5), ds, params.to_c(), cpg.a_mean.reshape(-1).repeat(5), batch=5)
             assert torch.isfinite(Hs).all()
         obs, state, reward, done, info = env.step(k_step, state, ue.cpu().numpy(), params)
+
+
+@pytest.mark.parametrize("name,task", [("covo-online", "tracking_zigzag"), ("mppi", "hovering")])
+def test_controller_step_on_the_jax_bitstream(name, task):
+    """noise_stream = "jax": the controller splits its key and draws epsilon exactly as quadjax does on jax.random
+    (covo.py:212-220 / mppi.py:53-60); the step then equals the oracle's on that epsilon, and differs from the Philox run."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    from covo_mpc_amd import random_jax as rj
+    N = 512
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="none", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params
+    c, cp = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
+    c.noise_stream = "jax"
+    obs, info, state = env.reset(cr.PRNGKey(3), params)
+    rng_act = rj.PRNGKey(11)
+    u, cp2, _ = c(obs, state, params, rng_act, cp, info)
+    eps = c.core.eps.cpu().numpy()
+    act_key = rj.split(rng_act)[1]
+    ref = rj.controller_epsilon(act_key, N) if name != "mppi" else rj.controller_epsilon_mppi(act_key, N)
+    assert np.abs(eps - ref).max() < 2e-6
+    a_dev = c.core.a.permute(1, 0, 2).contiguous().cpu().numpy()
+    am = R.shift_mean(cp.a_mean.cpu().numpy().astype(np.float64))
+    if name == "mppi":
+        a_ref, _ = R.sample_actions_blockdiag(am, np.tile(np.eye(4) * 0.25, (32, 1, 1)), ref.reshape(N, 32, 4).astype(np.float64))
+    else:
+        a_ref, _ = R.sample_actions_full(am, cp2.a_cov.cpu().numpy().astype(np.float64), ref.astype(np.float64))
+    assert np.abs(a_dev - a_ref).max() < 2e-5
+    assert np.all(np.isfinite(cp2.a_mean.cpu().numpy())) and abs(float(u[0])) <= 1.0
+    c.noise_stream = "philox"
+    c.materialize_eps = True
+    c(obs, state, params, rng_act, cp, info)
+    assert np.abs(c.core.eps.cpu().numpy() - eps).max() > 0.5
 
 
 def test_errors_are_reported_through_the_abi():

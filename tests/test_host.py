@@ -123,3 +123,28 @@ def test_rollover_flag_reaches_the_c_params():
     for off in (True, False):
         env = cm.envs.Quad3D(task="hovering", enable_randomizer=False, disturb_type="none", disable_rollover_terminate=off)
         assert BaseController(env, None)._params_c(p).rollover_terminate == (0 if off else 1)
+
+
+def test_jax_bitstream_known_answers():
+    """covo_mpc_amd/random_jax.py restates jax.random's threefry stream.  jax is not installable here; what
+    IS published pins it: the three Random123 threefry2x32-20 vectors (the ones jax's own tests use) and the values jax's
+    documentation prints for PRNGKey(0) / split / uniform / normal."""
+    from covo_mpc_amd import random_jax as rj
+    for key, ctr, exp in [((0, 0), (0, 0), (0x6B200159, 0x99BA4EFE)),
+                          ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+                          ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))]:
+        y0, y1 = rj.threefry2x32(key[0], key[1], [ctr[0]], [ctr[1]])
+        assert (int(y0[0]), int(y1[0])) == exp
+    k = rj.PRNGKey(0)
+    assert k.tolist() == [0, 0]
+    assert rj.split(k).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]   # jax docs, "JAX PRNG design"
+    assert abs(float(rj.uniform(k)) - 0.41845703) < 1e-8
+    assert abs(float(rj.normal(k)) - (-0.20584226)) < 2e-8                               # "Sharp bits": random.normal(key)
+    quick = [-0.3721109, 0.26423115, -0.18252768, -0.7368197, -0.44030377, -0.1521442, -0.67135346, -0.5908641, 0.73168886,
+             0.5673026]                                                                  # jax quickstart: normal(PRNGKey(0), (10,))
+    assert np.abs(rj.normal(k, (10,)) - np.array(quick, dtype=np.float32)).max() < 1e-7
+    assert abs(float(rj.normal(rj.PRNGKey(42))) - (-0.18471177)) < 2e-8
+    # layout: an odd count is padded with one zero counter and cut again
+    assert np.array_equal(rj.random_bits(k, 3), rj._threefry_counts(k, [0, 1, 2]))
+    e = rj.controller_epsilon(rj.PRNGKey(7), 6, n=128, sample_offset=2, n_samples=3)
+    assert e.shape == (3, 128) and np.array_equal(e[0], rj.normal(rj.split(rj.PRNGKey(7), 6)[2], (128,)))
