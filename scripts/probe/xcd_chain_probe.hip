@@ -134,7 +134,7 @@ static void run(const char *name, int nw, double *dA, double *dB, Ctl *ctl, cons
             Ctl z; for (int i = 0; i < 8; ++i) z.tickets[i] = 0; z.leader = -1; z.bar = 0; z.failed = 0;
             hipMemcpy(ctl, &z, sizeof(z), hipMemcpyHostToDevice);
             hipEventRecord(e0);
-            hipLaunchKernelGGL((persist_k<LD, SCOPE, SLEEP>), dim3(256), dim3(256), 0, 0, dA, dB, ctl, ph, nw);
+            hipLaunchKernelGGL((persist_k<LD, SCOPE, SLEEP>), dim3(nw > 32 ? 512 : 256), dim3(256), 0, 0, dA, dB, ctl, ph, nw);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -165,12 +165,10 @@ int main()
     hipDeviceSynchronize();
     std::vector<double> ref(SN * SN);
     hipMemcpy(ref.data(), (phases & 1) ? dB : dA, SN * SN * 8, hipMemcpyDeviceToHost);
-    for (int nw : {8, 16, 32}) {
-        run<1, 0, 1>("sc1 loads, L2-local counter, sleep 1", nw, dA, dB, ctl, h, ref, phases);
-        run<2, 0, 1>("nt loads, L2-local counter, sleep 1", nw, dA, dB, ctl, h, ref, phases);
+    for (int nw : {16, 32, 64}) {
         run<1, 1, 1>("sc1 loads, agent counter, sleep 1", nw, dA, dB, ctl, h, ref, phases);
         run<2, 1, 1>("nt loads, agent counter, sleep 1", nw, dA, dB, ctl, h, ref, phases);
-        run<1, 0, 0>("sc1 loads, L2-local counter, sleep 0", nw, dA, dB, ctl, h, ref, phases);
+        run<1, 1, 0>("sc1 loads, agent counter, sleep 0", nw, dA, dB, ctl, h, ref, phases);
     }
     printf("final: %s\n", hipGetErrorString(hipDeviceSynchronize()));
     return 0;
