@@ -326,6 +326,8 @@ __device__ __forceinline__ void adj_tri_tile(int w, int &ti, int &tj)
 __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
 {
     __shared__ double red[8][4][64];
+    __shared__ double sMu[4][64];  // Mxu of the four step indices 4I .. 4I+3 the rows (and, on diagonal tiles, columns) of this tile have
+    __shared__ double sMuu[64];    // Muu of the same four steps
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
     const double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
     double *__restrict__ R = A.R + (size_t)b * NA * NA;
@@ -335,34 +337,54 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
     // S_k[:, 16 I ..] is zero for k <= 4 I (I >= J): k = 4I+1 .. 31, round-robin over the 8 waves.
     // MFMA f64 16x16x4: A[m = lo][kk = hi], B[kk = hi][n = lo]; C/D: column lo, rows hi + 4 r.
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    // epilogue operands of the element this lane will finish (waves 0..3: register wv of the tile), loaded up front
-    const int i = 16 * I + hi + 4 * (wv & 3), j = 16 * J + lo;
-    const int ti = i >> 2, di = i & 3, tj = j >> 2, dj = j & 3;
-    double es[NX], em[NX];
-    {
-        const int tk = ti > tj ? ti : tj, col = ti > tj ? j : i, dk = ti > tj ? di : dj;
-        const double *__restrict__ Sk = S + (size_t)tk * 16 * NA, *__restrict__ Mu = ws + WS_MXU + (size_t)tk * 64;
-#pragma unroll
-        for (int m = 0; m < NX; ++m) {
-            es[m] = Sk[(size_t)m * NA + col];
-            em[m] = Mu[m * 4 + dk];
-        }
-        if (ti == tj) em[0] = ws[WS_MUU + (size_t)ti * 16 + di * 4 + dj];
-    }
-    // at most 4 values of k per wave: all operand loads are issued before the first MFMA
+#ifdef KD_PROF
+    const long long kp0 = clock64();
+#endif
+    // A wave keeps at most 63 loads in flight (vmcnt); one more and the launch pays a second memory round trip to data the
+    // previous launch has just written from other XCDs (round 1's order -- 26 epilogue loads, then 48 operands, in every
+    // wave -- took 8.6 us for ~1 us of MFMA).  So: the <= 48 MFMA operands first, then the 13 sensitivities of the epilogue
+    // (finishing waves only); the action blocks Mxu / Muu travel through LDS, one load per thread.
+    // at most 4 values of k per wave
+    // The contraction index of the FIRST product runs as kk = 4 hi + g (any order serves, A and B agree): a lane then owns
+    // 32 contiguous bytes of the row-major Mxx_k and a wave reads each of its 16 lines once (as Mxx[lo][4g + hi] every one of the
+    // four loads touched all 16 lines for 8 bytes each -- 2 KiB through the L1 per instruction, and the L1's 64 B/clk is what
+    // this kernel waits for: 8 waves x ~55 KiB).  The second product contracts over the C/D row order 4g + hi of Q.
     double ma[4][4], sj[4][4], si[4][4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int k = 4 * I + 1 + wv + 8 * it;
         const bool on = k < HH;
         const double *__restrict__ Sk = S + (size_t)(on ? k : 0) * 16 * NA, *__restrict__ Mk = Mxx + (size_t)(on ? k : 0) * 256;
+        const double2 *__restrict__ Mk2 = reinterpret_cast<const double2 *>(Mk + lo * 16 + 4 * hi);
+        const double2 m01 = on ? Mk2[0] : make_double2(0.0, 0.0), m23 = on ? Mk2[1] : make_double2(0.0, 0.0);
+        ma[it][0] = m01.x;  // Mxx[m = lo][4 hi + g]
+        ma[it][1] = m01.y;
+        ma[it][2] = m23.x;
+        ma[it][3] = m23.y;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            ma[it][g] = on ? Mk[lo * 16 + 4 * g + hi] : 0.0;                    // Mxx[m = lo][4g + hi]
-            sj[it][g] = on ? Sk[(size_t)(4 * g + hi) * NA + 16 * J + lo] : 0.0;  // S[4g + hi][n = 16J + lo]
+            sj[it][g] = on ? Sk[(size_t)(4 * hi + g) * NA + 16 * J + lo] : 0.0;  // S[4 hi + g][n = 16J + lo]
             si[it][g] = on ? Sk[(size_t)(4 * g + hi) * NA + 16 * I + lo] : 0.0;  // S^T: A[m = lo][kk = hi] = S[4g + hi][16I + lo]
         }
     }
+    // epilogue operands of the element this lane will finish (waves 0..3: register wv of the tile)
+    const int i = 16 * I + hi + 4 * (wv & 3), j = 16 * J + lo;
+    const int ti = i >> 2, di = i & 3, tj = j >> 2, dj = j & 3;
+    const int tk = ti > tj ? ti : tj, dk = ti > tj ? di : dj;
+    double es[NX];
+    if (wv < 4) {
+        const int col = ti > tj ? j : i;
+        const double *__restrict__ Sk = S + (size_t)tk * 16 * NA;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) es[m] = Sk[(size_t)m * NA + col];
+    } else if (wv == 4) {
+        sMuu[lane] = ws[WS_MUU + (size_t)(4 * I) * 16 + lane];
+    }
+    if (tid < 256) sMu[wv][lane] = ws[WS_MXU + (size_t)(4 * I + wv) * 64 + lane];  // [step][m * 4 + d], m < 16 (rows 13..15 zero)
+#ifdef KD_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long kp1 = clock64();
+#endif
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         if (4 * I + 1 + wv + 8 * it >= HH) break;
@@ -375,17 +397,25 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv][r][lane] = acc[r];
+#ifdef KD_PROF
+    const long long kp2 = clock64();
+#endif
     __syncthreads();
+#ifdef KD_PROF
+    const long long kp3 = clock64();
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 35)) printf("KD wg %d: loads %lld mfma %lld barrier %lld\n", (int)blockIdx.x, kp1 - kp0, kp2 - kp1, kp3 - kp2);
+#endif
     if (wv >= 4) return;
     double v = 0.0;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) v += red[w8][wv][lane];
     // action blocks: u_i enters at step t_i where column j has sensitivity S_{t_i}[:, j] (t_j < t_i), and vice versa
     if (ti != tj) {
+        const double *mu = sMu[tk - 4 * I];
 #pragma unroll
-        for (int m = 0; m < NX; ++m) v = fma(es[m], em[m], v);
+        for (int m = 0; m < NX; ++m) v = fma(es[m], mu[m * 4 + dk], v);
     } else {
-        v += em[0];
+        v += sMuu[(ti - 4 * I) * 16 + di * 4 + dj];
     }
     // C = -J.  Off-diagonal tiles mirror; in diagonal tiles the lower half writes both copies (exactly symmetric R)
     if (I != J || i >= j) {
