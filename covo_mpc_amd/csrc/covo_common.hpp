@@ -83,10 +83,19 @@ __device__ __forceinline__ float wave_sum(float v)
 int launch_randn(uint32_t k0, uint32_t k1, int64_t off, int n_samples, int n_cols, float *out, hipStream_t s);
 int launch_randn_jax(uint32_t k0, uint32_t k1, int64_t n_total, int64_t off, int n_samples, int mppi, float *out, hipStream_t s);
 // eps == null: epsilon is drawn in-kernel from (k0, k1, sample_offset + n) (rng_device.hpp)
+// cov != null (fused covo-online step): a_cov = cz sym(Z) is NOT written by the chain's finalize launch -- one workgroup that
+// everything after it waits for -- but by the first workgroups of the noise GEMM that follows (same expression, same bits);
+// launch_sigma_ns fills *cov with where Z, its transpose and the scalars live.
+struct CovDeferred {
+    const double *Z[2], *Zt[2];  // the two Newton-Schulz buffers of Z and of its stored transpose
+    const double *zbuf;          // != 0: buffer 1 holds the final iterate
+    const double *cz;            // Sigma = cz sym(Z) (NaN when a grid barrier of the chain timed out)
+    float *out;                  // a_cov [128][128]; null: nothing deferred
+};
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr, const float *state_for_time = nullptr,
                       int n_table = 0, int batch = 1,  // batch > 1 (in-kernel Philox only): dense per-instance L, mu, dyn, a
-                      bool eps_tiled = false);       // eps is the tile-ordered image of eps_tiles.hpp
+                      bool eps_tiled = false, const CovDeferred *cov = nullptr);       // eps is the tile-ordered image of eps_tiles.hpp
 int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
                            int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr);
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
@@ -124,7 +133,8 @@ struct EpsGenArgs;  // eps_tiles.hpp
 // status: the handle's sticky status word (a timed-out grid barrier raises COVO_DEVSTAT_GRID_BARRIER there, next to the NaN
 // outputs); persistent_ok = false (COVO_FLAG_SHARED_DEVICE): every phase its own launch
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, const EpsGenArgs *gen = nullptr, int *status = nullptr, bool persistent_ok = true);
+                    hipStream_t s, const EpsGenArgs *gen = nullptr, int *status = nullptr, bool persistent_ok = true,
+                    CovDeferred *cov = nullptr);
 void step_state_destroy(covo_ctx *h);
 void step_graphs_drop(covo_ctx *h);  // before re-allocating h->ws_sigma / h->ws_hess: captured graphs hold their addresses
 void batch_state_destroy(covo_ctx *h);

@@ -24,6 +24,7 @@
 //     layout a[H][N][4] the rollout kernel reads.
 // fp32 MFMA roofline: 2*128*128 flop per sample (dense-equivalent), 157.3 TFLOP/s peak.
 #include "covo_common.hpp"
+#include <cstring>
 #include "eps_tiles.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
                                                               const float *__restrict__ eps, uint32_t k0, uint32_t k1,
                                                               int64_t sample_offset, int N, int ntiles,
                                                               float4 *__restrict__ a_out, const uint32_t *__restrict__ dyn,
-                                                              const float *__restrict__ state_for_time, int n_table)
+                                                              const float *__restrict__ state_for_time, int n_table,
+                                                              const CovDeferred cov)
 {
     // dyn (nullable): {key0, key1} in device memory -- lets a captured graph see a fresh key every replay.
     // state_for_time (nullable): L is a table [n_table][128][128]; use row state.time (covo.py:107-108, clamped
@@ -223,6 +225,18 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
     if (STREAM) cur.g[0] = fetch_group(tile < ntiles ? tile : 0, 0);
     else cur = tile_of(tile < ntiles ? tile : 0);
     __builtin_amdgcn_sched_barrier(0);
+    // a_cov = cz sym(Z), left over by the Sigma chain's single-workgroup finalize launch (CovDeferred): the first 64
+    // workgroups take 256 elements each; the loads ride with the epsilon request above, the stores leave after the staging of L
+    double cov_z = 0.0, cov_zt = 0.0, cov_cz = 0.0;
+    const bool cov_on = cov.out != nullptr && blockIdx.y == 0 && blockIdx.x < 64;
+    const int cov_zb = cov_on ? ((*cov.zbuf != 0.0) ? 1 : 0) : 0;
+    if (cov_on) {
+        cov_cz = *cov.cz;
+        if (gridDim.x >= 64) {
+            cov_z = cov.Z[cov_zb][blockIdx.x * NG_BLOCK + tid];
+            cov_zt = cov.Zt[cov_zb][blockIdx.x * NG_BLOCK + tid];
+        }
+    }
 
     // ---- stage L (masked to its lower triangle) and mu.  All of a thread's loads are issued before the first LDS
     // write (a rolled load -> write loop pays one L2 round trip per trip: 3.8 us of a 17 us launch, scripts/probe/
@@ -256,6 +270,14 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
         }
     }
     if (tid < COVO_NA) mus[tid] = mu[tid];
+    if (cov_on) {
+        if (gridDim.x >= 64) {
+            cov.out[blockIdx.x * NG_BLOCK + tid] = (float)(cov_cz * 0.5 * (cov_z + cov_zt));  // covo.py:132 symmetrise; a_cov is fp32
+        } else {  // small launches (N < 16 384): the workgroups there are stride over the matrix
+            for (int e = blockIdx.x * NG_BLOCK + tid; e < COVO_NA * COVO_NA; e += gridDim.x * NG_BLOCK)
+                cov.out[e] = (float)(cov_cz * 0.5 * (cov.Z[cov_zb][e] + cov.Zt[cov_zb][e]));
+        }
+    }
     __syncthreads();
 
     const float *__restrict__ La = Ls + j * NG_LDA + kh;  // this lane's row / k-parity of every A fragment
@@ -358,8 +380,11 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
 
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table, int batch,
-                      bool eps_tiled)
+                      bool eps_tiled, const CovDeferred *cov)
 {
+    CovDeferred cv;
+    std::memset(&cv, 0, sizeof(cv));
+    if (cov != nullptr) cv = *cov;
     const int ntiles = (N + 31) / 32;
     const int waves_per_block = NG_BLOCK / 64;
     int grid = (ntiles + waves_per_block - 1) / waves_per_block;
@@ -377,13 +402,13 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
     }
     if (eps != nullptr && eps_tiled)
         hipLaunchKernelGGL((noise_gemm_kernel<false, true>), dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
-                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table);
+                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv);
     else if (eps != nullptr)
         hipLaunchKernelGGL(noise_gemm_kernel<false>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
-                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table);
+                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv);
     else
         hipLaunchKernelGGL(noise_gemm_kernel<true>, dim3(grid, batch), dim3(NG_BLOCK), lds, s, L, mu, (const float *)nullptr, k0,
-                           k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn, state_for_time, n_table);
+                           k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn, state_for_time, n_table, cv);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -41,6 +41,7 @@
 // Agreement with the LAPACK-eigh oracle: ~1e-13 relative (fp64), tests/test_gpu_parity.py.
 // `batch` matrices per launch (grid.z / grid.y): covo-offline's 300-step table, env-batched configs.
 #include "covo_common.hpp"
+#include <cstring>
 #include "wave_reduce.hpp"
 #include "chol_lds.hpp"
 #include "eps_tiles.hpp"
@@ -67,6 +68,7 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug)
        SC_BAR = 24,            // grid-barrier counters of the two persistent launches (unsigned in slots 24, 25; zeroed with the scalars)
        SC_BARFAIL = 26,        // != 0: a grid barrier timed out -> the finalize launch poisons Sigma and L with NaN
+       SC_CZ = 27,             // Sigma = cz sym(Z): read by the noise GEMM when it writes a_cov for the finalize launch (CovDeferred)
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
@@ -709,42 +711,60 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     const double n = (double)SN;
     long long tk[5];
     tk[0] = clock64();
-    // Z and its stored transpose are both read coalesced; the symmetrised matrix is row/column agnostic
+    // Only the 36 lower 16x16 tiles are fetched (Z and its stored transpose, both coalesced: 8 lanes x 16 B per tile row) and
+    // written to both mirror positions -- the factorisation reads the lower triangle and the diagonal blocks as stored.  This
+    // one workgroup pulls everything through one CU's L1 (64 B/clk): 144 KiB instead of 256.
     {
-        constexpr int TR = SN * SN / 2 / 512;  // 16 double2 per thread and matrix: all loads in flight first
+        constexpr int TR = NS_TILES * 128 / 512;  // 9 double2 per thread and matrix: all loads in flight first
         double2 za[TR], zt[TR];
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
-            za[t] = Z[tid + 512 * t];
-            zt[t] = Zt[tid + 512 * t];
+            const int w = __builtin_amdgcn_readfirstlane((tid >> 7) + 4 * t), in = tid & 127;  // tile: uniform over the wave
+            int ti, tj;
+            tri_tile(w, ti, tj);
+            const int e2 = ((16 * ti + (in >> 3)) * SN + 16 * tj + 2 * (in & 7)) >> 1;
+            za[t] = Z[e2];
+            zt[t] = Zt[e2];
         }
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
-            const int e2 = tid + 512 * t, r = (2 * e2) / SN, c = (2 * e2) % SN;
-            sm[r * LD + c] = 0.5 * (za[t].x + zt[t].x);  // covo.py:132 symmetrise
-            sm[r * LD + c + 1] = 0.5 * (za[t].y + zt[t].y);
+            const int w = __builtin_amdgcn_readfirstlane((tid >> 7) + 4 * t), in = tid & 127;
+            int ti, tj;
+            tri_tile(w, ti, tj);
+            const int r = 16 * ti + (in >> 3), c = 16 * tj + 2 * (in & 7);
+            const double v0 = 0.5 * (za[t].x + zt[t].x), v1 = 0.5 * (za[t].y + zt[t].y);  // covo.py:132 symmetrise
+            sm[r * LD + c] = v0;
+            sm[r * LD + c + 1] = v1;
+            sm[c * LD + r] = v0;
+            sm[(c + 1) * LD + r] = v1;
         }
     }
     __syncthreads();
     tk[1] = clock64();
     chol128_lds_mfma<LD>(sm, tid);
     tk[2] = clock64();
-    red[tid] = (tid < SN) ? log(sm[tid * LD + tid]) : 0.0;
-    __syncthreads();
-    for (int o = 256; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
+    // log det Z = 2 sum log diag(chol Z) with ONE libm log: mantissas multiplied (64 factors in [1/2, 1) per wave), exponents added
+    if (tid < SN) {
+        const double d = sm[tid * LD + tid];
+        const double pm = wr::wave64_allprod(__builtin_amdgcn_frexp_mant(d));
+        const double pe = wr::wave64_allsum((double)__builtin_amdgcn_frexp_exp(d));
+        if ((tid & 63) == 0) {
+            red[2 * (tid >> 6)] = pm;
+            red[2 * (tid >> 6) + 1] = pe;
+        }
     }
-    const double scale = s[SC_SCALE];
-    const double logdetB = fma(n, log(scale), -4.0 * red[0]);  // log det Z = 2 sum log diag(chol Z)
-    if (tid == 0) s[SC_LOGDET] = logdetB;
-    // log_s = 0.5*log_const - 0.5*log_o with log_const = (2*log_det_a_cov + sum log_o)/n  (covo.py:124-128)
-    const double log_c = 0.5 * (2.0 * n * (log((double)sample_sigma) * 2.0) + logdetB) / n;
+    __syncthreads();
+    const double sumlog = fma(red[1] + red[3], 0.6931471805599453, log(red[0] * red[2]));  // sum_i log diag_i
+    // covo.py:124-128: log_s = 0.5 log_const - 0.5 log_o, log_const = (2 n 2 log(sigma) + sum log o)/n, i.e. Sigma = c B^(-1/2) with
+    // log c = 2 log(sigma) + log det B / (2n); log det B = n log(scale) - 4 sumlog and Z = sqrt(scale) B^(-1/2), so the scale
+    // cancels in cz = c / sqrt(scale) = sigma^2 exp(-2 sumlog / n)
     // a timed-out grid barrier (ns_grid_barrier) left Z unconverged: fail like the reference's numerical failures do, in NaNs
     const double poison = (s[SC_BARFAIL] != 0.0) ? __builtin_nan("") : 1.0;
     if (tid == 0 && s[SC_BARFAIL] != 0.0 && status != nullptr)  // ... and loudly: the next C call on this handle fails (capi.hip)
         __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const double cz = poison * exp(log_c) / sqrt(scale), sq = sqrt(cz);
+    const double cz = poison * ((double)sample_sigma * (double)sample_sigma) * exp(-2.0 * sumlog / n);
+    const double sq = cz * qm::rsq64_(cz);
+    if (tid == 0) s[SC_CZ] = cz;
     tk[3] = clock64();
     // a_cov = cz sym(Z) needs Z once more: its 32 loads go out first and land while L is written from LDS
     constexpr int TRS = SN * SN / 2 / 512;
@@ -769,8 +789,10 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
             So[tid + 512 * t] = make_float2((float)(cz * 0.5 * (za[t].x + zt[t].x)), (float)(cz * 0.5 * (za[t].y + zt[t].y)));
     }
     tk[4] = clock64();
-    if (tid == 0)
+    if (tid == 0) {
+        s[SC_LOGDET] = fma(n, log(s[SC_SCALE]), -4.0 * sumlog);  // log det B (diagnostics)
         for (int i = 0; i < 5; ++i) s[SC_PROF + i] = (double)(tk[i] - tk[0]);
+    }
 }
 
 // how many of the chain's last squarings / Newton-Schulz iterations run inside the persistent launches; covo_debug_set_ns_tail.
@@ -785,7 +807,7 @@ int g_ns_tail_iters = 3, g_ns_tail_squarings = 6;
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok)
+                    hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok, CovDeferred *cov)
 {
     double *ws = reinterpret_cast<double *>(workspace);
     const size_t M = (size_t)batch * SN * SN;
@@ -850,6 +872,19 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         const int ntiles = (g.N + 31) / 32;
         passengers = (ntiles + 7) / 8;         // 8 waves per workgroup, one tile per wave ...
         if (passengers > 255) passengers = 255;  // ... at most one workgroup on every other CU, waves stride over tiles
+    }
+    if (cov != nullptr) {
+        std::memset(cov, 0, sizeof(*cov));
+        if (batch == 1 && Sigma != nullptr) {  // a_cov is left to the consumer of L (CovDeferred)
+            for (int k = 0; k < 2; ++k) {
+                cov->Z[k] = Z[k];
+                cov->Zt[k] = Zt[k];
+            }
+            cov->zbuf = sc + SC_ZBUF;
+            cov->cz = sc + SC_CZ;
+            cov->out = Sigma;
+            Sigma = nullptr;
+        }
     }
     hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch + passengers), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma,
                        Sigma, L, batch, g, status);

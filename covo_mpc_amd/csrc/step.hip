@@ -213,13 +213,18 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         gen.dyn = st->dyn;
         gen.sample_offset = a.sample_offset;
         gen.N = N;
+        // a_cov is written by the GEMM's first workgroups, not by the chain's one-workgroup finalize launch (CovDeferred)
+        CovDeferred cov;
+        std::memset(&cov, 0, sizeof(cov));
+        const bool defer = (M & 8) && g_dbg_sigma_stages >= 4;
         if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen, h->status_dev,
-                                             (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0))) return rc;
+                                             (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, defer ? &cov : nullptr))) return rc;
         if (ahead) {
             if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, reinterpret_cast<const float *>(st->eps_tiled), 0, 0,
-                                                   a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true)))
+                                                   a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true, &cov)))
                 return rc;
-        } else if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn)))
+        } else if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, nullptr, 0,
+                                                      1, false, &cov)))
             return rc;
     } else if (a.mode == COVO_MODE_COVO_OFFLINE) {
         if ((M & 8) && (rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, state,

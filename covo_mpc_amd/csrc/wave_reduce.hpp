@@ -40,6 +40,24 @@ __device__ __forceinline__ double wave64_allsum(double v)
     const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
 }
+// every lane of the wave receives the wave product (same data path as wave64_allsum)
+__device__ __forceinline__ double wave64_allprod(double v)
+{
+    v *= dpp_f64<0x128>(v);
+    v *= dpp_f64<0x124>(v);
+    v *= dpp_f64<0x122>(v);
+    v *= dpp_f64<0x121>(v);
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) * __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) * __hiloint2double((int)rh[1], (int)rl[1]);
+}
 // every lane of the wave receives the wave maximum (same data path as wave64_allsum)
 __device__ __forceinline__ double wave64_allmax(double v)
 {
