@@ -343,6 +343,9 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     double acol[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) acol[c] = A[(size_t)(32 * cq + c) * SN + r_av];  // A symmetric: coalesced in r
+    // the per-row data of the Gershgorin bound at the end: requested now, one round trip to HBM less on the serial tail
+    const double pre_dg = (tid < SN) ? s[SC_DIAG + tid] : 0.0, pre_ra = (tid < SN) ? s[SC_ROWABS + tid] : 0.0;
+    const double pre_tr = s[SC_TRACE], pre_f2 = s[SC_FRO2];
     if (tid < 64) {
         // ---- wave 0: pick the RITZ largest diagonal entries, orthonormalise those columns (two-pass MGS,
         // everything in registers: lane l owns rows l and l+64; reductions on the VALU)
@@ -450,13 +453,12 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     const double delta = sh_delta;
     // Gershgorin bound of B = A + delta I from the row sums of A: only the diagonal term changes
     if (tid < SN) {
-        const double dg = s[SC_DIAG + tid];
-        const double m = wr::wave64_allmax(s[SC_ROWABS + tid] - fabs(dg) + fabs(dg + delta));
+        const double m = wr::wave64_allmax(pre_ra - fabs(pre_dg) + fabs(pre_dg + delta));
         if (lane == 0) red[wave] = m;
     }
     __syncthreads();
     if (tid == 0) {
-        const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, s[SC_TRACE], s[SC_FRO2]));  // |A + delta I|_F^2
+        const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, pre_tr, pre_f2));  // |A + delta I|_F^2
         const double scale = fmin(fmax(red[0], red[1]), sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
         s[SC_SCALE] = scale;
         // Chen-Chow scaled Newton-Schulz: x -> x (a + b x^2) on [l, 1] with a = 1.5 rho, b = -0.5 rho^3,
