@@ -315,7 +315,22 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
                     v.y = qm::clip11_(m4.y + acc[rt][4 * g + 1]);
                     v.z = qm::clip11_(m4.z + acc[rt][4 * g + 2]);
                     v.w = qm::clip11_(m4.w + acc[rt][4 * g + 3]);
+                    // -DNG_STORE_WT / -DNG_STORE_NT (write-through / nontemporal stores, so that the 33.5 MB do not wait dirty in
+                    // the L2s for the end-of-kernel write-back): 24.6 -> 21.3 us in the isolated replay of the in-kernel-Philox
+                    // variant, but bench.py on every config moves by less than its run-to-run spread (4 791 / 4 824 / 4 786
+                    // covo-online, 22 390 / 22 845 / 22 140 covo-offline): the rollout then misses the L2 on every stripe.  Plain stores stay.
+#ifdef NG_STORE_WT
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v vv = {v.x, v.y, v.z, v.w};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a_out + (size_t)t * N + n), "v"(vv) : "memory");
+#elif defined(NG_STORE_NT)
+                    __builtin_nontemporal_store(v.x, &a_out[(size_t)t * N + n].x);
+                    __builtin_nontemporal_store(v.y, &a_out[(size_t)t * N + n].y);
+                    __builtin_nontemporal_store(v.z, &a_out[(size_t)t * N + n].z);
+                    __builtin_nontemporal_store(v.w, &a_out[(size_t)t * N + n].w);
+#else
                     a_out[(size_t)t * N + n] = v;
+#endif
                 }
             }
         };
