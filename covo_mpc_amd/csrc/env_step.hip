@@ -53,7 +53,25 @@ __device__ __forceinline__ void host_split(const uint32_t (&key)[2], uint32_t i,
 __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
 {
     __shared__ float z[16];
+    __shared__ float sst[COVO_STATE_FLOATS];   // the state as loaded, then as stepped
+    __shared__ float sact[4];
+    __shared__ float straj[2][9];              // pos / vel / acc targets of row `guess` (speculative) and of row time + 1
     const int lane = threadIdx.x;
+    // One launch of one wave is latency: everything that does not depend on anything is requested first -- the state (lanes
+    // 0..31, one coalesced load), the action, and the trajectory row the NEXT state will point at, guessed from the step count
+    // (time = steps since reset for every episode the drivers run; checked against the state's own clock below and re-read if
+    // wrong) -- and lands while lanes 0..15 hash the step's noise.  (Round 1: lane 0 alone, state -> time -> row -> state read
+    // back for the noisy copy: four dependent round trips, 9.5 us.)
+    float *__restrict__ st = A.state;
+    const int guess = A.log_index + 1 < 0 ? 0 : (A.log_index + 1 > A.T - 1 ? A.T - 1 : A.log_index + 1);
+    float ld_state = 0.0f, ld_act = 0.0f, ld_traj = 0.0f;
+    if (lane < COVO_STATE_FLOATS) ld_state = st[lane];
+    if (lane >= 32 && lane < 36) ld_act = A.action[lane - 32];
+    if (lane >= 40 && lane < 49) {
+        const int q = lane - 40;
+        const float *__restrict__ tr = q < 3 ? A.pos_traj : (q < 6 ? A.vel_traj : A.acc_traj);
+        ld_traj = tr[3 * guess + q % 3];
+    }
     // ---- the 16 normals of the step: disturb(3) pos(3) vel(3) quat(4) omega(3).  Key tree of Quad3D.step(key, ...):
     //   k = split(key)[0]                       base.py:22 (child 1 is the reset key)
     //   info_key = split(k)[0], raw = split(k)[1]      quadrotor.py:246 / :262 (both split the SAME key)
@@ -78,63 +96,78 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
         }
         z[lane] = host_normal(key, n, lane - base);
     }
+    if (lane < COVO_STATE_FLOATS) sst[lane] = ld_state;
+    if (lane >= 32 && lane < 36) sact[lane - 32] = ld_act;
+    if (lane >= 40 && lane < 49) straj[0][lane - 40] = ld_traj;
     __syncthreads();
-    if (lane != 0) return;
-    float *__restrict__ st = A.state;
-    qm::State<float> s;
-    s.px = st[ST_POS + 0]; s.py = st[ST_POS + 1]; s.pz = st[ST_POS + 2];
-    s.vx = st[ST_VEL + 0]; s.vy = st[ST_VEL + 1]; s.vz = st[ST_VEL + 2];
-    s.qx = st[ST_QUAT + 0]; s.qy = st[ST_QUAT + 1]; s.qz = st[ST_QUAT + 2]; s.qw = st[ST_QUAT + 3];
-    s.ox = st[ST_OMEGA + 0]; s.oy = st[ST_OMEGA + 1]; s.oz = st[ST_OMEGA + 2];
-    const float fx = st[ST_FDIST + 0], fy = st[ST_FDIST + 1], fz = st[ST_FDIST + 2];
-    const float tx = st[ST_POSTAR + 0], ty = st[ST_POSTAR + 1], tz = st[ST_POSTAR + 2];
-    const float tvx = st[ST_VELTAR + 0], tvy = st[ST_VELTAR + 1], tvz = st[ST_VELTAR + 2];
-    const int time = __float_as_int(st[ST_TIME]);
-    // ---- reward / errors / termination of the PRE-step state (quadrotor.py:243-244, 479-490; utils.py:285-294)
-    if (A.log != nullptr) {
-        const float r = qm::reward<float, float>(s, tx, ty, tz, tvx, tvy, tvz);
-        const float ex = tx - s.px, ey = ty - s.py, ez = tz - s.pz;
-        const float wx = tvx - s.vx, wy = tvy - s.vy, wz = tvz - s.vz;
-        bool done = (time >= A.max_steps) || fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz)) > A.c.pos_limit;
-        if (A.rollover)  // quadrotor.py:486-490
-            done = done || s.qw < 0.70710678118654752f || fmaxf(fmaxf(fabsf(s.ox), fabsf(s.oy)), fabsf(s.oz)) > 100.0f;
-        float *__restrict__ lg = A.log + 4 * A.log_index;
-        lg[0] = r;
-        lg[1] = sqrtf(ex * ex + ey * ey + ez * ez);
-        lg[2] = sqrtf(wx * wx + wy * wy + wz * wz);
-        lg[3] = done ? 1.0f : 0.0f;
-    }
-    // ---- one Euler step with the state's current disturbance (free.py:91,98)
-    const float a0 = qm::clip11_(qm::clip11_(A.action[0])), a1 = qm::clip11_(qm::clip11_(A.action[1]));
-    const float a2 = qm::clip11_(qm::clip11_(A.action[2])), a3 = qm::clip11_(qm::clip11_(A.action[3]));
-    qm::dyn_step<float, float>(s, a0, a1, a2, a3, A.c, fx, fy, fz);
+    const int time = __float_as_int(sst[ST_TIME]);
     const int t1 = time + 1;
     const int idx = t1 < 0 ? 0 : (t1 > A.T - 1 ? A.T - 1 : t1);  // JAX gather clamps (free.py:150-155)
-    st[ST_POS + 0] = s.px; st[ST_POS + 1] = s.py; st[ST_POS + 2] = s.pz;
-    st[ST_VEL + 0] = s.vx; st[ST_VEL + 1] = s.vy; st[ST_VEL + 2] = s.vz;
-    st[ST_QUAT + 0] = s.qx; st[ST_QUAT + 1] = s.qy; st[ST_QUAT + 2] = s.qz; st[ST_QUAT + 3] = s.qw;
-    st[ST_OMEGA + 0] = s.ox; st[ST_OMEGA + 1] = s.oy; st[ST_OMEGA + 2] = s.oz;
-    const float sc = A.gaussian ? A.dyn_noise_scale : 0.0f;  // free.py:66-72
-    st[ST_FDIST + 0] = sc * z[0]; st[ST_FDIST + 1] = sc * z[1]; st[ST_FDIST + 2] = sc * z[2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        st[ST_POSTAR + i] = A.pos_traj[3 * idx + i];
-        st[ST_VELTAR + i] = A.vel_traj[3 * idx + i];
-        st[ST_ACCTAR + i] = A.acc_traj[3 * idx + i];
+    const bool reread = idx != guess;  // uniform
+    if (reread && lane >= 40 && lane < 49) {
+        const int q = lane - 40;
+        const float *__restrict__ tr = q < 3 ? A.pos_traj : (q < 6 ? A.vel_traj : A.acc_traj);
+        straj[1][q] = tr[3 * idx + q % 3];
     }
-    st[ST_TIME] = __int_as_float(t1);
-    // ---- the noisy copy the controller plans from (quadrotor.py:322-350; quaternion NOT re-normalised)
-    float *__restrict__ ns = A.noisy;
-    const float on = A.noisy_on ? A.obs_noise_scale : 0.0f;
-    for (int i = 0; i < COVO_STATE_FLOATS; ++i) ns[i] = st[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        ns[ST_POS + i] = st[ST_POS + i] + z[3 + i] * on * 0.25f;
-        ns[ST_VEL + i] = st[ST_VEL + i] + z[6 + i] * on * 0.5f;
-        ns[ST_OMEGA + i] = st[ST_OMEGA + i] + z[13 + i] * on * 0.5f;
+    if (lane == 0) {
+        qm::State<float> s;
+        s.px = sst[ST_POS + 0]; s.py = sst[ST_POS + 1]; s.pz = sst[ST_POS + 2];
+        s.vx = sst[ST_VEL + 0]; s.vy = sst[ST_VEL + 1]; s.vz = sst[ST_VEL + 2];
+        s.qx = sst[ST_QUAT + 0]; s.qy = sst[ST_QUAT + 1]; s.qz = sst[ST_QUAT + 2]; s.qw = sst[ST_QUAT + 3];
+        s.ox = sst[ST_OMEGA + 0]; s.oy = sst[ST_OMEGA + 1]; s.oz = sst[ST_OMEGA + 2];
+        const float fx = sst[ST_FDIST + 0], fy = sst[ST_FDIST + 1], fz = sst[ST_FDIST + 2];
+        const float tx = sst[ST_POSTAR + 0], ty = sst[ST_POSTAR + 1], tz = sst[ST_POSTAR + 2];
+        const float tvx = sst[ST_VELTAR + 0], tvy = sst[ST_VELTAR + 1], tvz = sst[ST_VELTAR + 2];
+        // ---- reward / errors / termination of the PRE-step state (quadrotor.py:243-244, 479-490; utils.py:285-294)
+        if (A.log != nullptr) {
+            const float r = qm::reward<float, float>(s, tx, ty, tz, tvx, tvy, tvz);
+            const float ex = tx - s.px, ey = ty - s.py, ez = tz - s.pz;
+            const float wx = tvx - s.vx, wy = tvy - s.vy, wz = tvz - s.vz;
+            bool done = (time >= A.max_steps) || fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz)) > A.c.pos_limit;
+            if (A.rollover)  // quadrotor.py:486-490
+                done = done || s.qw < 0.70710678118654752f || fmaxf(fmaxf(fabsf(s.ox), fabsf(s.oy)), fabsf(s.oz)) > 100.0f;
+            float *__restrict__ lg = A.log + 4 * A.log_index;
+            lg[0] = r;
+            lg[1] = sqrtf(ex * ex + ey * ey + ez * ez);
+            lg[2] = sqrtf(wx * wx + wy * wy + wz * wz);
+            lg[3] = done ? 1.0f : 0.0f;
+        }
+        // ---- one Euler step with the state's current disturbance (free.py:91,98)
+        const float a0 = qm::clip11_(qm::clip11_(sact[0])), a1 = qm::clip11_(qm::clip11_(sact[1]));
+        const float a2 = qm::clip11_(qm::clip11_(sact[2])), a3 = qm::clip11_(qm::clip11_(sact[3]));
+        qm::dyn_step<float, float>(s, a0, a1, a2, a3, A.c, fx, fy, fz);
+        sst[ST_POS + 0] = s.px; sst[ST_POS + 1] = s.py; sst[ST_POS + 2] = s.pz;
+        sst[ST_VEL + 0] = s.vx; sst[ST_VEL + 1] = s.vy; sst[ST_VEL + 2] = s.vz;
+        sst[ST_QUAT + 0] = s.qx; sst[ST_QUAT + 1] = s.qy; sst[ST_QUAT + 2] = s.qz; sst[ST_QUAT + 3] = s.qw;
+        sst[ST_OMEGA + 0] = s.ox; sst[ST_OMEGA + 1] = s.oy; sst[ST_OMEGA + 2] = s.oz;
+        const float sc = A.gaussian ? A.dyn_noise_scale : 0.0f;  // free.py:66-72
+        sst[ST_FDIST + 0] = sc * z[0]; sst[ST_FDIST + 1] = sc * z[1]; sst[ST_FDIST + 2] = sc * z[2];
+        sst[ST_TIME] = __int_as_float(t1);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ns[ST_QUAT + i] = st[ST_QUAT + i] + z[9 + i] * on * 0.02f;
+    __syncthreads();  // also: the re-read row (if any) has landed in straj[1] -- its writers waited for their own loads
+    if (lane < 9) {
+        const float v = straj[reread ? 1 : 0][lane];
+        sst[(lane < 3 ? ST_POSTAR : (lane < 6 ? ST_VELTAR : ST_ACCTAR)) + lane % 3] = v;
+    }
+    __syncthreads();
+    // ---- the new state, and the noisy copy the controller plans from (quadrotor.py:322-350; quaternion NOT re-normalised)
+    if (lane < COVO_STATE_FLOATS) {
+        const float v = sst[lane];
+        st[lane] = v;
+        // noise = (z * scale) * c, then state + noise: three separately rounded operations as in quadrotor.py:322-350 (no FMA
+        // contraction: the copy then equals the Python env's bit for bit given the same true state)
+        const float on = A.noisy_on ? A.obs_noise_scale : 0.0f;
+        float zz = 0.0f, cc = 0.0f;
+        bool noisy_field = true;
+        if (lane >= ST_POS && lane < ST_POS + 3) { zz = z[3 + lane - ST_POS]; cc = 0.25f; }
+        else if (lane >= ST_VEL && lane < ST_VEL + 3) { zz = z[6 + lane - ST_VEL]; cc = 0.5f; }
+        else if (lane >= ST_QUAT && lane < ST_QUAT + 4) { zz = z[9 + lane - ST_QUAT]; cc = 0.02f; }
+        else if (lane >= ST_OMEGA && lane < ST_OMEGA + 3) { zz = z[13 + lane - ST_OMEGA]; cc = 0.5f; }
+        else noisy_field = false;
+        float nz = (zz * on) * cc;
+        asm volatile("" : "+v"(nz));  // keeps hipcc from contracting the product into the add below (__fadd_rn / __fmul_rn do not)
+        A.noisy[lane] = noisy_field ? v + nz : v;
+    }
 }
 
 int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,

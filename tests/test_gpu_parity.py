@@ -697,6 +697,13 @@ def test_env_step_kernel_vs_host_env():
         assert np.abs(t_dev - state.pack()).max() < 2e-5, (t, np.abs(t_dev - state.pack()).max())
         assert t_dev[25:26].view(np.int32)[0] == state.time
         assert np.abs(n_dev - info["noisy_state"].pack()).max() < 2e-5, t
+        # the noise itself is bit-exact: noisy - true on the device = the env's (z * scale) * c added to the DEVICE's true state
+        f32 = np.float32
+        kp, kv, kq, ko = cr.split(cr.split(cr.split(k_step)[0])[0], 5)[:4]   # base.py:22 -> step_env's info_key -> get_info's four keys
+        s_ = f32(params.obs_noise_scale)
+        for sl, kk, n_, c_ in ((slice(0, 3), kp, 3, 0.25), (slice(3, 6), kv, 3, 0.5), (slice(6, 10), kq, 4, 0.02), (slice(10, 13), ko, 3, 0.5)):
+            want = (t_dev[sl] + cr.normal(kk, (n_,)) * s_ * f32(c_)).astype(f32)
+            assert np.array_equal(n_dev[sl], want), (t, sl)
     log = ep.read_log()
     assert log.shape == (60, 4) and np.all(log[:, 3] == 0)
     assert np.abs(log[:, 0] - np.asarray(rewards)).max() < 2e-5 and np.abs(log[:, 1] - np.asarray(errs)).max() < 2e-5
