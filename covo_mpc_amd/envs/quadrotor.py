@@ -421,7 +421,9 @@ def main(args: Args):
                  enable_randomizer=not args.noDR, disturb_type=args.disturb_type, disable_rollover_terminate=True,
                  generate_noisy_state=True, device="cuda")
     print("starting test...")
-    controller, control_params = get_controller(env, args.controller, args.controller_params)
+    # eval never reads the controller's info dict: quadjax's jitted run_one_step drops pos_mean / pos_std as dead code
+    # (quadrotor.py:523-538), here the per-step position statistics are simply not requested
+    controller, control_params = get_controller(env, args.controller, args.controller_params, compute_info=args.mode != "eval")
     if args.mode == "eval":
         if not args.host_env and hasattr(controller, "core"):
             # same protocol, env step on the device, whole episodes enqueued by one C call (eval_env_device)
