@@ -82,6 +82,7 @@ _SIGS = {
     "covo_noise_blockdiag_philox": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, _P, _P]),
     "covo_rollout_cost": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P,
                                     C.c_int32, _P, _P, _P, _P]),
+    "covo_pos_info": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P]),
     "covo_debug_time_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P,
                                           C.c_int32, _P, _P, C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_softmax_reduce": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),

@@ -324,16 +324,14 @@ class SamplingCore:
         return out
 
     def info(self, dstate):
-        """{"pos_mean","pos_std"} (H,3) from the per-step sums (controllers/covo.py:281)."""
+        """{"pos_mean","pos_std"} (H,3) from the per-step sums (controllers/covo.py:281): covo_pos_info, one launch."""
         torch = self.torch
         stats = self.stats
         if self.world > 1:
             import torch.distributed as dist
             stats = stats.clone()
             dist.all_reduce(stats, group=self.pg)
-        s = stats.view(COVO_H, 6)
-        n = float(self.N)
-        m1 = s[:, :3] / n
-        var = torch.clamp(s[:, 3:] / n - m1 * m1, min=0.0)
-        p0 = dstate.packed[0:3].to(torch.float64)
-        return {"pos_mean": (p0[None, :] + m1).to(torch.float32), "pos_std": torch.sqrt(var).to(torch.float32)}
+        out = torch.empty((2, COVO_H, 3), dtype=torch.float32, device=self.device)
+        check(self.lib.covo_pos_info(self.h, ptr(stats), ptr(dstate.packed), int(self.N), ptr(out[0]), ptr(out[1]), self.stream()),
+              "covo_pos_info")
+        return {"pos_mean": out[0], "pos_std": out[1]}

@@ -60,7 +60,7 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     const int nb = (cfg->n_local + 255) / 256, ng = (cfg->n_local + 63) / 64;
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
-    COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)nb * COVO_H * 6 * sizeof(double)));
+    COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)(nb > 256 ? nb : 256) * COVO_H * 6 * sizeof(double)));  // one row per rollout workgroup
     h->ws_sigma_bytes = sigma_ns_workspace_bytes(1);
     COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, h->ws_sigma_bytes));
     h->ws_hess_bytes = hessian_workspace_bytes(1);
@@ -182,6 +182,30 @@ int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj
     return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount,
                           (h->cfg.flags & COVO_FLAG_ACTIONS_CLIPPED) != 0, cost_out, groupmin, pos_stats, h->ws_stats,
                           (hipStream_t)stream);
+}
+
+__global__ void pos_info_kernel(const double *__restrict__ stats, const float *__restrict__ state, double inv_n,
+                                float *__restrict__ mean, float *__restrict__ sd)
+{
+    const int t = threadIdx.x;  // (step, axis)
+    if (t >= COVO_H * 3) return;
+    const int k = t / 3, ax = t % 3;
+    const double m1 = stats[k * 6 + ax] * inv_n;
+    const double var = fmax(stats[k * 6 + 3 + ax] * inv_n - m1 * m1, 0.0);
+    mean[t] = (float)((double)state[ST_POS + ax] + m1);
+    sd[t] = (float)sqrt(var);
+}
+
+int covo_pos_info(covo_handle_t h, const double *pos_stats, const float *state, int64_t n_total, float *pos_mean_out,
+                  float *pos_std_out, void *stream)
+{
+    REQUIRE(h, "covo_pos_info: null handle");
+    CHECK_DEVICE(h, "covo_pos_info");
+    REQUIRE(pos_stats && state && pos_mean_out && pos_std_out && n_total > 0, "covo_pos_info: bad argument");
+    hipLaunchKernelGGL(pos_info_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, pos_stats, state, 1.0 / (double)n_total,
+                       pos_mean_out, pos_std_out);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int covo_debug_time_rollout(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,

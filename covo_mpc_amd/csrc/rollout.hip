@@ -343,17 +343,17 @@ static int pipe_groups(int N, int nbatch)
     return ng > 256 ? 2 : 1;
 }
 
-template <bool DISC1, bool ROLL, bool BATCHED>
+template <bool DISC1, bool ROLL, bool BATCHED, bool STATS = false>
 static void launch_pipe3(const RolloutArgs &A, const RolloutArgs *batch, int nb, int groups, hipStream_t s)
 {
     const int ng = (A.N + COVO_WAVE - 1) / COVO_WAVE;
     const dim3 grid((ng + groups - 1) / groups, nb);
     if (groups == 4)
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 4, BATCHED>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 4, BATCHED, -1, 3, STATS>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
     else if (groups == 2)
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 2, BATCHED>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 2, BATCHED, -1, 3, STATS>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
     else
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 1, BATCHED>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 1, BATCHED, -1, 3, STATS>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
 }
 
 // nbatch == 0: one rollout described by A; else nbatch instances described by the device array `batch` (all with A's
@@ -373,13 +373,12 @@ static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int 
         return 0;
     }
     if constexpr (!BATCHED) {
-        const int grid = (N + RO_BLOCK - 1) / RO_BLOCK;
-        const bool deep = grid <= 2 * 256;  // <= 2 waves per SIMD: prefetch the whole horizon
-        const bool clip = A.clip != 0;
-#define RO_DISPATCH(D1, CL) launch_rollout_pf<true, D1, CL, false>(A, batch, nb, grid, deep, s)
-        if (d1) { if (!clip) RO_DISPATCH(true, false); else RO_DISPATCH(true, true); }
-        else    { if (!clip) RO_DISPATCH(false, false); else RO_DISPATCH(false, true); }
-#undef RO_DISPATCH
+        // position statistics: the same pipelined kernel, its T waves also summing the new positions (rollout_pipe.hpp);
+        // one fp64 partial per workgroup and (step, statistic), summed by one workgroup per column
+        const int groups = pipe_groups(N, nb);
+        const int grid = ((N + COVO_WAVE - 1) / COVO_WAVE + groups - 1) / groups;
+        if (d1) { if (A.rollover) launch_pipe3<true, true, false, true>(A, batch, nb, groups, s); else launch_pipe3<true, false, false, true>(A, batch, nb, groups, s); }
+        else    { if (A.rollover) launch_pipe3<false, true, false, true>(A, batch, nb, groups, s); else launch_pipe3<false, false, false, true>(A, batch, nb, groups, s); }
         hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(COVO_H * 6), dim3(256), 0, s, A.stats_ws, grid, pos_stats);
     }
     COVO_CHECK_HIP(hipGetLastError());
@@ -403,7 +402,7 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
 // instance -- mirrors dispatch_rollout
 int rollout_workgroups(int N, bool stats, int nbatch)
 {
-    if (stats) return (N + RO_BLOCK - 1) / RO_BLOCK;
+    (void)stats;  // the statistics ride in the same launch shape
     const int ng = (N + COVO_WAVE - 1) / COVO_WAVE, groups = pipe_groups(N, nbatch);
     return (ng + groups - 1) / groups;
 }

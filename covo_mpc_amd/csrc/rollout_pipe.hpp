@@ -92,13 +92,15 @@ __device__ __forceinline__ float rp3_atan2abs(float y, float x)
 //   groups every SIMD of the CU hosts one wave of each stage); CH: steps per barrier.
 // ONLY >= 0 (scripts/probe/rollout_lab.hip): every wave runs stage ONLY on its own LDS copy, no barriers -- the stage's
 //   instruction stream in isolation; ONLY == -2: all three stages without barriers (timing bound, garbage results).
-template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3>
+// STATS: the per-step position sums of covo.py:281 (pos_mean / pos_std) are formed by the T waves (see there).
+template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3, bool STATS = false>
 __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) void rollout_pipe3_kernel(
     const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
 {
     static_assert(COVO_H % CH == 0, "CH must divide the horizon");
     const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
     __shared__ Rp3Lds<CH> lds_all[ONLY >= 0 ? ONLY_WAVES : GROUPS];
+    __shared__ float lds_st[STATS ? GROUPS : 1][STATS ? COVO_H : 1][6];  // STATS: per group and step {sum d, sum d^2} (d: see stage T)
     RP3_DECL();
     const int lane = threadIdx.x & (COVO_WAVE - 1);
     const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -172,7 +174,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         RP3_FLUSH(0);
         rp3_barrier<ONLY>();
         rp3_barrier<ONLY>();
-        if (A.records == nullptr) return;
+        if (A.records == nullptr && !STATS) return;
     }
 
     if (role == 1) {
@@ -196,6 +198,50 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         const int kdone = A.max_steps - time0;  // steps k >= kdone see time >= max_steps (quadrotor.py:483)
         float px = st[ST_POS + 0], py = st[ST_POS + 1], pz = st[ST_POS + 2];
         float vx = st[ST_VEL + 0], vy = st[ST_VEL + 1], vz = st[ST_VEL + 2];
+        // STATS (covo.py:234-237, 281: mean / std over the samples of every step's NEW position).  Per step the wave reduces six
+        // numbers -- d and d^2 per axis, d = position minus the force-free point p0 + (k+1) dt v0 (wave-uniform, so that the
+        // early steps, where all samples still coincide, sum exact zeros; the workgroup puts the shift back in fp64) -- in
+        // 19 instructions: v_permlane32_swap / v_permlane16_swap fold two quantities at a time into the halves / rows of ONE
+        // register (6 -> 3 -> 2 registers), four DPP row rotations finish both; the row sums are parked in lane (k & 15) of
+        // their row and written to LDS every 16 steps.  (One butterfly per quantity: 6 x 8; round 1's one-lane kernel parked
+        // the offsets in LDS and had 24 lanes walk them in fp64 every 8 steps: 27.6 us at N = 65 536.)
+        const float p0x = px, p0y = py, p0z = pz, v0x = vx, v0y = vy, v0z = vz;
+        float st_a = 0.0f, st_b = 0.0f;
+        auto stats_step = [&](int k, float nx, float ny, float nz) {
+            const float tk = (float)(k + 1) * c.dt;
+            float d0 = nx - __builtin_fmaf(v0x, tk, p0x), d1 = ny - __builtin_fmaf(v0y, tk, p0y), d2 = nz - __builtin_fmaf(v0z, tk, p0z);
+            d0 = valid ? d0 : 0.0f;
+            d1 = valid ? d1 : 0.0f;
+            d2 = valid ? d2 : 0.0f;
+            auto fold32 = [](float a, float b) {  // lanes < 32: a[l] + a[l + 32]; lanes >= 32: b[l - 32] + b[l]
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+                return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            };
+            auto fold16 = [](float a, float b) {  // rows 0 / 2: a's row pair sums; rows 1 / 3: b's
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+                return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            };
+            const float r0 = fold32(d0, d1), r1 = fold32(d2, d0 * d0), r2 = fold32(d1 * d1, d2 * d2);
+            float sa = fold16(r0, r1);  // rows: sum d0 | sum d2 | sum d1 | sum d0^2   (4 samples per lane)
+            float sb = fold16(r2, r2);  // rows: sum d1^2 | (same) | sum d2^2 | (same)
+            sa += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sa), 0x128, 0xf, 0xf, false));
+            sb += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sb), 0x128, 0xf, 0xf, false));
+            sa += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sa), 0x124, 0xf, 0xf, false));
+            sb += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sb), 0x124, 0xf, 0xf, false));
+            sa += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sa), 0x122, 0xf, 0xf, false));
+            sb += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sb), 0x122, 0xf, 0xf, false));
+            sa += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sa), 0x121, 0xf, 0xf, false));
+            sb += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sb), 0x121, 0xf, 0xf, false));
+            const bool mine = (lane & 15) == (k & 15);
+            st_a = mine ? sa : st_a;
+            st_b = mine ? sb : st_b;
+            if ((k & 15) == 15) {
+                const int row = lane >> 4, step = (k - 15) + (lane & 15);
+                const int qa = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
+                lds_st[gsub][step][qa] = st_a;
+                if ((row & 1) == 0) lds_st[gsub][step][row == 0 ? 4 : 5] = st_b;
+            }
+        };
         const float kf = c.inv_m * c.dt;  // v += dt/m f (free.py:98,103)
         const float c0x = st[ST_FDIST + 0] * kf, c0y = st[ST_FDIST + 1] * kf, c0z = __builtin_fmaf(st[ST_FDIST + 2], kf, c.neg_g * c.dt);
         const float fsx = A.f_shared_dev ? A.f_shared_dev[0] : A.f_shared[0];
@@ -254,6 +300,9 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
                 vz = __builtin_fmaf(-tau2, s2, vz + tau);
                 if (k == 0) { vx += c0x; vy += c0y; vz += c0z; }
                 else { vx += csx; vy += csy; vz += csz; }
+                if (STATS) stats_step(k, px, py, pz);
+            } else if (STATS) {  // the last step's new position enters no cost, only the statistics
+                stats_step(k, __builtin_fmaf(vx, c.dt, px), __builtin_fmaf(vy, c.dt, py), __builtin_fmaf(vz, c.dt, pz));
             }
             if ((k + 1) % CH == 0) {
                 if (k + 1 == CH) RP3_STAMP(1);
@@ -264,7 +313,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         }
         RP3_FLUSH(1);
         rp3_barrier<ONLY>();
-        if (A.records == nullptr) return;
+        if (A.records == nullptr && !STATS) return;
     }
 
     float cost = 0.0f;
@@ -316,5 +365,32 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         __shared__ __attribute__((aligned(16))) float rec_v[GROUPS][COVO_NA];
         rollout_record<3 * GROUPS, GROUPS>(A, cost, valid && role == 2, n, role == 2 ? gsub : 0, role == 2, lane, blockIdx.x, rec_m,
                                            rec_s, rec_v);
+    }
+    if (STATS) {
+        // this workgroup's {sum (p - p0), sum (p - p0)^2} per step and axis, in fp64, with the T waves' shift put back:
+        // p - p0 = d + D, D = (k+1) dt v0 as formed above  ->  sum = S1 + n D,  sum of squares = S2 + 2 D S1 + n D^2
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < COVO_H * 6) {
+            const int k = t / 6, q = t % 6, ax = q % 3;
+            const float p0 = st[ST_POS + ax], v0 = st[ST_VEL + ax];
+            const float tk = (float)(k + 1) * c.dt;
+            const double D = (double)__builtin_fmaf(v0, tk, p0) - (double)p0;
+            double tot = 0.0;
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                int grp = blockIdx.x * GROUPS + g;
+                if (A.xcd_remap) {
+                    const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + g;
+                    grp = 2 * (x + 8 * (m >> 1)) + (m & 1);
+                }
+                int nv = A.N - grp * COVO_WAVE;
+                nv = nv < 0 ? 0 : (nv > COVO_WAVE ? COVO_WAVE : nv);
+                const double s1 = (double)lds_st[g][k][ax];
+                if (q < 3) tot += s1 + (double)nv * D;
+                else tot += (double)lds_st[g][k][q] + 2.0 * D * s1 + (double)nv * D * D;
+            }
+            A.stats_ws[(size_t)blockIdx.x * (COVO_H * 6) + t] = tot;
+        }
     }
 }

@@ -168,6 +168,12 @@ int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj
                       const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
                       float *cost_out, float *groupmin, double *pos_stats, void *stream);
 
+/* controllers/covo.py:281 (mppi.py:134) from the sums covo_rollout_cost / covo_mpc_step leave in pos_stats (after the
+ * all-reduce when the samples are sharded): pos_mean[k][i] = pos0[i] + S1/n, pos_std[k][i] = sqrt(max(S2/n - (S1/n)^2, 0))
+ * (ddof 0), both float[COVO_H][3]; n_total = the global sample count.  One launch instead of the caller's elementwise ops. */
+int covo_pos_info(covo_handle_t h, const double *pos_stats, const float *state, int64_t n_total, float *pos_mean_out,
+                  float *pos_std_out, void *stream);
+
 /* softmax weights + weighted sum as ONE online-softmax record of this shard
  * (controllers/covo.py:266-272 before normalisation): two-stage wavefront reduction.
  * groupmin (nullable): the per-64-sample minima covo_rollout_cost left for exactly this

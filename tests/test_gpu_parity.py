@@ -193,7 +193,7 @@ def test_rollout_freeze_and_box_exit():
 def test_rollout_rollover_termination(want_stats):
     """Quad3D(disable_rollover_terminate=False), the constructor's default: is_terminal also fires on quat[3] < cos(pi/4)
     or |omega| > 100 (quadrotor.py:486-490).  Large body-rate commands tip a good share of the samples over within the
-    horizon; both rollout kernels (pipelined / one-lane-per-sample with position statistics) against the oracle."""
+    horizon; the pipelined kernel without and with the position statistics (its STATS variant) against the oracle."""
     s, p, rng = make_problem(seed=31, time=60)
     N = 3000
     a = np.clip(R.hover_action(p, 32, np.float64)[None] + np.array([0.3, 1.5, 1.5, 0.5]) * rng.normal(size=(N, 32, 4)), -1, 1)
