@@ -198,17 +198,29 @@ __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__
                                                       double *__restrict__ scall)
 {
     __shared__ double sm[3][16];
+    __shared__ double tr[SN][17];  // R[c][16 g + a]: the transposed block, read as 128-byte row segments and turned through LDS
     const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const double *R = Rin + (size_t)b * SN * SN;
     double *A = Aall + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
     if (g == 0 && tid < SC_COEF) s[tid] = 0.0;  // scalars and the two "done" flags
     const int r = 16 * g + (tid >> 4), cq = tid & 15;
+    // both orientations are fetched coalesced, all 16 loads of a thread in flight (R[c][r] read in place made every lane of a
+    // load touch its own cache line: 8 KiB through the L1 per instruction)
+    double vr[8], vt[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        vr[m] = R[(size_t)r * SN + cq + 16 * m];
+        vt[m] = R[(size_t)((tid >> 4) + 16 * m) * SN + 16 * g + cq];  // row c = (tid >> 4) + 16 m, column 16 g + cq
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) tr[(tid >> 4) + 16 * m][cq] = vt[m];
+    __syncthreads();
     double rowabs = 0.0, fro = 0.0, diag = 0.0;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int c = cq + 16 * m;
-        const double v = 0.5 * (R[(size_t)r * SN + c] + R[(size_t)c * SN + r]);  // covo.py:117 (bitwise symmetric)
+        const double v = 0.5 * (vr[m] + tr[c][tid >> 4]);  // covo.py:117 (bitwise symmetric): R[r][c] + R[c][r]
         A[(size_t)r * SN + c] = v;
         rowabs += fabs(v);
         fro = fma(v, v, fro);
