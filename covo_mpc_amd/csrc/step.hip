@@ -17,9 +17,10 @@
 // MPPI's three tiny launches in one (mppi.py:43-49,59-61): shift the H covariance blocks in place (drop the first, repeat
 // the last) and factor each 4x4 block -- thread t owns block t; same arithmetic as covo_cholesky (sigma.hip:
 // symmetrise, fp64 right-looking Cholesky with sqrt and one division per column, fp32 out)
-__global__ void mppi_prep_kernel(float *__restrict__ a_cov, float *__restrict__ Ls)
+// (called by every thread of the launch: it contains a barrier)
+__device__ __forceinline__ void mppi_prep(float *__restrict__ a_cov, float *__restrict__ Ls)
 {
-    const int t = threadIdx.x;  // 64 threads, H = 32 active
+    const int t = threadIdx.x;  // >= 32 threads, H = 32 active
     float blk[16];
     if (t < COVO_H) {
         const float *src = a_cov + 16 * ((t < COVO_H - 1) ? t + 1 : t);
@@ -83,8 +84,12 @@ struct DynBlock {
 };
 __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
                                   uint32_t *__restrict__ dyn, float *__restrict__ state_buf, int derive_keys,
-                                  float shared_noise_scale, const DynBlock blk)
+                                  float shared_noise_scale, const DynBlock blk, float *__restrict__ mppi_cov,
+                                  float *__restrict__ mppi_Ls)
 {
+    // MPPI (mppi_cov != null): the covariance shift + the 4x4 block factors ride in this launch (one launch less on a path
+    // that is host bound at small N)
+    if (mppi_cov != nullptr) mppi_prep(mppi_cov, mppi_Ls);
     const int i = threadIdx.x;  // 128 + 32 + 4 threads
     const uint32_t raw[2] = {blk.w[0], blk.w[1]};
     if (i < COVO_NA) {
@@ -231,7 +236,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
                                     a.n_table)))
             return rc;
     } else {  // MPPI: shift a_cov, factor the 4x4 blocks, per-step draws (mppi.py:43-66)
-        hipLaunchKernelGGL(mppi_prep_kernel, dim3(1), dim3(64), 0, s, a.a_cov, st->Ls);
+        // (a_cov was shifted and factored into st->Ls by the begin launch)
         if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
     }
     const bool clipped = true;  // a comes straight from the noise kernels above
@@ -275,7 +280,7 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     std::memcpy(&blk.w[8], &args->state, sizeof(const float *));
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s, args->a_mean,
                        args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
-                       args->shared_noise_scale, blk);
+                       args->shared_noise_scale, blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls);
 
     StepKey k;
     std::memset(&k, 0, sizeof(k));
