@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
 // registers: 2000 cycles per step; 16-lane rows with ds_swizzle broadcasts: 1000.)
 __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
 {
-    __shared__ double sjf[(HH - 1) * NX * NZ];
+    __shared__ double sjf[(HH - 1) * NX * NZ + 1];  // + one zero: what the lanes outside the 13 x 13 block read
     __shared__ double sgl[HH * 16];
     // one chain per WORKGROUP (the f64 MFMA pipe of a SIMD is not shared with another chain: nine chains in one
     // workgroup put 76 steps on one SIMD); the four waves fill LDS together, wave 0 runs the chain
@@ -194,9 +194,15 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
             if (tid + 256 * t < NJ) sjf[tid + 256 * t] = vj[t];
         sgl[tid] = vg0;
         sgl[256 + tid] = vg1;
+        if (tid == 0) sjf[NJ] = 0.0;
     }
     __syncthreads();
     if (tid >= 64) return;
+    // The chains are fully unrolled (k is a compile-time constant: every LDS / global address is base + immediate) and the lanes
+    // outside the 13 x 13 block read a zero slot instead of being masked off: as a rolled loop with `cond ? sjf[..] : 0` operands
+    // hipcc spent ~420 of a step's 755 cycles on exec-mask sequences, index arithmetic and accumulator copies around the four
+    // dependent MFMAs (KC_PROF stamps; the MFMAs + their result -> operand hazard are ~330).
+    constexpr int ZI = (HH - 1) * NX * NZ;
     if (w == 8) {
         // ---- costate: lam_31 = grad r_31, lam_k = grad r_k + A_k^T lam_{k+1}; the vector is column 0 of the tile
         const double *__restrict__ G = sgl;  // grad r_k, staged in LDS: a global load per step would BE the step time
@@ -211,12 +217,23 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
                 L[16 * HH + hi + 4 * r] = 0.0;
             }
         }
+        int offA[4];  // A^T[lo][4g+hi] = df/dz[4g+hi][lo]
+        bool okA[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            okA[g] = lo < NX && 4 * g + hi < NX;
+            offA[g] = (4 * g + hi) * NZ + lo;
+        }
+        bool okG[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) okG[r] = lo == 0 && hi + 4 * r < NX;
         double an[4];
         f64x4 gn;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[((HH - 2) * NX + 4 * g + hi) * NZ + lo] : 0.0;  // A^T[lo][4g+hi]
+        for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? (HH - 2) * NX * NZ + offA[g] : ZI];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gn[r] = (lo == 0 && hi + 4 * r < NX) ? G[16 * (HH - 2) + hi + 4 * r] : 0.0;
+        for (int r = 0; r < 4; ++r) gn[r] = okG[r] ? G[16 * (HH - 2) + hi + 4 * r] : 0.0;
+#pragma unroll
         for (int k = HH - 2; k >= 1; --k) {
             double ac[4];
             f64x4 acc = gn;
@@ -224,9 +241,9 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
             for (int g = 0; g < 4; ++g) ac[g] = an[g];
             if (k > 1) {  // next step's operands in flight
 #pragma unroll
-                for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[((k - 1) * NX + 4 * g + hi) * NZ + lo] : 0.0;
+                for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? (k - 1) * NX * NZ + offA[g] : ZI];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gn[r] = (lo == 0 && hi + 4 * r < NX) ? G[16 * (k - 1) + hi + 4 * r] : 0.0;
+                for (int r = 0; r < 4; ++r) gn[r] = okG[r] ? G[16 * (k - 1) + hi + 4 * r] : 0.0;
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g], lam[g], acc, 0, 0, 0);
@@ -246,29 +263,45 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
         for (int r = 0; r < 4; ++r) S[((size_t)k * 16 + hi + 4 * r) * NA + col] = 0.0;
     }
     f64x4 sv = {0.0, 0.0, 0.0, 0.0};
+    int offA[4];  // A[lo][4g+hi]
+    bool okA[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        okA[g] = lo < NX && 4 * g + hi < NX;
+        offA[g] = lo * NZ + 4 * g + hi;
+    }
     double an[4];
     f64x4 bn;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[(k0 * NX + lo) * NZ + 4 * g + hi] : 0.0;  // A[lo][4g+hi]
+    for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? k0 * NX * NZ + offA[g] : ZI];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bn[r] = (tcol == k0 && hi + 4 * r < NX) ? sjf[(k0 * NX + hi + 4 * r) * NZ + NX + dcol] : 0.0;  // B_k E_k
-    for (int k = k0; k < HH - 1; ++k) {
+    double *__restrict__ Sp = S + (size_t)hi * NA + col;
+#pragma unroll
+    for (int k = 0; k < HH - 1; ++k) {
+        if (k < k0) continue;  // (uniform)
         double ac[4];
         f64x4 acc = bn;
 #pragma unroll
         for (int g = 0; g < 4; ++g) ac[g] = an[g];
         if (k + 1 < HH - 1) {  // next step's operands in flight
 #pragma unroll
-            for (int g = 0; g < 4; ++g) an[g] = (lo < NX && 4 * g + hi < NX) ? sjf[((k + 1) * NX + lo) * NZ + 4 * g + hi] : 0.0;
+            for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? (k + 1) * NX * NZ + offA[g] : ZI];
+            // B_k E_k is non-zero only while the tile's own four steps enter (uniform branch)
+            if (k + 1 <= k0 + 3) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                bn[r] = (tcol == k + 1 && hi + 4 * r < NX) ? sjf[((k + 1) * NX + hi + 4 * r) * NZ + NX + dcol] : 0.0;
+                for (int r = 0; r < 4; ++r)
+                    bn[r] = (tcol == k + 1 && hi + 4 * r < NX) ? sjf[((k + 1) * NX + hi + 4 * r) * NZ + NX + dcol] : 0.0;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bn[r] = 0.0;
+            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g], sv[g], acc, 0, 0, 0);
         sv = acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[((size_t)(k + 1) * 16 + hi + 4 * r) * NA + col] = sv[r];
+        for (int r = 0; r < 4; ++r) Sp[((size_t)(k + 1) * 16 + 4 * r) * NA] = sv[r];
     }
 }
 
