@@ -130,7 +130,10 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     for (int t = 0; t < k; ++t) {
         const double a0 = qm::clip11_((double)am[4 * t + 0]), a1 = qm::clip11_((double)am[4 * t + 1]);
         const double a2 = qm::clip11_((double)am[4 * t + 2]), a3 = qm::clip11_((double)am[4 * t + 3]);
-        qm::dyn_step<double, double>(p, a0, a1, a2, a3, c, t == 0 ? f0x : 0.0, t == 0 ? f0y : 0.0, t == 0 ? f0z : 0.0);
+        // the prefix is the launch's critical path (31 steps of ~80 dependent-issue fp64 instructions for wave 31): from step 1 on
+        // the entry normalisation of the just-normalised quaternion is skipped (<= 1 ulp; the dual step below keeps both)
+        if (t == 0) qm::dyn_step<double, double>(p, a0, a1, a2, a3, c, f0x, f0y, f0z);
+        else qm::dyn_step<double, double, false>(p, a0, a1, a2, a3, c, 0.0, 0.0, 0.0);
     }
     if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
     // the step with ONE first-order seed per lane (17 lanes): reward gradient and column `lane` of df/dz

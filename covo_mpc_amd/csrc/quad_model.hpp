@@ -255,14 +255,20 @@ __device__ __forceinline__ S reward(const State<S> &s, U tx, U ty, U tz, U tvx, 
 
 // envs/quadrotor.py:250-263 + dynamics/free.py:114-155 (+74-112).  a* are already clipped.
 // (fx,fy,fz) = f_disturb acting during THIS step (free.py:91,98).
-template <class S, class U>
+// ENTRY_NORM = false: the stored quaternion is the one free.py:139 normalised at the end of the previous step -- normalising it
+// again on entry (free.py:88) moves it by <= 1 ulp; used only for the plain primal prefix of the adjoint Hessian (steps >= 1),
+// never where derivatives are taken.
+template <class S, class U, bool ENTRY_NORM = true>
 __device__ __forceinline__ void dyn_step(State<S> &s, S a0, S a1, S a2, S a3, const Consts<U> &c, U fx, U fy, U fz)
 {
     const S thrust = (a0 + U(1)) * c.thrust_half;  // quadrotor.py:259, free.py:82
     const S wtx = a1 * c.komega[0], wty = a2 * c.komega[1], wtz = a3 * c.komega[2];  // quadrotor.py:260, free.py:122,82
     // q = x[3:7] / norm (free.py:88)
-    const S rn = rsqrt_(s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw);
-    const S x = s.qx * rn, y = s.qy * rn, z = s.qz * rn, w = s.qw * rn;
+    S x = s.qx, y = s.qy, z = s.qz, w = s.qw;
+    if (ENTRY_NORM) {
+        const S rn = rsqrt_(s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw);
+        x = s.qx * rn; y = s.qy * rn; z = s.qz * rn; w = s.qw * rn;
+    }
     // Q @ [0,0,T]: third column of qtoQ(q) (geom.py:68-77)
     const S Qz0 = U(2) * (x * z + y * w), Qz1 = U(2) * (y * z - x * w), Qz2 = w * w - x * x - y * y + z * z;
     // v_dot = [0,0,-g] + 1/m (Q [0,0,T] + f)   (free.py:97-99)
