@@ -444,15 +444,21 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
                     const double z2 = fma(zeta, zeta, 1.0);
                     const double t = copysign(1.0, zeta) * qm::rcp64_(fabs(zeta) + z2 * qm::rsq64_(z2));
                     const double c = qm::rsq64_(fma(t, t, 1.0)), sn = c * t;
-                    for (int k = 0; k < RITZ; ++k) {  // columns
+                    // J^T h J for the symmetric h, written out: the 2 x 2 pivot block in closed form (h_pq -> 0), the other rows
+                    // and columns once, mirrored (two full 4 x 4 products cost three times the arithmetic on this one serial lane)
+                    const double hpq = h[p][q2] * t;
+                    h[p][p] -= hpq;
+                    h[q2][q2] += hpq;
+                    h[p][q2] = 0.0;
+                    h[q2][p] = 0.0;
+                    for (int k = 0; k < RITZ; ++k) {
+                        if (k == p || k == q2) continue;
                         const double hp = h[k][p], hq = h[k][q2];
-                        h[k][p] = c * hp - sn * hq;
-                        h[k][q2] = sn * hp + c * hq;
-                    }
-                    for (int k = 0; k < RITZ; ++k) {  // rows
-                        const double hp = h[p][k], hq = h[q2][k];
-                        h[p][k] = c * hp - sn * hq;
-                        h[q2][k] = sn * hp + c * hq;
+                        const double np_ = c * hp - sn * hq, nq_ = sn * hp + c * hq;
+                        h[k][p] = np_;
+                        h[p][k] = np_;
+                        h[k][q2] = nq_;
+                        h[q2][k] = nq_;
                     }
                 }
         }
@@ -473,18 +479,17 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     if (tid == 0) {
         const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, pre_tr, pre_f2));  // |A + delta I|_F^2
         const double scale = fmin(fmax(red[0], red[1]), sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
-        s[SC_SCALE] = scale;
-        // Chen-Chow scaled Newton-Schulz: x -> x (a + b x^2) on [l, 1] with a = 1.5 rho, b = -0.5 rho^3,
-        // rho^2 = 3/(1 + l + l^2) (equal values at both ends of the interval); lambda_min(Y0) = 1e-2/scale
-        double l = sqrt(1e-2 / scale);
-        for (int k = 0; k < NS_ITERS; ++k) {
-            const double rho = (l < 1.0 - 1e-9) ? 1.7320508075688772 * qm::rsq64_(1.0 + l + l * l) : 1.0;
-            const double a = 1.5 * rho, bq = -0.5 * rho * rho * rho;
-            s[SC_COEF + 2 * k] = a;
-            s[SC_COEF + 2 * k + 1] = bq;
-            l = fmin(1.0, l * fma(bq * l, l, a));
-        }
+        s[SC_SCALE] = scale;  // the Newton-Schulz coefficient table follows from it: ns_first_kernel's extra workgroup
     }
+}
+
+// Chen-Chow scaled Newton-Schulz: x -> x (a + b x^2) on [l, 1] with a = 1.5 rho, b = -0.5 rho^3, rho^2 = 3/(1 + l + l^2) (equal
+// values at both ends of the interval); lambda_min(Y0) = 1e-2/scale, so l_0 = sqrt(1e-2/scale) and l_(k+1) = l_k (a_k + b_k l_k^2)
+__device__ __forceinline__ void ns_coef(double l, double &a, double &bq)
+{
+    const double rho = (l < 1.0 - 1e-9) ? 1.7320508075688772 * qm::rsq64_(1.0 + l + l * l) : 1.0;
+    a = 1.5 * rho;
+    bq = -0.5 * rho * rho * rho;
 }
 
 // ---- Newton-Schulz iteration 0 (Z0 = I, Y0 = B/s read from A on load):  Y1 = a0 Y0 + b0 Y0^2,  Z1 = a0 I + b0 Y0
@@ -497,7 +502,25 @@ __global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict_
     const size_t off = (size_t)b * SN * SN;
     const double *A = Aall + off;
     double *s = scall + (size_t)b * SC_COUNT;
-    const double delta = s[SC_DELTA], inv = 1.0 / s[SC_SCALE], a0 = s[SC_COEF], b0 = s[SC_COEF + 1];
+    const double scale = s[SC_SCALE];
+    const double delta = s[SC_DELTA], inv = 1.0 / scale;
+    if (w == 64) {
+        // the extra workgroup: the coefficient table of the iterations to come (a serial recurrence, ~1 us on one lane -- under
+        // this launch's GEMM instead of on the tail of the single-workgroup Ritz launch before it)
+        if (tid == 0) {
+            double l = sqrt(1e-2 / scale);
+            for (int k = 0; k < NS_ITERS; ++k) {
+                double a, bq;
+                ns_coef(l, a, bq);
+                s[SC_COEF + 2 * k] = a;
+                s[SC_COEF + 2 * k + 1] = bq;
+                l = fmin(1.0, l * fma(bq * l, l, a));
+            }
+        }
+        return;
+    }
+    double a0, b0;
+    ns_coef(sqrt(1e-2 / scale), a0, b0);
     if (w == 0 && tid == 0) {
         s[SC_ZBUF] = (double)zbuf_out;
         s[SC_ITERS] = 1.0;
@@ -538,7 +561,7 @@ __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztal
     const int ti = w >> 3, tj = w & 7;
     TileOps ops;
     tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // written by the Ritz launch
+    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // written by ns_first_kernel's extra workgroup
     if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
     const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
@@ -853,7 +876,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc);
     if (g_dbg_sigma_stages < 3) return 0;
-    hipLaunchKernelGGL(ns_first_kernel, dim3(64, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);
+    hipLaunchKernelGGL(ns_first_kernel, dim3(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);  // 64 tiles + the table
     int n_tail = (batch == 1 && persistent_ok) ? g_ns_tail_iters : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
     const int n_sep = NS_ITERS - n_tail;
