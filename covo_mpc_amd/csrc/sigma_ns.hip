@@ -771,10 +771,12 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
             tri_tile(w, ti, tj);
             const int r = 16 * ti + (in >> 3), c = 16 * tj + 2 * (in & 7);
             const double v0 = 0.5 * (za[t].x + zt[t].x), v1 = 0.5 * (za[t].y + zt[t].y);  // covo.py:132 symmetrise
-            sm[r * LD + c] = v0;
-            sm[r * LD + c + 1] = v1;
-            sm[c * LD + r] = v0;
+            sm[c * LD + r] = v0;        // column-major element (r, c), r >= c up to the diagonal block: what the factorisation reads
             sm[(c + 1) * LD + r] = v1;
+            if (ti == tj) {             // diagonal blocks are read as stored: both triangles
+                sm[r * LD + c] = v0;
+                sm[r * LD + c + 1] = v1;
+            }
         }
     }
     __syncthreads();
