@@ -100,7 +100,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
     static_assert(COVO_H % CH == 0, "CH must divide the horizon");
     const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
     __shared__ Rp3Lds<CH> lds_all[ONLY >= 0 ? ONLY_WAVES : GROUPS];
-    __shared__ float lds_st[STATS ? GROUPS : 1][STATS ? COVO_H : 1][6];  // STATS: per group and step {sum d, sum d^2} (d: see stage T)
+    __shared__ float lds_st[STATS ? GROUPS : 1][STATS ? COVO_H : 1][9];  // STATS: per group and step {sum d, sum d^2, shift} (d: see stage T)
     RP3_DECL();
     const int lane = threadIdx.x & (COVO_WAVE - 1);
     const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -199,17 +199,17 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         float px = st[ST_POS + 0], py = st[ST_POS + 1], pz = st[ST_POS + 2];
         float vx = st[ST_VEL + 0], vy = st[ST_VEL + 1], vz = st[ST_VEL + 2];
         // STATS (covo.py:234-237, 281: mean / std over the samples of every step's NEW position).  Per step the wave reduces six
-        // numbers -- d and d^2 per axis, d = position minus the force-free point p0 + (k+1) dt v0 (wave-uniform, so that the
-        // early steps, where all samples still coincide, sum exact zeros; the workgroup puts the shift back in fp64) -- in
-        // 19 instructions: v_permlane32_swap / v_permlane16_swap fold two quantities at a time into the halves / rows of ONE
-        // register (6 -> 3 -> 2 registers), four DPP row rotations finish both; the row sums are parked in lane (k & 15) of
-        // their row and written to LDS every 16 steps.  (One butterfly per quantity: 6 x 8; round 1's one-lane kernel parked
-        // the offsets in LDS and had 24 lanes walk them in fp64 every 8 steps: 27.6 us at N = 65 536.)
-        const float p0x = px, p0y = py, p0z = pz, v0x = vx, v0y = vy, v0z = vz;
-        float st_a = 0.0f, st_b = 0.0f;
+        // numbers -- d and d^2 per axis, d = position minus the position of the wave's FIRST sample (a v_readlane; wave-uniform, so
+        // coinciding samples sum exact zeros whatever their distance from the start and the fp32 squares stay as small as the
+        // spread; the workgroup puts the shift back in fp64) -- in 19 instructions: v_permlane32_swap / v_permlane16_swap fold
+        // two quantities at a time into the halves / rows of ONE register (6 -> 3 -> 2 registers), four DPP row rotations finish
+        // both; the row sums and the shift are parked in lane (k & 15) of their row and written to LDS every 16 steps.  (One
+        // butterfly per quantity: 6 x 8; round 1's one-lane kernel parked the offsets in LDS and had 24 lanes walk them in fp64
+        // every 8 steps: 27.6 us at N = 65 536.)
+        float st_a = 0.0f, st_b = 0.0f, st_c = 0.0f;
         auto stats_step = [&](int k, float nx, float ny, float nz) {
-            const float tk = (float)(k + 1) * c.dt;
-            float d0 = nx - __builtin_fmaf(v0x, tk, p0x), d1 = ny - __builtin_fmaf(v0y, tk, p0y), d2 = nz - __builtin_fmaf(v0z, tk, p0z);
+            const float cx = lane_bcast(nx, 0), cy = lane_bcast(ny, 0), cz = lane_bcast(nz, 0);
+            float d0 = nx - cx, d1 = ny - cy, d2 = nz - cz;
             d0 = valid ? d0 : 0.0f;
             d1 = valid ? d1 : 0.0f;
             d2 = valid ? d2 : 0.0f;
@@ -233,13 +233,16 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
             sa += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sa), 0x121, 0xf, 0xf, false));
             sb += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sb), 0x121, 0xf, 0xf, false));
             const bool mine = (lane & 15) == (k & 15);
+            const int row = lane >> 4;
             st_a = mine ? sa : st_a;
             st_b = mine ? sb : st_b;
+            st_c = mine ? (row == 0 ? cx : (row == 1 ? cy : cz)) : st_c;
             if ((k & 15) == 15) {
-                const int row = lane >> 4, step = (k - 15) + (lane & 15);
+                const int step = (k - 15) + (lane & 15);
                 const int qa = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
                 lds_st[gsub][step][qa] = st_a;
                 if ((row & 1) == 0) lds_st[gsub][step][row == 0 ? 4 : 5] = st_b;
+                if (row < 3) lds_st[gsub][step][6 + row] = st_c;
             }
         };
         const float kf = c.inv_m * c.dt;  // v += dt/m f (free.py:98,103)
@@ -367,15 +370,13 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
                                            rec_s, rec_v);
     }
     if (STATS) {
-        // this workgroup's {sum (p - p0), sum (p - p0)^2} per step and axis, in fp64, with the T waves' shift put back:
-        // p - p0 = d + D, D = (k+1) dt v0 as formed above  ->  sum = S1 + n D,  sum of squares = S2 + 2 D S1 + n D^2
+        // this workgroup's {sum (p - p0), sum (p - p0)^2} per step and axis, in fp64, with each T wave's shift put back:
+        // p - p0 = d + D, D = (the wave's first sample) - p0  ->  sum = S1 + n D,  sum of squares = S2 + 2 D S1 + n D^2
         __syncthreads();
         const int t = threadIdx.x;
         if (t < COVO_H * 6) {
             const int k = t / 6, q = t % 6, ax = q % 3;
-            const float p0 = st[ST_POS + ax], v0 = st[ST_VEL + ax];
-            const float tk = (float)(k + 1) * c.dt;
-            const double D = (double)__builtin_fmaf(v0, tk, p0) - (double)p0;
+            const float p0 = st[ST_POS + ax];
             double tot = 0.0;
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) {
@@ -387,6 +388,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
                 int nv = A.N - grp * COVO_WAVE;
                 nv = nv < 0 ? 0 : (nv > COVO_WAVE ? COVO_WAVE : nv);
                 const double s1 = (double)lds_st[g][k][ax];
+                const double D = (double)lds_st[g][k][6 + ax] - (double)p0;
                 if (q < 3) tot += s1 + (double)nv * D;
                 else tot += (double)lds_st[g][k][q] + 2.0 * D * s1 + (double)nv * D * D;
             }
