@@ -34,4 +34,34 @@ for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         print("  std dev/ref at worst step", info["pos_std"].cpu().numpy()[k], ps[k], " step0:", info["pos_std"].cpu().numpy()[0], ps[0])
 for N in (4097, 20000, 66000):
     T.test_rollout_workgroup_shapes(N)
-print("all", n_ok, "passed")
+print("rollout:", n_ok, "passed", flush=True)
+
+
+class _MP:  # pytest's monkeypatch, as far as the tests use it
+    def setenv(self, k, v):
+        os.environ[k] = v
+    def delenv(self, k, raising=False):
+        os.environ.pop(k, None)
+
+
+n2 = 0
+for i in range(int(sys.argv[3]) if len(sys.argv) > 3 else 12):
+    name = rnd.choice(["covo-online", "mppi", "covo-online"])
+    N = rnd.choice([1, 31, 64, 65, 100, 1000, 2047, 4096, 9000, 16384, 40000, 131072])
+    lam = rnd.choice(["0.01", "0.1", "1.0"])
+    graph = rnd.choice(["graph", "eager"])
+    for k in ("COVO_GRAPH", "COVO_NO_GRAPH"):
+        os.environ.pop(k, None)
+    try:
+        T.test_fused_step_ragged_sizes_and_warm_lambda(name, N, lam, graph, _MP())
+        n2 += 1
+        print("ok fused", name, N, lam, graph, flush=True)
+    except AssertionError as e:
+        print("FAIL fused", name, N, lam, graph, repr(e)[:300], flush=True)
+for k in ("COVO_GRAPH", "COVO_NO_GRAPH"):
+    os.environ.pop(k, None)
+for N in (33, 129, 200):
+    T.test_tiny_and_ragged_sample_counts(N)
+for lam, N in ((0.01, 100000), (0.5, 777), (10.0, 65)):
+    T.test_softmax_update_vs_oracle(lam, N)
+print("fused:", n2, "passed")
