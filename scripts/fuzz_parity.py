@@ -65,3 +65,62 @@ for N in (33, 129, 200):
 for lam, N in ((0.01, 100000), (0.5, 777), (10.0, 65)):
     T.test_softmax_update_vs_oracle(lam, N)
 print("fused:", n2, "passed")
+
+# ---- Sigma chain on random spectra: bottom multiplicity, bottom gap, width, exact null spaces; batch 1 (persistent tails) and batched
+import numpy as np, torch
+nrng = np.random.default_rng(rnd.randrange(1 << 30))
+core = T.SamplingCore(256, 32, 0.01, 1.0, device=T.DEV)
+worst = 0.0
+n3 = 0
+for trial in range(int(sys.argv[4]) if len(sys.argv) > 4 else 24):
+    Q, _ = np.linalg.qr(nrng.standard_normal((128, 128)))
+    lmin = nrng.uniform(-5.0, 0.5)
+    width = float(nrng.choice([5.0, 50.0, 500.0, 5000.0]))
+    mult = int(nrng.choice([1, 1, 2, 3, 5]))
+    gap = float(nrng.choice([1e-9, 1e-6, 1e-3, 0.1, 1.0]))
+    w = np.sort(nrng.uniform(lmin + gap, lmin + width, 128))
+    w[:mult] = lmin
+    if mult < 128 and nrng.random() < 0.5:
+        w[mult] = lmin + gap
+    Rm = (Q * w) @ Q.T
+    if nrng.random() < 0.3:  # exact 4-dim null block like a real CoVO Hessian (last action never reaches a reward)
+        Rm[124:, :] = 0
+        Rm[:, 124:] = 0
+    Rm = 0.5 * (Rm + Rm.T)
+    ref = T.R.optimize_sigma(Rm, 0.5, 32, 4)
+    for batch in (1, 3):
+        Rb = np.stack([Rm] * batch)
+        Sigma, L = core.sigma(torch.from_numpy(Rb).to(T.DEV), 0.5, batch=batch)
+        S = Sigma[batch - 1].cpu().numpy()
+        err = np.linalg.norm(S - ref) / np.linalg.norm(ref)
+        worst = max(worst, err)
+        L64 = L[batch - 1].cpu().numpy().astype(np.float64)
+        errL = np.linalg.norm(L64 @ L64.T - S) / np.linalg.norm(S)
+        ok = err < 1e-6 and errL < 2e-7 and np.all(np.isfinite(S))
+        if not ok:
+            print("FAIL sigma", trial, "batch", batch, "lmin %.3f width %g mult %d gap %g" % (lmin, width, mult, gap), "err", err, "errL", errL, flush=True)
+        else:
+            n3 += 1
+print("sigma:", n3, "passed, worst rel err", worst)
+
+# ---- adjoint Hessian against the C oracle's hyper-dual one: random states / times / action scales, clip ties and saturated actions
+n4 = 0
+worst = 0.0
+for trial in range(int(sys.argv[5]) if len(sys.argv) > 5 else 16):
+    time = rnd.choice([0, 3, 37, 150, 268, 275, 290, 299, 310])
+    s, p, rng = T.make_problem(seed=rnd.randrange(10000), time=time)
+    scale = rnd.choice([0.02, 0.1, 0.5, 1.5])
+    a = (T.R.hover_action(p, 32, np.float64) + scale * rng.normal(size=(32, 4))).astype(np.float32)
+    if rnd.random() < 0.5:
+        a[rnd.randrange(32), rnd.randrange(4)] = 1.0   # exact clip tie
+        a[rnd.randrange(32), rnd.randrange(4)] = -1.0
+    ds = T.dev_state(s)
+    Rm = core.hessian(ds.packed, ds, T.EnvParams3D().to_c(), torch.from_numpy(a.reshape(-1)).to(T.DEV))[0].cpu().numpy()
+    ref = T.CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32)
+    err = np.abs(Rm - ref).max() / max(1.0, np.abs(ref).max())
+    worst = max(worst, err)
+    if not (err < 1e-9 and np.abs(Rm - Rm.T).max() == 0.0):
+        print("FAIL hessian", trial, "time", time, "scale", scale, "err", err, "|ref|", np.abs(ref).max(), flush=True)
+    else:
+        n4 += 1
+print("hessian:", n4, "passed, worst", worst)
