@@ -127,13 +127,27 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     p.qx = st[ST_QUAT + 0]; p.qy = st[ST_QUAT + 1]; p.qz = st[ST_QUAT + 2]; p.qw = st[ST_QUAT + 3];
     p.ox = st[ST_OMEGA + 0]; p.oy = st[ST_OMEGA + 1]; p.oz = st[ST_OMEGA + 2];
     const double f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
+    // The prefix is the launch's critical path: for wave 31, 31 steps of dependent-issue fp64 instructions, one per ~7 cycles
+    // whatever their dependencies.  What does not depend on the state -- clip, thrust and body-rate targets of every step's
+    // action (quadrotor.py:223,258-260; 16 of a step's 80 instructions) -- is computed by lane t for step t in ONE pass and
+    // read back per step (uniform LDS reads); from step 1 on the entry normalisation of the just-normalised quaternion is
+    // skipped (<= 1 ulp; the dual step below keeps both).  80 -> 52 instructions per step, 10.1 -> 7.8 us.  (Measured and
+    // dropped: the attitude / translation cascade as TWO waves through LDS, as in the rollout -- the three LDS writes per step
+    // on the attitude wave cost more issue time than the 13 instructions they move away: 9.3 us.)
+    __shared__ double sact[HH][4];
+    if (lane < HH) {
+        const double a0 = qm::clip11_((double)am[4 * lane + 0]), a1 = qm::clip11_((double)am[4 * lane + 1]);
+        const double a2 = qm::clip11_((double)am[4 * lane + 2]), a3 = qm::clip11_((double)am[4 * lane + 3]);
+        sact[lane][0] = (a0 + 1.0) * c.thrust_half;
+        sact[lane][1] = a1 * c.komega[0];
+        sact[lane][2] = a2 * c.komega[1];
+        sact[lane][3] = a3 * c.komega[2];
+    }
+    __syncthreads();
     for (int t = 0; t < k; ++t) {
-        const double a0 = qm::clip11_((double)am[4 * t + 0]), a1 = qm::clip11_((double)am[4 * t + 1]);
-        const double a2 = qm::clip11_((double)am[4 * t + 2]), a3 = qm::clip11_((double)am[4 * t + 3]);
-        // the prefix is the launch's critical path (31 steps of ~80 dependent-issue fp64 instructions for wave 31): from step 1 on
-        // the entry normalisation of the just-normalised quaternion is skipped (<= 1 ulp; the dual step below keeps both)
-        if (t == 0) qm::dyn_step<double, double>(p, a0, a1, a2, a3, c, f0x, f0y, f0z);
-        else qm::dyn_step<double, double, false>(p, a0, a1, a2, a3, c, 0.0, 0.0, 0.0);
+        const double th = sact[t][0], w0 = sact[t][1], w1 = sact[t][2], w2 = sact[t][3];
+        if (t == 0) qm::dyn_core<double, double>(p, th, w0, w1, w2, c, f0x, f0y, f0z);
+        else qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, 0.0, 0.0, 0.0);
     }
     if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
     // the step with ONE first-order seed per lane (17 lanes): reward gradient and column `lane` of df/dz

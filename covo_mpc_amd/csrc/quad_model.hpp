@@ -258,11 +258,21 @@ __device__ __forceinline__ S reward(const State<S> &s, U tx, U ty, U tz, U tvx, 
 // ENTRY_NORM = false: the stored quaternion is the one free.py:139 normalised at the end of the previous step -- normalising it
 // again on entry (free.py:88) moves it by <= 1 ulp; used only for the plain primal prefix of the adjoint Hessian (steps >= 1),
 // never where derivatives are taken.
+// dyn_core: the step given the action's thrust and body-rate targets (dyn_step = action terms + dyn_core, same operations)
+template <class S, class U, bool ENTRY_NORM = true>
+__device__ __forceinline__ void dyn_core(State<S> &s, S thrust, S wtx, S wty, S wtz, const Consts<U> &c, U fx, U fy, U fz);
+
 template <class S, class U, bool ENTRY_NORM = true>
 __device__ __forceinline__ void dyn_step(State<S> &s, S a0, S a1, S a2, S a3, const Consts<U> &c, U fx, U fy, U fz)
 {
     const S thrust = (a0 + U(1)) * c.thrust_half;  // quadrotor.py:259, free.py:82
     const S wtx = a1 * c.komega[0], wty = a2 * c.komega[1], wtz = a3 * c.komega[2];  // quadrotor.py:260, free.py:122,82
+    dyn_core<S, U, ENTRY_NORM>(s, thrust, wtx, wty, wtz, c, fx, fy, fz);
+}
+
+template <class S, class U, bool ENTRY_NORM>
+__device__ __forceinline__ void dyn_core(State<S> &s, S thrust, S wtx, S wty, S wtz, const Consts<U> &c, U fx, U fy, U fz)
+{
     // q = x[3:7] / norm (free.py:88)
     S x = s.qx, y = s.qy, z = s.qz, w = s.qw;
     if (ENTRY_NORM) {
