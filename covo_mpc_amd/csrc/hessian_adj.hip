@@ -40,7 +40,9 @@ constexpr size_t WS_MXX = WS_LAM + 33 * 16;      // [32][16][16]   zero padded
 constexpr size_t WS_MXU = WS_MXX + 32 * 256;     // [32][16][4]
 constexpr size_t WS_MUU = WS_MXU + 32 * 64;      // [32][4][4]
 constexpr size_t WS_S = WS_MUU + 32 * 16;        // [32][16][128]  rows 13..15 zero
-constexpr size_t WS_COUNT = WS_S + (size_t)32 * 16 * NA;
+constexpr int NPAIR = NZ * (NZ + 1) / 2;         // 153 pairs a <= b of step inputs
+constexpr size_t WS_H14 = WS_S + (size_t)32 * 16 * NA;  // [32][14][153]  second derivatives of r_k and of the 13 components of f_k per pair
+constexpr size_t WS_COUNT = WS_H14 + (size_t)32 * 14 * NPAIR + 2;
 
 struct AdjArgs {
     const float *state;     // [batch][COVO_STATE_FLOATS]
@@ -182,6 +184,32 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     }
 }
 
+// ---- the lambda-independent 9/10 of KM: one hyper-dual step per pair a <= b of the 17 step inputs -> the mixed second derivative of
+// r_k and of each of the 13 components of f_k (14 numbers per pair).  M_k = Hess_z(r_k + lam_{k+1} . f_k) is their combination
+// with the costate -- which the chains of KC are still computing: these 32 workgroups ride in KC's launch on otherwise idle
+// CUs (5 us in the shadow of the 10 us recursions), and the launch after it only contracts (adj_hess_kernel).
+__device__ __forceinline__ void adj_hd_pairs(const AdjArgs &A, int k, int b, int tid)
+{
+    if (tid >= NPAIR) return;
+    const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
+    const float *__restrict__ am = A.a_mean + (size_t)b * NA;
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    const int time0 = __float_as_int(st[ST_TIME]);
+    int q = tid, a = 0;
+    while (q >= NZ - a) { q -= NZ - a; ++a; }
+    const int bb = a + q;
+    qm::State<double> p;
+    adj_load_state(p, ws + WS_X + 16 * k);
+    qm::HD r;
+    qm::State<qm::HD> s;
+    adj_hd_step(st, am, A, b, time0, k, p, a, bb, r, s);
+    double *__restrict__ H = ws + WS_H14 + (size_t)k * 14 * NPAIR + tid;  // [component][pair]: coalesced over the pairs
+    H[0] = r.ab;
+#define OP(m, i) H[(size_t)(1 + i) * NPAIR] = s.m.ab;
+    ADJ_FOR_STATE(OP)
+#undef OP
+}
+
 // ---- KC: the two linear recursions on the matrix cores.
 // S_{k+1} = A_k S_k + B_k E_k is a (13x13).(13x128) product per step: wave w keeps a 16-column tile of S in
 // the MFMA C/D layout (lane (lo, hi), register g = row 4g + hi, column lo) -- which is exactly the B operand
@@ -197,8 +225,12 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
     // one chain per WORKGROUP (the f64 MFMA pipe of a SIMD is not shared with another chain: nine chains in one
     // workgroup put 76 steps on one SIMD); the four waves fill LDS together, wave 0 runs the chain
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
-    const int w = blockIdx.x;  // 0..7: column tile of S, 8: costate
+    const int w = blockIdx.x;  // 0..7: column tile of S, 8: costate, 9..40: the hyper-dual steps of KM (see adj_hd_pairs)
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    if (w >= 9) {
+        adj_hd_pairs(A, w - 9, b, tid);
+        return;
+    }
     {
         // all global loads in flight before the first LDS store (a rolled loop pays one L2 latency per trip)
         constexpr int NJ = (HH - 1) * NX * NZ, TJ = (NJ + 255) / 256;
@@ -322,35 +354,32 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
     }
 }
 
-// ---- KM: M_k = Hess_z( r_k(x) + lam_{k+1} . f_k(z) ), one hyper-dual step per pair a <= b of the 17 inputs
+// ---- KM: M_k = Hess_z( r_k(x) + lam_{k+1} . f_k(z) ) = (second derivatives of r_k) + sum_i lam_{k+1,i} (second derivatives of f_k^i):
+// the contraction of what adj_hd_pairs left behind (KC's launch) with the costate -- 15 loads and 13 FMAs per pair
 __global__ __launch_bounds__(192) void adj_hess_kernel(const AdjArgs A)
 {
     const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
-    const float *__restrict__ am = A.a_mean + (size_t)b * NA;
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
-    const int time0 = __float_as_int(st[ST_TIME]);
     double *__restrict__ Mxx = ws + WS_MXX + (size_t)k * 256, *__restrict__ Mxu = ws + WS_MXU + (size_t)k * 64;
     double *__restrict__ Muu = ws + WS_MUU + (size_t)k * 16;
+    const int pr = tid < NPAIR ? tid : 0;
+    const double *__restrict__ H = ws + WS_H14 + (size_t)k * 14 * NPAIR + pr;
+    double h[14], lam[NX];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) h[i] = H[(size_t)i * NPAIR];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lam[i] = (k <= HH - 2) ? ws[WS_LAM + 16 * (k + 1) + i] : 0.0;
     // zero padding of the x block (rows / columns 13..15)
     for (int e = tid; e < 256; e += 192)
         if ((e >> 4) >= NX || (e & 15) >= NX) Mxx[e] = 0.0;
     if (tid < 12) Mxu[NX * 4 + tid] = 0.0;
-    constexpr int NPAIR = NZ * (NZ + 1) / 2;  // 153
-    int q = tid < NPAIR ? tid : 0, a = 0;
+    int q = pr, a = 0;
     while (q >= NZ - a) { q -= NZ - a; ++a; }
     const int bb = a + q;
-    qm::State<double> p;
-    adj_load_state(p, ws + WS_X + 16 * k);
-    qm::HD r;
-    qm::State<qm::HD> s;
-    adj_hd_step(st, am, A, b, time0, k, p, a, bb, r, s);
-    double g = r.ab;
+    double g = h[0];
     if (k <= HH - 2) {
-        const double *__restrict__ lam = ws + WS_LAM + 16 * (k + 1);
-#define OP(m, i) g = fma(lam[i], s.m.ab, g);
-        ADJ_FOR_STATE(OP)
-#undef OP
+#pragma unroll
+        for (int i = 0; i < NX; ++i) g = fma(lam[i], h[1 + i], g);
     }
     if (tid < NPAIR) {
         if (bb < NX) {
@@ -493,7 +522,7 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.cs = reinterpret_cast<const qm::Consts<double> *>(consts_dev);
     A.traj_stride = traj_stride;
     if (g_dbg_hess_mask & 1) hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
-    if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(adj_chain_kernel, dim3(9, batch), dim3(256), 0, s, A);
+    if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(adj_chain_kernel, dim3(9 + HH, batch), dim3(256), 0, s, A);  // 9 chains + KM's 32 hyper-dual workgroups
     if (g_dbg_hess_mask & 4) hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);
     if (g_dbg_hess_mask & 8) hipLaunchKernelGGL(adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());
