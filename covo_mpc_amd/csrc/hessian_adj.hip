@@ -26,6 +26,7 @@
 // Critical path: 30 plain steps + 2 hyper-dual steps + a 31-step recursion of 13-vectors ~ 25 us.
 #include "covo_common.hpp"
 #include "wave_reduce.hpp"
+#include "sym_stats.hpp"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -55,6 +56,7 @@ struct AdjArgs {
     qm::Consts<double> c;            // shared model constants ...
     const qm::Consts<double> *cs;    // ... or one per batch entry (device, nullable): env instances with their own parameters
     size_t traj_stride;              // floats between the trajectories of consecutive batch entries (0: shared)
+    SymStatsOut stats;               // batch 1, rpart != null: KD also leaves the Sigma chain's input statistics of R there
 };
 
 __device__ __forceinline__ void adj_targets(const float *__restrict__ st, const float *__restrict__ pos_traj,
@@ -484,22 +486,37 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
     const long long kp3 = clock64();
     if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 35)) printf("KD wg %d: loads %lld mfma %lld barrier %lld\n", (int)blockIdx.x, kp1 - kp0, kp2 - kp1, kp3 - kp2);
 #endif
-    if (wv >= 4) return;
     double v = 0.0;
+    if (wv < 4) {
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) v += red[w8][wv][lane];
-    // action blocks: u_i enters at step t_i where column j has sensitivity S_{t_i}[:, j] (t_j < t_i), and vice versa
-    if (ti != tj) {
-        const double *mu = sMu[tk - 4 * I];
+        for (int w8 = 0; w8 < 8; ++w8) v += red[w8][wv][lane];
+        // action blocks: u_i enters at step t_i where column j has sensitivity S_{t_i}[:, j] (t_j < t_i), and vice versa
+        if (ti != tj) {
+            const double *mu = sMu[tk - 4 * I];
 #pragma unroll
-        for (int m = 0; m < NX; ++m) v = fma(es[m], mu[m * 4 + dk], v);
-    } else {
-        v += sMuu[(ti - 4 * I) * 16 + di * 4 + dj];
+            for (int m = 0; m < NX; ++m) v = fma(es[m], mu[m * 4 + dk], v);
+        } else {
+            v += sMuu[(ti - 4 * I) * 16 + di * 4 + dj];
+        }
+        // C = -J.  Off-diagonal tiles mirror; in diagonal tiles the lower half writes both copies (exactly symmetric R)
+        if (I != J || i >= j) {
+            R[(size_t)i * NA + j] = -v;
+            R[(size_t)j * NA + i] = -v;
+        }
     }
-    // C = -J.  Off-diagonal tiles mirror; in diagonal tiles the lower half writes both copies (exactly symmetric R)
-    if (I != J || i >= j) {
-        R[(size_t)i * NA + j] = -v;
-        R[(size_t)j * NA + i] = -v;
+    if (A.stats.rpart != nullptr && b == 0) {
+        // the Sigma chain's input statistics of R = -v, tile by tile (sym_stats.hpp): the chain then needs no prep launch.  In a
+        // diagonal tile R holds the lower half and its mirror image, so the statistics take the mirrored values too
+        __shared__ double st_tmp[16][17];
+        __shared__ double st_part[4];
+        __shared__ double st_diag[16][17];
+        double rv = -v;
+        if (I == J) {
+            if (wv < 4) st_diag[hi + 4 * wv][lo] = rv;
+            __syncthreads();
+            if (wv < 4 && i < j) rv = st_diag[lo][hi + 4 * wv];
+        }
+        sym_tile_stats(wv < 4, rv, I, J, (int)blockIdx.x, lane, wv & 3, A.stats, st_tmp, st_part);
     }
 }
 }  // namespace
@@ -508,7 +525,7 @@ size_t hessian_workspace_bytes(int batch) { return (size_t)batch * WS_COUNT * si
 
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev,
-                   size_t traj_stride)
+                   size_t traj_stride, const SymStatsOut *stats)
 {
     AdjArgs A;
     A.state = state;
@@ -521,6 +538,10 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.c = make_consts<double>(p);
     A.cs = reinterpret_cast<const qm::Consts<double> *>(consts_dev);
     A.traj_stride = traj_stride;
+    A.stats.rpart = nullptr;
+    A.stats.fpart = nullptr;
+    A.stats.diag = nullptr;
+    if (stats != nullptr && batch == 1) A.stats = *stats;
     if (g_dbg_hess_mask & 1) hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
     if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(adj_chain_kernel, dim3(9 + HH, batch), dim3(256), 0, s, A);  // 9 chains + KM's 32 hyper-dual workgroups
     if (g_dbg_hess_mask & 4) hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);

@@ -45,6 +45,7 @@
 #include "wave_reduce.hpp"
 #include "chol_lds.hpp"
 #include "eps_tiles.hpp"
+#include "sym_stats.hpp"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -76,7 +77,9 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_PREP = 320,          // prep partials: 8 x {max rowabs, sum v^2, trace, min diag}
        SC_SQN = 384,           // |X_i|_F^2 partials: (NS_SQUARINGS + 1) x 64 (36 used)
        SC_ERR = SC_SQN + (NS_SQUARINGS + 1) * 64,  // |Z_k Y_k - I|_F^2 partials: NS_ITERS x 64
-       SC_COUNT = SC_ERR + NS_ITERS * 64 };
+       SC_RPART = SC_ERR + NS_ITERS * 64,          // sym_stats.hpp: per-row, per-column-block |.|-sums (128 x 8)
+       SC_FPART = SC_RPART + 128 * 8,              // per-tile sums of squares (36)
+       SC_COUNT = SC_FPART + 64 };
 static_assert(SC_COEF + 2 * NS_ITERS <= SC_ROWABS, "scalar slots");
 
 // ---- one 256-thread workgroup = one 16x16 tile of C = At^T . B  (At, B row-major 128x128); wave q takes
@@ -192,64 +195,34 @@ __device__ __forceinline__ void store_sym(double *O, int row, int col, double v)
     }
 }
 
-// ---- prep (8 workgroups x 16 rows): A = (R + R^T)/2, per-row |.|-sums and diagonal, partials of
-// max-row-sum / |A|_F^2 / trace / min diagonal.  The affine map Y0 = alpha I - beta A is formed by the first squaring on load.
+// ---- prep (one workgroup per lower 16x16 tile): A = (R + R^T)/2 (covo.py:117, bitwise symmetric) and the tile's share of the
+// input statistics (sym_stats.hpp).  The affine map Y0 = alpha I - beta A is formed by the first squaring on load.  The fused
+// step does not run this launch: its Hessian is exactly symmetric and KD leaves the same statistics (A is then R itself).
+__device__ __forceinline__ SymStatsOut ns_stats_out(double *s)
+{
+    SymStatsOut o;
+    o.rpart = s + SC_RPART;
+    o.fpart = s + SC_FPART;
+    o.diag = s + SC_DIAG;
+    return o;
+}
 __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ Aall,
                                                       double *__restrict__ scall)
 {
-    __shared__ double sm[3][16];
-    __shared__ double tr[SN][17];  // R[c][16 g + a]: the transposed block, read as 128-byte row segments and turned through LDS
-    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    __shared__ double tmp[16][17];
+    __shared__ double part[4];
+    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *R = Rin + (size_t)b * SN * SN;
     double *A = Aall + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
-    if (g == 0 && tid < SC_COEF) s[tid] = 0.0;  // scalars and the two "done" flags
-    const int r = 16 * g + (tid >> 4), cq = tid & 15;
-    // both orientations are fetched coalesced, all 16 loads of a thread in flight (R[c][r] read in place made every lane of a
-    // load touch its own cache line: 8 KiB through the L1 per instruction)
-    double vr[8], vt[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        vr[m] = R[(size_t)r * SN + cq + 16 * m];
-        vt[m] = R[(size_t)((tid >> 4) + 16 * m) * SN + 16 * g + cq];  // row c = (tid >> 4) + 16 m, column 16 g + cq
-    }
-#pragma unroll
-    for (int m = 0; m < 8; ++m) tr[(tid >> 4) + 16 * m][cq] = vt[m];
-    __syncthreads();
-    double rowabs = 0.0, fro = 0.0, diag = 0.0;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int c = cq + 16 * m;
-        const double v = 0.5 * (vr[m] + tr[c][tid >> 4]);  // covo.py:117 (bitwise symmetric): R[r][c] + R[c][r]
-        A[(size_t)r * SN + c] = v;
-        rowabs += fabs(v);
-        fro = fma(v, v, fro);
-        if (c == r) diag = v;
-    }
-    rowabs = wr::row16_allsum(rowabs);
-    fro = wr::row16_allsum(fro);
-    diag = wr::row16_allsum(diag);
-    if (cq == 0) {
-        s[SC_ROWABS + r] = rowabs;
-        s[SC_DIAG + r] = diag;
-        sm[0][tid >> 4] = rowabs;
-        sm[1][tid >> 4] = fro;
-        sm[2][tid >> 4] = diag;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double gm = 0.0, f2 = 0.0, tr = 0.0, md = sm[2][0];
-        for (int i = 0; i < 16; ++i) {
-            gm = fmax(gm, sm[0][i]);
-            f2 += sm[1][i];
-            tr += sm[2][i];
-            md = fmin(md, sm[2][i]);
-        }
-        s[SC_PREP + 4 * g + 0] = gm;
-        s[SC_PREP + 4 * g + 1] = f2;
-        s[SC_PREP + 4 * g + 2] = tr;
-        s[SC_PREP + 4 * g + 3] = md;
-    }
+    if (w == 0 && tid < SC_COEF) s[tid] = 0.0;  // scalars and the two "done" flags
+    int I, J;
+    tri_tile(w, I, J);
+    const int i = 16 * I + (lane >> 4) + 4 * wv, j = 16 * J + (lane & 15);
+    const double v = 0.5 * (R[(size_t)i * SN + j] + R[(size_t)j * SN + i]);
+    A[(size_t)i * SN + j] = v;
+    A[(size_t)j * SN + i] = v;
+    sym_tile_stats(true, v, I, J, w, lane, wv, ns_stats_out(s), tmp, part);
 }
 
 // ---- one doubling of the Chebyshev degree: Xout = Xin^2 / |Xin|_F^2 - I / t_out, t_out = 2 t_in^2 |Xin|_F^2 (36 lower
@@ -266,13 +239,28 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
     double *s = scall + (size_t)b * SC_COUNT;
     double nrm, t_in = 1.0, alpha = 0.0, beta = 0.0;
     if (FIRST) {
-        double gm = 0.0, f2 = 0.0, tr = 0.0, md = s[SC_PREP + 3];
-        for (int i = 0; i < 8; ++i) {
-            gm = fmax(gm, s[SC_PREP + 4 * i + 0]);
-            f2 += s[SC_PREP + 4 * i + 1];
-            tr += s[SC_PREP + 4 * i + 2];
-            md = fmin(md, s[SC_PREP + 4 * i + 3]);
+        // the input statistics from the per-tile partials (sym_stats.hpp), every workgroup for itself in the same fixed order;
+        // workgroup 0 keeps the per-row sums for the Ritz launch and (fused step: there was no prep launch) clears the scalars
+        if (w == 0 && tid < SC_COEF) s[tid] = 0.0;
+        double ra = 0.0, dgv = 0.0;
+        if (tid < SN) {
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) ra += s[SC_RPART + tid * 8 + cb];
+            dgv = s[SC_DIAG + tid];
+            if (w == 0) s[SC_ROWABS + tid] = ra;
         }
+        const double fp = (lane < NS_TILES) ? s[SC_FPART + lane] : 0.0;
+        const double f2 = wr::wave64_allsum(fp);
+        const double gmw = wr::wave64_allmax(tid < SN ? ra : 0.0), mdw = -wr::wave64_allmax(tid < SN ? -dgv : -1e300);
+        const double trw = wr::wave64_allsum(tid < SN ? dgv : 0.0);
+        if (lane == 0) {
+            part[wv] = gmw;
+            red[0][0][wv] = mdw;
+            red[0][1][wv] = trw;
+        }
+        __syncthreads();
+        const double gm = fmax(part[0], part[1]), md = fmin(red[0][0][0], red[0][0][1]), tr = red[0][1][0] + red[0][1][1];
+        __syncthreads();  // part / red are reused below
         // any hi >= lambda_max(A) and any cut > lambda_min(A) work; the tighter they are the faster the filter separates
         const double hi = fmin(gm, sqrt(f2)) * (1.0 + 1e-12) + 1e-3;
         const double cut = fma(NS_CUT_MARGIN, hi - md, md);
@@ -844,10 +832,20 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // closed loop unchanged (4 126 -> 4 120); folding everything: 4 550 / 4 078.
 int g_ns_tail_iters = 3, g_ns_tail_squarings = 6;
 
+SymStatsOut sigma_ns_stats_out(void *workspace)
+{
+    double *ws = reinterpret_cast<double *>(workspace);
+    double *sc = ws + (size_t)11 * SN * SN;
+    SymStatsOut o;
+    o.rpart = sc + SC_RPART;
+    o.fpart = sc + SC_FPART;
+    o.diag = sc + SC_DIAG;
+    return o;
+}
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok, CovDeferred *cov)
+                    hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok, CovDeferred *cov, bool r_has_stats)
 {
     double *ws = reinterpret_cast<double *>(workspace);
     const size_t M = (size_t)batch * SN * SN;
@@ -863,7 +861,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(ns_prep_kernel, dim3(8, batch), dim3(256), 0, s, R, A, sc);
+    if (r_has_stats && batch == 1) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
+    else hipLaunchKernelGGL(ns_prep_kernel, dim3(NS_TILES, batch), dim3(256), 0, s, R, A, sc);
     hipLaunchKernelGGL(ns_square_kernel<true>, dim3(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0);
     // batch 1: the remaining squarings / iterations run inside persistent launches (co-residency: 36 / 128 workgroups)
     int sq_tail = (batch == 1 && persistent_ok) ? g_ns_tail_squarings : 0;

@@ -12,6 +12,7 @@
 #include <vector>
 #include "covo_common.hpp"
 #include "eps_tiles.hpp"
+#include "sym_stats.hpp"
 #include "rng_device.hpp"
 
 // MPPI's three tiny launches in one (mppi.py:43-49,59-61): shift the H covariance blocks in place (drop the first, repeat
@@ -209,7 +210,11 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     int rc;
     const float *state = st->state_buf;
     if (a.mode == COVO_MODE_COVO_ONLINE) {
-        if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s))) return rc;  // :134-185
+        // the Hessian's last launch leaves the Sigma chain's input statistics in the chain's workspace: no prep launch
+        const bool stats = (M & 2) && (M & 4) && (g_dbg_hess_mask & 15) == 15;
+        const SymStatsOut so = sigma_ns_stats_out(h->ws_sigma);
+        if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s, nullptr, 0,
+                                            stats ? &so : nullptr))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
         // epsilon needs only the act key: it is drawn under the chain's single-workgroup finalize launch, the GEMM loads it
         const bool ahead = st->eps_tiled != nullptr && (M & 4) && g_dbg_sigma_stages >= 4 && g_dbg_eps_ahead;
@@ -223,7 +228,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         std::memset(&cov, 0, sizeof(cov));
         const bool defer = (M & 8) && g_dbg_sigma_stages >= 4;
         if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen, h->status_dev,
-                                             (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, defer ? &cov : nullptr))) return rc;
+                                             (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, defer ? &cov : nullptr, stats))) return rc;
         if (ahead) {
             if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, reinterpret_cast<const float *>(st->eps_tiled), 0, 0,
                                                    a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true, &cov)))
