@@ -12,9 +12,11 @@ covo-online, tracking_zigzag, N = 65536 samples x H = 32, lambda = 0.01, sigma =
 the sample axis is sharded (N/G per GPU, "strong" scaling: total work fixed) and ONE all-gather of the
 132-float online-softmax records crosses xGMI per step.
 
-Rank 0 prints ONE JSON line with `roofline` (the fused rollout kernel, HBM bound, 516 B/sample
-algorithmic, launch duration measured live with events on the launch stream; `traffic` from the committed
-PMC passes of this command) and, at N=1, `cpu_baseline` (the plain-C oracle port of the same sampling
+Rank 0 prints ONE JSON line with `roofline` (the fused rollout kernel in the variant the timed step runs -- it also
+leaves the softmax records --, HBM bound, 516 B/sample algorithmic, mean launch duration measured live with events on
+the launch stream; `traffic` / `counters` from the committed PMC passes of this command, dropped when the kernel
+sources changed since), `roofline_gemm` (the noise GEMM against the fp32 MFMA peak), `value_with_pos_info` (the same
+steps with covo.py:281's pos_mean / pos_std computed) and, at N=1, `cpu_baseline` (the plain-C oracle port of the same
 step on the host cores).
 """
 from __future__ import annotations
@@ -31,7 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 flop/clk/CU)
 ROLLOUT_BYTES_PER_SAMPLE = 516  # 32 x 16 B action read + 4 B cost write
+GEMM_FLOP_PER_SAMPLE_DENSE = 2 * 128 * 128  # dense-equivalent 2 n^2
+GEMM_FLOP_PER_SAMPLE_ISSUED = 20480         # lower-triangular k-skip in 32-wide groups: (1 + 2 + 3 + 4)/16 of the dense MFMAs
 
 
 def make_states(env, params, n_states, seed):
@@ -128,22 +133,37 @@ def closed_loop(env, controller, params, T):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_bench_pmc_summary.json")
+KERNEL_SRCS = ["covo_mpc_amd/csrc/rollout_pipe.hpp", "covo_mpc_amd/csrc/rollout.hip", "covo_mpc_amd/csrc/quad_model.hpp",
+               "covo_mpc_amd/csrc/noise_gemm.hip", "covo_mpc_amd/csrc/eps_tiles.hpp"]  # = scripts/pmc_summary.py
 
 
-def pmc_traffic(args, n_local):
-    """HBM-side bytes per rollout launch.  PMC counters cannot be read inside this process; the number comes from the two
-    separate `rocprofv3 --pmc` passes over THIS command that scripts/profile_bench.sh committed (profiles/, with the
-    commit they were taken at), and is only attached when the run is that command's workload: default controller,
-    N_local = 65 536, no --info.  -> (bytes or None, provenance or None)."""
+def kernel_src_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SRCS:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_counters(args, n_local):
+    """PMC-derived numbers per launch.  Counters cannot be read inside this process; they come from the separate
+    `rocprofv3 --pmc` passes over THIS command that scripts/profile_bench.sh committed (profiles/, with the commit and the
+    hash of the kernel sources they were taken at).  Attached only when the run is that command's workload (default
+    controller, N_local = 65 536, no --info) AND the kernel sources are unchanged since -- otherwise null (stale counters
+    would describe another kernel).  -> (summary dict or None, provenance or None)."""
     if args.controller != "covo-online" or args.info or n_local != 65536:
         return None, None
     try:
         with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             d = json.load(f)
         src = {"kind": "committed_profile", "file": PMC_SUMMARY, "command": d.get("command"), "commit": d.get("commit"),
-               "kernel": d.get("kernel")}
-        return d["traffic_bytes_per_launch"], src
+               "kernel_src_sha": d.get("kernel_src_sha")}
+        if d.get("kernel_src_sha") != kernel_src_sha():
+            src["stale"] = "kernel sources changed since the profile was taken: counters dropped"
+            return None, src
+        return d, src
     except Exception:
         return None, None
 
@@ -160,6 +180,7 @@ def main():
                     "them as dead code in the reference's eval loop (quadrotor.py:523-538)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop episodes (profiler counter passes)")
+    ap.add_argument("--no-info-leg", action="store_true", help="skip the second timed loop with pos_mean/pos_std on")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -240,14 +261,50 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(cp.a_mean).all(), "non-finite a_mean after the timed region"
 
-    # The rollout kernel of the timed steps runs inside the fused step (one hipGraph replay per step) and
-    # cannot be bracketed individually from the host.  Its launch duration is measured here, right after the
-    # timed region, with events on the launch stream over back-to-back launches of the SAME kernel on the
-    # SAME buffers; `in_step_us` is the graph-replay time of the (noise GEMM -> rollout) pair minus the GEMM
-    # alone (covo_debug_time_step: 20 copies in one graph), i.e. the rollout reading stripes the GEMM has
-    # just written.  The rocprofv3 kernel-trace of this command (profiles/) gives the same kernel's average.
+    # ---- the same steps with covo.py:281's pos_mean / pos_std (a22) computed: a second controller, same inputs, same keys,
+    # same barrier + sync bracket; reported NEXT to `value` (the reference's jitted eval loop drops the info as dead code,
+    # a plain controller __call__ returns it)
+    elapsed_other = None
+    if not args.no_info_leg:
+        ctrl2, cp2 = cm.envs.get_controller(env, args.controller, f"N{args.N}_H{H}_lam{args.lam}", device=device,
+                                            process_group=pg, compute_info=not args.info)
+        cp2 = ctrl2.reset(s_reset, params, ctrl2.init_control_params, cr.PRNGKey(7))
+        ctrl2.alias_outputs = True
+
+        def step2(i, cp2):
+            u, cp2, _ = ctrl2(None, None, params, act_keys[i], cp2, {"noisy_state": dstates[i % n_states]})
+            return cp2
+
+        for i in range(args.warmup):
+            cp2 = step2(i, cp2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            cp2 = step2(args.warmup + i, cp2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_other = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed_other], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_other = float(t.item())
+        del ctrl2, cp2
+
+    # The rollout kernel of the timed steps runs inside the fused step and cannot be bracketed individually from the host.
+    # `launch_us` = MEAN duration of back-to-back launches of the SAME kernel variant the step runs (with the softmax
+    # records; with the position statistics under --info) on the SAME buffers, measured right here with events on the launch
+    # stream, 3 x 100 launches issued from C (covo_debug_time_rollout; `launch_us_min` = the fastest batch of 100);
+    # `in_step_us` = graph-replay time of the (noise GEMM -> rollout) pair minus the GEMM alone (covo_debug_time_step: 20
+    # copies in one graph), i.e. the rollout reading stripes the GEMM has just written; `standalone_*` = the variant WITHOUT
+    # the records (covo_rollout_cost as a stand-alone call).  The rocprofv3 kernel trace of this command (profiles/) lists
+    # the two variants under their own names (last template argument).
     pc = params.to_c()
-    if args.info:  # the position statistics take the one-lane-per-sample kernel + a finalize launch: timed from Python
+    standalone = None
+    if args.info:  # position statistics + finalize launch: two launches per call, timed from Python with events
         reps = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
@@ -257,23 +314,36 @@ def main():
             core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), True)
         e1.record()
         torch.cuda.synchronize()
-        rollout_b2b_ms = e0.elapsed_time(e1) / reps
-    else:  # launches issued from C (a Python loop of ctypes calls is host-bound below ~10 us per launch)
-        rollout_b2b_ms = 1e-3 * core.time_rollout(dstates[40], pc, reps=100)
-    in_step_us = None
+        launch_us = launch_us_min = 1e3 * e0.elapsed_time(e1) / reps
+        kernel_name = "rollout_pipe3_kernel<STATS> + pos_stats_finalize_kernel"
+    else:
+        launch_us, launch_us_min = core.time_rollout(dstates[40], pc, reps=100, with_records=True)
+        standalone = core.time_rollout(dstates[40], pc, reps=100, with_records=False)
+        kernel_name = "rollout_pipe3_kernel<..., REC = true>"
+    in_step_us = gemm_in_step_us = None
     if world == 1:
         try:
-            in_step_us = core.time_phases(8 | 16) - core.time_phases(8)
+            if args.controller == "covo-online":
+                # the product order: the Sigma chain's last launch draws epsilon, the GEMM streams it (tiled variant)
+                t_sig = core.time_phases(4)
+                t_sig_gemm = core.time_phases(4 | 8)
+                gemm_in_step_us = t_sig_gemm - t_sig
+                in_step_us = core.time_phases(4 | 8 | 16) - t_sig_gemm
+            else:
+                gemm_in_step_us = core.time_phases(8)
+                in_step_us = core.time_phases(8 | 16) - gemm_in_step_us
         except Exception:
-            in_step_us = None
+            in_step_us = gemm_in_step_us = None
 
     if rank == 0:
         n_local = core.n_local
         alg_bytes = n_local * ROLLOUT_BYTES_PER_SAMPLE
-        achieved = alg_bytes / (rollout_b2b_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args, n_local)
+        achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+        pmc, pmc_src = pmc_counters(args, n_local)
+        kin = (pmc or {}).get("kernels", {})
+        value = args.steps / elapsed
         out = {
-            "metric": "mpc_control_steps_per_sec", "value": args.steps / elapsed, "unit": "control-steps/s",
+            "metric": "mpc_control_steps_per_sec", "value": value, "unit": "control-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.controller} tracking_zigzag N={args.N} H={H} lam={args.lam} sigma=0.5 "
@@ -281,12 +351,32 @@ def main():
                                    f"{n_local}, one 132-float all-gather per step)",
                        "controller": args.controller, "N_global": args.N, "N_local": n_local, "H": H,
                        "pos_stats_info": bool(args.info)},
-            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.info else "rollout_pipe3_kernel",
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_us": 1e3 * rollout_b2b_ms,
-                         "in_step_us": in_step_us},
+                         "traffic": (pmc or {}).get("traffic_bytes_per_launch"), "counters_source": pmc_src,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_us": launch_us, "launch_us_statistic":
+                         "mean of 3 x 100 back-to-back launches (events on the launch stream)", "launch_us_min": launch_us_min,
+                         "in_step_us": in_step_us,
+                         "frac_in_step": (alg_bytes / (in_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if in_step_us else None,
+                         "standalone_without_records": None if standalone is None else {
+                             "kernel": "rollout_pipe3_kernel<..., REC = false>", "launch_us": standalone[0],
+                             "launch_us_min": standalone[1],
+                             "frac": alg_bytes / (standalone[0] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                         "counters": (kin.get("rollout_in_step") or {}).get("derived")},
         }
+        if elapsed_other is not None:
+            v2 = args.steps / elapsed_other
+            out["value_with_pos_info" if not args.info else "value_without_pos_info"] = v2
+        if gemm_in_step_us:
+            dense = n_local * GEMM_FLOP_PER_SAMPLE_DENSE / (gemm_in_step_us * 1e-6) / 1e12
+            issued = n_local * GEMM_FLOP_PER_SAMPLE_ISSUED / (gemm_in_step_us * 1e-6) / 1e12
+            out["roofline_gemm"] = {"bound": "mfma", "kernel": "noise_gemm_kernel", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "in_step_us": gemm_in_step_us, "achieved_dense_equivalent": dense,
+                                    "frac_dense_equivalent": dense / MFMA_F32_PEAK_TFLOPS, "achieved": issued,
+                                    "frac": issued / MFMA_F32_PEAK_TFLOPS,
+                                    "flop_per_sample": {"dense_equivalent": GEMM_FLOP_PER_SAMPLE_DENSE,
+                                                        "issued": GEMM_FLOP_PER_SAMPLE_ISSUED},
+                                    "counters": (kin.get("noise_gemm") or {}).get("derived")}
         if world == 1 and not args.no_closed_loop:
             out["closed_loop"] = closed_loop(env, controller, params, n_states)
         if world == 1 and not args.no_cpu_baseline:

@@ -84,7 +84,7 @@ _SIGS = {
                                     C.c_int32, _P, _P, _P, _P]),
     "covo_pos_info": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P]),
     "covo_debug_time_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P,
-                                          C.c_int32, _P, _P, C.c_int32, C.POINTER(C.c_float), _P]),
+                                          C.c_int32, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_softmax_reduce": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "covo_softmax_update": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_float, _P, _P]),
     "covo_merge": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P]),

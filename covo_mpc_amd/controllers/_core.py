@@ -86,6 +86,15 @@ class SamplingCore:
         # on the handle fails with COVO_E_DEVICE (covo_device_status).
         if shared_device is None:
             shared_device = os.environ.get("COVO_SHARED_DEVICE") == "1"
+            if not shared_device and self.world > 1:
+                # ranks of this group that sit on the SAME physical device compete for its CUs: detected here (one
+                # object all-gather at construction), not left to the caller
+                import socket
+                import torch.distributed as dist
+                mine = (socket.gethostname(), int(self._dev_index))
+                seen = [None] * self.world
+                dist.all_gather_object(seen, mine, group=process_group)
+                shared_device = seen.count(mine) > 1
         self.shared_device = bool(shared_device)
         flags = ((_lib.COVO_FLAG_ACTIONS_CLIPPED if trust_clipped else 0) | (_lib.COVO_FLAG_NO_GRAPH if eager else 0) |
                  (_lib.COVO_FLAG_SHARED_DEVICE if self.shared_device else 0))
@@ -184,15 +193,16 @@ class SamplingCore:
               "covo_rollout_cost")
         return self.cost
 
-    def time_rollout(self, dstate, params_c, f_shared=(0.0, 0.0, 0.0), reps=100):
-        """GPU microseconds per covo_rollout_cost launch, `reps` launches issued back to back from C between two events."""
+    def time_rollout(self, dstate, params_c, f_shared=(0.0, 0.0, 0.0), reps=100, with_records=False):
+        """(mean, min-batch) GPU microseconds per covo_rollout_cost launch: three batches of `reps` launches issued back to
+        back from C between two events.  with_records: the record-emitting variant the fused step runs."""
         fs = (C.c_float * 3)(*[float(x) for x in f_shared])
-        us = C.c_float(0.0)
+        us = (C.c_float * 2)(0.0, 0.0)
         check(self.lib.covo_debug_time_rollout(self.h, ptr(dstate.packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj), dstate.T,
                                                C.byref(params_c), fs, ptr(self.a), self.n_local, ptr(self.cost),
-                                               ptr(self.blockmin), int(reps), C.byref(us), self.stream()),
+                                               ptr(self.blockmin), 1 if with_records else 0, int(reps), us, self.stream()),
               "covo_debug_time_rollout")
-        return float(us.value)
+        return float(us[0]), float(us[1])
 
     def hessian(self, packed, dstate, params_c, a_mean, batch=1, method="adjoint"):
         """d^2 C / da^2 (covo.py:134-185); method "adjoint" (default, hessian_adj.hip) or "pairs" (hessian.hip)."""

@@ -9,9 +9,10 @@
 // and the 4-byte cost write: 516 B / sample.  HBM-roofline kernel by bytes, VALU-issue bound in fact
 // (~100-135 instructions per sample-step), so instruction count and waves per SIMD matter as much as bytes.
 //   rollout_pipe3_kernel (rollout_pipe.hpp): the product kernel -- three waves per 64 samples (attitude / translation /
-//     reward) pipelined through LDS rings;
-//   rollout_kernel (below): one lane = one sample, everything in VGPRs, targets by v_readlane; kept for the position
-//     statistics of --info (covo.py:281).
+//     reward) pipelined through
+//     LDS rings, with or without the position statistics of covo.py:281 (STATS) and the softmax records (REC);
+//   rollout_kernel (below, ROLLOUT_LAB_BASELINE only): round 1's one-lane-per-sample kernel, the baseline of
+//     scripts/probe/rollout_lab.hip -- not part of the library.
 #include "covo_common.hpp"
 
 struct RolloutArgs {
@@ -34,7 +35,6 @@ struct RolloutArgs {
     qm::Consts<float> c;
 };
 
-constexpr int RO_BLOCK = 256;
 
 // scripts/probe/rollout_probe.hip compiles this file with ROLLOUT_PROBE: every workgroup leaves {XCC, HW_ID, start, end}
 // (s_memrealtime, 100 MHz) -- where the dispatcher put it and when it ran.  Compiled out of the library.
@@ -140,6 +140,8 @@ __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost,
     }
 }
 
+#ifdef ROLLOUT_LAB_BASELINE  // the one-lane-per-sample kernel of round 1: only scripts/probe/rollout_lab.hip still compiles it
+constexpr int RO_BLOCK = 256;
 // STATS: accumulate per-step position sums (covo.py:281).  DISC1: discount == 1 (skip the multiply).
 // CLIP: re-apply step_env's clip (quadrotor.py:223,258); off when the producer guarantees clipped
 // stripes.  PF: how many action stripes are in flight (32 = the whole horizon is issued up front:
@@ -279,6 +281,8 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
     RO_PROBE_END(0);
 }
 
+#endif  // ROLLOUT_LAB_BASELINE
+
 #include "rollout_pipe.hpp"
 
 // sums the per-block position statistics in fp64: out[k*6+i]
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(256) void pos_stats_finalize_kernel(const double *_
     if (tid == 0) out[i] = red[0];
 }
 
+#ifdef ROLLOUT_LAB_BASELINE
 template <bool STATS, bool DISC1, bool CLIP, bool BATCHED = false>
 static void launch_rollout_pf(const RolloutArgs &A, const RolloutArgs *batch, int nbatch, int grid, bool deep, hipStream_t s)
 {
@@ -308,6 +313,7 @@ static void launch_rollout_pf(const RolloutArgs &A, const RolloutArgs *batch, in
     else
         hipLaunchKernelGGL((rollout_kernel<STATS, DISC1, CLIP, 8, BATCHED>), dim3(grid, nbatch), dim3(RO_BLOCK), 0, s, A, batch);
 }
+#endif
 
 static void fill_rollout_args(RolloutArgs &A, const float *state, const float *pos_traj, const float *vel_traj, int T,
                               const covo_env_params &p, const float *f_shared, const float *a, int N, float discount,
@@ -343,17 +349,25 @@ static int pipe_groups(int N, int nbatch)
     return ng > 256 ? 2 : 1;
 }
 
-template <bool DISC1, bool ROLL, bool BATCHED, bool STATS = false>
-static void launch_pipe3(const RolloutArgs &A, const RolloutArgs *batch, int nb, int groups, hipStream_t s)
+template <bool DISC1, bool ROLL, bool BATCHED, bool STATS, bool REC>
+static void launch_pipe3_rec(const RolloutArgs &A, const RolloutArgs *batch, int nb, int groups, hipStream_t s)
 {
     const int ng = (A.N + COVO_WAVE - 1) / COVO_WAVE;
     const dim3 grid((ng + groups - 1) / groups, nb);
     if (groups == 4)
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 4, BATCHED, -1, 3, STATS>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 4, BATCHED, -1, 3, STATS, REC>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
     else if (groups == 2)
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 2, BATCHED, -1, 3, STATS>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 2, BATCHED, -1, 3, STATS, REC>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
     else
-        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 1, BATCHED, -1, 3, STATS>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
+        hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 1, BATCHED, -1, 3, STATS, REC>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
+}
+
+// A.records (all instances of a batch alike) selects the record-emitting variant
+template <bool DISC1, bool ROLL, bool BATCHED, bool STATS = false>
+static void launch_pipe3(const RolloutArgs &A, const RolloutArgs *batch, int nb, int groups, hipStream_t s)
+{
+    if (A.records != nullptr) launch_pipe3_rec<DISC1, ROLL, BATCHED, STATS, true>(A, batch, nb, groups, s);
+    else launch_pipe3_rec<DISC1, ROLL, BATCHED, STATS, false>(A, batch, nb, groups, s);
 }
 
 // nbatch == 0: one rollout described by A; else nbatch instances described by the device array `batch` (all with A's

@@ -16,8 +16,7 @@ __device__ __forceinline__ void rp_pin(float &a, float &b, float &c, float &d, f
 }
 __device__ __forceinline__ void rp_pin(float &a, float &b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
-// Three-stage pipeline (the product kernel; the one-lane-per-sample kernel of rollout.hip remains for the position
-// statistics of --info).  Measured on gfx950 (scripts/probe/valu_probe.hip, rollout_lab.hip): one wave
+// Three-stage pipeline (the product kernel, with and without the position statistics of --info).  Measured on gfx950 (scripts/probe/valu_probe.hip, rollout_lab.hip): one wave
 // retires a dependent VALU instruction per ~4 ns, a SIMD with three such waves one per ~1.2-1.5 ns, and every LDS
 // instruction costs about as much SIMD time as 6-8 VALU instructions.  So a launch wants >= 3 waves per SIMD, as few VALU
 // instructions as the arithmetic allows, and as few dwords through LDS as the stages can do with.  Every 64 samples get
@@ -93,7 +92,10 @@ __device__ __forceinline__ float rp3_atan2abs(float y, float x)
 // ONLY >= 0 (scripts/probe/rollout_lab.hip): every wave runs stage ONLY on its own LDS copy, no barriers -- the stage's
 //   instruction stream in isolation; ONLY == -2: all three stages without barriers (timing bound, garbage results).
 // STATS: the per-step position sums of covo.py:281 (pos_mean / pos_std) are formed by the T waves (see there).
-template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3, bool STATS = false>
+// REC: every workgroup also leaves its online-softmax record (rollout_record; A.records != null) -- the variant the fused
+//   step runs; a template argument so that the profiler lists it under its own name.
+template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3, bool STATS = false,
+          bool REC = false>
 __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) void rollout_pipe3_kernel(
     const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
 {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         RP3_FLUSH(0);
         rp3_barrier<ONLY>();
         rp3_barrier<ONLY>();
-        if (A.records == nullptr && !STATS) return;
+        if (!REC && !STATS) return;
     }
 
     if (role == 1) {
@@ -316,7 +318,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         }
         RP3_FLUSH(1);
         rp3_barrier<ONLY>();
-        if (A.records == nullptr && !STATS) return;
+        if (!REC && !STATS) return;
     }
 
     float cost = 0.0f;
@@ -363,7 +365,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         if (lane == 0 && group * COVO_WAVE < A.N) A.groupmin[group] = wm;
     }
     }
-    if (ONLY == -1 && A.records != nullptr) {  // every wave of the workgroup (the A and T waves carry no cost)
+    if (ONLY == -1 && REC) {  // every wave of the workgroup (the A and T waves carry no cost)
         __shared__ float rec_m[GROUPS], rec_s[GROUPS];
         __shared__ __attribute__((aligned(16))) float rec_v[GROUPS][COVO_NA];
         rollout_record<3 * GROUPS, GROUPS>(A, cost, valid && role == 2, n, role == 2 ? gsub : 0, role == 2, lane, blockIdx.x, rec_m,

@@ -257,8 +257,16 @@ class DeviceEpisode:
         self.n_steps += 1
 
     def read_log(self):
-        """-> float32[n_steps, 4] = reward, err_pos, err_vel, done (pre-step state); synchronises."""
-        return self.log[:self.n_steps].cpu().numpy()
+        """-> float32[n_steps, 4] = reward, err_pos, err_vel, done (pre-step state); synchronises, then checks the handle's
+        sticky device status: a kernel of the enqueued steps that failed (a starved grid barrier of the Sigma chain, see
+        SamplingCore.shared_device) has poisoned every later step of the segment -- raise instead of returning its log."""
+        out = self.log[:self.n_steps].cpu().numpy()
+        st = int(self.lib.covo_device_status(self.h, 0))
+        if st != 0:
+            raise self._lib.CovoError(f"device status 0x{st:x} after the episode segment (covo_device_status): a kernel of an "
+                                      "enqueued step failed; its mean / Sigma and everything after it are invalid.  "
+                                      "Build the controller with shared_device=True when the GPU is shared.")
+        return out
 
 
 def eval_env_device(env: Quad3D, controller, total_steps=30000, num_trajs=4, seed=1, verbose=True):

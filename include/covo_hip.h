@@ -358,12 +358,16 @@ int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const c
  * (device store to host-mapped memory); covo_device_status / COVO_E_DEVICE can then be exercised without starving a barrier. */
 int covo_debug_raise_device_status(covo_handle_t h, int32_t bits, void *stream);
 
-/* Profiling aid: covo_rollout_cost `reps` times back to back on `stream` between two events; *us_out = GPU microseconds
- * per launch (what bench.py reports as roofline.launch_us: a Python loop of single calls is host-bound below ~10 us per
- * launch).  Synchronises the stream.  Arguments as covo_rollout_cost (no position statistics). */
+/* Profiling aid: covo_rollout_cost `reps` times back to back on `stream` between two events, three batches; us_out[0] =
+ * mean GPU microseconds per launch over all batches, us_out[1] = the fastest batch's (what bench.py reports as
+ * roofline.launch_us / launch_us_min: a Python loop of single calls is host-bound below ~10 us per launch).
+ * with_records != 0: the variant covo_mpc_step runs -- every workgroup also leaves its online-softmax record
+ * (rollout_pipe3_kernel<..., REC = true>).  Synchronises the stream.  Other arguments as covo_rollout_cost (no position
+ * statistics). */
 int covo_debug_time_rollout(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
                             const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
-                            float *cost_out, float *groupmin, int32_t reps, float *us_out, void *stream);
+                            float *cost_out, float *groupmin, int32_t with_records, int32_t reps, float *us_out /* [host float[2]] */,
+                            void *stream);
 
 #ifdef __cplusplus
 }

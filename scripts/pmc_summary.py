@@ -1,34 +1,144 @@
 #!/usr/bin/env python
-"""Per-kernel means of the two separate rocprofv3 --pmc passes over bench.py (FETCH_SIZE, WRITE_SIZE; KB per
-dispatch) -> profiles/<round>_bench_pmc_{fetch,write}_size.csv and profiles/<round>_bench_pmc_summary.json.
-FETCH_SIZE is doubled for the rollout's 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM section).
-usage: pmc_summary.py [gpurun_out dir] [round tag, default r02]"""
-import csv, collections, json, os, subprocess, sys
+"""Per-kernel means of the separate rocprofv3 --pmc passes over bench.py -> profiles/<round>_bench_pmc_*.csv and
+profiles/<round>_bench_pmc_summary.json (what bench.py attaches as roofline.traffic / roofline.counters /
+roofline_gemm.counters).
+
+  fetch / write : FETCH_SIZE, WRITE_SIZE in KB per dispatch; FETCH_SIZE is doubled for the rollout's 16-B/lane streaming
+                  reads (MI355X_MICROARCH.md, HBM section); the fabric counters include Infinity-Cache hits
+  sq_a / sq_b   : SQ counters (quad-cycles for *_CYCLES / WAIT_* / ACTIVE_INST_*; SQ_VALU_MFMA_BUSY_CYCLES in cycles) and
+                  GRBM_GUI_ACTIVE (cycles) -- effective shader clock = GRBM_GUI_ACTIVE / dispatch duration
+
+usage: pmc_summary.py [gpurun_out dir] [round tag, default r03]"""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
-RND = sys.argv[2] if len(sys.argv) > 2 else "r02"
-out = {}
-for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    rows = list(csv.DictReader(open(os.path.join(src, f"pmc_{which}", "bench_counter_collection.csv"))))
-    agg = collections.defaultdict(list)
-    for r in rows:
-        if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    with open(os.path.join(root, "profiles", f"{RND}_bench_pmc_{which}_size.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["Kernel_Name", "Dispatches", f"{counter}_KB_mean", f"{counter}_KB_min", f"{counter}_KB_max"])
-        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-            w.writerow([k, len(v), f"{sum(v) / len(v):.3f}", f"{min(v):.3f}", f"{max(v):.3f}"])
-    for k, v in agg.items():
-        if k.startswith("void rollout_pipe3_kernel") and "GROUPS" not in k:  # the product rollout (one variant per run)
-            out[counter + "_KB"] = sum(v) / len(v)
-out["traffic_bytes_per_launch"] = int(round((2.0 * out["FETCH_SIZE_KB"] + out["WRITE_SIZE_KB"]) * 1024))
-out["kernel"] = "rollout_pipe3_kernel"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+N_LOCAL, H = 65536, 32
+CU, SIMD = 256, 1024
+KERNEL_SRCS = ["covo_mpc_amd/csrc/rollout_pipe.hpp", "covo_mpc_amd/csrc/rollout.hip", "covo_mpc_amd/csrc/quad_model.hpp",
+               "covo_mpc_amd/csrc/noise_gemm.hip", "covo_mpc_amd/csrc/eps_tiles.hpp"]
+
+
+def kernel_src_sha():
+    h = hashlib.sha256()
+    for f in KERNEL_SRCS:
+        with open(os.path.join(root, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load(which):
+    """-> {kernel: {counter: [values per dispatch]}}, {kernel: [duration ns per dispatch] or []}"""
+    files = glob.glob(os.path.join(src, f"pmc_{which}", "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(dict)
+    for fn in files:
+        for r in csv.DictReader(open(fn)):
+            k = r["Kernel_Name"]
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                dur[k][r.get("Dispatch_Id", len(dur[k]))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return agg, {k: list(v.values()) for k, v in dur.items()}
+
+
+def mean(v):
+    return sum(v) / len(v) if v else None
+
+
+def pick(agg, pred):
+    ks = [k for k in agg if pred(k)]
+    return max(ks, key=lambda k: sum(len(v) for v in agg[k].values())) if ks else None
+
+
+def rollout_targs(k):
+    """template arguments of `void rollout_pipe3_kernel<DISC1, ROLL, CH, GROUPS, BATCHED, ONLY, ONLY_WAVES, STATS, REC, ...>(...)`"""
+    if not k.startswith("void rollout_pipe3_kernel<"):
+        return None
+    return [t.strip() for t in k[k.index("<") + 1:k.index(">(")].split(",")]
+
+
+def is_rollout_rec(k):   # the in-step variant: REC (9th template argument) true
+    t = rollout_targs(k)
+    return t is not None and len(t) >= 9 and t[8] == "true"
+
+
+def is_rollout_plain(k):
+    t = rollout_targs(k)
+    return t is not None and not (len(t) >= 9 and t[8] == "true")
+
+
+def is_gemm(k):
+    return "noise_gemm_kernel" in k
+
+
+out = {"kernel_src_sha": kernel_src_sha(), "n_local": N_LOCAL}
 try:
     out["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
 except Exception:
     out["commit"] = None
-out["note"] = "rollout_pipe3_kernel at N_local=65536: 2 x FETCH_SIZE (gfx950 16-B/lane correction) + WRITE_SIZE; fabric counters include Infinity-Cache hits"
-out["command"] = "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-closed-loop"
+
+per_kernel = {}
+for which in ("fetch", "write", "sq_a", "sq_b"):
+    agg, dur = load(which)
+    if not agg:
+        continue
+    counters = sorted({c for k in agg for c in agg[k]})
+    with open(os.path.join(root, "profiles", f"{RND}_bench_pmc_{which}.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Dispatches", "Duration_ns_mean"] + [c + "_mean" for c in counters])
+        for k in sorted(agg, key=lambda k: -sum(sum(v) for v in agg[k].values())):
+            n = max(len(v) for v in agg[k].values())
+            d = mean(dur.get(k, []))
+            w.writerow([k, n, f"{d:.0f}" if d else ""] + [f"{mean(agg[k][c]):.3f}" if agg[k].get(c) else "" for c in counters])
+    for tag, pred in (("rollout_in_step", is_rollout_rec), ("rollout_standalone", is_rollout_plain), ("noise_gemm", is_gemm)):
+        k = pick(agg, pred)
+        if k is None:
+            continue
+        e = per_kernel.setdefault(tag, {"kernel": k})
+        for c, v in agg[k].items():
+            e[c] = mean(v)
+        if dur.get(k):
+            e.setdefault("duration_us_under_pmc", {})[which] = mean(dur[k]) / 1e3
+        e.setdefault("dispatches", {})[which] = max(len(v) for v in agg[k].values())
+
+for tag, e in per_kernel.items():
+    d = {}
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e and tag.startswith("rollout"):
+        d["traffic_bytes_per_launch"] = int(round((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024))
+    if "SQ_WAVE_CYCLES" in e:
+        wc = e["SQ_WAVE_CYCLES"]
+        d["wave_cycle_shares"] = {"active_inst_any": e["SQ_ACTIVE_INST_ANY"] / wc, "active_inst_valu": e["SQ_ACTIVE_INST_VALU"] / wc,
+                                  "wait_inst_any": e["SQ_WAIT_INST_ANY"] / wc, "wait_inst_lds": e["SQ_WAIT_INST_LDS"] / wc,
+                                  "wait_any": e["SQ_WAIT_ANY"] / wc}
+        d["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+        if tag.startswith("rollout"):
+            d["valu_wave_insts_per_64_samples_per_step"] = e["SQ_INSTS_VALU"] / (N_LOCAL / 64) / H
+        # quad-cycles -> cycles (x4); share of the chip's SIMD cycles during the dispatch that issued a VALU instruction
+        d["valu_busy_frac_of_gui_active"] = e["SQ_ACTIVE_INST_VALU"] * 4 / (e["GRBM_GUI_ACTIVE"] * SIMD) if e.get("GRBM_GUI_ACTIVE") else None
+    if "GRBM_GUI_ACTIVE" in e and e.get("duration_us_under_pmc"):
+        du = e["duration_us_under_pmc"].get("sq_a") or e["duration_us_under_pmc"].get("sq_b")
+        d["effective_clock_GHz_under_pmc"] = e["GRBM_GUI_ACTIVE"] / (du * 1e3)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
+        d["mfma_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * SIMD)  # rocprofiler's MfmaUtil formula
+    if "SQ_INSTS_LDS" in e and tag.startswith("rollout"):
+        d["lds_wave_insts_per_64_samples_per_step"] = e["SQ_INSTS_LDS"] / (N_LOCAL / 64) / H
+    e["derived"] = d
+
+out["kernels"] = per_kernel
+if "rollout_in_step" in per_kernel and "traffic_bytes_per_launch" in per_kernel["rollout_in_step"]["derived"]:
+    out["traffic_bytes_per_launch"] = per_kernel["rollout_in_step"]["derived"]["traffic_bytes_per_launch"]
+    out["kernel"] = "rollout_pipe3_kernel<..., REC = true> (the in-step variant)"
+out["note"] = ("N_local=65536; traffic = 2 x FETCH_SIZE (gfx950 16-B/lane correction) + WRITE_SIZE, fabric counters include "
+               "Infinity-Cache hits; SQ *_CYCLES / WAIT_* / ACTIVE_INST_* are quad-cycles summed over all waves")
+out["command"] = ("rocprofv3 --pmc <one counter set per pass> -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline "
+                  "--no-closed-loop --no-info-leg   (scripts/profile_bench.sh)")
 json.dump(out, open(os.path.join(root, "profiles", f"{RND}_bench_pmc_summary.json"), "w"), indent=1)
-print(out)
+print(json.dumps({k: v.get("derived") for k, v in per_kernel.items()}, indent=1))

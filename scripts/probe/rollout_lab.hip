@@ -10,6 +10,7 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#define ROLLOUT_LAB_BASELINE
 #include "../../covo_mpc_amd/csrc/rollout.hip"
 
 void covo_set_error(const char *fmt, ...) { (void)fmt; }

@@ -1,21 +1,31 @@
 #!/bin/bash
 # Everything profiles/ holds for one round, in one GPU call: the unprofiled bench line, the rocprofv3 kernel stats of the
-# same command, the two separate --pmc passes (FETCH_SIZE / WRITE_SIZE; counters are never combined with traces), the
-# phase times and the stand-alone kernel table.  Run on the GPU box from the repo root; outputs land in gpurun_out/.
+# same command, the separate --pmc passes (FETCH_SIZE, WRITE_SIZE, two SQ passes; counters are never combined with
+# traces, every pass has the program itself right after `--`), the phase times and the stand-alone kernel table.
+# Run on the GPU box from the repo root; outputs land in gpurun_out/.   usage: scripts/profile_bench.sh [round tag, default r03]
 R="$(cd "$(dirname "$0")/.." && pwd)"
+RND="${1:-r03}"
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" > "$R/gpurun_out/bench_line.json" 2> "$R/gpurun_out/bench_line.err"
-rm -rf "$R/gpurun_out/prof_stats" "$R/gpurun_out/pmc_fetch" "$R/gpurun_out/pmc_write"
+rm -rf "$R/gpurun_out/prof_stats" "$R/gpurun_out/pmc_fetch" "$R/gpurun_out/pmc_write" "$R/gpurun_out/pmc_sq_a" "$R/gpurun_out/pmc_sq_b"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -o bench -- python3 "$R/bench.py" \
     > "$R/gpurun_out/bench_line_under_rocprof.json" 2> "$R/gpurun_out/prof_stats.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -o bench -- python3 "$R/bench.py" --steps 30 --warmup 5 \
-    --no-cpu-baseline --no-closed-loop > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -o bench -- python3 "$R/bench.py" --steps 30 --warmup 5 \
-    --no-cpu-baseline --no-closed-loop > /dev/null 2> "$R/gpurun_out/pmc_write.err"
+PMC_ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-closed-loop --no-info-leg"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -o bench -- python3 "$R/bench.py" $PMC_ARGS \
+    > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -o bench -- python3 "$R/bench.py" $PMC_ARGS \
+    > /dev/null 2> "$R/gpurun_out/pmc_write.err"
+# SQ pass A (8 SQ slots + GRBM): where the waves' cycles go -- issue (ACTIVE_INST_*), issue stalls (WAIT_INST_*), parked (WAIT_ANY)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE \
+    --output-format csv -d "$R/gpurun_out/pmc_sq_a" -o bench -- python3 "$R/bench.py" $PMC_ARGS > /dev/null 2> "$R/gpurun_out/pmc_sq_a.err"
+# SQ pass B: matrix-pipe busy cycles (MFMA utilisation of the noise GEMM), LDS instruction counts / conflicts
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE \
+    --output-format csv -d "$R/gpurun_out/pmc_sq_b" -o bench -- python3 "$R/bench.py" $PMC_ARGS > /dev/null 2> "$R/gpurun_out/pmc_sq_b.err"
 cd "$R"
 python3 scripts/phase_times.py > gpurun_out/phase_times.log 2>/dev/null
 python3 scripts/kbench.py > gpurun_out/kbench.log 2>/dev/null
-python3 scripts/pmc_summary.py gpurun_out r02 > gpurun_out/pmc_summary.log 2>&1
-find gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" | head -20
-tail -c 600 gpurun_out/bench_line.json
+python3 scripts/pmc_summary.py gpurun_out "$RND" > gpurun_out/pmc_summary.log 2>&1
+find gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b -name "*.csv" | head -30
+tail -c 1500 gpurun_out/bench_line.json
+tail -5 gpurun_out/pmc_summary.log
