@@ -338,6 +338,11 @@ def main():
     if rank == 0:
         n_local = core.n_local
         alg_bytes = n_local * ROLLOUT_BYTES_PER_SAMPLE
+        # the judged duration is the kernel's IN-STEP duration (what the timed region ran and what the rocprofv3 kernel trace
+        # of this command averages, cold stripes fresh from the GEMM); the warm back-to-back figure rides along
+        b2b_us, b2b_min_us = launch_us, launch_us_min
+        if in_step_us:
+            launch_us = in_step_us
         achieved = alg_bytes / (launch_us * 1e-6) / 1e9
         pmc, pmc_src = pmc_counters(args, n_local)
         kin = (pmc or {}).get("kernels", {})
@@ -355,9 +360,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc or {}).get("traffic_bytes_per_launch"), "counters_source": pmc_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_us": launch_us, "launch_us_statistic":
-                         "mean of 3 x 100 back-to-back launches (events on the launch stream)", "launch_us_min": launch_us_min,
+                         ("in-step: graph replay of 20 x (Sigma chain, GEMM, rollout) minus 20 x (Sigma chain, GEMM), events around "
+                          "the replay" if in_step_us else "mean of 3 x 100 back-to-back launches (events on the launch stream)"),
                          "in_step_us": in_step_us,
-                         "frac_in_step": (alg_bytes / (in_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if in_step_us else None,
+                         "back_to_back": {"launch_us": b2b_us, "launch_us_min": b2b_min_us,
+                                          "frac": alg_bytes / (b2b_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                          "statistic": "mean / fastest batch of 3 x 100 back-to-back launches on warm stripes"},
                          "standalone_without_records": None if standalone is None else {
                              "kernel": "rollout_pipe3_kernel<..., REC = false>", "launch_us": standalone[0],
                              "launch_us_min": standalone[1],

@@ -40,22 +40,39 @@ def state22(s, dtype) -> np.ndarray:
     return np.concatenate([s.pos, s.vel, s.quat, s.omega, s.f_disturb, s.pos_tar, s.vel_tar]).astype(dtype)
 
 
+REWARD_KINDS = {"penyaw": 0, "realworld": 1}
+DISTURB_KINDS = {"none": 0, "gaussian": 1, "periodic": 2, "sin": 3, "drag": 4, "mixed": 5}
+
+
+def dist_vec(p, kind: str) -> np.ndarray:
+    """[kind, disturb_period, disturb_scale, disturb_params[6]] (dynamics/dataclass.py:86-88)"""
+    return np.asarray([DISTURB_KINDS[kind], p.disturb_period, p.disturb_scale, *p.disturb_params], dtype=np.float64)
+
+
 def _p(a, ct):
     return a.ctypes.data_as(C.POINTER(ct)) if a is not None else None
 
 
 def rollout(s, p, a_sampled, discount=1.0, f_shared=None, dtype=np.float32, want_rewards=False, want_poses=False,
-            rollover=False):
+            rollover=False, reward="penyaw", disturb=None):
     """a_sampled (N,H,4).  Returns cost[, rewards (N,H)][, poses (H,N,3)].  rollover: is_terminal's rollover test
-    (envs/quadrotor.py:486-490, Quad3D(disable_rollover_terminate=False))."""
+    (envs/quadrotor.py:486-490, Quad3D(disable_rollover_terminate=False)).  reward: "penyaw" (utils.py:285-294) or
+    "realworld" (:297-313).  disturb: None (f_shared is the explicit next disturbance of every step) or a ref_np.Disturb
+    with kind periodic / sin / drag / mixed and the ONE shared draw (free.py:10-58)."""
     ct = C.c_float if dtype == np.float32 else C.c_double
-    fn = lib().oracle_rollout_f32 if dtype == np.float32 else lib().oracle_rollout_f64
+    fn = lib().oracle_rollout_ex_f32 if dtype == np.float32 else lib().oracle_rollout_ex_f64
     a = np.ascontiguousarray(a_sampled, dtype=dtype)
     N, H, _ = a.shape
     prm = params_vec(p)
     st = state22(s, dtype)
     pt = np.ascontiguousarray(s.pos_traj, dtype=dtype)
     vt = np.ascontiguousarray(s.vel_traj, dtype=dtype)
+    dist = None
+    if disturb is not None and disturb.kind not in ("none", "gaussian"):
+        dist = dist_vec(p, disturb.kind)
+        f_shared = np.zeros(3) if disturb.draw is None else disturb.draw
+    elif disturb is not None and disturb.kind == "gaussian" and f_shared is None:
+        f_shared = (0.0 if disturb.deterministic else p.dyn_noise_scale) * np.asarray(disturb.draw)
     fs = np.zeros(3, dtype=dtype) if f_shared is None else np.ascontiguousarray(f_shared, dtype=dtype)
     cost = np.empty(N, dtype=dtype)
     rew = np.empty((N, H), dtype=dtype) if want_rewards else None
@@ -63,7 +80,7 @@ def rollout(s, p, a_sampled, discount=1.0, f_shared=None, dtype=np.float32, want
     fn.restype = None
     fn(_p(prm, C.c_double), C.c_int(p.max_steps_in_episode), _p(st, ct), C.c_int(int(s.time)), _p(pt, ct), _p(vt, ct),
        C.c_int(pt.shape[0]), _p(a, ct), C.c_long(N), C.c_int(H), ct(discount), _p(fs, ct), _p(cost, ct), _p(rew, ct),
-       _p(pos, ct), C.c_int(1 if rollover else 0))
+       _p(pos, ct), C.c_int(1 if rollover else 0), C.c_int(REWARD_KINDS[reward]), _p(dist, C.c_double))
     out = [cost]
     if want_rewards:
         out.append(rew)
@@ -136,8 +153,10 @@ def sampling_step(s, p, L, a_mean, eps, lam, gamma_mean=1.0, discount=1.0, threa
     return out.reshape(H, 4), cost, a_work
 
 
-def hessian(s, p, a_flat, H=32, threads=None):
-    """covo.py:134-185 by hyper-dual forward-over-forward AD in C (fp64, OpenMP over the n(n+1)/2 pairs)."""
+def hessian(s, p, a_flat, H=32, threads=None, reward="penyaw", kind="none", draws=None):
+    """covo.py:134-185 by hyper-dual forward-over-forward AD in C (fp64, OpenMP over the n(n+1)/2 pairs).
+    kind / draws (H,3): the disturbance model and its per-step uniform draws (free.py:10-58; get_hessian splits its key
+    once per step, covo.py:151)."""
     if threads is not None:
         os.environ["OMP_NUM_THREADS"] = str(threads)
     prm = params_vec(p)
@@ -147,9 +166,11 @@ def hessian(s, p, a_flat, H=32, threads=None):
     a = np.ascontiguousarray(a_flat, dtype=np.float64).reshape(-1)
     n = 4 * H
     R = np.zeros((n, n), dtype=np.float64)
-    f = lib().oracle_hessian_f64
+    dist = dist_vec(p, kind) if kind not in ("none", "gaussian") else None
+    dr = np.ascontiguousarray(draws, dtype=np.float64).reshape(H, 3) if draws is not None else None
+    f = lib().oracle_hessian_ex_f64
     f.restype = None
     cd = C.c_double
     f(_p(prm, cd), _p(st, cd), C.c_int(int(s.time)), _p(pt, cd), _p(vt, cd), C.c_int(pt.shape[0]), _p(a, cd), C.c_int(H),
-      _p(R, cd))
+      _p(R, cd), C.c_int(REWARD_KINDS[reward]), _p(dist, cd), _p(dr, cd))
     return R

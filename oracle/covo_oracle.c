@@ -22,6 +22,7 @@
 #define EXP expf
 #define ATAN2 atan2f
 #define FABS fabsf
+#define SIN sinf
 #include "covo_oracle_body.h"
 #undef SUF
 #undef REAL
@@ -30,6 +31,7 @@
 #undef EXP
 #undef ATAN2
 #undef FABS
+#undef SIN
 
 #define SUF(x) x##_f64
 #define REAL double
@@ -38,6 +40,7 @@
 #define EXP exp
 #define ATAN2 atan2
 #define FABS fabs
+#define SIN sin
 #include "covo_oracle_body.h"
 #undef SUF
 #undef REAL
@@ -148,7 +151,7 @@ static inline hd_t hd_atan2(hd_t y, hd_t x)
     return r;
 }
 
-typedef struct { hd_t pos[3], vel[3], quat[4], omega[3]; } hd_state;
+typedef struct { hd_t pos[3], vel[3], quat[4], omega[3], f[3]; } hd_state;
 
 /* dynamics/utils.py:266-274, 285-294 */
 static hd_t hd_reward(const hd_state *s, const double *pos_tar, const double *vel_tar)
@@ -175,9 +178,44 @@ static hd_t hd_reward(const hd_state *s, const double *pos_tar, const double *ve
     return hd_sub(r, hd_scale(yaw, 0.2));
 }
 
-/* envs/quadrotor.py:250-263 + dynamics/free.py:74-155; prm as in dyn_step above; f = disturbance of THIS step */
-static void hd_dyn_step(hd_state *s, const hd_t *act, const double *prm, const double *f)
+/* dynamics/utils.py:297-313 */
+static hd_t hd_reward_realworld(const hd_state *s, const double *pos_tar)
 {
+    hd_t pe = hd_c(0);
+    for (int i = 0; i < 3; ++i) {
+        hd_t d = hd_addc(s->pos[i], -pos_tar[i]);
+        pe = hd_add(pe, hd_mul(d, d));
+    }
+    hd_t cost = hd_add(hd_scale(hd_scale(pe, 1.0 / 3.0), 5.0), hd_scale(hd_addc(hd_neg(hd_mul(s->quat[3], s->quat[3])), 1.0), 3.0));
+    return hd_neg(hd_scale(cost, 0.02));
+}
+
+/* dynamics/free.py:10-58 on hyper-dual numbers: the disturbance of the NEXT step from the PRE-step state (time = its
+ * clock); dist = [kind, period, scale, disturb_params[6]], draw[3] = this step's uniform draw (periodic / mixed) */
+static void hd_disturb_next(const hd_state *s, int time, const double *dist, const double *draw, hd_t *out)
+{
+    const int kind = dist ? (int)dist[0] : 0;
+    hd_t drag[3], sn[3], per[3];
+    for (int i = 0; i < 3; ++i) {
+        hd_t rel = hd_addc(s->vel[i], -dist[3 + i] * 0.5);
+        drag[i] = hd_scale(hd_mul(rel, hd_abs(rel)), -fabs(dist[2]) / (1.5 * 1.5));
+        const double period = dist[3 + i] * (dist[1] / 3) + dist[1];
+        sn[i] = hd_c(dist[3 + i] * dist[2] * sin(2.0 * M_PI / period * (double)time + dist[6 + i] * 2.0 * M_PI));
+        per[i] = (time % (int)dist[1]) == 0 ? hd_c(draw[i]) : s->f[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        if (kind == 2) out[i] = per[i];
+        else if (kind == 3) out[i] = sn[i];
+        else if (kind == 4) out[i] = drag[i];
+        else if (kind == 5) out[i] = hd_scale(hd_add(hd_add(drag[i], sn[i]), per[i]), 1.0 / 3.0);
+        else out[i] = hd_c(0.0); /* none; gaussian under deterministic=True (quadrotor.py:234) */
+    }
+}
+
+/* envs/quadrotor.py:250-263 + dynamics/free.py:74-155; prm as in dyn_step above; s->f = disturbance of THIS step */
+static void hd_dyn_step(hd_state *s, const hd_t *act, const double *prm)
+{
+    const hd_t *f = s->f;
     const double max_thrust = prm[0], dt = prm[7], g = prm[8], m = prm[9], ascale = prm[10], alpha = prm[11];
     hd_t a[4], u[4];
     for (int i = 0; i < 4; ++i) a[i] = hd_clip(hd_clip(act[i], -1.0, 1.0), -1.0, 1.0); /* quadrotor.py:223,258 */
@@ -200,7 +238,7 @@ static void hd_dyn_step(hd_state *s, const hd_t *act, const double *prm, const d
     hd_t qq[4] = {hd_add(x, hd_scale(qd[0], dt)), hd_add(y, hd_scale(qd[1], dt)), hd_add(z, hd_scale(qd[2], dt)),
                   hd_add(w, hd_scale(qd[3], dt))};
     for (int i = 0; i < 3; ++i) {
-        hd_t vd = hd_addc(hd_scale(hd_addc(hd_mul(Qz[i], u[0]), f[i]), 1.0 / m), i == 2 ? -g : 0.0);
+        hd_t vd = hd_addc(hd_scale(hd_add(hd_mul(Qz[i], u[0]), f[i]), 1.0 / m), i == 2 ? -g : 0.0);
         s->pos[i] = hd_add(s->pos[i], hd_scale(s->vel[i], dt));
         s->vel[i] = hd_add(s->vel[i], hd_scale(vd, dt));
         s->omega[i] = hd_add(hd_scale(om[i], alpha), hd_scale(u[1 + i], 1.0 - alpha));
@@ -211,9 +249,12 @@ static void hd_dyn_step(hd_state *s, const hd_t *act, const double *prm, const d
     for (int i = 0; i < 4; ++i) s->quat[i] = hd_mul(qq[i], rn2);
 }
 
-/* state22 = [pos vel quat omega f_disturb pos_tar vel_tar] (fp64); a_mean (H*4); R (H*4, H*4) row-major */
-void oracle_hessian_f64(const double *prm, const double *state22, int time, const double *pos_traj, const double *vel_traj,
-                        int T, const double *a_mean, int H, double *R)
+/* state22 = [pos vel quat omega f_disturb pos_tar vel_tar] (fp64); a_mean (H*4); R (H*4, H*4) row-major.
+ * reward_kind: 0 penyaw (utils.py:285-294), 1 realworld (:297-313); dist (nullable) = [kind, period, scale, disturb_params[6]],
+ * draws (H,3) = the per-step uniform draws of the disturbance model (get_hessian splits its key once per step, covo.py:151) */
+void oracle_hessian_ex_f64(const double *prm, const double *state22, int time, const double *pos_traj, const double *vel_traj,
+                           int T, const double *a_mean, int H, double *R, int reward_kind, const double *dist,
+                           const double *draws)
 {
     const int n = H * 4;
     const long npairs = (long)n * (n + 1) / 2;
@@ -224,21 +265,26 @@ void oracle_hessian_f64(const double *prm, const double *state22, int time, cons
         while (rem >= n - i) { rem -= n - i; ++i; }
         const int j = i + (int)rem;
         hd_state s;
-        for (int c = 0; c < 3; ++c) { s.pos[c] = hd_c(state22[c]); s.vel[c] = hd_c(state22[3 + c]); s.omega[c] = hd_c(state22[10 + c]); }
+        for (int c = 0; c < 3; ++c) {
+            s.pos[c] = hd_c(state22[c]); s.vel[c] = hd_c(state22[3 + c]); s.omega[c] = hd_c(state22[10 + c]);
+            s.f[c] = hd_c(state22[13 + c]);
+        }
         for (int c = 0; c < 4; ++c) s.quat[c] = hd_c(state22[6 + c]);
-        double f[3] = {state22[13], state22[14], state22[15]};
         double pos_tar[3] = {state22[16], state22[17], state22[18]}, vel_tar[3] = {state22[19], state22[20], state22[21]};
         double acc = 0.0;
         for (int k = 0; k < H; ++k) {
-            acc += hd_reward(&s, pos_tar, vel_tar).ab; /* covo.py:169-174 (pre-step reward) */
+            acc += (reward_kind == 1 ? hd_reward_realworld(&s, pos_tar) : hd_reward(&s, pos_tar, vel_tar)).ab; /* covo.py:169-174 */
             hd_t act[4];
             for (int d = 0; d < 4; ++d) {
                 const int idx = 4 * k + d;
                 hd_t x = {a_mean[idx], idx == i ? 1.0 : 0.0, idx == j ? 1.0 : 0.0, 0.0};
                 act[d] = x;
             }
-            hd_dyn_step(&s, act, prm, f);
-            f[0] = f[1] = f[2] = 0.0; /* deterministic=True: disturb_func returns 0 (quadrotor.py:234) */
+            hd_t fn[3];
+            const double zero9[9] = {0, 1, 0, 0, 0, 0, 0, 0, 0};
+            hd_disturb_next(&s, time + k, dist ? dist : zero9, draws ? draws + 3 * k : zero9 + 3, fn); /* free.py:147 (pre-step state) */
+            hd_dyn_step(&s, act, prm);
+            for (int c = 0; c < 3; ++c) s.f[c] = fn[c];
             int idx = time + k + 1;
             idx = idx < 0 ? 0 : (idx > T - 1 ? T - 1 : idx);
             for (int c = 0; c < 3; ++c) { pos_tar[c] = pos_traj[3 * idx + c]; vel_tar[c] = vel_traj[3 * idx + c]; }
@@ -246,4 +292,10 @@ void oracle_hessian_f64(const double *prm, const double *state22, int time, cons
         R[(size_t)i * n + j] = -acc; /* r(s_0) (covo.py:176-178) is constant */
         R[(size_t)j * n + i] = -acc;
     }
+}
+
+void oracle_hessian_f64(const double *prm, const double *state22, int time, const double *pos_traj, const double *vel_traj,
+                        int T, const double *a_mean, int H, double *R)
+{
+    oracle_hessian_ex_f64(prm, state22, time, pos_traj, vel_traj, T, a_mean, H, R, 0, NULL, NULL);
 }

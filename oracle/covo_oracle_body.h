@@ -36,6 +36,61 @@ static inline REAL SUF(reward)(const SUF(ostate) * s)
     return (REAL)1.3 - (REAL)0.05 * err_vel - SUF(log_pos)(err_pos) - FABS(yaw) * (REAL)0.2;
 }
 
+/* dynamics/utils.py:297-313 (task "tracking_slow", envs/quadrotor.py:58-66) */
+static inline REAL SUF(reward_realworld)(const SUF(ostate) * s)
+{
+    REAL pe = 0;
+    for (int i = 0; i < 3; ++i) { REAL d = s->pos[i] - s->pos_tar[i]; pe = pe + d * d; }
+    REAL pos_err = pe / (REAL)3;                      /* jnp.mean(pos_err**2) */
+    REAL quat_err = (REAL)1 - s->quat[3] * s->quat[3];
+    REAL cost = (REAL)5.0 * pos_err + (REAL)3.0 * quat_err;
+    cost = cost * (REAL)0.02;
+    return -cost;
+}
+static inline REAL SUF(reward_kind)(const SUF(ostate) * s, int kind) { return kind == 1 ? SUF(reward_realworld)(s) : SUF(reward)(s); }
+
+/* dynamics/free.py:10-58: the disturbance the NEXT step uses, from the PRE-step state (free.py:147).
+ * dist = [kind (2 periodic, 3 sin, 4 drag, 5 mixed), disturb_period, disturb_scale, disturb_params[6]];
+ * draw[3] = the explicit value of uniform(disturb_key, (3,), -scale, scale) for this call (periodic / mixed). */
+static inline void SUF(disturb_sin)(const SUF(ostate) * s, const double *dist, REAL *out)
+{
+    const REAL two_pi = (REAL)2 * (REAL)3.14159265358979323846;
+    for (int i = 0; i < 3; ++i) {
+        REAL scale = (REAL)dist[3 + i] * (REAL)dist[2];
+        REAL period = (REAL)dist[3 + i] * (REAL)(dist[1] / 3) + (REAL)dist[1];
+        REAL phase = (REAL)dist[6 + i] * (REAL)2 * (REAL)3.14159265358979323846;
+        out[i] = scale * SIN(two_pi / period * (REAL)s->time + phase);
+    }
+}
+static inline void SUF(disturb_drag)(const SUF(ostate) * s, const double *dist, REAL *out)
+{
+    for (int i = 0; i < 3; ++i) {
+        REAL rel = s->vel[i] - (REAL)dist[3 + i] * (REAL)0.5;
+        out[i] = -FABS((REAL)dist[2]) * rel * FABS(rel) / (REAL)(1.5 * 1.5);
+    }
+}
+static inline void SUF(disturb_period)(const SUF(ostate) * s, const double *dist, const REAL *draw, REAL *out)
+{
+    const int hit = (s->time % (int)dist[1]) == 0;
+    for (int i = 0; i < 3; ++i) out[i] = hit ? draw[i] : s->f[i];
+}
+static inline void SUF(disturb_next)(const SUF(ostate) * s, const double *dist, const REAL *draw, REAL *out)
+{
+    const int kind = (int)dist[0];
+    if (kind == 2) SUF(disturb_period)(s, dist, draw, out);
+    else if (kind == 3) SUF(disturb_sin)(s, dist, out);
+    else if (kind == 4) SUF(disturb_drag)(s, dist, out);
+    else if (kind == 5) {
+        REAL a[3], b[3], c[3];
+        SUF(disturb_drag)(s, dist, a);
+        SUF(disturb_sin)(s, dist, b);
+        SUF(disturb_period)(s, dist, draw, c);
+        for (int i = 0; i < 3; ++i) out[i] = (a[i] + b[i] + c[i]) / (REAL)3;
+    } else {
+        out[0] = out[1] = out[2] = 0;
+    }
+}
+
 /* envs/quadrotor.py:479-490; rollover = !disable_rollover_terminate (:486-490) */
 static inline int SUF(terminal)(const SUF(ostate) * s, int max_steps, int rollover)
 {
@@ -89,9 +144,10 @@ static inline void SUF(dyn_step)(SUF(ostate) * s, const REAL *act, const double 
 /* controllers/covo.py:227-263 / mppi.py:71-106.
  * state22 = [pos vel quat omega f_disturb pos_tar vel_tar]; a is (N,H,4) row-major.
  * rewards (N,H) and poses (H,N,3) may be NULL. */
-void SUF(oracle_rollout)(const double *prm, int max_steps, const REAL *state22, int time, const REAL *pos_traj,
-                         const REAL *vel_traj, int T, const REAL *a, long N, int H, REAL discount,
-                         const REAL *f_shared, REAL *cost, REAL *rewards, REAL *poses, int rollover)
+void SUF(oracle_rollout_ex)(const double *prm, int max_steps, const REAL *state22, int time, const REAL *pos_traj,
+                            const REAL *vel_traj, int T, const REAL *a, long N, int H, REAL discount,
+                            const REAL *f_shared, REAL *cost, REAL *rewards, REAL *poses, int rollover, int reward_kind,
+                            const double *dist)
 {
 #pragma omp parallel for schedule(static)
     for (long n = 0; n < N; ++n) {
@@ -107,9 +163,13 @@ void SUF(oracle_rollout)(const double *prm, int max_steps, const REAL *state22, 
         REAL reward_before = 0, acc = 0, disc = 1;
         int done_before = 0;
         for (int k = 0; k < H; ++k) {
-            REAL r = SUF(reward)(&s);               /* quadrotor.py:243 (pre-step) */
+            REAL r = SUF(reward_kind)(&s, reward_kind); /* quadrotor.py:243 (pre-step) */
             int done = SUF(terminal)(&s, max_steps, rollover); /* quadrotor.py:244 */
-            SUF(dyn_step)(&s, a + ((size_t)n * H + k) * 4, prm, f_shared, pos_traj, vel_traj, T);
+            REAL fn[3] = {f_shared[0], f_shared[1], f_shared[2]};
+            /* dist != NULL: a state/time-dependent model (free.py:10-58) evaluated on the pre-step state; f_shared is
+             * then the ONE draw all steps share (every step_env call of the scan has the same key, covo.py:225,231) */
+            if (dist) SUF(disturb_next)(&s, dist, f_shared, fn);
+            SUF(dyn_step)(&s, a + ((size_t)n * H + k) * 4, prm, fn, pos_traj, vel_traj, T);
             if (done_before) r = reward_before; /* covo.py:233 */
             done_before |= done;
             reward_before = r;
@@ -120,6 +180,14 @@ void SUF(oracle_rollout)(const double *prm, int max_steps, const REAL *state22, 
         }
         cost[n] = -acc; /* covo.py:263 */
     }
+}
+
+void SUF(oracle_rollout)(const double *prm, int max_steps, const REAL *state22, int time, const REAL *pos_traj,
+                         const REAL *vel_traj, int T, const REAL *a, long N, int H, REAL discount,
+                         const REAL *f_shared, REAL *cost, REAL *rewards, REAL *poses, int rollover)
+{
+    SUF(oracle_rollout_ex)(prm, max_steps, state22, time, pos_traj, vel_traj, T, a, N, H, discount, f_shared, cost, rewards,
+                           poses, rollover, 0, NULL);
 }
 
 /* controllers/covo.py:266-275 as an online-softmax partial over one shard:

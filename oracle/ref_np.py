@@ -196,6 +196,87 @@ def tracking_penyaw_reward_fn(state: State):
     return dt(1.3) - dt(0.05) * err_vel - log_pos_fn(err_pos) - np.abs(yaw) * dt(0.2)
 
 
+def tracking_realworld_reward_fn(state: State):
+    """utils.py:297-313 (task "tracking_slow", envs/quadrotor.py:58-66): quadratic position cost + attitude cost on
+    the STORED quaternion's w."""
+    dt = state.pos.dtype.type
+    pos_err = state.pos - state.pos_tar
+    pos_err = np.mean(pos_err ** 2, axis=-1)
+    quat_err = dt(1) - state.quat[..., 3] ** 2
+    cost = dt(5.0) * pos_err + dt(3.0) * quat_err
+    cost = cost * dt(0.02)
+    return -cost
+
+
+REWARD_FNS = {"penyaw": tracking_penyaw_reward_fn, "realworld": tracking_realworld_reward_fn}
+
+
+# ----------------------------------------------------------------------------
+# disturbance models: dynamics/free.py:9-72.  Each returns the f_disturb the NEXT step uses, from the PRE-step state
+# (free.py:147).  Randomness is explicit: `draw` stands for the value jax.random would return for this call's key --
+#   periodic / mixed: uniform(disturb_key, (3,), -disturb_scale, disturb_scale)      (free.py:16-21)
+#   gaussian:         normal(disturb_key, (3,))                                      (free.py:66-70)
+# ----------------------------------------------------------------------------
+def period_disturb(draw, p: Params, s: State):
+    """free.py:10-24."""
+    return np.where(s.time % p.disturb_period == 0, np.asarray(draw, dtype=s.pos.dtype), s.f_disturb)
+
+
+def sin_disturb(p: Params, s: State):
+    """free.py:27-38."""
+    t = s.pos.dtype.type
+    dp = _c(p.disturb_params, s.pos.dtype)
+    scale = dp[:3] * t(p.disturb_scale)
+    period = dp[:3] * t(p.disturb_period / 3) + t(p.disturb_period)
+    phase = dp[3:6] * t(2) * t(np.pi)
+    return scale * np.sin(t(2) * t(np.pi) / period * t(s.time) + phase)
+
+
+def drag_disturb(p: Params, s: State):
+    """free.py:41-47."""
+    t = s.pos.dtype.type
+    rel_vel = s.vel - _c(p.disturb_params, s.pos.dtype)[:3] * t(0.5)
+    return -np.abs(t(p.disturb_scale)) * rel_vel * np.abs(rel_vel) / t(1.5 ** 2)
+
+
+def mixed_disturb(draw, p: Params, s: State):
+    """free.py:50-56."""
+    t = s.pos.dtype.type
+    return (drag_disturb(p, s) + sin_disturb(p, s) + period_disturb(draw, p, s)) / t(3)
+
+
+DISTURB_KINDS = ("none", "gaussian", "periodic", "sin", "drag", "mixed")
+
+
+def disturb_func(kind: str, p: Params, s: State, draw=None, deterministic: bool = False):
+    """free.py:58-72 + the deterministic switch of envs/quadrotor.py:234-235 (it zeroes dyn_noise_scale ONLY: the
+    other models keep acting in deterministic rollouts)."""
+    t = s.pos.dtype.type
+    if kind == "none":
+        return np.zeros(3, dtype=s.pos.dtype)
+    if kind == "gaussian":
+        scale = t(p.dyn_noise_scale) * t(0.0 if deterministic else 1.0)
+        return scale * np.asarray(draw if draw is not None else np.zeros(3), dtype=s.pos.dtype)
+    if kind == "periodic":
+        return period_disturb(draw, p, s)
+    if kind == "sin":
+        return sin_disturb(p, s)
+    if kind == "drag":
+        return drag_disturb(p, s)
+    if kind == "mixed":
+        return mixed_disturb(draw, p, s)
+    raise NotImplementedError(kind)
+
+
+@dataclass
+class Disturb:
+    """How step_env gets its next disturbance: the model name, the explicit random input of this call (see above)
+    and step_env's `deterministic` argument."""
+    kind: str = "none"
+    draw: Optional[np.ndarray] = None
+    deterministic: bool = False
+
+
 def is_terminal(state: State, p: Params, rollover: bool = False):
     """envs/quadrotor.py:479-490; rollover = not disable_rollover_terminate (main() passes True, :779 -> rollover False)."""
     done = (state.time >= p.max_steps_in_episode) | np.any(np.abs(state.pos) > 3.0, axis=-1)
@@ -269,17 +350,20 @@ def raw_step(s: State, sub_action, p: Params, f_disturb_next):
     return free_dynamics_3d_bodyrate(p, s, thrust, torque, f_disturb_next, p.dt)
 
 
-def step_env(s: State, action, p: Params, f_disturb_next, rollover: bool = False):
+def step_env(s: State, action, p: Params, f_disturb_next, rollover: bool = False, reward_fn=tracking_penyaw_reward_fn):
     """envs/quadrotor.py:215-248 (lower_controller='base', substeps=1).
 
     Reward and termination are evaluated on the PRE-step state (:243-244).
-    ``f_disturb_next`` stands for disturb_func's draw (deterministic rollouts: 0).
+    ``f_disturb_next``: either the explicit next disturbance vector (what disturb_func returned; deterministic
+    rollouts of 'none' / 'gaussian': 0) or a `Disturb` (model evaluated on the pre-step state, free.py:147).
     Returns (next_state, reward, done).
     """
     t = s.pos.dtype.type
     action = np.clip(action, t(-1.0), t(1.0))
+    if isinstance(f_disturb_next, Disturb):
+        f_disturb_next = disturb_func(f_disturb_next.kind, p, s, f_disturb_next.draw, f_disturb_next.deterministic)
     nxt = raw_step(s, action, p, f_disturb_next)
-    return nxt, tracking_penyaw_reward_fn(s), is_terminal(s, p, rollover)
+    return nxt, reward_fn(s), is_terminal(s, p, rollover)
 
 
 # ----------------------------------------------------------------------------
@@ -306,12 +390,15 @@ def sample_actions_blockdiag(a_mean, a_cov, eps):
     return np.clip(a, -1.0, 1.0).astype(a_mean.dtype), Ls
 
 
-def rollout(s0: State, p: Params, a_sampled, discount, f_disturb_shared, rollover: bool = False):
+def rollout(s0: State, p: Params, a_sampled, discount, f_disturb_shared, rollover: bool = False,
+            reward_fn=tracking_penyaw_reward_fn):
     """covo.py:227-263 / mppi.py:71-106.
 
-    a_sampled (N,H,du) already clipped.  ``f_disturb_shared`` (3,) is the single
+    a_sampled (N,H,du) already clipped.  ``f_disturb_shared``: (3,) the single
     vector every sample/step receives from the shared ``step_key`` (0 for CoVO's
-    deterministic=True and for disturb_type='none'; 0.05*z for MPPI+gaussian).
+    deterministic=True and for disturb_type='none'; 0.05*z for MPPI+gaussian), or a
+    `Disturb` whose ``draw`` is that one shared draw (every step_env call of the scan
+    gets the SAME key, covo.py:225,231): periodic / sin / drag / mixed.
     Returns cost (N,), rewards (N,H), poses (H,N,3).
     """
     dtype = s0.pos.dtype
@@ -322,7 +409,7 @@ def rollout(s0: State, p: Params, a_sampled, discount, f_disturb_shared, rollove
     rewards = np.zeros((N, H), dtype=dtype)
     poses = np.zeros((H, N, 3), dtype=dtype)
     for k in range(H):
-        s, reward, done = step_env(s, a_sampled[:, k], p, f_disturb_shared, rollover)
+        s, reward, done = step_env(s, a_sampled[:, k], p, f_disturb_shared, rollover, reward_fn)
         reward = np.where(done_before, reward_before, reward)  # covo.py:233
         done_before = done | done_before
         reward_before = reward
@@ -388,24 +475,25 @@ def optimize_sigma(R, sample_sigma, H, du):
     return (a_cov + a_cov.T) / 2.0
 
 
-def hessian_objective(s0: State, p: Params, a_flat, H):
-    """covo.py:165-180: -(sum_k r(s_k) + r(s_0)); deterministic, no discount/freeze."""
+def hessian_objective(s0: State, p: Params, a_flat, H, reward_fn=tracking_penyaw_reward_fn, kind: str = "none", draws=None):
+    """covo.py:165-180: -(sum_k r(s_k) + r(s_0)); deterministic=True, no discount/freeze.  ``draws`` (H,3): the
+    per-step random inputs of the disturbance model (get_hessian splits its key once per step, covo.py:151)."""
     a = a_flat.reshape(H, -1)
     s = s0
-    zero = np.zeros(3, dtype=s0.pos.dtype)
     total = s0.pos.dtype.type(0)
     for i in range(H):
-        s, reward, _ = step_env(s, a[i], p, zero)
+        d = Disturb(kind, None if draws is None else draws[i], deterministic=True)
+        s, reward, _ = step_env(s, a[i], p, d, reward_fn=reward_fn)
         total = total + reward
-    total = total + tracking_penyaw_reward_fn(s0)
+    total = total + reward_fn(s0)
     return -total
 
 
-def hessian_fd(s0: State, p: Params, a_flat, H, h=1e-4):
+def hessian_fd(s0: State, p: Params, a_flat, H, h=1e-4, **kw):
     """Central finite-difference Hessian of ``hessian_objective`` (fp64 only;
     O(h^2) truncation -- a coarse cross-check of the AD oracle)."""
     n = a_flat.size
-    f = lambda a: hessian_objective(s0, p, a, H)
+    f = lambda a: hessian_objective(s0, p, a, H, **kw)
     R = np.zeros((n, n))
     f0 = f(a_flat)
     E = np.eye(n) * h

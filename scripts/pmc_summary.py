@@ -113,21 +113,39 @@ for tag, e in per_kernel.items():
     d = {}
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e and tag.startswith("rollout"):
         d["traffic_bytes_per_launch"] = int(round((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024))
+    # SQ_BUSY_CU_CYCLES: quad-cycles summed over the SIMDs -> cycles a SIMD was busy during the dispatch.  (GRBM_GUI_ACTIVE of
+    # a per-dispatch counter pass spans the profiler's whole sampling window -- 3e5 cycles around a 3 us copy -- and is NOT
+    # the kernel's duration; it is kept in the csv but not used.)
+    busy = e["SQ_BUSY_CU_CYCLES"] * 4 / SIMD if "SQ_BUSY_CU_CYCLES" in e else None
+    du = (e.get("duration_us_under_pmc") or {})
+    du = du.get("sq_b") or du.get("sq_a")
+    if busy:
+        d["busy_cycles_per_simd"] = busy
+        if du:
+            d["duration_us_under_pmc"] = du
+            d["effective_clock_GHz_under_pmc"] = busy / (du * 1e3)   # lower bound: the launch ramp is inside `du`
     if "SQ_WAVE_CYCLES" in e:
         wc = e["SQ_WAVE_CYCLES"]
         d["wave_cycle_shares"] = {"active_inst_any": e["SQ_ACTIVE_INST_ANY"] / wc, "active_inst_valu": e["SQ_ACTIVE_INST_VALU"] / wc,
                                   "wait_inst_any": e["SQ_WAIT_INST_ANY"] / wc, "wait_inst_lds": e["SQ_WAIT_INST_LDS"] / wc,
                                   "wait_any": e["SQ_WAIT_ANY"] / wc}
+        d["cycles_per_wave"] = wc * 4 / e["SQ_WAVES"]
         d["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+        d["cycles_per_valu_inst"] = e["SQ_ACTIVE_INST_VALU"] * 4 / e["SQ_INSTS_VALU"]
         if tag.startswith("rollout"):
             d["valu_wave_insts_per_64_samples_per_step"] = e["SQ_INSTS_VALU"] / (N_LOCAL / 64) / H
-        # quad-cycles -> cycles (x4); share of the chip's SIMD cycles during the dispatch that issued a VALU instruction
-        d["valu_busy_frac_of_gui_active"] = e["SQ_ACTIVE_INST_VALU"] * 4 / (e["GRBM_GUI_ACTIVE"] * SIMD) if e.get("GRBM_GUI_ACTIVE") else None
-    if "GRBM_GUI_ACTIVE" in e and e.get("duration_us_under_pmc"):
-        du = e["duration_us_under_pmc"].get("sq_a") or e["duration_us_under_pmc"].get("sq_b")
-        d["effective_clock_GHz_under_pmc"] = e["GRBM_GUI_ACTIVE"] / (du * 1e3)
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
-        d["mfma_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * SIMD)  # rocprofiler's MfmaUtil formula
+        valu = e["SQ_ACTIVE_INST_VALU"] * 4 / SIMD   # cycles a SIMD's VALU pipe executed instructions
+        d["valu_pipe_cycles_per_simd"] = valu
+        if busy:
+            d["valu_pipe_util"] = valu / busy
+            if du:
+                d["valu_pipe_floor_us_at_that_clock"] = valu / (busy / du)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and busy and e["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+        mf = e["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMD   # cycles a SIMD's matrix pipe was busy
+        d["mfma_pipe_cycles_per_simd"] = mf
+        d["mfma_util"] = mf / busy
+        d["mfma_insts_per_wave"] = e["SQ_INSTS_MFMA"] / e["SQ_WAVES"] if e.get("SQ_WAVES") else None
+        d["mfma_busy_cycles_per_inst"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_INSTS_MFMA"]
     if "SQ_INSTS_LDS" in e and tag.startswith("rollout"):
         d["lds_wave_insts_per_64_samples_per_step"] = e["SQ_INSTS_LDS"] / (N_LOCAL / 64) / H
     e["derived"] = d

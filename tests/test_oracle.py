@@ -187,3 +187,83 @@ def test_rollover_termination_oracle():
     calm = np.clip(R.hover_action(p, 32, np.float64)[None] + 0.05 * rng.normal(size=(N, 32, 4)), -1, 1)
     assert np.array_equal(CO.rollout(s, p, calm, 1.0, np.zeros(3), dtype=np.float64, rollover=True),
                           CO.rollout(s, p, calm, 1.0, np.zeros(3), dtype=np.float64))
+
+
+# ---- round 3: the other disturbance models (free.py:10-58) and the "tracking_slow" reward (utils.py:297-313) -----------
+def test_kat_realworld_reward_and_disturbance_models():
+    """Hand-derived from the cited lines (KAT 11-14)."""
+    s, p = _rest_state(np.float64)
+    # KAT 11: r = -0.02 (5 mean(dp^2) + 3 (1 - w^2))
+    assert abs(R.tracking_realworld_reward_fn(s.replace(pos=np.array([1.0, 0, 0]))) - (-1.0 / 30.0)) < 1e-15
+    sq = s.replace(quat=np.array([0, 0, np.sin(np.pi / 4), np.cos(np.pi / 4)]))
+    assert abs(R.tracking_realworld_reward_fn(sq) - (-0.03)) < 1e-15
+    assert abs(R.tracking_realworld_reward_fn(s.replace(pos=np.array([0.3, -0.6, 0.9]), quat=np.array([0.0, 0.6, 0.0, 0.8])))
+               - (-(5 * (0.09 + 0.36 + 0.81) / 3 + 3 * 0.36) * 0.02)) < 1e-15
+    # KAT 12: drag = -|scale| rel |rel| / 1.5^2, rel = v - 0.5 dp[:3]
+    pd = p.replace(disturb_params=(1.0, 0.0, -2.0, 0, 0, 0))
+    f = R.drag_disturb(pd, s.replace(vel=np.array([2.0, -3.0, 0.5])))
+    assert np.allclose(f, [-0.2 * 1.5 * 1.5 / 2.25, 0.2 * 9 / 2.25, -0.2 * 1.5 * 1.5 / 2.25], atol=1e-15)
+    # KAT 13: sin = dp[:3] scale sin(2 pi t / (dp[:3] period/3 + period) + 2 pi dp[3:6])
+    ps = p.replace(disturb_params=(1.0, 0.5, 0.0, 0.25, 0.0, 0.0))
+    f = R.sin_disturb(ps, s.replace(time=10))
+    assert np.allclose(f, [0.2 * np.cos(0.3 * np.pi), 0.1 * np.sin(2 * np.pi * 10 / (50 / 6 + 50)), 0.0], atol=1e-15)
+    # KAT 14: periodic holds the state's vector except when time % period == 0
+    u = np.array([0.11, -0.07, 0.19])
+    sf = s.replace(f_disturb=np.array([0.01, 0.02, 0.03]))
+    assert np.array_equal(R.period_disturb(u, p, sf.replace(time=100)), u)
+    assert np.array_equal(R.period_disturb(u, p, sf.replace(time=101)), sf.f_disturb)
+    # mixed = (drag + sin + periodic) / 3
+    sm = sf.replace(time=150, vel=np.array([2.0, -3.0, 0.5]))
+    pm = p.replace(disturb_params=(1.0, 0.5, -2.0, 0.25, 0.0, 0.5))
+    assert np.allclose(R.mixed_disturb(u, pm, sm), (R.drag_disturb(pm, sm) + R.sin_disturb(pm, sm) + u) / 3, atol=1e-16)
+    # deterministic=True only switches the gaussian model off (quadrotor.py:234-235)
+    assert np.array_equal(R.disturb_func("gaussian", p, s, np.ones(3), deterministic=True), np.zeros(3))
+    assert np.allclose(R.disturb_func("gaussian", p, s, np.ones(3)), 0.05)
+    assert np.array_equal(R.disturb_func("drag", pd, s.replace(vel=np.array([2.0, -3.0, 0.5])), None, deterministic=True),
+                          R.drag_disturb(pd, s.replace(vel=np.array([2.0, -3.0, 0.5]))))
+
+
+@pytest.mark.parametrize("kind", ["periodic", "sin", "drag", "mixed"])
+@pytest.mark.parametrize("reward", ["penyaw", "realworld"])
+def test_c_oracle_disturbance_models_match_numpy(kind, reward):
+    """The C rollout with each disturbance model / reward against the literal numpy form, fp64 and fp32; the horizon
+    crosses a multiple of disturb_period so that the periodic model both holds and redraws."""
+    s, p, rng = make_problem(seed=11, time=35)
+    p = p.replace(disturb_params=tuple(float(np.float32(x)) for x in rng.uniform(-1, 1, 6)))
+    a = np.clip(R.hover_action(p, 32, np.float64)[None] + 0.3 * rng.normal(size=(24, 32, 4)), -1, 1)
+    a = a.astype(np.float32).astype(np.float64)
+    draw = rng.uniform(-p.disturb_scale, p.disturb_scale, 3).astype(np.float32).astype(np.float64)
+    d = R.Disturb(kind, draw, deterministic=True)
+    cost_np, rew_np, poses_np = R.rollout(s, p, a, 0.97, d, reward_fn=R.REWARD_FNS[reward])
+    cost_c, rew_c, poses_c = CO.rollout(s, p, a, 0.97, dtype=np.float64, want_rewards=True, want_poses=True, reward=reward,
+                                        disturb=d)
+    assert np.abs(cost_np - cost_c).max() < 1e-12 and np.abs(rew_np - rew_c).max() < 1e-13
+    assert np.abs(poses_np - poses_c).max() < 1e-13
+    cost32 = CO.rollout(s.astype(np.float32), p, a, 0.97, dtype=np.float32, reward=reward, disturb=d)
+    assert np.abs(cost32 - cost_c).max() < 2e-5 * max(1.0, np.abs(cost_c).max())
+    # the model matters: the same rollout without it differs
+    cost_0 = CO.rollout(s, p, a, 0.97, dtype=np.float64, reward=reward)
+    assert np.abs(cost_0 - cost_c).max() > 1e-6
+
+
+@pytest.mark.parametrize("kind,reward", [("periodic", "penyaw"), ("sin", "realworld"), ("drag", "penyaw"),
+                                         ("mixed", "realworld"), ("none", "realworld")])
+def test_c_hessian_with_disturbance_models_matches_torch_ad(kind, reward):
+    from oracle import ref_torch as RT
+    s, p, rng = make_problem(seed=12, time=40)
+    p = p.replace(disturb_params=tuple(float(np.float32(x)) for x in rng.uniform(-1, 1, 6)))
+    H = 12
+    a = (R.hover_action(p, H, np.float64) + 0.2 * rng.normal(size=(H, 4))).reshape(-1)
+    draws = rng.uniform(-p.disturb_scale, p.disturb_scale, (H, 3))
+    Rc = CO.hessian(s, p, a, H, reward=reward, kind=kind, draws=draws)
+    Rt = RT.hessian(s, p, a, H, reward_kind=reward, kind=kind, draws=draws)
+    assert np.abs(Rc - Rt).max() < 1e-10 * max(1.0, np.abs(Rt).max())
+    assert np.abs(Rc - Rc.T).max() == 0 and np.all(Rc[-4:] == 0)
+    if kind in ("drag", "mixed"):  # the velocity-dependent force enters the second derivatives
+        R0 = CO.hessian(s, p, a, H, reward=reward, kind="none")
+        assert np.abs(R0 - Rc).max() > 1e-8
+    # value check of the objective itself: numpy literal form == torch restatement
+    f_np = R.hessian_objective(s, p, a, H, reward_fn=R.REWARD_FNS[reward], kind=kind, draws=draws)
+    import torch
+    f_t = RT.make_objective(s, p, H, reward, kind, draws)(torch.as_tensor(a)).item()
+    assert abs(f_np - f_t) < 1e-12
