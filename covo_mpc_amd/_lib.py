@@ -18,7 +18,7 @@ COVO_NA = COVO_H * COVO_DU
 COVO_STATE_FLOATS = 32
 COVO_PARTIAL_FLOATS = 132
 COVO_POS_STATS_DOUBLES = COVO_H * 6
-ABI_VERSION = 2
+ABI_VERSION = 3
 COVO_FLAG_ACTIONS_CLIPPED = 1
 
 
@@ -32,7 +32,9 @@ class EnvParamsC(C.Structure):
         ("max_thrust", C.c_float), ("max_torque", C.c_float * 3), ("max_omega", C.c_float * 3),
         ("dt", C.c_float), ("g", C.c_float), ("m", C.c_float), ("action_scale", C.c_float),
         ("alpha_bodyrate", C.c_float), ("max_steps_in_episode", C.c_int32), ("pos_limit", C.c_float),
-        ("rollover_terminate", C.c_int32),
+        ("rollover_terminate", C.c_int32), ("reward_kind", C.c_int32), ("disturb_kind", C.c_int32),
+        ("disturb_period", C.c_int32), ("disturb_scale", C.c_float), ("disturb_params", C.c_float * 6),
+        ("dyn_noise_scale", C.c_float),
     ]
 
 
@@ -51,7 +53,7 @@ class StepArgsC(C.Structure):
                 ("state", _P), ("pos_traj", _P), ("vel_traj", _P), ("a_mean", _P), ("a_mean_shift", _P), ("a_cov", _P),
                 ("L_table", _P), ("a", _P), ("cost", _P), ("groupmin", _P), ("pos_stats", _P), ("partial_out", _P),
                 ("sample_offset", C.c_int64), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float),
-                ("derive_keys", C.c_int32), ("shared_noise_scale", C.c_float)]
+                ("derive_keys", C.c_int32), ("rollout_deterministic", C.c_int32)]
 
 
 class BatchArgsC(C.Structure):
@@ -61,6 +63,10 @@ class BatchArgsC(C.Structure):
                 ("groupmin", _P), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float)]
 
 
+REWARD_KINDS = {"penyaw": 0, "realworld": 1}                 # COVO_REWARD_*
+DISTURB_KINDS = {"none": 0, "gaussian": 1, "periodic": 2, "sin": 3, "drag": 4, "mixed": 5}  # COVO_DISTURB_*
+TABLE_DISTURB_KINDS = (2, 3, 4, 5)                            # models that need covo_disturb_table's per-step table
+DISTURB_KEYS_SHARED, DISTURB_KEYS_HESSIAN, DISTURB_KEYS_NOMINAL = 0, 1, 2
 COVO_MAX_ENVS = 64
 MODE_MPPI, MODE_COVO_ONLINE, MODE_COVO_OFFLINE = 0, 1, 2
 COVO_FLAG_NO_GRAPH = 2
@@ -80,25 +86,27 @@ _SIGS = {
     "covo_noise_blockdiag": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
     "covo_noise_gemm_philox": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, _P, _P]),
     "covo_noise_blockdiag_philox": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, _P, _P]),
-    "covo_rollout_cost": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P,
+    "covo_rollout_cost": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P, _P,
                                     C.c_int32, _P, _P, _P, _P]),
+    "covo_disturb_table": (C.c_int, [_P, C.POINTER(EnvParamsC), _P, C.c_int32, _P, C.c_uint32, C.c_uint32, C.c_int32,
+                                     C.c_int32, _P, _P]),
     "covo_pos_info": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P]),
-    "covo_debug_time_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P,
+    "covo_debug_time_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(C.c_float), _P, _P,
                                           C.c_int32, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_softmax_reduce": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "covo_softmax_update": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_float, _P, _P]),
     "covo_merge": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P]),
     "covo_shift_mean": (C.c_int, [_P, _P, _P, _P]),
-    "covo_hessian": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, C.c_int32, _P, _P]),
-    "covo_hessian_pairs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, C.c_int32, _P, _P]),
+    "covo_hessian": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, _P, C.c_int32, _P, _P]),
+    "covo_hessian_pairs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, _P, C.c_int32, _P, _P]),
     "covo_sigma": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "covo_debug_sigma_workspace": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "covo_debug_hess_workspace": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "covo_env_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, C.POINTER(C.c_uint32),
-                                C.c_int32, C.c_int32, C.c_float, C.c_float, _P, C.c_int32, _P]),
+                                C.c_int32, C.c_float, _P, C.c_int32, _P]),
     "covo_pid_nominal": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(EnvParamsC), C.c_float,
-                                   C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_int32, _P, _P, _P]),
-    "covo_run_episode": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), _P, _P, C.c_int32, C.c_int32, C.c_float,
+                                   C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_int32, _P, _P, _P, _P]),
+    "covo_run_episode": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), _P, _P, C.c_int32,
                                    C.c_float, _P, C.POINTER(C.c_uint32), C.c_int32, _P]),
     "covo_mpc_step_batched": (C.c_int, [_P, C.POINTER(BatchArgsC), C.POINTER(EnvParamsC), C.POINTER(C.c_uint32), _P]),
     "covo_debug_set_ns_tail": (C.c_int, [C.c_int, C.c_int]),

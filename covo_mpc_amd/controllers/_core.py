@@ -185,31 +185,44 @@ class SamplingCore:
         check(self.lib.covo_cholesky(self.h, ptr(A), n, batch, ptr(out), self.stream()), "covo_cholesky")
         return out
 
-    def rollout(self, dstate, params_c, f_shared, want_stats):
+    def disturb_table(self, params_c, packed, key=None, keys_dev=None, key_mode=_lib.DISTURB_KEYS_SHARED, deterministic=True,
+                      batch=1):
+        """covo_disturb_table: the per-step disturbance table(s) [batch, H, 4] of rollouts starting at `packed` ([batch, 32]
+        device states) for params_c.disturb_kind periodic / sin / drag / mixed (free.py:10-58).  `key` (two uint32) for every
+        entry, or `keys_dev` (uint32 [batch, 2] device tensor): the key whose threading `key_mode` describes."""
+        out = self.torch.empty((batch, COVO_H, 4), dtype=self.torch.float32, device=self.device)
+        k0, k1 = (int(key[0]), int(key[1])) if key is not None else (0, 0)
+        check(self.lib.covo_disturb_table(self.h, C.byref(params_c), ptr(packed), int(batch), ptr(keys_dev), k0, k1,
+                                          int(key_mode), 1 if deterministic else 0, ptr(out), self.stream()), "covo_disturb_table")
+        return out
+
+    def rollout(self, dstate, params_c, f_shared, want_stats, f_steps=None):
+        """f_shared: host 3-vector (none / gaussian); f_steps: the device table of disturb_table (periodic / sin / drag / mixed)."""
         fs = (C.c_float * 3)(*[float(x) for x in f_shared])
         check(self.lib.covo_rollout_cost(self.h, ptr(dstate.packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj),
-                                         dstate.T, C.byref(params_c), fs, ptr(self.a), self.n_local, ptr(self.cost),
+                                         dstate.T, C.byref(params_c), fs, ptr(f_steps), ptr(self.a), self.n_local, ptr(self.cost),
                                          ptr(self.blockmin), ptr(self.stats) if want_stats else None, self.stream()),
               "covo_rollout_cost")
         return self.cost
 
-    def time_rollout(self, dstate, params_c, f_shared=(0.0, 0.0, 0.0), reps=100, with_records=False):
+    def time_rollout(self, dstate, params_c, f_shared=(0.0, 0.0, 0.0), reps=100, with_records=False, f_steps=None):
         """(mean, min-batch) GPU microseconds per covo_rollout_cost launch: three batches of `reps` launches issued back to
         back from C between two events.  with_records: the record-emitting variant the fused step runs."""
         fs = (C.c_float * 3)(*[float(x) for x in f_shared])
         us = (C.c_float * 2)(0.0, 0.0)
         check(self.lib.covo_debug_time_rollout(self.h, ptr(dstate.packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj), dstate.T,
-                                               C.byref(params_c), fs, ptr(self.a), self.n_local, ptr(self.cost),
+                                               C.byref(params_c), fs, ptr(f_steps), ptr(self.a), self.n_local, ptr(self.cost),
                                                ptr(self.blockmin), 1 if with_records else 0, int(reps), us, self.stream()),
               "covo_debug_time_rollout")
         return float(us[0]), float(us[1])
 
-    def hessian(self, packed, dstate, params_c, a_mean, batch=1, method="adjoint"):
-        """d^2 C / da^2 (covo.py:134-185); method "adjoint" (default, hessian_adj.hip) or "pairs" (hessian.hip)."""
+    def hessian(self, packed, dstate, params_c, a_mean, batch=1, method="adjoint", f_steps=None):
+        """d^2 C / da^2 (covo.py:134-185); method "adjoint" (default, hessian_adj.hip) or "pairs" (hessian.hip).  f_steps: the
+        [batch, H, 4] table of disturb_table(key_mode=DISTURB_KEYS_HESSIAN) for periodic / sin / drag / mixed."""
         R = self.torch.empty((batch, COVO_NA, COVO_NA), dtype=self.torch.float64, device=self.device)
         fn = self.lib.covo_hessian if method == "adjoint" else self.lib.covo_hessian_pairs
         check(fn(self.h, ptr(packed), ptr(dstate.pos_traj), ptr(dstate.vel_traj), dstate.T,
-                 C.byref(params_c), ptr(a_mean), batch, ptr(R), self.stream()), "covo_hessian")
+                 C.byref(params_c), ptr(a_mean), ptr(f_steps), batch, ptr(R), self.stream()), "covo_hessian")
         return R
 
     def sigma(self, R, sample_sigma, batch=1, method="ns"):
@@ -230,7 +243,7 @@ class SamplingCore:
         return t
 
     def _prepare_step(self, mode, dstate, a_mean, *, a_cov=None, L_table=None, gamma_mean=1.0, sample_sigma=0.5,
-                      want_stats=False, derive_keys=False, shared_noise_scale=0.0):
+                      want_stats=False, derive_keys=False, rollout_deterministic=True):
         """Fixed-address buffers + struct covo_step_args of the fused step -> (args, a_mean buffer, shifted-mean
         buffer, a_cov buffer or None)."""
         torch = self.torch
@@ -252,7 +265,7 @@ class SamplingCore:
         # the argument block only changes when a buffer does (new episode -> new trajectory tensors): it is rebuilt
         # then, otherwise only the state pointer is refreshed (this call sits on the per-step host path)
         sig = (mode, dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr(), L_table.data_ptr() if L_table is not None else 0,
-               bool(want_stats), float(gamma_mean), float(sample_sigma), bool(derive_keys), float(shared_noise_scale))
+               bool(want_stats), float(gamma_mean), float(sample_sigma), bool(derive_keys), bool(rollout_deterministic))
         cached = self._args_cache
         if cached is not None and cached[0] == sig:
             args = cached[1]
@@ -270,7 +283,7 @@ class SamplingCore:
             args.pos_stats = self.stats.data_ptr() if want_stats else None
             args.partial_out = self.partial.data_ptr() if self.world > 1 else None
             args.sample_offset, args.gamma_mean, args.sample_sigma = self.offset, float(gamma_mean), float(sample_sigma)
-            args.derive_keys, args.shared_noise_scale = (1 if derive_keys else 0), float(shared_noise_scale)
+            args.derive_keys, args.rollout_deterministic = (1 if derive_keys else 0), (1 if rollout_deterministic else 0)
             self._args_cache = (sig, args, (dstate.pos_traj, dstate.vel_traj, L_table))  # keep the tensors alive
         args.state = packed.data_ptr()
         return args, am, am_shift, cov_out
@@ -300,8 +313,7 @@ class SamplingCore:
         key = (C.c_uint32 * 2)(int(rng[0]), int(rng[1]))
         env = episode.env
         check(self.lib.covo_run_episode(self.h, C.byref(params_c), C.byref(args), ptr(episode.true), ptr(episode.acc_traj),
-                                        1 if env.disturb_type == "gaussian" else 0, 1 if env.generate_noisy_state else 0,
-                                        float(episode.params.dyn_noise_scale), float(env.default_params.obs_noise_scale),
+                                        1 if env.generate_noisy_state else 0, float(env.default_params.obs_noise_scale),
                                         ptr(episode.log[episode.n_steps:]), key, int(n_steps), self.stream()),
               "covo_run_episode")
         episode.n_steps += int(n_steps)

@@ -21,9 +21,33 @@ class BaseController:
         return control_params
 
     def _params_c(self, env_params):
-        """struct covo_env_params for `env_params` plus the env's rollover-termination switch (quadrotor.py:486), rebuilt
-        only when a different (frozen, hence never mutated) parameter object comes in."""
+        """struct covo_env_params for `env_params` plus what the kernels need to know about the ENV object: its
+        rollover-termination switch (quadrotor.py:486), which reward function env.reward_fn is (quadrotor.py:49-84) and its
+        disturbance model (quadrotor.py:35,87-89).  Rebuilt only when a different (frozen, hence never mutated) parameter
+        object comes in."""
         if self._c_params[0] is not env_params:
-            roll_on = not getattr(self.env, "disable_rollover_terminate", True)
-            self._c_params = (env_params, env_params.to_c(rollover_terminate=roll_on))
+            self._c_params = (env_params, env_model_params_c(self.env, env_params))
         return self._c_params[1]
+
+
+def env_reward_kind(env) -> str:
+    """Which of the kernels' rewards `env.reward_fn` is.  The fused rollout, the Hessian and the env-step kernel evaluate the
+    reward themselves (csrc/rollout_pipe.hpp, quad_model.hpp): an env bound to any OTHER function would make the controller
+    plan against one objective while env.step pays another -- refuse instead of diverging silently."""
+    from ..dynamics import utils
+    fn = getattr(env, "reward_fn", None)
+    if fn is None or fn is utils.tracking_penyaw_reward_fn:
+        return "penyaw"
+    if fn is utils.tracking_realworld_reward_fn:
+        return "realworld"
+    raise NotImplementedError(f"env.reward_fn={getattr(fn, '__name__', fn)!r} is not one of the rewards the kernels evaluate "
+                              "(tracking_penyaw_reward_fn, tracking_realworld_reward_fn: quadjax/envs/quadrotor.py:49-84)")
+
+
+def env_model_params_c(env, env_params):
+    from .._lib import DISTURB_KINDS
+    disturb = getattr(env, "disturb_type", "none")
+    if disturb not in DISTURB_KINDS:
+        raise NotImplementedError(f"disturb_type={disturb!r}")
+    return env_params.to_c(rollover_terminate=not getattr(env, "disable_rollover_terminate", True),
+                           reward=env_reward_kind(env), disturb_type=disturb)

@@ -29,7 +29,9 @@ class BatchedCoVOController:
         self.gamma_mean, self.sample_sigma = float(gamma_mean), float(sample_sigma)
         self.rollover_terminate = not getattr(env, "disable_rollover_terminate", True)  # quadrotor.py:486
         if getattr(env, "disturb_type", "none") not in ("gaussian", "none"):
-            raise NotImplementedError(f"disturb_type={env.disturb_type!r} inside the fused rollout")
+            # the per-step disturbance tables (csrc/disturb.hip) are built per control step of ONE instance; the env-batched
+            # graph does not carry them (covo_mpc_step_batched refuses as well)
+            raise NotImplementedError(f"disturb_type={env.disturb_type!r} in the env-batched step (only 'gaussian' and 'none')")
         # one call advances all instances: the ~56 launches are worth a graph (same GPU time as eager, 40 us instead of
         # 150-270 us of host time per call)
         self.core = SamplingCore(N, H, lam, discount, device=device, compute_info=False, trust_clipped=True, use_graph=True)
@@ -58,7 +60,8 @@ class BatchedCoVOController:
         pos = torch.stack([d.pos_traj.reshape(T, 3) for d in ds]).contiguous()
         vel = torch.stack([d.vel_traj.reshape(T, 3) for d in ds]).contiguous()
         self._traj = (pos, vel, T)
-        self._params = (_lib.EnvParamsC * self.E)(*[p.to_c(rollover_terminate=self.rollover_terminate) for p in env_params])
+        from .base import env_model_params_c
+        self._params = (_lib.EnvParamsC * self.E)(*[env_model_params_c(self.env, p) for p in env_params])
         a = _lib.BatchArgsC()
         a.n_envs, a.n_samples, a.T = self.E, self.N, T
         a.states, a.pos_traj, a.vel_traj = self._states.data_ptr(), pos.data_ptr(), vel.data_ptr()

@@ -51,7 +51,7 @@ class CoVOController(BaseController):
         self.action_dim = self.env.action_dim
         if mode not in ("online", "offline"):
             raise NotImplementedError(mode)  # covo.py:113-114
-        self._check_disturb_type()
+        self._params_c(env.default_params)  # raises now if env.reward_fn / disturb_type is not one the kernels evaluate
         if mode == "offline":
             assert env.action_dim == 4, "only support 4D action space Quadrotor environment for now"  # covo.py:45-47
             self.expansion_control_params = PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0)  # covo.py:48-53
@@ -61,22 +61,26 @@ class CoVOController(BaseController):
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
 
-    def _check_disturb_type(self):
-        """The fused rollout and the Hessian take f_disturb = 0 for every step k >= 1: what the reference's
-        deterministic=True gives for 'gaussian' (dyn_noise_scale zeroed, quadrotor.py:234-235) and 'none'.  The other
-        models (periodic, sin, drag, mixed: free.py:10-58) keep or recompute a state/time-dependent force that
-        deterministic=True does not switch off -- not built, so refuse instead of diverging silently."""
-        dt = getattr(self.env, "disturb_type", "none")
-        if dt not in ("gaussian", "none"):
-            raise NotImplementedError(f"disturb_type={dt!r} inside the fused rollout / Hessian (only 'gaussian' and 'none': "
-                                      "state- and time-dependent disturbance models are outside the kernels' scope)")
+    def _needs_table(self, params_c) -> bool:
+        """periodic / sin / drag / mixed (free.py:10-58): quadjax's deterministic=True only zeroes dyn_noise_scale
+        (quadrotor.py:234-235), so these models act in the sampling rollouts AND in get_hessian -- through the per-step
+        table of csrc/disturb.hip."""
+        from .. import _lib
+        return params_c.disturb_kind in _lib.TABLE_DISTURB_KINDS
 
     # ---- Sigma selection (covo.py:36-41 / 107-108) ----------------------------------------------
     def get_hessian(self, env_state, env_params, control_params, a_mean, rng_act=None):
-        """covo.py:134-185 -> (128,128) fp64 tensor."""
-        self._check_disturb_type()
+        """covo.py:134-185 -> (128,128) fp64 tensor.  rng_act: the key whose per-step splits (covo.py:150-153) feed the
+        disturbance model's draws (periodic / mixed)."""
+        from .. import _lib
         dstate = as_device_state(env_state, self.core.device)
-        return self.core.hessian(dstate.packed, dstate, env_params.to_c(), a_mean.reshape(-1))[0]
+        pc = self._params_c(env_params)
+        tab = None
+        if self._needs_table(pc):
+            if rng_act is None:
+                raise ValueError(f"disturb_type={self.env.disturb_type!r}: get_hessian needs rng_act")
+            tab = self.core.disturb_table(pc, dstate.packed, key=rng_act, key_mode=_lib.DISTURB_KEYS_HESSIAN, deterministic=True)
+        return self.core.hessian(dstate.packed, dstate, pc, a_mean.reshape(-1), f_steps=tab)[0]
 
     def optimize_sigma(self, R, control_params):
         """covo.py:116-132 -> (Sigma, chol(Sigma)) fp32."""
@@ -117,31 +121,35 @@ class CoVOController(BaseController):
         from .. import _lib
         core, env = self.core, self.env
         torch = core.torch
-        if env.disturb_type not in ("gaussian", "none"):
-            raise NotImplementedError(f"disturb_type={env.disturb_type!r} in the device nominal rollout")
         T = env.default_params.max_steps_in_episode
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(core.device)
         dstate = as_device_state(env_state, core.device)
         state0, acc_traj = up(env_state.pack()), up(env_state.acc_traj)
         packed_d = torch.empty((T, 32), dtype=torch.float32, device=core.device)
         a_means_d = torch.empty((T, COVO_NA), dtype=torch.float32, device=core.device)
+        keys_d = torch.empty((T, 2), dtype=torch.int32, device=core.device)  # uint32 bits: the scan's carry key per start state
         g = self.expansion_control_params
         assert float(g.Ki) == 0.0, "the device PID law carries no integral state (covo.py:48-53 uses Ki = 0)"
-        scale = float(env_params.dyn_noise_scale) if env.disturb_type == "gaussian" else 0.0
-        pc, pid_pc = env_params.to_c(), self.expansion_controller.param.to_c()
+        pc, pid_pc = self._params_c(env_params), self.expansion_controller.param.to_c()
         _lib.check(core.lib.covo_pid_nominal(core.h, _lib.ptr(state0), _lib.ptr(dstate.pos_traj), _lib.ptr(dstate.vel_traj),
                                              _lib.ptr(acc_traj), dstate.T, C.byref(pc), C.byref(pid_pc), float(g.Kp),
-                                             float(g.Kd), float(g.Kp_att), scale, int(key[0]), int(key[1]), T,
-                                             _lib.ptr(packed_d), _lib.ptr(a_means_d), core.stream()), "covo_pid_nominal")
+                                             float(g.Kd), float(g.Kp_att), int(key[0]), int(key[1]), T,
+                                             _lib.ptr(packed_d), _lib.ptr(a_means_d), _lib.ptr(keys_d), core.stream()),
+                   "covo_pid_nominal")
         self._nominal_keep = (state0, acc_traj)  # alive until the stream has consumed them
-        return packed_d, a_means_d
+        return packed_d, a_means_d, keys_d
 
     def reset_a_cov_offline(self, env_state, env_params, control_params, key):
+        from .. import _lib
         core = self.core
         T = self.env.default_params.max_steps_in_episode
         dstate = as_device_state(env_state, core.device)
-        packed_d, a_means_d = self._nominal_device(env_state, env_params, key)
-        R = core.hessian(packed_d, dstate, env_params.to_c(), a_means_d, batch=T)
+        packed_d, a_means_d, keys_d = self._nominal_device(env_state, env_params, key)
+        pc = self._params_c(env_params)
+        tab = None
+        if self._needs_table(pc):  # get_hessian(env_state_t, ..., a_mean_t, key_t) (covo.py:77): per-step keys from the carry key
+            tab = core.disturb_table(pc, packed_d, keys_dev=keys_d, key_mode=_lib.DISTURB_KEYS_HESSIAN, deterministic=True, batch=T)
+        R = core.hessian(packed_d, dstate, pc, a_means_d, batch=T, f_steps=tab)
         Sigma, L = core.sigma(R, control_params.sample_sigma, batch=T)
         return control_params.replace(a_cov_offline=Sigma, a_chol_offline=L)
 
@@ -149,7 +157,6 @@ class CoVOController(BaseController):
         """n_steps closed-loop steps (this controller + the device env step) enqueued by one C call; keys threaded like
         eval_env's run_one_step.  -> (control_params with the final mean / Sigma, rng).  See SamplingCore.run_episode."""
         from .. import _lib
-        self._check_disturb_type()
         if self.mode == "offline" and control_params.a_chol_offline is None:
             raise RuntimeError("covo-offline: call controller.reset(...) first (a_cov_offline table missing)")
         mode = _lib.MODE_COVO_ONLINE if self.mode == "online" else _lib.MODE_COVO_OFFLINE
@@ -168,7 +175,6 @@ class CoVOController(BaseController):
         from .. import random as crandom
         from .. import _lib
         core = self.core
-        self._check_disturb_type()
         dstate = as_device_state(info["noisy_state"], core.device)  # covo.py:198
         params_c = self._params_c(env_params)
         if self.mode == "offline" and control_params.a_chol_offline is None:
@@ -177,8 +183,9 @@ class CoVOController(BaseController):
             raise ValueError(f"noise_stream={self.noise_stream!r}")
         if not self.materialize_eps and self.noise_stream == "philox":
             # ---- production path: the whole step is one C call / one hipGraph replay (csrc/step.hip)
-            # rng_act, act_key = split(rng_act) (covo.py:212) and the unused step_key (covo.py:225: deterministic
-            # rollouts draw nothing) are derived on the device from the raw key (step.hip: step_begin_kernel)
+            # rng_act, act_key = split(rng_act) (covo.py:212), the rollouts' step_key (covo.py:225: deterministic, so only the
+            # periodic / mixed models draw from it) and get_hessian's per-step keys (covo.py:39,150-153) are derived on the
+            # device from the raw key (step.hip: step_begin_kernel, disturb.hip)
             mode = _lib.MODE_COVO_ONLINE if self.mode == "online" else _lib.MODE_COVO_OFFLINE
             am, cov = core.step(mode, dstate, params_c, control_params.a_mean, rng_act,
                                 L_table=control_params.a_chol_offline, gamma_mean=control_params.gamma_mean,
@@ -202,8 +209,11 @@ class CoVOController(BaseController):
         # ---- kernel-by-kernel path with epsilon materialised in HBM (identical values; parity/debug)
         a_mean = core.shift_mean(control_params.a_mean.reshape(-1))  # covo.py:201-203
         control_params = control_params.replace(a_mean=a_mean.view(self.H, 4))
-        if self.mode == "online":  # optimal Sigma (covo.py:205-208)
-            R = core.hessian(dstate.packed, dstate, params_c, a_mean)
+        tables = self._needs_table(params_c)
+        if self.mode == "online":  # optimal Sigma (covo.py:205-208); get_hessian receives the RAW rng_act (covo.py:205)
+            tab_h = core.disturb_table(params_c, dstate.packed, key=rng_act, key_mode=_lib.DISTURB_KEYS_HESSIAN,
+                                       deterministic=True) if tables else None
+            R = core.hessian(dstate.packed, dstate, params_c, a_mean, f_steps=tab_h)
             Sigma, L = core.sigma(R, control_params.sample_sigma)
             a_cov, L = Sigma[0], L[0]
         else:
@@ -220,8 +230,10 @@ class CoVOController(BaseController):
             rng_act, act_key = crandom.split(rng_act)  # covo.py:212-224
             core.randn(act_key)
         core.noise_gemm(L, a_mean)
-        rng_act, step_key = crandom.split(rng_act)  # covo.py:225-263: deterministic=True -> no disturbance draw
-        core.rollout(dstate, params_c, (0.0, 0.0, 0.0), core.compute_info)
+        rng_act, step_key = crandom.split(rng_act)  # covo.py:225-263: deterministic=True -> the gaussian model is off
+        tab_r = core.disturb_table(params_c, dstate.packed, key=step_key, key_mode=_lib.DISTURB_KEYS_SHARED,
+                                   deterministic=True) if tables else None
+        core.rollout(dstate, params_c, (0.0, 0.0, 0.0), core.compute_info, f_steps=tab_r)
         a_mean_new = core.update(a_mean, control_params.gamma_mean).view(self.H, 4)  # covo.py:266-278
         control_params = control_params.replace(a_mean=a_mean_new)
         out_info = core.info(dstate) if core.compute_info else {}

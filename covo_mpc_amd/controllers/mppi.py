@@ -36,6 +36,7 @@ class MPPIController(BaseController):
         self.materialize_eps = False  # True: epsilon is written to HBM and the kernels are called one by one (parity)
         self.noise_stream = "philox"  # "jax": sampling keys / epsilon from jax.random's own bitstream (random_jax.py)
         self.alias_outputs = False    # True: returned a_mean / a_cov alias the controller's buffers (no clones)
+        self._params_c(env.default_params)  # raises now if env.reward_fn / disturb_type is not one the kernels evaluate
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
 
@@ -45,15 +46,9 @@ class MPPIController(BaseController):
         from .. import _lib
         if control_params.gamma_sigma != 0.0:
             raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0, mppi.py:119-125) is not built")
-        if self.env.disturb_type == "gaussian":
-            noise_scale = float(env_params.dyn_noise_scale)
-        elif self.env.disturb_type == "none":
-            noise_scale = 0.0
-        else:
-            raise NotImplementedError(f"disturb_type={self.env.disturb_type!r} inside the fused rollout")
         am, cov, rng = self.core.run_episode(_lib.MODE_MPPI, episode, self._params_c(env_params), control_params.a_mean, rng,
                                              n_steps, a_cov=control_params.a_cov, gamma_mean=control_params.gamma_mean,
-                                             sample_sigma=control_params.sample_sigma, shared_noise_scale=noise_scale)
+                                             sample_sigma=control_params.sample_sigma, rollout_deterministic=False)
         a_mean = am.view(self.H, 4)
         if not self.alias_outputs:
             a_mean, cov = a_mean.clone(), cov.clone()
@@ -72,20 +67,14 @@ class MPPIController(BaseController):
         if not self.materialize_eps and self.noise_stream == "philox":
             # ---- production path: one C call / one hipGraph replay (csrc/step.hip)
             from .. import _lib
-            # rng_act, act_key = split(rng_act) (mppi.py:53); rng_act, step_key = split(rng_act) and the ONE shared
-            # disturbance vector every sample/step draws from step_key (mppi.py:69,74, deterministic=False;
-            # env.rollout_disturbance is the host restatement) are derived on the device (step.hip: step_begin_kernel)
-            if self.env.disturb_type == "gaussian":
-                noise_scale = float(env_params.dyn_noise_scale)
-            elif self.env.disturb_type == "none":
-                noise_scale = 0.0
-            else:
-                raise NotImplementedError(f"disturb_type={self.env.disturb_type!r} inside the fused rollout "
-                                          "(state/time-dependent models are outside the kernel's first scope)")
+            # rng_act, act_key = split(rng_act) (mppi.py:53); rng_act, step_key = split(rng_act) and what every sample/step
+            # draws from the ONE shared step_key (mppi.py:69,74, deterministic=False: the gaussian vector -- env.rollout_disturbance
+            # is its host restatement --, the periodic / mixed redraw) are derived on the device (step.hip: step_begin_kernel,
+            # disturb.hip)
             am, cov = core.step(_lib.MODE_MPPI, dstate, self._params_c(env_params), control_params.a_mean, rng_act,
                                 a_cov=control_params.a_cov, gamma_mean=control_params.gamma_mean,
                                 sample_sigma=control_params.sample_sigma, want_stats=core.compute_info,
-                                derive_keys=True, shared_noise_scale=noise_scale)
+                                derive_keys=True, rollout_deterministic=False)
             a_mean_new = am.view(self.H, 4)
             if not self.alias_outputs:
                 a_mean_new, cov = a_mean_new.clone(), cov.clone()
@@ -106,9 +95,23 @@ class MPPIController(BaseController):
             rng_act, act_key = crandom.split(rng_act)  # mppi.py:53-66
             core.randn(act_key)
         core.noise_blockdiag(Ls, a_mean)
-        rng_act, step_key = crandom.split(rng_act)  # mppi.py:69-106
-        f_shared = self.env.rollout_disturbance(step_key, env_params, deterministic=False)
-        core.rollout(dstate, self._params_c(env_params), f_shared, core.compute_info)
+        from .. import _lib
+        params_c = self._params_c(env_params)
+        if self.noise_stream == "jax":  # the step key and the shared gaussian draw from jax's bitstream too (mppi.py:69,74)
+            rng_act, step_key = random_jax.split(rng_act)
+            if params_c.disturb_kind in _lib.TABLE_DISTURB_KINDS:
+                raise NotImplementedError("noise_stream='jax' with a periodic / sin / drag / mixed disturbance: the table kernel "
+                                          "draws from the Philox stream")
+            f_shared, tab = self.env.rollout_disturbance(step_key, env_params, deterministic=False, rng=random_jax), None
+        else:
+            rng_act, step_key = crandom.split(rng_act)  # mppi.py:69-106
+            if params_c.disturb_kind in _lib.TABLE_DISTURB_KINDS:  # periodic / sin / drag / mixed (free.py:10-58)
+                f_shared = (0.0, 0.0, 0.0)
+                tab = core.disturb_table(params_c, dstate.packed, key=step_key, key_mode=_lib.DISTURB_KEYS_SHARED,
+                                         deterministic=False)
+            else:
+                f_shared, tab = self.env.rollout_disturbance(step_key, env_params, deterministic=False), None
+        core.rollout(dstate, params_c, f_shared, core.compute_info, f_steps=tab)
         a_mean_new = core.update(a_mean.reshape(-1), control_params.gamma_mean).view(self.H, 4)  # mppi.py:109-125
         control_params = control_params.replace(a_mean=a_mean_new)
         out_info = core.info(dstate) if core.compute_info else {}

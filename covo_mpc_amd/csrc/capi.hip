@@ -36,6 +36,30 @@ void covo_set_error(const char *fmt, ...)
         }                                                                                                                    \
     } while (0)
 
+// reward / disturbance selectors of covo_env_params
+static int check_model(const covo_env_params *p, const char *what)
+{
+    if (p->reward_kind != COVO_REWARD_PENYAW && p->reward_kind != COVO_REWARD_REALWORLD) {
+        covo_set_error("%s: reward_kind=%d (COVO_REWARD_*)", what, p->reward_kind);
+        return COVO_E_BADARG;
+    }
+    if (p->disturb_kind < COVO_DISTURB_NONE || p->disturb_kind > COVO_DISTURB_MIXED) {
+        covo_set_error("%s: disturb_kind=%d (COVO_DISTURB_*)", what, p->disturb_kind);
+        return COVO_E_BADARG;
+    }
+    if (p->disturb_kind >= COVO_DISTURB_PERIODIC && p->disturb_period <= 0) {
+        covo_set_error("%s: disturb_period=%d", what, p->disturb_period);
+        return COVO_E_BADARG;
+    }
+    return 0;
+}
+static bool needs_table(const covo_env_params *p) { return p->disturb_kind >= COVO_DISTURB_PERIODIC && p->disturb_kind <= COVO_DISTURB_MIXED; }
+#define CHECK_MODEL(p, what)               \
+    do {                                   \
+        const int rc_ = check_model(p, what); \
+        if (rc_) return rc_;               \
+    } while (0)
+
 __global__ void raise_status_kernel(int *status, int bits)
 {
     __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -172,16 +196,30 @@ int covo_noise_blockdiag_philox(covo_handle_t h, const float *Ls, const float *m
 }
 
 int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                      const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
-                      float *cost_out, float *groupmin, double *pos_stats, void *stream)
+                      const covo_env_params *params, const float *f_disturb_shared, const float *f_disturb_steps,
+                      const float *a, int32_t N, float *cost_out, float *groupmin, double *pos_stats, void *stream)
 {
     REQUIRE(h, "covo_rollout_cost: null handle");
     CHECK_DEVICE(h, "covo_rollout_cost");
     REQUIRE(state && pos_traj && vel_traj && params && a && cost_out && T > 0, "covo_rollout_cost: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_rollout_cost: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    CHECK_MODEL(params, "covo_rollout_cost");
+    REQUIRE(!needs_table(params) || f_disturb_steps, "covo_rollout_cost: disturb_kind=%d needs f_disturb_steps (covo_disturb_table)",
+            params->disturb_kind);
     return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount,
                           (h->cfg.flags & COVO_FLAG_ACTIONS_CLIPPED) != 0, cost_out, groupmin, pos_stats, h->ws_stats,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, nullptr, nullptr, 0.0f, f_disturb_steps);
+}
+
+int covo_disturb_table(covo_handle_t h, const covo_env_params *params, const float *state, int32_t batch,
+                       const uint32_t *keys_dev, uint32_t key0, uint32_t key1, int32_t key_mode, int32_t deterministic,
+                       float *out, void *stream)
+{
+    REQUIRE(h, "covo_disturb_table: null handle");
+    REQUIRE(params && state && out && batch > 0, "covo_disturb_table: bad argument");
+    REQUIRE(key_mode >= COVO_DISTURB_KEYS_SHARED && key_mode <= COVO_DISTURB_KEYS_NOMINAL, "covo_disturb_table: key_mode=%d", key_mode);
+    CHECK_MODEL(params, "covo_disturb_table");
+    return launch_disturb_table(*params, state, batch, keys_dev, key0, key1, key_mode, deterministic, out, (hipStream_t)stream);
 }
 
 __global__ void pos_info_kernel(const double *__restrict__ stats, const float *__restrict__ state, double inv_n,
@@ -209,12 +247,15 @@ int covo_pos_info(covo_handle_t h, const double *pos_stats, const float *state, 
 }
 
 int covo_debug_time_rollout(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                            const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
-                            float *cost_out, float *groupmin, int32_t with_records, int32_t reps, float *us_out, void *stream)
+                            const covo_env_params *params, const float *f_disturb_shared, const float *f_disturb_steps,
+                            const float *a, int32_t N, float *cost_out, float *groupmin, int32_t with_records, int32_t reps,
+                            float *us_out, void *stream)
 {
     REQUIRE(h, "covo_debug_time_rollout: null handle");
     REQUIRE(state && pos_traj && vel_traj && params && a && cost_out && us_out && T > 0 && reps > 0, "covo_debug_time_rollout: bad argument");
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_debug_time_rollout: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    CHECK_MODEL(params, "covo_debug_time_rollout");
+    REQUIRE(!needs_table(params) || f_disturb_steps, "covo_debug_time_rollout: disturb_kind=%d needs f_disturb_steps", params->disturb_kind);
     hipStream_t s = (hipStream_t)stream;
     const bool clipped = (h->cfg.flags & COVO_FLAG_ACTIONS_CLIPPED) != 0;
     // with_records: the variant the fused step runs (every workgroup also leaves its online-softmax record), when the launch
@@ -226,7 +267,8 @@ int covo_debug_time_rollout(covo_handle_t h, const float *state, const float *po
     int rc = 0;
     auto launch = [&]() {
         return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount, clipped, cost_out,
-                              rec ? nullptr : groupmin, nullptr, h->ws_stats, s, nullptr, rec ? h->ws_partials : nullptr, h->cfg.lam);
+                              rec ? nullptr : groupmin, nullptr, h->ws_stats, s, nullptr, rec ? h->ws_partials : nullptr, h->cfg.lam,
+                              f_disturb_steps);
     };
     for (int i = 0; i < 3 && !rc && err == hipSuccess; ++i) rc = launch();
     constexpr int BATCHES = 3;
@@ -292,11 +334,15 @@ int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, 
 }
 
 int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                 const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream)
+                 const covo_env_params *params, const float *a_mean, const float *f_disturb_steps, int32_t batch,
+                 double *R_out, void *stream)
 {
     REQUIRE(h, "covo_hessian: null handle");
     CHECK_DEVICE(h, "covo_hessian");
     REQUIRE(state && pos_traj && vel_traj && params && a_mean && R_out && T > 0 && batch > 0, "covo_hessian: bad argument");
+    CHECK_MODEL(params, "covo_hessian");
+    REQUIRE(!needs_table(params) || f_disturb_steps, "covo_hessian: disturb_kind=%d needs f_disturb_steps (covo_disturb_table)",
+            params->disturb_kind);
     const size_t need = hessian_workspace_bytes(batch);
     if (need > h->ws_hess_bytes) {  // only for batch sizes not seen before (never inside the steady-state step)
         COVO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -307,15 +353,18 @@ int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, con
         COVO_CHECK_HIP(hipMalloc(&h->ws_hess, need));
         h->ws_hess_bytes = need;
     }
-    return launch_hessian(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, h->ws_hess, (hipStream_t)stream);
+    return launch_hessian(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, h->ws_hess, (hipStream_t)stream, nullptr, 0,
+                          nullptr, f_disturb_steps);
 }
 
 int covo_hessian_pairs(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                       const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream)
+                       const covo_env_params *params, const float *a_mean, const float *f_disturb_steps, int32_t batch,
+                       double *R_out, void *stream)
 {
     REQUIRE(h, "covo_hessian_pairs: null handle");
     REQUIRE(state && pos_traj && vel_traj && params && a_mean && R_out && T > 0 && batch > 0, "covo_hessian_pairs: bad argument");
-    return launch_hessian_pairs(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, (hipStream_t)stream);
+    CHECK_MODEL(params, "covo_hessian_pairs");
+    return launch_hessian_pairs(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, (hipStream_t)stream, f_disturb_steps);
 }
 
 int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out, float *L_out,
@@ -360,28 +409,30 @@ int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doub
 
 int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float *pos_traj, const float *vel_traj,
                   const float *acc_traj, int32_t T, const covo_env_params *params, const float *action,
-                  const uint32_t *step_key, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
-                  float obs_noise_scale, float *log, int32_t log_index, void *stream)
+                  const uint32_t *step_key, int32_t noisy_on, float obs_noise_scale, float *log, int32_t log_index,
+                  void *stream)
 {
     REQUIRE(h, "covo_env_step: null handle");
     REQUIRE(state && noisy_state && pos_traj && vel_traj && acc_traj && params && action && step_key && T > 0 &&
                 log_index >= 0,
             "covo_env_step: bad argument");
-    return launch_env_step(state, noisy_state, pos_traj, vel_traj, acc_traj, T, *params, action, step_key, disturb_gaussian,
-                           noisy_on, dyn_noise_scale, obs_noise_scale, log, log_index, (hipStream_t)stream);
+    CHECK_MODEL(params, "covo_env_step");
+    return launch_env_step(state, noisy_state, pos_traj, vel_traj, acc_traj, T, *params, action, step_key, noisy_on,
+                           obs_noise_scale, log, log_index, (hipStream_t)stream);
 }
 
 int covo_pid_nominal(covo_handle_t h, const float *state0, const float *pos_traj, const float *vel_traj,
                      const float *acc_traj, int32_t T, const covo_env_params *params, const covo_env_params *pid_params,
-                     float Kp, float Kd, float Kp_att, float noise_scale, uint32_t key0, uint32_t key1, int32_t n_steps,
-                     float *states_out, float *a_means_out, void *stream)
+                     float Kp, float Kd, float Kp_att, uint32_t key0, uint32_t key1, int32_t n_steps,
+                     float *states_out, float *a_means_out, uint32_t *keys_out, void *stream)
 {
     REQUIRE(h, "covo_pid_nominal: null handle");
     REQUIRE(state0 && pos_traj && vel_traj && acc_traj && params && pid_params && states_out && a_means_out && T > 0 &&
                 n_steps > 0,
             "covo_pid_nominal: bad argument");
-    return launch_pid_nominal(state0, pos_traj, vel_traj, acc_traj, T, *params, *pid_params, Kp, Kd, Kp_att, noise_scale, key0,
-                              key1, n_steps, states_out, a_means_out, (hipStream_t)stream);
+    CHECK_MODEL(params, "covo_pid_nominal");
+    return launch_pid_nominal(state0, pos_traj, vel_traj, acc_traj, T, *params, *pid_params, Kp, Kd, Kp_att, key0, key1, n_steps,
+                              states_out, a_means_out, keys_out, (hipStream_t)stream);
 }
 
 // Philox4x32-10 on the host: child i of split(key, num) as covo_mpc_amd/random.py forms it
@@ -400,13 +451,14 @@ static void host_philox_split(const uint32_t key[2], uint32_t i, uint32_t child[
 }
 
 int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, float *state_true,
-                     const float *acc_traj, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
-                     float obs_noise_scale, float *log, uint32_t *rng, int32_t n_steps, void *stream)
+                     const float *acc_traj, int32_t noisy_on, float obs_noise_scale, float *log, uint32_t *rng,
+                     int32_t n_steps, void *stream)
 {
     REQUIRE(h, "covo_run_episode: null handle");
     CHECK_DEVICE(h, "covo_run_episode");
     REQUIRE(params && args && state_true && acc_traj && rng && n_steps > 0, "covo_run_episode: bad argument");
     REQUIRE(args->derive_keys == 1, "covo_run_episode: args->derive_keys must be 1 (the controller key is the raw rng_act)");
+    CHECK_MODEL(params, "covo_run_episode");
     REQUIRE(args->partial_out == nullptr, "covo_run_episode: a sample-sharded step needs its all-gather between the calls");
     REQUIRE(args->state && args->pos_traj && args->vel_traj && args->a_mean && args->a && args->cost && args->groupmin &&
                 args->T > 0 && args->mode >= 0 && args->mode <= 2,
@@ -422,8 +474,7 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
         int rc = covo_step_impl(h, params, args, rng_act[0], rng_act[1], nullptr, s);
         if (rc) return rc;
         rc = launch_env_step(state_true, const_cast<float *>(args->state), args->pos_traj, args->vel_traj, acc_traj, args->T,
-                             *params, args->a_mean, rng_step, disturb_gaussian, noisy_on, dyn_noise_scale, obs_noise_scale, log,
-                             t, s);
+                             *params, args->a_mean, rng_step, noisy_on, obs_noise_scale, log, t, s);
         if (rc) return rc;
         host_philox_split(nrng, 0u, key);
     }
@@ -445,6 +496,13 @@ int covo_mpc_step_batched(covo_handle_t h, const covo_batch_args *args, const co
     REQUIRE(args->states && args->pos_traj && args->vel_traj && args->a_mean && args->a && args->cost && args->groupmin &&
                 args->T > 0,
             "covo_mpc_step_batched: null buffer");
+    for (int e = 0; e < args->n_envs; ++e) {
+        CHECK_MODEL(&params[e], "covo_mpc_step_batched");
+        REQUIRE(!needs_table(&params[e]), "covo_mpc_step_batched: disturb_kind=%d of instance %d: the env-batched step takes "
+                "COVO_DISTURB_NONE / GAUSSIAN only (the per-step tables are per control step)", params[e].disturb_kind, e);
+        REQUIRE(params[e].reward_kind == params[0].reward_kind && params[e].rollover_terminate == params[0].rollover_terminate,
+                "covo_mpc_step_batched: all instances must share reward_kind and rollover_terminate");
+    }
     return covo_step_batched_impl(h, args, params, keys, (hipStream_t)stream);
 }
 
@@ -494,6 +552,9 @@ int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_ste
             "covo_mpc_step: null buffer");
     REQUIRE(args->mode != COVO_MODE_COVO_OFFLINE || (args->L_table && args->n_table > 0), "covo_mpc_step: offline needs L_table");
     REQUIRE(args->mode != COVO_MODE_MPPI || args->a_cov, "covo_mpc_step: mppi needs a_cov");
+    CHECK_MODEL(params, "covo_mpc_step");
+    REQUIRE(!needs_table(params) || args->derive_keys == 1, "covo_mpc_step: disturb_kind=%d needs derive_keys = 1 (the per-step "
+            "disturbance tables are derived from the raw controller key on the device)", params->disturb_kind);
     return covo_step_impl(h, params, args, key0, key1, f_disturb_shared, (hipStream_t)stream);
 }
 

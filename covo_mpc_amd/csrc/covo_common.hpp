@@ -101,7 +101,12 @@ int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, u
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr,
-                   float *records = nullptr, float lam = 0.0f);  // records: one online-softmax record per workgroup (rollout.hip)
+                   float *records = nullptr, float lam = 0.0f,   // records: one online-softmax record per workgroup (rollout.hip)
+                   const float *f_tab = nullptr);                // [H][4] per-step disturbance table (disturb.hip), device
+int launch_disturb_table(const covo_env_params &p, const float *state, int batch, const uint32_t *keys_dev, uint32_t key0,
+                         uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s);
+int launch_disturb_tables_step(const covo_env_params &p, const float *state, const uint32_t *dyn, int rollout_deterministic,
+                               float *tab_rollout, float *tab_hess, hipStream_t s);
 int rollout_workgroups(int N, bool stats, int nbatch = 1);
 size_t rollout_args_bytes(int n);
 void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
@@ -121,12 +126,19 @@ struct SymStatsOut;  // sym_stats.hpp
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev = nullptr,
                    size_t traj_stride = 0,
-                   const SymStatsOut *stats = nullptr);  // batch 1: KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
+                   const SymStatsOut *stats = nullptr,   // batch 1: KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
+                   const float *f_tab = nullptr);        // [batch][H][4] per-step disturbance table (disturb.hip), device
+// true: launch_hessian leaves R's Sigma-chain statistics when asked to (the adjoint kernels; the per-pair kernel that takes
+// the drag / mixed models does not)
+inline bool hessian_leaves_stats(const covo_env_params &p)
+{
+    return p.disturb_kind != COVO_DISTURB_DRAG && p.disturb_kind != COVO_DISTURB_MIXED;
+}
 size_t hessian_consts_bytes(int n);
 void hessian_fill_consts(const covo_env_params *params, int n, void *out);
 // the per-pair hyper-dual rollout version (hessian.hip): slower, independent derivation, kept as a cross-check
 int launch_hessian_pairs(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                         const float *a_mean, int batch, double *R, hipStream_t s);
+                         const float *a_mean, int batch, double *R, hipStream_t s, const float *f_tab = nullptr);
 int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, unsigned long long *prof,
                  hipStream_t s);
 size_t sigma_ns_workspace_bytes(int batch);
@@ -150,11 +162,11 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
                    const float *f_shared, hipStream_t s);
 int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);
 int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
-                    const covo_env_params &p, const float *action, const uint32_t *step_key, int gaussian, int noisy_on,
-                    float dyn_noise_scale, float obs_noise_scale, float *log, int log_index, hipStream_t s);
+                    const covo_env_params &p, const float *action, const uint32_t *step_key, int noisy_on,
+                    float obs_noise_scale, float *log, int log_index, hipStream_t s);
 int launch_pid_nominal(const float *state0, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
                        const covo_env_params &p, const covo_env_params &pid_params, float Kp, float Kd, float Kp_att,
-                       float noise_scale, uint32_t key0, uint32_t key1, int n_steps, float *states, float *a_means,
+                       uint32_t key0, uint32_t key1, int n_steps, float *states, float *a_means, uint32_t *keys_out,
                        hipStream_t s);
 int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, int step_mask,
                               int hess_mask, int sigma_stages, int reps, float *us_out, hipStream_t run);

@@ -1,0 +1,125 @@
+// disturb.hip -- the per-step disturbance table of a rollout (gfx950): covo_disturb_table.
+//
+// Inside a controller every rollout step k >= 1 integrates the force disturb_func returned for the PRE-step state of step
+// k-1 (quadjax/dynamics/free.py:147,91,98).  Four of the six models (free.py:9-72) never look at the sample: none, gaussian,
+// periodic (one uniform draw or the held vector), sin (time only) -- their whole horizon is 32 wave-uniform vectors, resolved
+// here once per control step so that the N x H rollout and the Hessian spend nothing per sample on them.  drag depends on the
+// sample's own velocity and mixed = (drag + sin + periodic) / 3 also on its own previous force; for those the table carries
+// the wave-uniform remainder:
+//     row k = {g_k[3], c_k}:   f_k = c_drag drag(vel_{k-1}) + c_k f_{k-1} + g_k          (k = 1 .. H-1; row 0 is unused:
+//     step 0 integrates the state's own f_disturb)
+// with c_drag = 1 (drag), 1/3 (mixed), 0 otherwise (dm::drag_coeff) and c_k = 1/3 while mixed's periodic part holds.
+// Keys: who calls step_env with which key decides which uniform a redraw step sees (COVO_DISTURB_KEYS_*, include/covo_hip.h).
+#include "disturb_model.hpp"
+
+struct DisturbTableArgs {
+    const float *state;      // [batch][COVO_STATE_FLOATS]
+    const uint32_t *keys;    // [batch][2] or null
+    uint32_t key[2];         // when keys == null
+    float4 *out;             // [batch][COVO_H]
+    int batch, key_mode, deterministic;
+    dm::Model m;
+};
+
+// one lane per batch entry: the key chain of the per-step modes is serial (split after split); a horizon holds at most
+// ceil(H / period) + 1 redraw steps, so only those derive a disturb key and hash a draw
+__device__ __forceinline__ void disturb_table_row_loop(const dm::Model &m, const float *__restrict__ st, const uint32_t (&key0)[2],
+                                                       int key_mode, bool deterministic, float4 *__restrict__ out)
+{
+    const int time0 = __float_as_int(st[ST_TIME]);
+    float f[3] = {st[ST_FDIST + 0], st[ST_FDIST + 1], st[ST_FDIST + 2]};  // periodic's hold resolves from the state's own force
+    uint32_t key[2] = {key0[0], key0[1]};
+    out[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int k = 0; k < COVO_H - 1; ++k) {
+        // the key step_env receives at rollout step k
+        uint32_t sk[2] = {key[0], key[1]};
+        if (key_mode == COVO_DISTURB_KEYS_HESSIAN) {  // rng_act, key = split(key) (covo.py:151)
+            uint32_t nk[2];
+            dm::split(key, 0u, sk);
+            dm::split(key, 1u, nk);
+            key[0] = nk[0]; key[1] = nk[1];
+        } else if (key_mode == COVO_DISTURB_KEYS_NOMINAL) {  // rng_act, key = split(key); rng_step, key = split(key) (covo.py:60,66)
+            uint32_t k1[2], nk[2];
+            dm::split(key, 1u, k1);
+            dm::split(k1, 0u, sk);
+            dm::split(k1, 1u, nk);
+            key[0] = nk[0]; key[1] = nk[1];
+        }
+        const int time = time0 + k;
+        const bool hit = (time % m.period) == 0;
+        float g[3] = {0.0f, 0.0f, 0.0f}, c = 0.0f;
+        const bool need_draw = (m.kind == COVO_DISTURB_GAUSSIAN && !deterministic) ||
+                               ((m.kind == COVO_DISTURB_PERIODIC || m.kind == COVO_DISTURB_MIXED) && hit);
+        uint32_t dk[2] = {0u, 0u};
+        if (need_draw) dm::disturb_key(sk, dk);
+        for (int i = 0; i < 3; ++i) {
+            switch (m.kind) {
+            case COVO_DISTURB_GAUSSIAN: g[i] = deterministic ? 0.0f : m.noise_scale * dm::normal3(dk, i); break;
+            case COVO_DISTURB_PERIODIC: g[i] = hit ? dm::uniform3(dk, i, -m.scale, m.scale) : f[i]; break;
+            case COVO_DISTURB_SIN: g[i] = dm::sin_term(m, time, i); break;
+            case COVO_DISTURB_MIXED:
+                g[i] = (dm::sin_term(m, time, i) + (hit ? dm::uniform3(dk, i, -m.scale, m.scale) : 0.0f)) / 3.0f;
+                break;
+            default: break;  // none, drag
+            }
+            f[i] = g[i];  // (only periodic reads it back)
+        }
+        if (m.kind == COVO_DISTURB_MIXED) c = hit ? 0.0f : 1.0f / 3.0f;
+        out[k + 1] = make_float4(g[0], g[1], g[2], c);
+    }
+}
+
+__global__ __launch_bounds__(64) void disturb_table_kernel(const DisturbTableArgs A)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.batch) return;
+    const uint32_t key[2] = {A.keys ? A.keys[2 * b] : A.key[0], A.keys ? A.keys[2 * b + 1] : A.key[1]};
+    disturb_table_row_loop(A.m, A.state + (size_t)b * COVO_STATE_FLOATS, key, A.key_mode, A.deterministic != 0,
+                           A.out + (size_t)b * COVO_H);
+}
+
+// fused step (step.hip): both tables of one control step in one launch -- lane 0 of workgroup 0 the rollouts' (shared step key
+// = split(split(rng_act)[0])[1], covo.py:212,225 / mppi.py:53,69), lane 0 of workgroup 1 the Hessian's (per-step keys from the
+// raw rng_act, covo.py:39,150-153); dyn = the step's device block {.., raw rng_act at [10], [11]} (step.hip: DynBlock)
+__global__ __launch_bounds__(64) void disturb_tables_step_kernel(const float *__restrict__ state, const uint32_t *__restrict__ dyn,
+                                                                 dm::Model m, int rollout_deterministic, float4 *__restrict__ tab_rollout,
+                                                                 float4 *__restrict__ tab_hess)
+{
+    if (threadIdx.x != 0) return;
+    const uint32_t raw[2] = {dyn[10], dyn[11]};
+    if (blockIdx.x == 0) {
+        uint32_t rng1[2], step_key[2];
+        dm::split(raw, 0u, rng1);
+        dm::split(rng1, 1u, step_key);
+        disturb_table_row_loop(m, state, step_key, COVO_DISTURB_KEYS_SHARED, rollout_deterministic != 0, tab_rollout);
+    } else if (tab_hess != nullptr) {
+        disturb_table_row_loop(m, state, raw, COVO_DISTURB_KEYS_HESSIAN, true, tab_hess);
+    }
+}
+
+int launch_disturb_table(const covo_env_params &p, const float *state, int batch, const uint32_t *keys_dev, uint32_t key0,
+                         uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s)
+{
+    DisturbTableArgs A;
+    A.state = state;
+    A.keys = keys_dev;
+    A.key[0] = key0;
+    A.key[1] = key1;
+    A.out = reinterpret_cast<float4 *>(out);
+    A.batch = batch;
+    A.key_mode = key_mode;
+    A.deterministic = deterministic;
+    A.m = dm::make_model(p);
+    hipLaunchKernelGGL(disturb_table_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, A);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_disturb_tables_step(const covo_env_params &p, const float *state, const uint32_t *dyn, int rollout_deterministic,
+                               float *tab_rollout, float *tab_hess, hipStream_t s)
+{
+    hipLaunchKernelGGL(disturb_tables_step_kernel, dim3(tab_hess ? 2 : 1), dim3(64), 0, s, state, dyn, dm::make_model(p),
+                       rollout_deterministic, reinterpret_cast<float4 *>(tab_rollout), reinterpret_cast<float4 *>(tab_hess));
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -2,8 +2,9 @@
 //
 // Replaces, for the quadrotor env the controllers are evaluated on, one call of
 //   Quad3D.step_env (quadjax/envs/quadrotor.py:215-248) = clip -> raw_step (250-263) ->
-//   free_dynamics_3d_bodyrate (dynamics/free.py:114-202: Euler step, re-normalised quaternion, gaussian
-//   disturbance for the NEXT step (66-70), time+1, targets = traj[time+1]) -> reward / done of the PRE-step
+//   free_dynamics_3d_bodyrate (dynamics/free.py:114-202: Euler step, re-normalised quaternion, the
+//   disturbance for the NEXT step from the PRE-step state (free.py:9-72,147: all six models, disturb_model.hpp),
+//   time+1, targets = traj[time+1]) -> reward / done of the PRE-step
 //   state (243-244) -> get_info (314-361: err_pos/err_vel of the pre-step state, the noisy copy of the NEXT
 //   state that the controller plans from).
 // The reference runs a whole episode as one XLA program (quadrotor.py:506-591); with this kernel between
@@ -14,7 +15,7 @@
 // z = sqrt(-2 ln u1) cos(2 pi u2) in fp64, rounded to fp32.  Auto-reset on done (base.py:33-39) stays on the
 // host: the done flag is logged, an episode of max_steps_in_episode steps never raises it before its end.
 #include "covo_common.hpp"
-#include "rng_device.hpp"
+#include "disturb_model.hpp"
 
 struct EnvStepArgs {
     float *state;          // [32] true state, updated in place
@@ -22,8 +23,10 @@ struct EnvStepArgs {
     const float *pos_traj, *vel_traj, *acc_traj;  // [T][3]
     const float *action;   // [4] (device): the controller's u = a_mean[0]
     float *log;            // [max_steps][4]: reward, err_pos, err_vel, done of the PRE-step state (nullable)
-    int T, log_index, gaussian, noisy_on;
-    float dyn_noise_scale, obs_noise_scale;
+    int T, log_index, noisy_on;
+    float obs_noise_scale;
+    dm::Model dist;        // the disturbance model (free.py:9-72)
+    int reward;            // COVO_REWARD_*
     uint32_t step_key[2];  // the key Quad3D.step receives; the five noise keys are derived from it on the device
     qm::Consts<float> c;
     int max_steps;
@@ -94,7 +97,12 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
             host_split(k, 0u, t);                      // info_key
             host_split(t, (uint32_t)(grp - 1), key);   // rng_pos / vel / quat / omega
         }
-        z[lane] = host_normal(key, n, lane - base);
+        // lanes 0..2: the disturbance model's own draw for this step -- the gaussian model's normal, or the uniform periodic /
+        // mixed redraw with when time % period == 0 (free.py:16-21; same disturb_key); lanes 3..15 the observation noise
+        if (grp == 0 && (A.dist.kind == COVO_DISTURB_PERIODIC || A.dist.kind == COVO_DISTURB_MIXED))
+            z[lane] = dm::uniform3(key, lane, -A.dist.scale, A.dist.scale);
+        else
+            z[lane] = host_normal(key, n, lane - base);
     }
     if (lane < COVO_STATE_FLOATS) sst[lane] = ld_state;
     if (lane >= 32 && lane < 36) sact[lane - 32] = ld_act;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
         const float tvx = sst[ST_VELTAR + 0], tvy = sst[ST_VELTAR + 1], tvz = sst[ST_VELTAR + 2];
         // ---- reward / errors / termination of the PRE-step state (quadrotor.py:243-244, 479-490; utils.py:285-294)
         if (A.log != nullptr) {
-            const float r = qm::reward<float, float>(s, tx, ty, tz, tvx, tvy, tvz);
+            const float r = qm::reward_kind<float, float>(A.reward, s, tx, ty, tz, tvx, tvy, tvz);
             const float ex = tx - s.px, ey = ty - s.py, ez = tz - s.pz;
             const float wx = tvx - s.vx, wy = tvy - s.vy, wz = tvz - s.vz;
             bool done = (time >= A.max_steps) || fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz)) > A.c.pos_limit;
@@ -135,13 +143,31 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
         // ---- one Euler step with the state's current disturbance (free.py:91,98)
         const float a0 = qm::clip11_(qm::clip11_(sact[0])), a1 = qm::clip11_(qm::clip11_(sact[1]));
         const float a2 = qm::clip11_(qm::clip11_(sact[2])), a3 = qm::clip11_(qm::clip11_(sact[3]));
+        // the next step's force from the PRE-step state (free.py:147)
+        float fn[3];
+        {
+            const float vel[3] = {s.vx, s.vy, s.vz}, fcur[3] = {fx, fy, fz};
+            const dm::Model &m = A.dist;
+            const bool hit = (time % m.period) == 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float per = hit ? z[i] : fcur[i];
+                switch (m.kind) {
+                case COVO_DISTURB_GAUSSIAN: fn[i] = m.noise_scale * z[i]; break;  // free.py:66-70
+                case COVO_DISTURB_PERIODIC: fn[i] = per; break;
+                case COVO_DISTURB_SIN: fn[i] = dm::sin_term(m, time, i); break;
+                case COVO_DISTURB_DRAG: fn[i] = dm::drag_term(m, vel[i], i); break;
+                case COVO_DISTURB_MIXED: fn[i] = (dm::drag_term(m, vel[i], i) + dm::sin_term(m, time, i) + per) / 3.0f; break;
+                default: fn[i] = 0.0f; break;
+                }
+            }
+        }
         qm::dyn_step<float, float>(s, a0, a1, a2, a3, A.c, fx, fy, fz);
         sst[ST_POS + 0] = s.px; sst[ST_POS + 1] = s.py; sst[ST_POS + 2] = s.pz;
         sst[ST_VEL + 0] = s.vx; sst[ST_VEL + 1] = s.vy; sst[ST_VEL + 2] = s.vz;
         sst[ST_QUAT + 0] = s.qx; sst[ST_QUAT + 1] = s.qy; sst[ST_QUAT + 2] = s.qz; sst[ST_QUAT + 3] = s.qw;
         sst[ST_OMEGA + 0] = s.ox; sst[ST_OMEGA + 1] = s.oy; sst[ST_OMEGA + 2] = s.oz;
-        const float sc = A.gaussian ? A.dyn_noise_scale : 0.0f;  // free.py:66-72
-        sst[ST_FDIST + 0] = sc * z[0]; sst[ST_FDIST + 1] = sc * z[1]; sst[ST_FDIST + 2] = sc * z[2];
+        sst[ST_FDIST + 0] = fn[0]; sst[ST_FDIST + 1] = fn[1]; sst[ST_FDIST + 2] = fn[2];
         sst[ST_TIME] = __int_as_float(t1);
     }
     __syncthreads();  // also: the re-read row (if any) has landed in straj[1] -- its writers waited for their own loads
@@ -171,8 +197,8 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
 }
 
 int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
-                    const covo_env_params &p, const float *action, const uint32_t *step_key, int gaussian, int noisy_on,
-                    float dyn_noise_scale, float obs_noise_scale, float *log, int log_index, hipStream_t s)
+                    const covo_env_params &p, const float *action, const uint32_t *step_key, int noisy_on,
+                    float obs_noise_scale, float *log, int log_index, hipStream_t s)
 {
     EnvStepArgs A;
     A.state = state;
@@ -184,10 +210,10 @@ int launch_env_step(float *state, float *noisy, const float *pos_traj, const flo
     A.log = log;
     A.T = T;
     A.log_index = log_index;
-    A.gaussian = gaussian;
     A.noisy_on = noisy_on;
-    A.dyn_noise_scale = dyn_noise_scale;
     A.obs_noise_scale = obs_noise_scale;
+    A.dist = dm::make_model(p);
+    A.reward = p.reward_kind;
     A.step_key[0] = step_key[0];
     A.step_key[1] = step_key[1];
     A.c = make_consts<float>(p);

@@ -18,6 +18,7 @@
 // min(max(x,lo),hi) whose lax.max/min JVPs split an exact tie 0.5/0.5 -- the action passes TWO
 // clips inside the Hessian objective (quadrotor.py:223 and :258); norm'(0) = NaN.
 #include "covo_common.hpp"
+#include "disturb_model.hpp"
 
 struct HessArgs {
     const float *state;     // [batch][COVO_STATE_FLOATS]
@@ -27,7 +28,31 @@ struct HessArgs {
     double *R;              // [batch][128][128]
     int T;
     qm::Consts<double> c;
+    const float4 *f_tab;  // [batch][H] rows {g_k[3], c_k} (disturb.hip) or null: no force after step 0
+    int reward;           // COVO_REWARD_*
+    double drag_k;        // c_drag * (-|disturb_scale| / 1.5^2): != 0 makes the force part of the differentiated state (free.py:41-56)
+    double drag_off[3];   // disturb_params[:3] / 2
 };
+
+// The force of step k+1 from the PRE-step state of step k (free.py:147): f' = drag_k rel |rel| + c f + g with row k+1 = {g, c} of
+// the table (disturb.hip); S = double (primal prefix) or HD.  Without a table: zero.
+template <class S>
+__device__ __forceinline__ void hs_next_force(const HessArgs &A, int b, int k, const qm::State<S> &s, S (&f)[3])
+{
+    if (A.f_tab == nullptr || k + 1 >= COVO_H) {
+        f[0] = f[1] = f[2] = S{};
+        return;
+    }
+    const float4 r = A.f_tab[(size_t)b * COVO_H + k + 1];
+    const double g[3] = {r.x, r.y, r.z}, c = r.w;
+    const S v[3] = {s.vx, s.vy, s.vz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        S n = f[i] * c + g[i];
+        if (A.drag_k != 0.0) n = n + qm::drag_force<S, double>(v[i], A.drag_off[i], A.drag_k);
+        f[i] = n;
+    }
+}
 
 constexpr int HS_TI = COVO_H - 1;  // t_i = 0..30 carry lanes; t_i = 31 rows are exact zeros
 
@@ -81,11 +106,14 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
     p.vx = st[ST_VEL + 0]; p.vy = st[ST_VEL + 1]; p.vz = st[ST_VEL + 2];
     p.qx = st[ST_QUAT + 0]; p.qy = st[ST_QUAT + 1]; p.qz = st[ST_QUAT + 2]; p.qw = st[ST_QUAT + 3];
     p.ox = st[ST_OMEGA + 0]; p.oy = st[ST_OMEGA + 1]; p.oz = st[ST_OMEGA + 2];
-    const double f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
+    double fp[3] = {st[ST_FDIST + 0], st[ST_FDIST + 1], st[ST_FDIST + 2]};  // the force acting during the current step
     for (int k = 0; k < ti; ++k) {
         const double a0 = qm::clip11_((double)am[4 * k + 0]), a1 = qm::clip11_((double)am[4 * k + 1]);
         const double a2 = qm::clip11_((double)am[4 * k + 2]), a3 = qm::clip11_((double)am[4 * k + 3]);
-        qm::dyn_step<double, double>(p, a0, a1, a2, a3, c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0, k == 0 ? f0z : 0.0);
+        double fn[3] = {fp[0], fp[1], fp[2]};
+        hs_next_force<double>(A, b, k, p, fn);  // from the PRE-step state
+        qm::dyn_step<double, double>(p, a0, a1, a2, a3, c, fp[0], fp[1], fp[2]);
+        fp[0] = fn[0]; fp[1] = fn[1]; fp[2] = fn[2];
     }
     // ---- hyper-dual part: steps t_i .. H-1
     qm::State<qm::HD> s;
@@ -93,12 +121,13 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
     s.vx = qm::hd(p.vx); s.vy = qm::hd(p.vy); s.vz = qm::hd(p.vz);
     s.qx = qm::hd(p.qx); s.qy = qm::hd(p.qy); s.qz = qm::hd(p.qz); s.qw = qm::hd(p.qw);
     s.ox = qm::hd(p.ox); s.oy = qm::hd(p.oy); s.oz = qm::hd(p.oz);
+    qm::HD fh[3] = {qm::hd(fp[0]), qm::hd(fp[1]), qm::hd(fp[2])};
     double acc = 0.0;
     for (int k = ti; k < COVO_H; ++k) {
         if (k > ti) {  // s_k depends on the seeds only for k > t_i
             double tar[6];
             hs_targets<double>(st, A, time0, k, tar);
-            const qm::HD r = qm::reward<qm::HD, double>(s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
+            const qm::HD r = qm::reward_kind<qm::HD, double>(A.reward, s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
             acc += r.ab;
         }
         if (k == COVO_H - 1) break;
@@ -109,8 +138,10 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
             qm::HD x{(double)am[idx], idx == i ? 1.0 : 0.0, idx == j ? 1.0 : 0.0, 0.0};
             a[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
         }
-        qm::dyn_step<qm::HD, double>(s, a[0], a[1], a[2], a[3], c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
-                                     k == 0 ? f0z : 0.0);
+        qm::HD fn[3] = {fh[0], fh[1], fh[2]};
+        hs_next_force<qm::HD>(A, b, k, s, fn);  // from the PRE-step state (free.py:147)
+        qm::dyn_step<qm::HD, double, true, qm::HD>(s, a[0], a[1], a[2], a[3], c, fh[0], fh[1], fh[2]);
+        fh[0] = fn[0]; fh[1] = fn[1]; fh[2] = fn[2];
     }
     if (active) {
         R[(size_t)i * COVO_NA + j] = -acc;
@@ -119,8 +150,13 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
 }
 
 int launch_hessian_pairs(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                   const float *a_mean, int batch, double *R, hipStream_t s)
+                   const float *a_mean, int batch, double *R, hipStream_t s, const float *f_tab)
 {
+    const bool needs_tab = p.disturb_kind >= COVO_DISTURB_PERIODIC && p.disturb_kind <= COVO_DISTURB_MIXED;
+    if (needs_tab && f_tab == nullptr) {
+        covo_set_error("hessian_pairs: disturb_kind=%d needs the per-step disturbance table (covo_disturb_table)", p.disturb_kind);
+        return COVO_E_BADARG;
+    }
     HessArgs A;
     A.state = state;
     A.pos_traj = pos_traj;
@@ -129,6 +165,11 @@ int launch_hessian_pairs(const float *state, const float *pos_traj, const float 
     A.R = R;
     A.T = T;
     A.c = make_consts<double>(p);
+    const dm::Model m = dm::make_model(p);
+    A.f_tab = needs_tab ? reinterpret_cast<const float4 *>(f_tab) : nullptr;
+    A.reward = p.reward_kind;
+    A.drag_k = -(m.kind == COVO_DISTURB_DRAG ? 1.0 : (m.kind == COVO_DISTURB_MIXED ? 1.0 / 3.0 : 0.0)) * fabs((double)m.scale) / 2.25;
+    for (int i = 0; i < 3; ++i) A.drag_off[i] = 0.5 * (double)m.dp[i];
     COVO_CHECK_HIP(hipMemsetAsync(R, 0, (size_t)batch * COVO_NA * COVO_NA * sizeof(double), s));
     hipLaunchKernelGGL(hessian_kernel, dim3(hs_total_waves(), batch), dim3(64), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());

@@ -57,7 +57,23 @@ struct AdjArgs {
     const qm::Consts<double> *cs;    // ... or one per batch entry (device, nullable): env instances with their own parameters
     size_t traj_stride;              // floats between the trajectories of consecutive batch entries (0: shared)
     SymStatsOut stats;               // batch 1, rpart != null: KD also leaves the Sigma chain's input statistics of R there
+    const float4 *f_tab;             // [batch][H] per-step disturbance table (disturb.hip; wave-uniform kinds only) or null: no force after step 0
+    int reward;                      // COVO_REWARD_*
 };
+
+// the disturbance force acting during step k (free.py:91,98,147): the state's own for k = 0, then the table's row k (periodic /
+// sin resolved per step by disturb.hip; none / deterministic gaussian: no table, zero)
+__device__ __forceinline__ void adj_force(const float *__restrict__ st, const AdjArgs &A, int bi, int k, double (&f)[3])
+{
+    if (k == 0) {
+        f[0] = st[ST_FDIST + 0]; f[1] = st[ST_FDIST + 1]; f[2] = st[ST_FDIST + 2];
+    } else if (A.f_tab != nullptr) {
+        const float4 r = A.f_tab[(size_t)bi * HH + k];
+        f[0] = r.x; f[1] = r.y; f[2] = r.z;
+    } else {
+        f[0] = f[1] = f[2] = 0.0;
+    }
+}
 
 __device__ __forceinline__ void adj_targets(const float *__restrict__ st, const float *__restrict__ pos_traj,
                                             const float *__restrict__ vel_traj, int T, int time0, int k, double (&tar)[6])
@@ -101,7 +117,7 @@ __device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const 
     if (k >= 1) {
         double tar[6];
         adj_targets(st, A.pos_traj + bi * A.traj_stride, A.vel_traj + bi * A.traj_stride, A.T, time0, k, tar);
-        r = qm::reward<qm::HD, double>(s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
+        r = qm::reward_kind<qm::HD, double>(A.reward, s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
     }
     if (k <= HH - 2) {
         qm::HD act[4];
@@ -110,13 +126,16 @@ __device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const 
             const qm::HD x{(double)am[4 * k + d], a == NX + d ? 1.0 : 0.0, b == NX + d ? 1.0 : 0.0, 0.0};
             act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
         }
-        const double f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
-        qm::dyn_step<qm::HD, double>(s, act[0], act[1], act[2], act[3], c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
-                                     k == 0 ? f0z : 0.0);
+        double f[3];
+        adj_force(st, A, bi, k, f);
+        qm::dyn_step<qm::HD, double>(s, act[0], act[1], act[2], act[3], c, f[0], f[1], f[2]);
     }
 }
 
 // ---- KB: wave k: x_k by a plain fp64 rollout, then df_k/dz (13 x 17) and grad r_k from 17 first-order seeds
+// FT: a per-step force table is present (periodic / sin); without it the force of steps >= 1 is a literal zero and its three
+// adds per step drop out of the prefix's serial chain
+template <bool FT>
 __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
 {
     const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -130,7 +149,6 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     p.vx = st[ST_VEL + 0]; p.vy = st[ST_VEL + 1]; p.vz = st[ST_VEL + 2];
     p.qx = st[ST_QUAT + 0]; p.qy = st[ST_QUAT + 1]; p.qz = st[ST_QUAT + 2]; p.qw = st[ST_QUAT + 3];
     p.ox = st[ST_OMEGA + 0]; p.oy = st[ST_OMEGA + 1]; p.oz = st[ST_OMEGA + 2];
-    const double f0x = st[ST_FDIST + 0], f0y = st[ST_FDIST + 1], f0z = st[ST_FDIST + 2];
     // The prefix is the launch's critical path: for wave 31, 31 steps of dependent-issue fp64 instructions, one per ~7 cycles
     // whatever their dependencies.  What does not depend on the state -- clip, thrust and body-rate targets of every step's
     // action (quadrotor.py:223,258-260; 16 of a step's 80 instructions) -- is computed by lane t for step t in ONE pass and
@@ -139,6 +157,12 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     // dropped: the attitude / translation cascade as TWO waves through LDS, as in the rollout -- the three LDS writes per step
     // on the attitude wave cost more issue time than the 13 instructions they move away: 9.3 us.)
     __shared__ double sact[HH][4];
+    __shared__ double sfd[HH][3];  // the force of every step (adj_force), read back per step like the action terms
+    if (lane < HH) {
+        double f[3];
+        adj_force(st, A, b, lane, f);
+        sfd[lane][0] = f[0]; sfd[lane][1] = f[1]; sfd[lane][2] = f[2];
+    }
     if (lane < HH) {
         const double a0 = qm::clip11_((double)am[4 * lane + 0]), a1 = qm::clip11_((double)am[4 * lane + 1]);
         const double a2 = qm::clip11_((double)am[4 * lane + 2]), a3 = qm::clip11_((double)am[4 * lane + 3]);
@@ -150,7 +174,8 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     __syncthreads();
     for (int t = 0; t < k; ++t) {
         const double th = sact[t][0], w0 = sact[t][1], w1 = sact[t][2], w2 = sact[t][3];
-        if (t == 0) qm::dyn_core<double, double>(p, th, w0, w1, w2, c, f0x, f0y, f0z);
+        if (t == 0) qm::dyn_core<double, double>(p, th, w0, w1, w2, c, sfd[0][0], sfd[0][1], sfd[0][2]);
+        else if (FT) qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, sfd[t][0], sfd[t][1], sfd[t][2]);
         else qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, 0.0, 0.0, 0.0);
     }
     if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
@@ -163,7 +188,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     if (k >= 1) {
         double tar[6];
         adj_targets(st, A.pos_traj + b * A.traj_stride, A.vel_traj + b * A.traj_stride, A.T, time0, k, tar);
-        r = qm::reward<qm::D1, double>(s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
+        r = qm::reward_kind<qm::D1, double>(A.reward, s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
     }
     if (k <= HH - 2) {
         qm::D1 act[4];
@@ -172,8 +197,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
             const qm::D1 x{(double)am[4 * k + d], lane == NX + d ? 1.0 : 0.0};
             act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
         }
-        qm::dyn_step<qm::D1, double>(s, act[0], act[1], act[2], act[3], c, k == 0 ? f0x : 0.0, k == 0 ? f0y : 0.0,
-                                     k == 0 ? f0z : 0.0);
+        qm::dyn_step<qm::D1, double>(s, act[0], act[1], act[2], act[3], c, sfd[k][0], sfd[k][1], sfd[k][2]);
     }
     if (lane < NZ) {
         if (lane < NX) ws[WS_GL + 16 * k + lane] = r.a;  // 0 for k = 0
@@ -525,9 +549,24 @@ size_t hessian_workspace_bytes(int batch) { return (size_t)batch * WS_COUNT * si
 
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev,
-                   size_t traj_stride, const SymStatsOut *stats)
+                   size_t traj_stride, const SymStatsOut *stats, const float *f_tab)
 {
+    if (p.disturb_kind == COVO_DISTURB_DRAG || p.disturb_kind == COVO_DISTURB_MIXED) {
+        // a velocity-dependent force is part of the differentiated state (16 components instead of the 13 this kernel's tiles
+        // are laid out for): the per-pair hyper-dual rollout takes these two models (hessian.hip)
+        if (consts_dev != nullptr || traj_stride != 0) {
+            covo_set_error("hessian: drag / mixed disturbance with per-instance parameters is not built");
+            return COVO_E_UNSUPPORTED;
+        }
+        return launch_hessian_pairs(state, pos_traj, vel_traj, T, p, a_mean, batch, R, s, f_tab);
+    }
+    if ((p.disturb_kind == COVO_DISTURB_PERIODIC || p.disturb_kind == COVO_DISTURB_SIN) && f_tab == nullptr) {
+        covo_set_error("hessian: disturb_kind=%d needs the per-step disturbance table (covo_disturb_table)", p.disturb_kind);
+        return COVO_E_BADARG;
+    }
     AdjArgs A;
+    A.f_tab = (p.disturb_kind == COVO_DISTURB_PERIODIC || p.disturb_kind == COVO_DISTURB_SIN) ? reinterpret_cast<const float4 *>(f_tab) : nullptr;
+    A.reward = p.reward_kind;
     A.state = state;
     A.pos_traj = pos_traj;
     A.vel_traj = vel_traj;
@@ -542,7 +581,10 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.stats.fpart = nullptr;
     A.stats.diag = nullptr;
     if (stats != nullptr && batch == 1) A.stats = *stats;
-    if (g_dbg_hess_mask & 1) hipLaunchKernelGGL(adj_jac_kernel, dim3(HH, batch), dim3(64), 0, s, A);
+    if (g_dbg_hess_mask & 1) {
+        if (A.f_tab != nullptr) hipLaunchKernelGGL(adj_jac_kernel<true>, dim3(HH, batch), dim3(64), 0, s, A);
+        else hipLaunchKernelGGL(adj_jac_kernel<false>, dim3(HH, batch), dim3(64), 0, s, A);
+    }
     if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(adj_chain_kernel, dim3(9 + HH, batch), dim3(256), 0, s, A);  // 9 chains + KM's 32 hyper-dual workgroups
     if (g_dbg_hess_mask & 4) hipLaunchKernelGGL(adj_hess_kernel, dim3(HH, batch), dim3(192), 0, s, A);
     if (g_dbg_hess_mask & 8) hipLaunchKernelGGL(adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);

@@ -9,7 +9,7 @@
 // here: one lane walks the 300-step chain (keys split exactly as covo_mpc_amd/random.py does, 2 ms), then one
 // lane per start state rolls its H nominal steps.
 #include "covo_common.hpp"
-#include "rng_device.hpp"
+#include "disturb_model.hpp"
 
 struct PidArgs {
     const float *state0;  // [32]
@@ -21,7 +21,9 @@ struct PidArgs {
     qm::Consts<float> c;  // the env's parameters (possibly domain-randomised)
     float pid_m, pid_g, pid_max_thrust, pid_max_omega[3];  // pid.py:33: the PID law uses the DEFAULT parameters
     float Kp, Kd, Kp_att;
-    float noise_scale;    // dyn_noise_scale of the gaussian disturbance (0: disturb_type "none")
+    dm::Model dist;       // the disturbance model (free.py:9-72); its gaussian part is off in the deterministic nominal steps
+    uint32_t *keys;       // [n_steps][2] the scan's carry key at every start state (nullable for the chain; the nominal kernel
+                          // reads it back when the model draws)
 };
 
 struct PidState {
@@ -121,6 +123,19 @@ __device__ __forceinline__ void pid_action(const PidState &p, const PidArgs &A, 
     for (int i = 0; i < 3; ++i) act[1 + i] = -A.Kp_att * err[i] / A.pid_max_omega[i];
 }
 
+// the disturbance of the NEXT step from the PRE-step state (free.py:147); sk = the key this step_env call receives
+__device__ __forceinline__ void pid_next_force(const PidState &p, const PidArgs &A, const uint32_t (&sk)[2], bool deterministic,
+                                               float (&fn)[3])
+{
+    const dm::Model &m = A.dist;
+    const bool draws = (m.kind == COVO_DISTURB_GAUSSIAN && !deterministic) ||
+                       ((m.kind == COVO_DISTURB_PERIODIC || m.kind == COVO_DISTURB_MIXED) && (p.time % m.period) == 0);
+    uint32_t dk[2] = {0u, 0u};
+    if (draws) dm::disturb_key(sk, dk);
+    const float vel[3] = {p.s.vx, p.s.vy, p.s.vz};
+    for (int i = 0; i < 3; ++i) fn[i] = dm::next_force(m, dk, p.time, vel[i], p.f[i], i, deterministic);
+}
+
 // one env step with action `act` (quadrotor.py:215-263, free.py:114-155); f_next = the disturbance of the NEXT step
 __device__ __forceinline__ void pid_env_step(PidState &p, const float (&act)[4], const PidArgs &A, const float (&f_next)[3])
 {
@@ -137,7 +152,7 @@ __device__ __forceinline__ void pid_env_step(PidState &p, const float (&act)[4],
     }
 }
 
-// covo.py:80-90: the chain of start states (one lane; lanes 0..2 of the wave draw the three normals of a step)
+// covo.py:80-90: the chain of start states (one lane; lanes 0..2 of the wave form the three components of a step's next force)
 __global__ __launch_bounds__(64) void pid_chain_kernel(const PidArgs A)
 {
     __shared__ float zf[3];
@@ -146,19 +161,27 @@ __global__ __launch_bounds__(64) void pid_chain_kernel(const PidArgs A)
     pid_load(p, A.state0);
     uint32_t key[2] = {A.key[0], A.key[1]};
     for (int t = 0; t < A.n_steps; ++t) {
-        if (lane == 0) pid_store(p, A.states + (size_t)t * COVO_STATE_FLOATS);
+        if (lane == 0) {
+            pid_store(p, A.states + (size_t)t * COVO_STATE_FLOATS);
+            if (A.keys) { A.keys[2 * t] = key[0]; A.keys[2 * t + 1] = key[1]; }
+        }
         // rng_step, key = split(key) (consumed by the PID call); rng_step, key = split(key) (the env step's key)
-        uint32_t k1[2], rs[2], k2[2], a[2], b[2];
+        uint32_t k1[2], rs[2], k2[2];
         pid_split(key, 1u, k1);
         pid_split(k1, 0u, rs);
         pid_split(k1, 1u, k2);
         key[0] = k2[0];
         key[1] = k2[1];
-        // step_env(rs): raw_step: step_key = split(rs)[1]; step_fn: key = split(step_key)[0]; disturb_key = split(key)[0]
-        pid_split(rs, 1u, a);
-        pid_split(a, 0u, b);
-        pid_split(b, 0u, a);
-        if (lane < 3) zf[lane] = A.noise_scale * pid_normal3(a, lane);
+        // step_env(rs, deterministic=False): the next force from the PRE-step state
+        if (lane < 3) {
+            const dm::Model &m = A.dist;
+            const bool draws = m.kind == COVO_DISTURB_GAUSSIAN ||
+                               ((m.kind == COVO_DISTURB_PERIODIC || m.kind == COVO_DISTURB_MIXED) && (p.time % m.period) == 0);
+            uint32_t dk[2] = {0u, 0u};
+            if (draws) dm::disturb_key(rs, dk);
+            const float vel = lane == 0 ? p.s.vx : (lane == 1 ? p.s.vy : p.s.vz);
+            zf[lane] = dm::next_force(m, dk, p.time, vel, p.f[lane], lane, false);
+        }
         __syncthreads();
         float act[4];
         pid_action(p, A, act);
@@ -175,18 +198,32 @@ __global__ __launch_bounds__(64) void pid_nominal_kernel(const PidArgs A)
     if (t >= A.n_steps) return;
     PidState p;
     pid_load(p, A.states + (size_t)t * COVO_STATE_FLOATS);
-    const float zero[3] = {0.0f, 0.0f, 0.0f};  // deterministic=True: the next disturbance is 0 (quadrotor.py:234)
+    // the scan's carry key at this start state (covo.py:73-75): only the drawing models thread it
+    const bool keyed = A.keys != nullptr && (A.dist.kind == COVO_DISTURB_PERIODIC || A.dist.kind == COVO_DISTURB_MIXED);
+    uint32_t key[2] = {keyed ? A.keys[2 * t] : 0u, keyed ? A.keys[2 * t + 1] : 0u};
     for (int k = 0; k < COVO_H; ++k) {
         float act[4];
         pid_action(p, A, act);
         for (int d = 0; d < 4; ++d) A.a_means[(size_t)t * COVO_NA + 4 * k + d] = act[d];
-        pid_env_step(p, act, A, zero);
+        // mppi_rollout_fn (covo.py:58-70): rng_act, key = split(key); rng_step, key = split(key); step_env(rng_step, deterministic=True)
+        uint32_t rs[2] = {0u, 0u};
+        if (keyed) {
+            uint32_t k1[2], k2[2];
+            pid_split(key, 1u, k1);
+            pid_split(k1, 0u, rs);
+            pid_split(k1, 1u, k2);
+            key[0] = k2[0];
+            key[1] = k2[1];
+        }
+        float fn[3];
+        pid_next_force(p, A, rs, true, fn);  // deterministic=True: only the gaussian model is off (quadrotor.py:234-235)
+        pid_env_step(p, act, A, fn);
     }
 }
 
 int launch_pid_nominal(const float *state0, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
                        const covo_env_params &p, const covo_env_params &pid_params, float Kp, float Kd, float Kp_att,
-                       float noise_scale, uint32_t key0, uint32_t key1, int n_steps, float *states, float *a_means,
+                       uint32_t key0, uint32_t key1, int n_steps, float *states, float *a_means, uint32_t *keys_out,
                        hipStream_t s)
 {
     PidArgs A;
@@ -208,7 +245,12 @@ int launch_pid_nominal(const float *state0, const float *pos_traj, const float *
     A.Kp = Kp;
     A.Kd = Kd;
     A.Kp_att = Kp_att;
-    A.noise_scale = noise_scale;
+    A.dist = dm::make_model(p);
+    A.keys = keys_out;
+    if ((A.dist.kind == COVO_DISTURB_PERIODIC || A.dist.kind == COVO_DISTURB_MIXED) && keys_out == nullptr) {
+        covo_set_error("pid_nominal: disturb_kind=%d draws in the nominal rollouts: keys_out must be given", A.dist.kind);
+        return COVO_E_BADARG;
+    }
     hipLaunchKernelGGL(pid_chain_kernel, dim3(1), dim3(64), 0, s, A);
     hipLaunchKernelGGL(pid_nominal_kernel, dim3((n_steps + 63) / 64), dim3(64), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());

@@ -253,25 +253,53 @@ __device__ __forceinline__ S reward(const State<S> &s, U tx, U ty, U tz, U tvx, 
     return reward_parts<S, U>(s.px, s.py, s.pz, s.vx, s.vy, s.vz, yn, yd, tx, ty, tz, tvx, tvy, tvz);
 }
 
+// dynamics/utils.py:297-313 (tracking_realworld_reward_fn, task "tracking_slow"): -0.02 (5 mean((p - p_tar)^2) + 3 (1 - w^2)) with
+// the STORED quaternion's w
+template <class S, class U>
+__device__ __forceinline__ S reward_realworld(const State<S> &s, U tx, U ty, U tz)
+{
+    const S dx = s.px - tx, dy = s.py - ty, dz = s.pz - tz;
+    const S pos_err = (dx * dx + dy * dy + dz * dz) * (U(1) / U(3));
+    const S quat_err = U(1) - s.qw * s.qw;
+    return -((pos_err * U(5) + quat_err * U(3)) * U(0.02));
+}
+
+// env.reward_fn by covo_env_params.reward_kind (0: penyaw, 1: realworld; wave-uniform)
+template <class S, class U>
+__device__ __forceinline__ S reward_kind(int kind, const State<S> &s, U tx, U ty, U tz, U tvx, U tvy, U tvz)
+{
+    if (kind == 1) return reward_realworld<S, U>(s, tx, ty, tz);
+    return reward<S, U>(s, tx, ty, tz, tvx, tvy, tvz);
+}
+
+// dynamics/free.py:41-47 with the model's constant folded: coeff = c_drag * (-|disturb_scale| / 1.5^2), off = disturb_params[:3] / 2
+template <class S, class U>
+__device__ __forceinline__ S drag_force(S v, U off, U coeff)
+{
+    const S rel = v - off;
+    return (rel * abs_(rel)) * coeff;
+}
+
 // envs/quadrotor.py:250-263 + dynamics/free.py:114-155 (+74-112).  a* are already clipped.
 // (fx,fy,fz) = f_disturb acting during THIS step (free.py:91,98).
 // ENTRY_NORM = false: the stored quaternion is the one free.py:139 normalised at the end of the previous step -- normalising it
 // again on entry (free.py:88) moves it by <= 1 ulp; used only for the plain primal prefix of the adjoint Hessian (steps >= 1),
 // never where derivatives are taken.
 // dyn_core: the step given the action's thrust and body-rate targets (dyn_step = action terms + dyn_core, same operations)
-template <class S, class U, bool ENTRY_NORM = true>
-__device__ __forceinline__ void dyn_core(State<S> &s, S thrust, S wtx, S wty, S wtz, const Consts<U> &c, U fx, U fy, U fz);
+// F: the type of the disturbance (U when it is wave-uniform, S when it is part of the differentiated / per-sample state)
+template <class S, class U, bool ENTRY_NORM = true, class F = U>
+__device__ __forceinline__ void dyn_core(State<S> &s, S thrust, S wtx, S wty, S wtz, const Consts<U> &c, F fx, F fy, F fz);
 
-template <class S, class U, bool ENTRY_NORM = true>
-__device__ __forceinline__ void dyn_step(State<S> &s, S a0, S a1, S a2, S a3, const Consts<U> &c, U fx, U fy, U fz)
+template <class S, class U, bool ENTRY_NORM = true, class F = U>
+__device__ __forceinline__ void dyn_step(State<S> &s, S a0, S a1, S a2, S a3, const Consts<U> &c, F fx, F fy, F fz)
 {
     const S thrust = (a0 + U(1)) * c.thrust_half;  // quadrotor.py:259, free.py:82
     const S wtx = a1 * c.komega[0], wty = a2 * c.komega[1], wtz = a3 * c.komega[2];  // quadrotor.py:260, free.py:122,82
-    dyn_core<S, U, ENTRY_NORM>(s, thrust, wtx, wty, wtz, c, fx, fy, fz);
+    dyn_core<S, U, ENTRY_NORM, F>(s, thrust, wtx, wty, wtz, c, fx, fy, fz);
 }
 
-template <class S, class U, bool ENTRY_NORM>
-__device__ __forceinline__ void dyn_core(State<S> &s, S thrust, S wtx, S wty, S wtz, const Consts<U> &c, U fx, U fy, U fz)
+template <class S, class U, bool ENTRY_NORM, class F>
+__device__ __forceinline__ void dyn_core(State<S> &s, S thrust, S wtx, S wty, S wtz, const Consts<U> &c, F fx, F fy, F fz)
 {
     // q = x[3:7] / norm (free.py:88)
     S x = s.qx, y = s.qy, z = s.qz, w = s.qw;

@@ -15,6 +15,7 @@ __device__ __forceinline__ void rp_pin(float &a, float &b, float &c, float &d, f
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
 __device__ __forceinline__ void rp_pin(float &a, float &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void rp_pin(float &a, float &b, float &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 
 // Three-stage pipeline (the product kernel, with and without the position statistics of --info).  Measured on gfx950 (scripts/probe/valu_probe.hip, rollout_lab.hip): one wave
 // retires a dependent VALU instruction per ~4 ns, a SIMD with three such waves one per ~1.2-1.5 ns, and every LDS
@@ -92,10 +93,17 @@ __device__ __forceinline__ float rp3_atan2abs(float y, float x)
 // ONLY >= 0 (scripts/probe/rollout_lab.hip): every wave runs stage ONLY on its own LDS copy, no barriers -- the stage's
 //   instruction stream in isolation; ONLY == -2: all three stages without barriers (timing bound, garbage results).
 // STATS: the per-step position sums of covo.py:281 (pos_mean / pos_std) are formed by the T waves (see there).
+// REWARD: env.reward_fn -- 0 tracking_penyaw_reward_fn (utils.py:285-294), 1 tracking_realworld_reward_fn (utils.py:297-313:
+//   ring T then carries {err_pos^2, done flag as +-1, w^2 of the stored quaternion}).
+// FDIST: how the disturbance of steps k >= 1 (free.py:147) reaches stage T -- 0: ONE wave-uniform vector for all of them
+//   (none; gaussian from the shared step key); 1: a wave-uniform vector per step from A.f_tab (periodic, sin: lane k carries
+//   step k's, v_readlane like the targets: 3 instructions per step, nothing per sample); 2: a per-sample force
+//   f_k = A.drag_k rel |rel| + c_k f_{k-1} + g_k, rel = vel_{k-1} - A.drag_off (drag, mixed = (drag + sin + periodic) / 3:
+//   free.py:41-56; rows {g_k, c_k} of A.f_tab, disturb.hip).
 // REC: every workgroup also leaves its online-softmax record (rollout_record; A.records != null) -- the variant the fused
 //   step runs; a template argument so that the profiler lists it under its own name.
 template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3, bool STATS = false,
-          bool REC = false>
+          bool REC = false, int REWARD = 0, int FDIST = 0>
 __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) void rollout_pipe3_kernel(
     const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
 {
@@ -248,16 +256,26 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
             }
         };
         const float kf = c.inv_m * c.dt;  // v += dt/m f (free.py:98,103)
-        const float c0x = st[ST_FDIST + 0] * kf, c0y = st[ST_FDIST + 1] * kf, c0z = __builtin_fmaf(st[ST_FDIST + 2], kf, c.neg_g * c.dt);
-        const float fsx = A.f_shared_dev ? A.f_shared_dev[0] : A.f_shared[0];
-        const float fsy = A.f_shared_dev ? A.f_shared_dev[1] : A.f_shared[1];
-        const float fsz = A.f_shared_dev ? A.f_shared_dev[2] : A.f_shared[2];
-        const float csx = fsx * kf, csy = fsy * kf, csz = __builtin_fmaf(fsz, kf, c.neg_g * c.dt);
-        float yn0, yd0;  // step 0: yaw terms of the un-normalised stored quaternion (utils.py:289-290)
+        const float gdt = c.neg_g * c.dt;
+        const float c0x = st[ST_FDIST + 0] * kf, c0y = st[ST_FDIST + 1] * kf, c0z = __builtin_fmaf(st[ST_FDIST + 2], kf, gdt);
+        float csx = 0.0f, csy = 0.0f, csz = 0.0f;       // FDIST 0: dt/m f_shared (+ dt g) for every step k >= 1
+        float wfx = 0.0f, wfy = 0.0f, wfz = 0.0f, wfc = 0.0f;  // FDIST 1 / 2: lane k carries row k of the table
+        float fpx = st[ST_FDIST + 0], fpy = st[ST_FDIST + 1], fpz = st[ST_FDIST + 2];  // FDIST 2: this sample's force
+        if (FDIST == 0) {
+            const float fsx = A.f_shared_dev ? A.f_shared_dev[0] : A.f_shared[0];
+            const float fsy = A.f_shared_dev ? A.f_shared_dev[1] : A.f_shared[1];
+            const float fsz = A.f_shared_dev ? A.f_shared_dev[2] : A.f_shared[2];
+            csx = fsx * kf; csy = fsy * kf; csz = __builtin_fmaf(fsz, kf, gdt);
+        } else {
+            const float4 row = A.f_tab[lane & (COVO_H - 1)];
+            if (FDIST == 1) { wfx = row.x * kf; wfy = row.y * kf; wfz = __builtin_fmaf(row.z, kf, gdt); }
+            else { wfx = row.x; wfy = row.y; wfz = row.z; wfc = row.w; }
+        }
+        float yn0, yd0;  // step 0: yaw terms of the un-normalised stored quaternion (utils.py:289-290); REWARD 1: yn0 = its w^2
         bool roll0 = false;
         {
             const float qx = st[ST_QUAT + 0], qy = st[ST_QUAT + 1], qz = st[ST_QUAT + 2], qw = st[ST_QUAT + 3];
-            yn0 = __builtin_fmaf(qw, qz, qx * qy);
+            yn0 = REWARD == 1 ? qw * qw : __builtin_fmaf(qw, qz, qx * qy);
             yd0 = __builtin_fmaf(-qz, qz, __builtin_fmaf(-qy, qy, 0.5f));
             if (ROLL) roll0 = (qw < RP_COS_PI_4) |
                               (fmaxf(fmaxf(fabsf(st[ST_OMEGA + 0]), fabsf(st[ST_OMEGA + 1])), fabsf(st[ST_OMEGA + 2])) > 100.0f);
@@ -269,6 +287,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         for (int k = 0; k < COVO_H; ++k) {
             if (k % CH == 0) {
                 rp_pin(px, py, pz, vx, vy, vz);
+                if (FDIST == 2) rp_pin(fpx, fpy, fpz);
             }
             const float4 q4 = lds.q[k % (2 * CH)][lane];
             const float tau_raw = lds.tau[k % (2 * CH)][lane];
@@ -287,10 +306,14 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
                 done = done | ((k == 0) ? roll0 : (__float_as_int(tau_raw) < 0));
                 tau = fabsf(tau_raw);
             }
-            ev2 = done ? -ev2 : ev2;
-            const float yn = (k == 0) ? yn0 : __builtin_fmaf(w, z, x * y);
-            const float yd = (k == 0) ? yd0 : __builtin_fmaf(-z, z, __builtin_fmaf(-y, y, 0.5f));
-            lds.t[k % (2 * CH)][lane] = make_float4(ep2, ev2, yn, yd);
+            if (REWARD == 1) {  // utils.py:297-313 needs err_pos^2 and the stored w^2 only; .y carries the termination flag
+                lds.t[k % (2 * CH)][lane] = make_float4(ep2, done ? -1.0f : 1.0f, (k == 0) ? yn0 : w * w, 0.0f);
+            } else {
+                ev2 = done ? -ev2 : ev2;
+                const float yn = (k == 0) ? yn0 : __builtin_fmaf(w, z, x * y);
+                const float yd = (k == 0) ? yd0 : __builtin_fmaf(-z, z, __builtin_fmaf(-y, y, 0.5f));
+                lds.t[k % (2 * CH)][lane] = make_float4(ep2, ev2, yn, yd);
+            }
             if (k < COVO_H - 1) {
                 // Q[:,2] of qtoQ(q) (geom.py:68-77) for a unit quaternion: 2 (xz + yw), 2 (yz - xw), 1 - 2 (x^2 + y^2);
                 // v += dt (Q [0,0,T] + f)/m + dt [0,0,-g] (free.py:97-99,103); position with the OLD velocity (free.py:102)
@@ -300,11 +323,27 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
                 px = __builtin_fmaf(vx, c.dt, px);
                 py = __builtin_fmaf(vy, c.dt, py);
                 pz = __builtin_fmaf(vz, c.dt, pz);
-                vx = __builtin_fmaf(u0, tau2, vx);
-                vy = __builtin_fmaf(u1, tau2, vy);
-                vz = __builtin_fmaf(-tau2, s2, vz + tau);
-                if (k == 0) { vx += c0x; vy += c0y; vz += c0z; }
-                else { vx += csx; vy += csy; vz += csz; }
+                if (FDIST == 2) {
+                    // the NEXT step's force from this step's PRE-step velocity (free.py:147,41-56), then this step's velocity
+                    // with the force it already carries (free.py:98,103)
+                    const float rx = vx - A.drag_off[0], ry = vy - A.drag_off[1], rz = vz - A.drag_off[2];
+                    const int kn = (k + 1) & (COVO_H - 1);
+                    const float cn = lane_bcast(wfc, kn);
+                    const float nfx = __builtin_fmaf(rx * __builtin_fabsf(rx), A.drag_k, __builtin_fmaf(cn, fpx, lane_bcast(wfx, kn)));
+                    const float nfy = __builtin_fmaf(ry * __builtin_fabsf(ry), A.drag_k, __builtin_fmaf(cn, fpy, lane_bcast(wfy, kn)));
+                    const float nfz = __builtin_fmaf(rz * __builtin_fabsf(rz), A.drag_k, __builtin_fmaf(cn, fpz, lane_bcast(wfz, kn)));
+                    vx = __builtin_fmaf(fpx, kf, __builtin_fmaf(u0, tau2, vx));
+                    vy = __builtin_fmaf(fpy, kf, __builtin_fmaf(u1, tau2, vy));
+                    vz = __builtin_fmaf(fpz, kf, __builtin_fmaf(-tau2, s2, vz + tau)) + gdt;
+                    fpx = nfx; fpy = nfy; fpz = nfz;
+                } else {
+                    vx = __builtin_fmaf(u0, tau2, vx);
+                    vy = __builtin_fmaf(u1, tau2, vy);
+                    vz = __builtin_fmaf(-tau2, s2, vz + tau);
+                    if (k == 0) { vx += c0x; vy += c0y; vz += c0z; }
+                    else if (FDIST == 1) { vx += lane_bcast(wfx, k); vy += lane_bcast(wfy, k); vz += lane_bcast(wfz, k); }
+                    else { vx += csx; vy += csy; vz += csz; }
+                }
                 if (STATS) stats_step(k, px, py, pz);
             } else if (STATS) {  // the last step's new position enters no cost, only the statistics
                 stats_step(k, __builtin_fmaf(vx, c.dt, px), __builtin_fmaf(vy, c.dt, py), __builtin_fmaf(vz, c.dt, pz));
@@ -336,16 +375,22 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
             rp_pin(acc, r_before);
         }
         const float4 e4 = lds.t[k % (2 * CH)][lane];
-        const float err_pos = qm::sqrt_(e4.x), err_vel = qm::sqrt_(fabsf(e4.y));
-        const float yaw = rp3_atan2abs(e4.z, e4.w);
-        const float l2 = __builtin_amdgcn_logf(err_pos + 1.0f);  // log2
-        // utils.py:266-274, 285-294: r = 1.3 - 0.05 err_vel - (0.4 e + 0.4 sat(4 l) + 0.2 sat(8 l) + 0.1 sat(16 l) + 0.1 sat(32 l)) - 0.2 |yaw|
-        float r = __builtin_fmaf(err_vel, -0.05f, 1.3f);
-        r = __builtin_fmaf(err_pos, -0.4f, r);
-        r = __builtin_fmaf(qm::sat01_(l2 * (4.0f * LN2)), -0.4f, r);
-        r = __builtin_fmaf(qm::sat01_(l2 * (8.0f * LN2)), -0.2f, r);
-        r = __builtin_fmaf(qm::sat01_(l2 * (16.0f * LN2)) + qm::sat01_(l2 * (32.0f * LN2)), -0.1f, r);
-        r = __builtin_fmaf(yaw, -0.2f, r);
+        float r;
+        if (REWARD == 1) {
+            // utils.py:297-313: r = -0.02 (5 err_pos^2 / 3 + 3 (1 - w^2)) = -(0.1 / 3) err_pos^2 + 0.06 w^2 - 0.06
+            r = __builtin_fmaf(e4.x, -0.1f / 3.0f, __builtin_fmaf(e4.z, 0.06f, -0.06f));
+        } else {
+            const float err_pos = qm::sqrt_(e4.x), err_vel = qm::sqrt_(fabsf(e4.y));
+            const float yaw = rp3_atan2abs(e4.z, e4.w);
+            const float l2 = __builtin_amdgcn_logf(err_pos + 1.0f);  // log2
+            // utils.py:266-274, 285-294: r = 1.3 - 0.05 err_vel - (0.4 e + 0.4 sat(4 l) + 0.2 sat(8 l) + 0.1 sat(16 l) + 0.1 sat(32 l)) - 0.2 |yaw|
+            r = __builtin_fmaf(err_vel, -0.05f, 1.3f);
+            r = __builtin_fmaf(err_pos, -0.4f, r);
+            r = __builtin_fmaf(qm::sat01_(l2 * (4.0f * LN2)), -0.4f, r);
+            r = __builtin_fmaf(qm::sat01_(l2 * (8.0f * LN2)), -0.2f, r);
+            r = __builtin_fmaf(qm::sat01_(l2 * (16.0f * LN2)) + qm::sat01_(l2 * (32.0f * LN2)), -0.1f, r);
+            r = __builtin_fmaf(yaw, -0.2f, r);
+        }
         const bool done = __float_as_int(e4.y) < 0;
         r = done_before ? r_before : r;  // covo.py:233
         done_before = done_before | done;

@@ -81,7 +81,7 @@ __device__ __forceinline__ float host_normal3(const uint32_t (&key)[2], int i)
 //   rng, act_key = split(rng_act); rng, step_key = split(rng)                (covo.py:212,225 / mppi.py:53,69)
 //   MPPI: f_shared = scale * normal(split(split(split(step_key)[1])[0])[0], (3,))   (quadrotor.py:262, free.py:136,144)
 struct DynBlock {
-    uint32_t w[12];  // {key0, key1, f_shared[3] as float bits, pad[3], state pointer (8 bytes), pad[2]}
+    uint32_t w[12];  // {key0, key1, f_shared[3] as float bits, pad[3], state pointer (8 bytes), raw rng_act (device block only)}
 };
 __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
                                   uint32_t *__restrict__ dyn, float *__restrict__ state_buf, int derive_keys,
@@ -101,6 +101,10 @@ __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__res
         state_buf[i - COVO_NA] = src[i - COVO_NA];
     } else {
         const int q = i - (COVO_NA + COVO_STATE_FLOATS);  // 0: act_key, 1..3: f_shared
+        if (q == 0) {  // the raw controller key, for what else is derived from it in the graph (disturb.hip: the step's tables)
+            dyn[10] = raw[0];
+            dyn[11] = raw[1];
+        }
         if (!derive_keys) {
             if (q == 0) {
                 dyn[0] = raw[0];
@@ -145,6 +149,7 @@ struct StepState {
     float *Sigma, *L;     // [128][128]
     float *Ls;            // [H][4][4] MPPI's block factors
     float4 *eps_tiled;    // covo-online: this step's epsilon in tile order, drawn under the Sigma chain (eps_tiles.hpp); or null
+    float *f_tab_rollout, *f_tab_hess;  // [H][4] per-step disturbance tables of the sampling rollouts / the Hessian (disturb.hip)
     // graph cache
     bool have_key, have_graph;
     StepKey key;
@@ -167,6 +172,8 @@ static int step_state_init(covo_ctx *h)
     COVO_CHECK_HIP(hipMalloc(&st->Sigma, (size_t)COVO_NA * COVO_NA * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->L, (size_t)COVO_NA * COVO_NA * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->Ls, COVO_H * 16 * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&st->f_tab_rollout, COVO_H * 4 * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&st->f_tab_hess, COVO_H * 4 * sizeof(float)));
     if (h->cfg.n_local <= EPS_AHEAD_MAX_N)
         COVO_CHECK_HIP(hipMalloc(&st->eps_tiled, (size_t)((h->cfg.n_local + 31) / 32) * 16 * 64 * sizeof(float4)));
     h->step = st;
@@ -189,6 +196,8 @@ void step_state_destroy(covo_ctx *h)
     (void)hipFree(st->L);
     (void)hipFree(st->Ls);
     (void)hipFree(st->eps_tiled);
+    (void)hipFree(st->f_tab_rollout);
+    (void)hipFree(st->f_tab_hess);
     delete st;
     h->step = nullptr;
 }
@@ -209,12 +218,17 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
     int rc;
     const float *state = st->state_buf;
+    // periodic / sin / drag / mixed (free.py:10-58): the wave-uniform part of every rollout step's force, for the sampling
+    // rollouts (shared step key) and for the Hessian's deterministic rollout (per-step keys), resolved once per control step
+    const bool tables = p.disturb_kind >= COVO_DISTURB_PERIODIC && p.disturb_kind <= COVO_DISTURB_MIXED;
+    if (tables && (rc = launch_disturb_tables_step(p, state, st->dyn, a.rollout_deterministic, st->f_tab_rollout,
+                                                   a.mode == COVO_MODE_COVO_ONLINE ? st->f_tab_hess : nullptr, s))) return rc;
     if (a.mode == COVO_MODE_COVO_ONLINE) {
         // the Hessian's last launch leaves the Sigma chain's input statistics in the chain's workspace: no prep launch
-        const bool stats = (M & 2) && (M & 4) && (g_dbg_hess_mask & 15) == 15;
+        const bool stats = (M & 2) && (M & 4) && (g_dbg_hess_mask & 15) == 15 && hessian_leaves_stats(p);
         const SymStatsOut so = sigma_ns_stats_out(h->ws_sigma);
         if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s, nullptr, 0,
-                                            stats ? &so : nullptr))) return rc;  // :134-185
+                                            stats ? &so : nullptr, tables ? st->f_tab_hess : nullptr))) return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
         // epsilon needs only the act key: it is drawn under the chain's single-workgroup finalize launch, the GEMM loads it
         const bool ahead = st->eps_tiled != nullptr && (M & 4) && g_dbg_sigma_stages >= 4 && g_dbg_eps_ahead;
@@ -251,7 +265,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     const bool records = G <= h->max_red_blocks;
     if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
                                          records ? nullptr : a.groupmin, a.pos_stats, h->ws_stats, s, fdev,
-                                         records ? h->ws_partials : nullptr, h->cfg.lam)))
+                                         records ? h->ws_partials : nullptr, h->cfg.lam, tables ? st->f_tab_rollout : nullptr)))
         return rc;
     if (!(M & 32)) return 0;
     if (records) {
@@ -283,9 +297,13 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
         std::memcpy(&blk.w[2 + i], &f, 4);
     }
     std::memcpy(&blk.w[8], &args->state, sizeof(const float *));
+    // the one shared gaussian vector of the sampling rollouts (free.py:66-70 from the shared step key): off under
+    // step_env(deterministic=True) (quadrotor.py:234-235)
+    const float shared_noise_scale =
+        (params->disturb_kind == COVO_DISTURB_GAUSSIAN && !args->rollout_deterministic) ? params->dyn_noise_scale : 0.0f;
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s, args->a_mean,
                        args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
-                       args->shared_noise_scale, blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls);
+                       shared_noise_scale, blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls);
 
     StepKey k;
     std::memset(&k, 0, sizeof(k));

@@ -66,10 +66,17 @@ class EnvParams3D:
     def replace(self, **kw) -> "EnvParams3D":
         return dataclasses.replace(self, **kw)
 
-    def to_c(self, rollover_terminate: bool = False) -> EnvParamsC:
-        """The rollout-relevant subset as struct covo_env_params.  `rollover_terminate` is the env's
-        `not disable_rollover_terminate` (envs/quadrotor.py:486-490): an attribute of Quad3D, not of the parameters."""
+    def to_c(self, rollover_terminate: bool = False, reward: str = "penyaw", disturb_type: str = "none") -> EnvParamsC:
+        """The rollout-relevant subset as struct covo_env_params.  `rollover_terminate` (the env's `not
+        disable_rollover_terminate`, envs/quadrotor.py:486-490), `reward` (which function env.reward_fn is,
+        quadrotor.py:49-84) and `disturb_type` (quadrotor.py:35,87-89) are attributes of Quad3D, not of the parameters."""
+        from .._lib import DISTURB_KINDS, REWARD_KINDS
         c = EnvParamsC()
+        c.reward_kind, c.disturb_kind = REWARD_KINDS[reward], DISTURB_KINDS[disturb_type]
+        c.disturb_period, c.disturb_scale = int(self.disturb_period), float(self.disturb_scale)
+        for i in range(6):
+            c.disturb_params[i] = float(self.disturb_params[i])
+        c.dyn_noise_scale = float(self.dyn_noise_scale)
         c.max_thrust = float(self.max_thrust)
         for i in range(3):
             c.max_torque[i] = float(self.max_torque[i])

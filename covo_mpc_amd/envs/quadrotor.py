@@ -116,20 +116,21 @@ class Quad3D(BaseEnvironment):
         key, step_key = crandom.split(key)
         return self.step_fn(params, state, Action3D(thrust=thrust, torque=torque.astype(f32)), step_key, self.sim_dt)
 
-    def rollout_disturbance(self, step_key, params, deterministic: bool):
-        """The single f_disturb vector every sample/step of a controller rollout receives: all N x H
-        step_env calls share `step_key` (covo.py:225,231 / mppi.py:69,74), so free.py:147's draw is one
-        vector.  Key derivation follows step_env -> raw_step -> step_fn (quadrotor.py:262, free.py:136,144)."""
+    def rollout_disturbance(self, step_key, params, deterministic: bool, rng=crandom):
+        """The single f_disturb vector every sample/step of a controller rollout receives under 'none' / 'gaussian': all
+        N x H step_env calls share `step_key` (covo.py:225,231 / mppi.py:69,74), so free.py:147's draw is one vector.  Key
+        derivation follows step_env -> raw_step -> step_fn (quadrotor.py:262, free.py:136,144); `rng`: the key module
+        (covo_mpc_amd.random, or random_jax for jax's own bitstream).  The other models (periodic / sin / drag / mixed) are
+        per-step or per-sample: csrc/disturb.hip builds their table on the device (SamplingCore.disturb_table)."""
         if self.disturb_type == "none":
             return np.zeros(3, dtype=f32)
         if self.disturb_type == "gaussian":
             scale = params.dyn_noise_scale * (1.0 - float(deterministic))
-            _, k = crandom.split(step_key)      # raw_step: key, step_key = split(key)
-            k, _ = crandom.split(k)             # step_fn:  key, key_dyn = split(key)
-            disturb_key, _ = crandom.split(k)   #           disturb_key, key = split(key)
-            return (f32(scale) * crandom.normal(disturb_key, (3,))).astype(f32)
-        raise NotImplementedError(f"disturb_type={self.disturb_type!r} inside the fused rollout "
-                                  "(state/time-dependent models are outside the kernel's first scope)")
+            _, k = rng.split(step_key)      # raw_step: key, step_key = split(key)
+            k, _ = rng.split(k)             # step_fn:  key, key_dyn = split(key)
+            disturb_key, _ = rng.split(k)   #           disturb_key, key = split(key)
+            return (f32(scale) * np.asarray(rng.normal(disturb_key, (3,)), dtype=f32)).astype(f32)
+        raise NotImplementedError(f"disturb_type={self.disturb_type!r}: no single shared vector (use SamplingCore.disturb_table)")
 
     def get_zero_state(self, key, params) -> EnvState3D:
         """quadrotor.py:265-312."""
@@ -222,10 +223,9 @@ class DeviceEpisode:
         self.pos_traj, self.vel_traj, self.acc_traj = up(state.pos_traj), up(state.vel_traj), up(state.acc_traj)
         self.T = int(state.pos_traj.shape[0])
         self.log = torch.zeros((params.max_steps_in_episode + 1, 4), dtype=torch.float32, device=device)
-        self.params_c = params.to_c(rollover_terminate=not env.disable_rollover_terminate)
+        from ..controllers.base import env_model_params_c
+        self.params_c = env_model_params_c(env, params)  # incl. the env's reward and disturbance model (env_step.hip runs all of them)
         self.n_steps = 0
-        if env.disturb_type not in ("gaussian", "none"):
-            raise NotImplementedError(f"disturb_type={env.disturb_type!r} in the device env step")
 
     @property
     def noisy_state(self) -> DeviceState:
@@ -250,8 +250,7 @@ class DeviceEpisode:
         self._lib.check(self.lib.covo_env_step(
             self.h, ptr(self.true), ptr(self.noisy), ptr(self.pos_traj), ptr(self.vel_traj), ptr(self.acc_traj), self.T,
             C.byref(self.params_c), ptr(action), keys.ctypes.data_as(C.POINTER(C.c_uint32)),
-            1 if self.env.disturb_type == "gaussian" else 0, 1 if self.env.generate_noisy_state else 0,
-            float(self.params.dyn_noise_scale), float(self.env.default_params.obs_noise_scale), ptr(self.log),
+            1 if self.env.generate_noisy_state else 0, float(self.env.default_params.obs_noise_scale), ptr(self.log),
             self.n_steps, st), "covo_env_step")
         self._keep = (keys, action)
         self.n_steps += 1

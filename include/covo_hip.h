@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define COVO_ABI_VERSION 2
+#define COVO_ABI_VERSION 3
 
 #define COVO_H 32            /* horizon (compile-time in the fused kernels)          */
 #define COVO_DU 4            /* action dim, quadjax/envs/quadrotor.py:198            */
@@ -70,6 +70,23 @@ extern "C" {
 #define COVO_DEVSTAT_GRID_BARRIER 1  /* a grid barrier of the Sigma chain's persistent launches timed out (its workgroups were not
                                         co-resident within 0.2 s: GPU shared with other work); that call's Sigma / L are NaN */
 
+/* covo_env_params.reward_kind: which reward Quad3D binds to env.reward_fn (quadjax/envs/quadrotor.py:49-84) */
+#define COVO_REWARD_PENYAW 0     /* tracking_penyaw_reward_fn (dynamics/utils.py:285-294): tasks tracking, tracking_zigzag, hovering */
+#define COVO_REWARD_REALWORLD 1  /* tracking_realworld_reward_fn (utils.py:297-313): task tracking_slow */
+
+/* covo_env_params.disturb_kind: Quad3D(disturb_type=...) -> get_quadrotor_1st_order_dyn (dynamics/free.py:8-72) */
+#define COVO_DISTURB_NONE 0      /* free.py:72 */
+#define COVO_DISTURB_GAUSSIAN 1  /* free.py:66-70: dyn_noise_scale * normal(key, (3,)); 0 under deterministic=True (quadrotor.py:234) */
+#define COVO_DISTURB_PERIODIC 2  /* free.py:10-24: redrawn uniform(-scale, scale) when time % period == 0, held otherwise */
+#define COVO_DISTURB_SIN 3       /* free.py:27-38: a function of time and disturb_params */
+#define COVO_DISTURB_DRAG 4      /* free.py:41-47: -|scale| rel |rel| / 1.5^2, rel = vel - disturb_params[:3] / 2 (per sample) */
+#define COVO_DISTURB_MIXED 5     /* free.py:50-56: (drag + sin + periodic) / 3 */
+
+/* covo_disturb_table key threading (who calls step_env with which key) */
+#define COVO_DISTURB_KEYS_SHARED 0    /* every step uses the SAME step key: the controllers' rollouts (covo.py:225,231; mppi.py:69,74) */
+#define COVO_DISTURB_KEYS_HESSIAN 1   /* per step rng_k, key = split(key); step_env(rng_k): get_hessian (covo.py:150-153) */
+#define COVO_DISTURB_KEYS_NOMINAL 2   /* per step _, key = split(key); rng_step, key = split(key): covo-offline's nominal rollout (covo.py:58-70) */
+
 typedef struct covo_ctx *covo_handle_t;
 
 /* Rollout-relevant subset of EnvParams3D (quadjax/dynamics/dataclass.py:40-100). [host] */
@@ -87,6 +104,12 @@ typedef struct covo_env_params {
     int32_t rollover_terminate; /* 1: is_terminal also fires on quat[3] < cos(pi/4) or any |omega| > 100 (quadrotor.py:486-490),
                                  *    i.e. Quad3D(disable_rollover_terminate=False), the constructor's default; quadjax's main()
                                  *    builds its env with disable_rollover_terminate=True (quadrotor.py:779) -> 0 */
+    int32_t reward_kind;        /* COVO_REWARD_*: env.reward_fn (quadrotor.py:56,66,73,82) */
+    int32_t disturb_kind;       /* COVO_DISTURB_*: Quad3D(disturb_type=...) (quadrotor.py:35,87-89) */
+    int32_t disturb_period;     /* 50   (dataclass.py:86) */
+    float disturb_scale;        /* .2   (dataclass.py:87) */
+    float disturb_params[6];    /* 0    (dataclass.py:88; domain randomisation / reset draw them, quadrotor.py:151,171) */
+    float dyn_noise_scale;      /* .05  (dataclass.py:93): scale of the gaussian model (zeroed by deterministic=True) */
 } covo_env_params;
 
 typedef struct covo_config {
@@ -158,15 +181,32 @@ int covo_noise_blockdiag_philox(covo_handle_t h, const float *Ls, const float *m
  * registers / LDS; only cost[N] (+ one min per 64-sample wave) is written.  Actions are re-clipped like
  * step_env does unless the handle was created with COVO_FLAG_ACTIONS_CLIPPED.  Termination follows
  * params->rollover_terminate (quadrotor.py:479-490).
- * f_disturb_shared [host float[3]]: the single disturbance vector every sample receives
- *   for rollout steps >= 1 from the shared step_key (0 for CoVO's deterministic=True).
+ * The disturbance acting during rollout step 0 is the state's own f_disturb; for steps k >= 1 (free.py:147) it follows
+ * params->disturb_kind:
+ *   NONE / GAUSSIAN: f_disturb_shared [host float[3]]: the single vector every sample and step receives from the shared
+ *     step_key (0 for CoVO's deterministic=True; dyn_noise_scale * normal for MPPI); NULL = 0.
+ *   PERIODIC / SIN / DRAG / MIXED: f_disturb_steps [DEVICE float[COVO_H][4]], the table covo_disturb_table builds
+ *     (COVO_DISTURB_KEYS_SHARED): row k = {g_k[3], c_k}, f_k = c_drag * drag(vel_{k-1}) + c_k * f_{k-1} + g_k with
+ *     c_drag = 1 (DRAG), 1/3 (MIXED), 0 otherwise -- PERIODIC and SIN are wave-uniform per step (c_k = 0, g_k = the force
+ *     itself: no per-sample work), DRAG and MIXED keep a per-sample force.  f_disturb_shared is then ignored.
  * pos_stats (nullable): double[COVO_H*6] accumulators, zeroed by the call, receiving
  *   per-step sum(pos - pos0) and sum((pos - pos0)^2) over samples of the post-step
  *   positions (controllers/covo.py:234-237,281); pos0 = state pos.
  * groupmin (nullable): float[ceil(N/64)] minimum of cost over each group of 64 consecutive samples. */
 int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                      const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
-                      float *cost_out, float *groupmin, double *pos_stats, void *stream);
+                      const covo_env_params *params, const float *f_disturb_shared, const float *f_disturb_steps,
+                      const float *a, int32_t N, float *cost_out, float *groupmin, double *pos_stats, void *stream);
+
+/* The per-step disturbance table of a rollout that starts at `state` (DEVICE float[batch][COVO_STATE_FLOATS]; it supplies
+ * time and, for PERIODIC's hold, f_disturb): out [DEVICE float[batch][COVO_H][4]], rows as described at covo_rollout_cost,
+ * for params->disturb_kind = PERIODIC / SIN / DRAG / MIXED (NONE: zeros; GAUSSIAN: g_k = dyn_noise_scale * normal unless
+ * `deterministic`).  The uniform draws of PERIODIC / MIXED (free.py:16-21) come from the key step_env would hand to
+ * disturb_func -- disturb_key = split(split(split(k)[1])[0])[0] for step_env(k) (quadrotor.py:262, free.py:136,144) -- with k
+ * threaded as `key_mode` (COVO_DISTURB_KEYS_*) says from the batch entry's key: keys_dev [DEVICE uint32[batch][2]] or, when
+ * NULL, (key0, key1) for every entry.  Philox keys / host formulas of covo_mpc_amd/random.py (the stream is build-defined). */
+int covo_disturb_table(covo_handle_t h, const covo_env_params *params, const float *state, int32_t batch,
+                       const uint32_t *keys_dev, uint32_t key0, uint32_t key1, int32_t key_mode, int32_t deterministic,
+                       float *out, void *stream);
 
 /* controllers/covo.py:281 (mppi.py:134) from the sums covo_rollout_cost / covo_mpc_step leave in pos_stats (after the
  * all-reduce when the samples are sharded): pos_mean[k][i] = pos0[i] + S1/n, pos_std[k][i] = sqrt(max(S2/n - (S1/n)^2, 0))
@@ -203,14 +243,20 @@ int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, 
  * the step model per (time, pair of step inputs), a costate and a sensitivity recursion, and
  * sum_k S_k^T M_k S_k on the matrix cores (hessian_adj.hip).  May (re)allocate scratch, with a stream sync,
  * the first time a batch size is seen.  R_out: double[batch][128][128]; state/a_mean are strided by
- * COVO_STATE_FLOATS / 128 per batch entry; traj is shared. */
+ * COVO_STATE_FLOATS / 128 per batch entry; traj is shared.  The reward is params->reward_kind's.
+ * f_disturb_steps [DEVICE float[batch][COVO_H][4], nullable]: covo_disturb_table(COVO_DISTURB_KEYS_HESSIAN, deterministic = 1)
+ * -- required for params->disturb_kind PERIODIC / SIN / DRAG / MIXED (get_hessian's deterministic=True only switches the
+ * gaussian model off, quadrotor.py:234-235); NULL = no force after step 0.  DRAG / MIXED make the force part of the
+ * differentiated state (16 instead of 13 components): those two run the per-pair kernel (covo_hessian_pairs). */
 int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                 const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream);
+                 const covo_env_params *params, const float *a_mean, const float *f_disturb_steps, int32_t batch,
+                 double *R_out, void *stream);
 
 /* The same Hessian by one hyper-dual ROLLOUT per unordered pair of actions (hessian.hip): ~4x slower,
  * derived independently; kept as the cross-check of covo_hessian. */
 int covo_hessian_pairs(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                       const covo_env_params *params, const float *a_mean, int32_t batch, double *R_out, void *stream);
+                       const covo_env_params *params, const float *a_mean, const float *f_disturb_steps, int32_t batch,
+                       double *R_out, void *stream);
 
 /* CoVO's optimal covariance (controllers/covo.py:116-132) and the lower Cholesky factor
  * jax.random.multivariate_normal takes of it (covo.py:216-218).  The reference's
@@ -275,10 +321,15 @@ typedef struct covo_step_args {
     int64_t sample_offset;   /* global id of this shard's first sample */
     float gamma_mean;
     float sample_sigma;
-    int32_t derive_keys;     /* 1: key0/key1 are the controller's raw rng_act; the sampling key (covo.py:212, mppi.py:53)
-                              *    and, for MPPI, the shared disturbance draw (mppi.py:69,74) are derived from it on the
-                              *    device exactly as the Python host does (random.py) -- f_disturb_shared is ignored */
-    float shared_noise_scale;/* derive_keys: dyn_noise_scale of the shared gaussian disturbance (0 -> none; CoVO: 0) */
+    int32_t derive_keys;     /* 1: key0/key1 are the controller's raw rng_act; the sampling key (covo.py:212, mppi.py:53), the
+                              *    rollouts' step key (covo.py:225, mppi.py:69) and everything drawn from it -- MPPI's shared
+                              *    gaussian vector, the uniform draws of PERIODIC / MIXED, get_hessian's per-step keys
+                              *    (covo.py:150-153, keyed by the raw rng_act) -- are derived on the device exactly as the Python
+                              *    host does (random.py); f_disturb_shared is ignored.
+                              * 0: key0/key1 = the sampling key; f_disturb_shared as given; PERIODIC / SIN / DRAG / MIXED need
+                              *    derive_keys = 1 */
+    int32_t rollout_deterministic; /* step_env's `deterministic` in the sampling rollouts: 1 for CoVO (covo.py:231), 0 for MPPI
+                              *    (mppi.py:74): switches the GAUSSIAN model off (quadrotor.py:234-235) */
 } covo_step_args;
 
 int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, uint32_t key0,
@@ -320,22 +371,26 @@ int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, flo
  * the true state, advanced in place; `noisy_state` receives the noisy copy of the NEW state (the controller's input);
  * `action` = float[4] on the device (the controller's u); `step_key` = uint32[2] on the HOST: the key Quad3D.step
  * receives -- the kernel derives the (disturbance, pos, vel, quat, omega) noise keys from it like the Python env; log (nullable) float[..][4] gets
- * {reward, err_pos, err_vel, done} of the PRE-step state at row log_index.  acc_traj: float[T][3]. */
+ * {reward, err_pos, err_vel, done} of the PRE-step state at row log_index.  acc_traj: float[T][3].  Reward and disturbance
+ * model (all six of free.py:9-72, the next step's force from the PRE-step state) follow params->reward_kind / disturb_kind. */
 int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float *pos_traj, const float *vel_traj,
                   const float *acc_traj, int32_t T, const covo_env_params *params, const float *action,
-                  const uint32_t *step_key, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
-                  float obs_noise_scale, float *log, int32_t log_index, void *stream);
+                  const uint32_t *step_key, int32_t noisy_on, float obs_noise_scale, float *log, int32_t log_index,
+                  void *stream);
 
 /* covo-offline's nominal trajectory (controllers/covo.py:58-99 with the PID law of controllers/pid.py:38-84 and the
  * expansion gains of covo.py:48-53): from `state0` (float[32], true reset state) `n_steps` PID-tracked,
  * NON-deterministic env steps (keys split from key0/key1 as the Python loop does) give states_out float[n_steps][32];
  * from each of them H deterministic PID steps give the nominal means a_means_out float[n_steps][128] -- the inputs of
  * the batched covo_hessian / covo_sigma that build the per-episode Sigma table.  `pid_params`: the parameters the PID
- * law uses (pid.py:33: the env's DEFAULT m, g, max_thrust, max_omega even under domain randomisation). */
+ * law uses (pid.py:33: the env's DEFAULT m, g, max_thrust, max_omega even under domain randomisation).  All disturbance
+ * models of params->disturb_kind act in both loops (the nominal one is deterministic=True: GAUSSIAN off).
+ * keys_out [DEVICE uint32[n_steps][2], nullable]: the scan's carry key at every start state = the key get_hessian receives
+ * for that row (covo.py:77) -> covo_disturb_table(keys_dev = keys_out, COVO_DISTURB_KEYS_HESSIAN). */
 int covo_pid_nominal(covo_handle_t h, const float *state0, const float *pos_traj, const float *vel_traj,
                      const float *acc_traj, int32_t T, const covo_env_params *params, const covo_env_params *pid_params,
-                     float Kp, float Kd, float Kp_att, float noise_scale, uint32_t key0, uint32_t key1, int32_t n_steps,
-                     float *states_out, float *a_means_out, void *stream);
+                     float Kp, float Kd, float Kp_att, uint32_t key0, uint32_t key1, int32_t n_steps,
+                     float *states_out, float *a_means_out, uint32_t *keys_out, void *stream);
 
 /* A whole closed-loop episode segment with no host work between the steps (the reference traces
  * eval_env's run_one_step into one XLA program, envs/quadrotor.py:506-591): n_steps x { covo_mpc_step on the noisy state
@@ -344,8 +399,8 @@ int covo_pid_nominal(covo_handle_t h, const float *state0, const float *pos_traj
  * NOISY state buffer (float[32], rewritten by every env step); state_true float[32]; rng uint32[2] in/out (host);
  * log float[n_steps][4] (nullable).  Asynchronous: returns after enqueueing; one sync at the end of the episode. */
 int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, float *state_true,
-                     const float *acc_traj, int32_t disturb_gaussian, int32_t noisy_on, float dyn_noise_scale,
-                     float obs_noise_scale, float *log, uint32_t *rng, int32_t n_steps, void *stream);
+                     const float *acc_traj, int32_t noisy_on, float obs_noise_scale, float *log, uint32_t *rng,
+                     int32_t n_steps, void *stream);
 
 /* Profiling aid: `reps` copies of the selected launches of one control step, captured into one hipGraph and
  * replayed; *us_out = GPU microseconds per copy.  step_mask bits: 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM,
@@ -365,7 +420,8 @@ int covo_debug_raise_device_status(covo_handle_t h, int32_t bits, void *stream);
  * (rollout_pipe3_kernel<..., REC = true>).  Synchronises the stream.  Other arguments as covo_rollout_cost (no position
  * statistics). */
 int covo_debug_time_rollout(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
-                            const covo_env_params *params, const float *f_disturb_shared, const float *a, int32_t N,
+                            const covo_env_params *params, const float *f_disturb_shared, const float *f_disturb_steps,
+                            const float *a, int32_t N,
                             float *cost_out, float *groupmin, int32_t with_records, int32_t reps, float *us_out /* [host float[2]] */,
                             void *stream);
 

@@ -33,7 +33,10 @@ def test_load_and_abi_version(built):
 
 
 def test_struct_layouts_match_header(built):
-    assert ctypes.sizeof(built.EnvParamsC) == 4 * (1 + 3 + 3 + 5 + 1 + 1 + 1)  # + rollover_terminate (ABI 2)
+    # + rollover_terminate (ABI 2); + reward_kind, disturb_kind, disturb_period, disturb_scale, disturb_params[6], dyn_noise_scale (ABI 3)
+    assert ctypes.sizeof(built.EnvParamsC) == 4 * (1 + 3 + 3 + 5 + 1 + 1 + 1 + 4 + 6 + 1)
+    assert built.EnvParamsC.reward_kind.offset == 60 and built.EnvParamsC.disturb_params.offset == 76
+    assert built.StepArgsC.rollout_deterministic.offset == built.StepArgsC.derive_keys.offset + 4
     assert ctypes.sizeof(built.ConfigC) == 24
 
 

@@ -1,0 +1,400 @@
+"""GPU parity tests (-m gpu) of the reward / disturbance variants: every disturbance model of
+quadjax/dynamics/free.py:9-72 and both rewards Quad3D binds (dynamics/utils.py:285-313) in the rollout, the Hessian, the env
+step, covo-offline's nominal kernels and the fused step -- through the C ABI, against the CPU oracle (oracle/ref_np.py,
+covo_oracle.c) on the same inputs and the same explicit draws.  Tolerances: rollout cost <= 1e-5 relative (north_star);
+Hessian <= 1e-9 (no force table) / 2e-8 relative to max|R| (force table: its entries are fp32 like the reference's f_disturb).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("needs the MI355X", allow_module_level=True)
+
+from covo_mpc_amd import _lib  # noqa: E402
+from covo_mpc_amd import random as cr  # noqa: E402
+from covo_mpc_amd.controllers._core import SamplingCore  # noqa: E402
+from covo_mpc_amd.dynamics.dataclass import EnvParams3D  # noqa: E402
+from oracle import c_oracle as CO  # noqa: E402
+from oracle import ref_np as R  # noqa: E402
+from tests.conftest import make_problem  # noqa: E402
+from tests.test_gpu_parity import DEV, dev_state, rel_err, sample_actions, to_stripes  # noqa: E402
+
+KINDS = ["periodic", "sin", "drag", "mixed"]
+DP = (0.7, -0.4, 0.9, 0.15, -0.35, 0.6)  # disturb_params: every component live (dataclass.py:88; DR / reset draw them)
+
+
+def params_c(p: R.Params, kind="none", reward="penyaw", rollover=False):
+    e = EnvParams3D(disturb_params=np.asarray(p.disturb_params, dtype=np.float32), disturb_period=p.disturb_period,
+                    disturb_scale=p.disturb_scale, dyn_noise_scale=p.dyn_noise_scale)
+    return e.to_c(rollover_terminate=rollover, reward=reward, disturb_type=kind)
+
+
+def disturb_key(k):
+    """disturb_key of step_env(k): quadrotor.py:262, free.py:136,144"""
+    return cr.split(cr.split(cr.split(k)[1])[0])[0]
+
+
+def step_keys(key, mode, H=32):
+    """the key step_env receives at every rollout step (include/covo_hip.h: COVO_DISTURB_KEYS_*)"""
+    out = []
+    for _ in range(H):
+        if mode == _lib.DISTURB_KEYS_SHARED:
+            out.append(key)
+        elif mode == _lib.DISTURB_KEYS_HESSIAN:  # covo.py:151
+            rk, key = cr.split(key)
+            out.append(rk)
+        else:  # covo.py:60,66
+            _, key = cr.split(key)
+            rs, key = cr.split(key)
+            out.append(rs)
+    return out
+
+
+def uniform_draws(p, key, mode, H=32):
+    """(H,3): uniform(disturb_key, (3,), -scale, scale) of every step (free.py:16-21)"""
+    return np.stack([cr.uniform(disturb_key(k), (3,), -p.disturb_scale, p.disturb_scale) for k in step_keys(key, mode, H)])
+
+
+def table_ref(p, s, kind, draws, H=32):
+    """The table of csrc/disturb.hip from the oracle's model functions: row k = {g_k, c_k},
+    f_k = c_drag drag(vel_{k-1}) + c_k f_{k-1} + g_k."""
+    tab = np.zeros((H, 4))
+    f = np.asarray(s.f_disturb, dtype=np.float64)
+    for k in range(H - 1):
+        sk = s.replace(time=s.time + k, f_disturb=f)
+        hit = (s.time + k) % p.disturb_period == 0
+        if kind == "periodic":
+            g = R.period_disturb(draws[k], p, sk)
+            f = g
+            c = 0.0
+        elif kind == "sin":
+            g, c = R.sin_disturb(p, sk), 0.0
+        elif kind == "mixed":
+            g = (R.sin_disturb(p, sk) + (draws[k] if hit else 0.0)) / 3.0
+            c = 0.0 if hit else 1.0 / 3.0
+        else:
+            g, c = np.zeros(3), 0.0
+        tab[k + 1, :3], tab[k + 1, 3] = g, c
+    return tab
+
+
+# ------------------------------------------------------------------------------------------ the table
+@pytest.mark.parametrize("kind", KINDS + ["gaussian"])
+@pytest.mark.parametrize("mode", [_lib.DISTURB_KEYS_SHARED, _lib.DISTURB_KEYS_HESSIAN, _lib.DISTURB_KEYS_NOMINAL])
+def test_disturb_table_vs_model_functions(kind, mode):
+    s, p, rng = make_problem(seed=5, time=93)  # steps 7 (time 100) and none other redraw; time 93 + 31 < 150
+    p = p.replace(disturb_params=DP, disturb_period=10 if mode == _lib.DISTURB_KEYS_HESSIAN else 50)  # period 10: three redraws
+    core = SamplingCore(64, 32, 0.01, 1.0, device=DEV)
+    key = cr.PRNGKey(77)
+    ds = dev_state(s)
+    tab = core.disturb_table(params_c(p, kind), ds.packed, key=key, key_mode=mode, deterministic=False)[0].cpu().numpy()
+    if kind == "gaussian":
+        z = np.stack([cr.normal(disturb_key(k), (3,)) for k in step_keys(key, mode)])
+        assert np.abs(tab[1:, :3] - np.float32(p.dyn_noise_scale) * z[:-1]).max() < 1e-7 and np.all(tab[:, 3] == 0)
+        det = core.disturb_table(params_c(p, kind), ds.packed, key=key, key_mode=mode, deterministic=True)[0].cpu().numpy()
+        assert np.all(det == 0)
+        return
+    draws = uniform_draws(p, key, mode)
+    ref = table_ref(p, s, kind, draws)
+    assert np.abs(tab - ref).max() < 2e-7, np.abs(tab - ref).max()
+    hits = [(s.time + k) % p.disturb_period == 0 for k in range(31)]
+    assert sum(hits) == (3 if mode == _lib.DISTURB_KEYS_HESSIAN else 1)
+    # batch: per-entry keys from a device array, per-entry states
+    keys = np.stack([cr.PRNGKey(77), cr.PRNGKey(78)]).astype(np.uint32)
+    s2 = s.replace(time=s.time + 3, f_disturb=s.f_disturb * 0.5)
+    packed = torch.stack([ds.packed, dev_state(s2).packed])
+    kd = torch.from_numpy(keys.view(np.int32)).to(DEV)
+    tb = core.disturb_table(params_c(p, kind), packed, keys_dev=kd, key_mode=mode, deterministic=True, batch=2).cpu().numpy()
+    assert np.array_equal(tb[0], tab)
+    assert np.abs(tb[1] - table_ref(p, s2, kind, uniform_draws(p, keys[1], mode))).max() < 2e-7
+
+
+# ------------------------------------------------------------------------------------------ rollout
+def _rollout_dev(core, s, pc, a, f_shared=(0.0, 0.0, 0.0), tab=None, want_stats=False):
+    core.a.copy_(to_stripes(a))
+    return core.rollout(dev_state(s), pc, f_shared, want_stats, f_steps=tab).cpu().numpy()
+
+
+@pytest.mark.parametrize("reward", ["penyaw", "realworld"])
+@pytest.mark.parametrize("kind", ["none", "gaussian"] + KINDS)
+def test_rollout_reward_and_disturbance_variants_vs_fp64_oracle(kind, reward):
+    if kind in ("none", "gaussian") and reward == "penyaw":
+        pytest.skip("the default family: tests/test_gpu_parity.py")
+    s, p, rng = make_problem(seed=17, time=37)  # time 37: step 13 (time 50) redraws the periodic part
+    p = p.replace(disturb_params=DP)
+    N = 3000
+    a = sample_actions(p, rng, N)
+    key = cr.PRNGKey(5)
+    core = SamplingCore(N, 32, 0.01, 0.97, device=DEV)
+    pc = params_c(p, kind, reward)
+    ds = dev_state(s)
+    if kind in KINDS:
+        tab = core.disturb_table(pc, ds.packed, key=key, key_mode=_lib.DISTURB_KEYS_SHARED, deterministic=True)
+        draw = cr.uniform(disturb_key(key), (3,), -p.disturb_scale, p.disturb_scale).astype(np.float64)
+        cost = _rollout_dev(core, s, pc, a, tab=tab, want_stats=True)
+        ref, rew, poses = CO.rollout(s, p, a.astype(np.float64), 0.97, dtype=np.float64, want_rewards=True, want_poses=True,
+                                     reward=reward, disturb=R.Disturb(kind, draw, True))
+    else:
+        fs = np.array([0.02, -0.03, 0.01], dtype=np.float32)
+        cost = _rollout_dev(core, s, pc, a, f_shared=fs, want_stats=True)
+        ref, rew, poses = CO.rollout(s, p, a.astype(np.float64), 0.97, fs.astype(np.float64), dtype=np.float64, want_rewards=True,
+                                     want_poses=True, reward=reward)
+    assert rel_err(cost, ref).max() < 1e-5, rel_err(cost, ref).max()
+    # the variant matters (guards against a silently ignored switch)
+    base = CO.rollout(s, p, a.astype(np.float64), 0.97, dtype=np.float64)
+    assert np.abs(base - ref).max() > 1e-3
+    # position statistics of the same launch (covo.py:281) and the per-wave minima
+    info = core.info(ds)
+    pm, ps = R.pos_stats(poses)
+    assert np.abs(info["pos_mean"].cpu().numpy() - pm).max() < 2e-5 and np.abs(info["pos_std"].cpu().numpy() - ps).max() < 2e-5
+    assert np.array_equal(core.blockmin.cpu().numpy(), np.array([cost[i:i + 64].min() for i in range(0, N, 64)], dtype=np.float32))
+    # no statistics: same costs bit for bit
+    cost2 = _rollout_dev(core, s, pc, a, f_shared=(0.02, -0.03, 0.01), tab=tab if kind in KINDS else None)
+    assert np.array_equal(cost, cost2)
+
+
+@pytest.mark.parametrize("kind,reward,N", [("mixed", "penyaw", 70016), ("periodic", "realworld", 20000), ("drag", "realworld", 257),
+                                           ("sin", "penyaw", 1)])
+def test_rollout_variants_shapes_rollover_and_freeze(kind, reward, N):
+    """1 / 2 / 4 groups per workgroup, ragged tails, rollover termination on, samples leaving the box (frozen rewards)."""
+    s, p, rng = make_problem(seed=23, time=290)  # the horizon passes the episode end: time >= 300 terminates
+    p = p.replace(disturb_params=DP, disturb_period=7)  # several redraws inside the horizon
+    s = s.replace(pos=s.pos + np.array([2.7, 0, 0]), vel=s.vel + np.array([2.0, 0, 0]))
+    a = np.clip(R.hover_action(p, 32, np.float64)[None] + np.array([0.3, 1.2, 1.2, 0.5]) * rng.normal(size=(N, 32, 4)), -1, 1)
+    a = a.astype(np.float32)
+    key = cr.PRNGKey(9)
+    core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
+    pc = params_c(p, kind, reward, rollover=True)
+    tab = core.disturb_table(pc, dev_state(s).packed, key=key, key_mode=_lib.DISTURB_KEYS_SHARED, deterministic=True)
+    cost = _rollout_dev(core, s, pc, a, tab=tab)
+    idx = rng.choice(N, min(N, 3000), replace=False)
+    draw = cr.uniform(disturb_key(key), (3,), -p.disturb_scale, p.disturb_scale).astype(np.float64)
+    d = R.Disturb(kind, draw, True)
+    ref = CO.rollout(s, p, a[idx].astype(np.float64), 1.0, dtype=np.float64, rollover=True, reward=reward, disturb=d)
+    ref32 = CO.rollout(s.astype(np.float32), p, a[idx], 1.0, dtype=np.float32, rollover=True, reward=reward, disturb=d)
+    err = np.minimum(rel_err(cost[idx], ref), rel_err(cost[idx], ref32.astype(np.float64)))  # rollover ties: see test_gpu_parity
+    assert (err < 1e-5).mean() > 0.995 and np.median(err) < 3e-6, (err.max(), np.median(err))
+
+
+# ------------------------------------------------------------------------------------------ Hessian
+@pytest.mark.parametrize("kind,reward,method", [("none", "realworld", "adjoint"), ("none", "realworld", "pairs"),
+                                                ("periodic", "penyaw", "adjoint"), ("periodic", "realworld", "pairs"),
+                                                ("sin", "realworld", "adjoint"), ("sin", "penyaw", "pairs"),
+                                                ("drag", "penyaw", "adjoint"), ("mixed", "realworld", "adjoint"),
+                                                ("mixed", "penyaw", "pairs")])
+def test_hessian_reward_and_disturbance_variants_vs_ad_oracle(kind, reward, method):
+    """covo_hessian for every model against the fp64 hyper-dual C oracle (itself equal to torch forward-over-forward AD:
+    tests/test_oracle.py).  drag / mixed: covo_hessian routes to the per-pair kernel (the force is differentiated state)."""
+    s, p, rng = make_problem(seed=3, time=41)  # step 9 (time 50) redraws
+    p = p.replace(disturb_params=DP)
+    a = (R.hover_action(p, 32, np.float64) + 0.1 * rng.normal(size=(32, 4))).astype(np.float32)
+    a[3, 1] = 1.0  # clip tie (two clips on the path)
+    key = cr.PRNGKey(21)
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    ds = dev_state(s)
+    pc = params_c(p, kind, reward)
+    tab = None
+    draws = None
+    if kind in KINDS:
+        tab = core.disturb_table(pc, ds.packed, key=key, key_mode=_lib.DISTURB_KEYS_HESSIAN, deterministic=True)
+        draws = uniform_draws(p, key, _lib.DISTURB_KEYS_HESSIAN).astype(np.float64)
+    Rm = core.hessian(ds.packed, ds, pc, torch.from_numpy(a.reshape(-1)).to(DEV), method=method, f_steps=tab)[0].cpu().numpy()
+    ref = CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32, reward=reward, kind=kind, draws=draws)
+    assert np.abs(Rm - Rm.T).max() == 0.0 and np.abs(Rm[124:]).max() == 0.0
+    tol = 1e-9 if kind == "none" else 2e-8
+    assert np.abs(Rm - ref).max() < tol * max(1.0, np.abs(ref).max()), np.abs(Rm - ref).max()
+    other = CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32)  # penyaw, no force: a different matrix
+    assert np.abs(other - ref).max() > 1e-6
+
+
+def test_hessian_batched_with_force_tables():
+    """batch > 1 (covo-offline's table): per-entry states, means, keys and force tables."""
+    s, p, rng = make_problem(seed=8, time=45)
+    p = p.replace(disturb_params=DP)
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    B = 5
+    states, means, keys, refs = [], [], [], []
+    pc = params_c(p, "periodic", "realworld")
+    for b in range(B):
+        sb = s.replace(time=s.time + b, pos=s.pos + 0.01 * b, f_disturb=s.f_disturb * (1 + 0.1 * b))
+        ab = (R.hover_action(p, 32, np.float64) + 0.1 * rng.normal(size=(32, 4))).astype(np.float32)
+        kb = cr.PRNGKey(100 + b)
+        states.append(dev_state(sb).packed)
+        means.append(torch.from_numpy(ab.reshape(-1)).to(DEV))
+        keys.append(kb)
+        refs.append(CO.hessian(sb, p, ab.reshape(-1).astype(np.float64), 32, reward="realworld", kind="periodic",
+                               draws=uniform_draws(p, kb, _lib.DISTURB_KEYS_HESSIAN).astype(np.float64)))
+    packed, am = torch.stack(states), torch.stack(means)
+    kd = torch.from_numpy(np.stack(keys).astype(np.uint32).view(np.int32)).to(DEV)
+    tab = core.disturb_table(pc, packed, keys_dev=kd, key_mode=_lib.DISTURB_KEYS_HESSIAN, deterministic=True, batch=B)
+    Rm = core.hessian(packed, dev_state(s), pc, am, batch=B, f_steps=tab).cpu().numpy()
+    for b in range(B):
+        assert np.abs(Rm[b] - refs[b]).max() < 2e-8 * max(1.0, np.abs(refs[b]).max()), b
+
+
+# ------------------------------------------------------------------------------------------ env step / nominal / fused step
+@pytest.mark.parametrize("task,kind", [("tracking_zigzag", "periodic"), ("tracking_slow", "mixed"), ("tracking_slow", "sin"),
+                                       ("tracking", "drag"), ("tracking_slow", "none")])
+def test_env_step_kernel_models_vs_host_env(task, kind):
+    """covo_env_step with every disturbance model / both rewards against the Python env on the same keys and actions."""
+    import covo_mpc_amd as cm
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params.replace(disturb_params=np.asarray(DP, dtype=np.float32), disturb_period=9)
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(11), params, (core.lib, core.h), DEV)
+    obs, info, state = env.reset(cr.PRNGKey(11), params)
+    rng = np.random.default_rng(5)
+    key = cr.PRNGKey(12)
+    rewards, forces = [], []
+    for t in range(40):
+        key, k_step = cr.split(key)
+        u = np.clip(np.array([-0.3378, 0, 0, 0]) + 0.3 * rng.normal(size=4), -1.2, 1.2).astype(np.float32)
+        ep.step(k_step, torch.from_numpy(u).to(DEV))
+        obs, state, reward, done, info = env.step(k_step, state, u, params)
+        rewards.append(reward)
+        forces.append(state.f_disturb.copy())
+        t_dev = ep.true.cpu().numpy()
+        assert np.abs(t_dev - state.pack()).max() < 2e-5, (t, np.abs(t_dev - state.pack()).max())
+        assert np.abs(ep.noisy.cpu().numpy() - info["noisy_state"].pack()).max() < 2e-5, t
+    log = ep.read_log()
+    assert np.abs(log[:, 0] - np.asarray(rewards)).max() < 2e-5
+    forces = np.asarray(forces)
+    if kind != "none":
+        assert np.abs(forces).max() > 1e-3 and len(np.unique(forces[:, 0])) > (2 if kind == "periodic" else 10)
+
+
+@pytest.mark.parametrize("kind", ["periodic", "mixed", "drag"])
+def test_offline_nominal_and_table_with_disturbance_models(kind):
+    """covo-offline reset under the state / time dependent models: device chain + nominal rollouts (covo_pid_nominal) against
+    the Python loop, and rows of the Sigma table against the oracle's Hessian -> optimize_sigma of those nominal means."""
+    import covo_mpc_amd as cm
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    controller, cp = cm.envs.get_controller(env, "covo-offline", "N1024_H32_lam0.01", device=DEV)
+    params = env.default_params.replace(disturb_params=np.asarray(DP, dtype=np.float32))
+    obs, info, state = env.reset(cr.PRNGKey(31), params)
+    ph, ah = controller._nominal_host(state, params, cr.PRNGKey(32))
+    pd, ad, kd = controller._nominal_device(state, params, cr.PRNGKey(32))
+    pd, ad = pd.cpu().numpy(), ad.cpu().numpy()
+    assert np.abs(pd[:, :25] - ph[:, :25]).max() < 5e-5, np.abs(pd[:, :25] - ph[:, :25]).max()
+    assert np.abs(ad - ah).max() < 3e-4, np.abs(ad - ah).max()
+    assert np.abs(ph[:, 13:16]).max() > 1e-3
+    # the scan's carry keys
+    key = cr.PRNGKey(32)
+    kd = kd.cpu().numpy().view(np.uint32)
+    for t in range(5):
+        assert np.array_equal(kd[t], key)
+        _, key = cr.split(key)
+        _, key = cr.split(key)
+    # the table rows (batch-300 Hessian + Sigma) against the oracle on the DEVICE's nominal states / means
+    cp2 = controller.reset(state, params, cp, cr.PRNGKey(32))
+    p = R.Params().fp32().replace(disturb_params=DP)
+    for t in (0, 49, 50, 137, 299):
+        st = pd[t]
+        so = R.State(pos=st[0:3], vel=st[3:6], quat=st[6:10], omega=st[10:13], f_disturb=st[13:16], pos_tar=st[16:19],
+                     vel_tar=st[19:22], acc_tar=st[22:25], time=int(st[25:26].view(np.int32)[0]), pos_traj=state.pos_traj,
+                     vel_traj=state.vel_traj, acc_traj=state.acc_traj).astype(np.float64)
+        draws = uniform_draws(p, kd[t], _lib.DISTURB_KEYS_HESSIAN).astype(np.float64)
+        Rm = CO.hessian(so, p, ad[t].astype(np.float64), 32, kind=kind, draws=draws)
+        Sref = R.optimize_sigma(Rm, 0.5, 32, 4)
+        S = cp2.a_cov_offline[t].cpu().numpy()
+        assert np.linalg.norm(S - Sref) / np.linalg.norm(Sref) < 2e-5, (t, np.linalg.norm(S - Sref) / np.linalg.norm(Sref))
+        L = cp2.a_chol_offline[t].cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(L @ L.T - S) / np.linalg.norm(S) < 1e-6
+
+
+@pytest.mark.parametrize("graph", ["graph", "eager"])
+@pytest.mark.parametrize("name,task,kind", [("covo-online", "tracking_zigzag", "periodic"), ("covo-online", "tracking_slow", "mixed"),
+                                            ("mppi", "tracking_slow", "drag"), ("covo-offline", "tracking_slow", "sin"),
+                                            ("mppi", "hovering", "periodic"), ("covo-online", "tracking_slow", "gaussian")])
+def test_fused_step_with_models_equals_kernel_by_kernel_and_oracle(name, task, kind, graph, monkeypatch):
+    """The fused step derives the step's force tables on the device from the raw controller key (disturb.hip); the
+    kernel-by-kernel path builds them through covo_disturb_table from host-split keys: same bits.  The costs of the last step
+    are then checked against the oracle with the draws the reference's key threading gives."""
+    import covo_mpc_amd as cm
+    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params.replace(disturb_params=np.asarray(DP, dtype=np.float32), disturb_period=4)
+    N = 2048
+    outs = []
+    for fused in (True, False):
+        controller, cp = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
+        controller.materialize_eps = not fused
+        obs, info, state = env.reset(cr.PRNGKey(3), params)
+        cp = controller.reset(state, params, cp, cr.PRNGKey(4))
+        key = cr.PRNGKey(6)
+        for i in range(5):
+            key, k_act, k_step = cr.split(key, 3)
+            u, cp_new, cinfo = controller(obs, state, params, k_act, cp, info)
+            ns, cp_prev, cp = info["noisy_state"], cp, cp_new
+            obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+        outs.append((cp.a_mean.cpu().numpy().copy(), controller.core.cost.cpu().numpy().copy(),
+                     controller.core.a.permute(1, 0, 2).contiguous().cpu().numpy().copy(),
+                     cinfo["pos_mean"].cpu().numpy().copy(), ns, k_act))
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][3], outs[1][3])
+    # oracle: the last step's costs on the device's own actions
+    a_dev, cost_dev, ns, k_act = outs[0][2], outs[0][1], outs[0][4], outs[0][5]
+    so = R.State(pos=ns.pos, vel=ns.vel, quat=ns.quat, omega=ns.omega, f_disturb=ns.f_disturb, pos_tar=ns.pos_tar,
+                 vel_tar=ns.vel_tar, acc_tar=ns.acc_tar, time=ns.time, pos_traj=ns.pos_traj, vel_traj=ns.vel_traj,
+                 acc_traj=ns.acc_traj).astype(np.float64)
+    p = R.Params().fp32().replace(disturb_params=DP, disturb_period=4)
+    step_key = cr.split(cr.split(k_act)[0])[1]  # rng, act_key = split(rng_act); rng, step_key = split(rng)  (covo.py:212,225)
+    det = name != "mppi"
+    reward = "realworld" if task == "tracking_slow" else "penyaw"
+    if kind == "gaussian":
+        d = R.Disturb("gaussian", cr.normal(disturb_key(step_key), (3,)).astype(np.float64), det)
+    else:
+        d = R.Disturb(kind, cr.uniform(disturb_key(step_key), (3,), -p.disturb_scale, p.disturb_scale).astype(np.float64), det)
+    ref = CO.rollout(so, p, a_dev.astype(np.float64), 1.0, dtype=np.float64, reward=reward, disturb=d)
+    assert rel_err(cost_dev, ref).max() < 1e-5, rel_err(cost_dev, ref).max()
+    if name == "covo-online":  # the Sigma the last step sampled from: oracle Hessian with get_hessian's per-step keys
+        am = R.shift_mean(cp_prev.a_mean.cpu().numpy().astype(np.float64))
+        draws = uniform_draws(p, k_act, _lib.DISTURB_KEYS_HESSIAN).astype(np.float64) if kind in KINDS else None
+        Rm = CO.hessian(so, p, am.reshape(-1), 32, reward=reward, kind=kind, draws=draws)
+        Sref = R.optimize_sigma(Rm, 0.5, 32, 4)
+        S = cp.a_cov.cpu().numpy()
+        assert np.linalg.norm(S - Sref) / np.linalg.norm(Sref) < 2e-5
+
+
+@pytest.mark.parametrize("name,task,kind", [("covo-online", "tracking_slow", "periodic"), ("mppi", "tracking_zigzag", "mixed")])
+def test_run_episode_with_models_equals_python_loop(name, task, kind):
+    import covo_mpc_amd as cm
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params.replace(disturb_params=np.asarray(DP, dtype=np.float32), disturb_period=5)
+    n = 16
+    outs = []
+    for fused in (False, True):
+        controller, _ = cm.envs.get_controller(env, name, "N2048_H32_lam0.01", device=DEV, compute_info=False)
+        controller.alias_outputs = True
+        core = controller.core
+        ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(41), params, (core.lib, core.h), DEV)
+        cp = controller.reset(ep.state0, params, controller.init_control_params, cr.PRNGKey(42))
+        rng = cr.PRNGKey(43)
+        if fused:
+            cp, rng = controller.run_episode(ep, params, cp, rng, n)
+        else:
+            for _ in range(n):
+                rng, rng_act, rng_step, rng_control = cr.split(rng, 4)
+                u, cp, _ = controller(None, None, params, rng_act, cp, {"noisy_state": ep.noisy_state})
+                ep.step(rng_step, u)
+                rng, rng_control = cr.split(rng)
+        outs.append((ep.read_log().copy(), cp.a_mean.cpu().numpy().copy(), ep.true.cpu().numpy().copy()))
+    assert all(np.array_equal(x, y) for x, y in zip(outs[0], outs[1]))
+    assert np.abs(outs[0][2][13:16]).max() > 1e-4  # a force is acting
+
+
+def test_tracking_slow_closed_loop_sanity():
+    """tracking_slow (quadratic reward, slow lissajous) closed loop on the device: the controller tracks."""
+    import covo_mpc_amd as cm
+    env = cm.envs.Quad3D(task="tracking_slow", enable_randomizer=False, disturb_type="periodic",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    controller, _ = cm.envs.get_controller(env, "covo-online", "N4096_H32_lam0.01", device=DEV, compute_info=False)
+    err = cm.envs.eval_env_device(env, controller, total_steps=300, num_trajs=1, verbose=False)
+    assert err.shape == (1,) and err[0] < 0.25, err
