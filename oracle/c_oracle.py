@@ -153,14 +153,16 @@ def sampling_step(s, p, L, a_mean, eps, lam, gamma_mean=1.0, discount=1.0, threa
     return out.reshape(H, 4), cost, a_work
 
 
-def hessian(s, p, a_flat, H=32, threads=None, reward="penyaw", kind="none", draws=None):
+def hessian(s, p, a_flat, H=32, threads=None, reward="penyaw", kind="none", draws=None, table=None):
     """covo.py:134-185 by hyper-dual forward-over-forward AD in C (fp64, OpenMP over the n(n+1)/2 pairs).
     kind / draws (H,3): the disturbance model and its per-step uniform draws (free.py:10-58; get_hessian splits its key
-    once per step, covo.py:151)."""
+    once per step, covo.py:151).  table (H,4): the per-step force table given explicitly instead (rows {g_k, c_k} of
+    include/covo_hip.h's covo_disturb_table; `kind` then only selects the drag coefficient)."""
     if threads is not None:
         os.environ["OMP_NUM_THREADS"] = str(threads)
     prm = params_vec(p)
     st = state22(s, np.float64)
+    tb = np.ascontiguousarray(table, dtype=np.float64).reshape(H, 4) if table is not None else None
     pt = np.ascontiguousarray(s.pos_traj, dtype=np.float64)
     vt = np.ascontiguousarray(s.vel_traj, dtype=np.float64)
     a = np.ascontiguousarray(a_flat, dtype=np.float64).reshape(-1)
@@ -172,5 +174,5 @@ def hessian(s, p, a_flat, H=32, threads=None, reward="penyaw", kind="none", draw
     f.restype = None
     cd = C.c_double
     f(_p(prm, cd), _p(st, cd), C.c_int(int(s.time)), _p(pt, cd), _p(vt, cd), C.c_int(pt.shape[0]), _p(a, cd), C.c_int(H),
-      _p(R, cd), C.c_int(REWARD_KINDS[reward]), _p(dist, cd), _p(dr, cd))
+      _p(R, cd), C.c_int(REWARD_KINDS[reward]), _p(dist, cd), _p(dr, cd), _p(tb, cd))
     return R

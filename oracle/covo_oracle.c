@@ -252,9 +252,12 @@ static void hd_dyn_step(hd_state *s, const hd_t *act, const double *prm)
 /* state22 = [pos vel quat omega f_disturb pos_tar vel_tar] (fp64); a_mean (H*4); R (H*4, H*4) row-major.
  * reward_kind: 0 penyaw (utils.py:285-294), 1 realworld (:297-313); dist (nullable) = [kind, period, scale, disturb_params[6]],
  * draws (H,3) = the per-step uniform draws of the disturbance model (get_hessian splits its key once per step, covo.py:151) */
+/* table (nullable, (H,4) rows {g_k[3], c_k}): the per-step table of include/covo_hip.h (covo_disturb_table) given explicitly --
+ * f_k = c_drag drag(vel_{k-1}) + c_k f_{k-1} + g_k with c_drag = 1 (drag), 1/3 (mixed), 0 otherwise -- instead of the model
+ * functions: checks a Hessian kernel on exactly the (fp32-rounded) forces it was handed. */
 void oracle_hessian_ex_f64(const double *prm, const double *state22, int time, const double *pos_traj, const double *vel_traj,
                            int T, const double *a_mean, int H, double *R, int reward_kind, const double *dist,
-                           const double *draws)
+                           const double *draws, const double *table)
 {
     const int n = H * 4;
     const long npairs = (long)n * (n + 1) / 2;
@@ -282,7 +285,22 @@ void oracle_hessian_ex_f64(const double *prm, const double *state22, int time, c
             }
             hd_t fn[3];
             const double zero9[9] = {0, 1, 0, 0, 0, 0, 0, 0, 0};
-            hd_disturb_next(&s, time + k, dist ? dist : zero9, draws ? draws + 3 * k : zero9 + 3, fn); /* free.py:147 (pre-step state) */
+            if (table) {
+                const int kind = dist ? (int)dist[0] : 0;
+                const double cd = kind == 4 ? 1.0 : (kind == 5 ? 1.0 / 3.0 : 0.0);
+                for (int c = 0; c < 3; ++c) {
+                    hd_t f = hd_c(0.0);
+                    if (k + 1 < H) {
+                        f = hd_addc(hd_scale(s.f[c], table[4 * (k + 1) + 3]), table[4 * (k + 1) + c]);
+                        if (cd != 0.0) {
+                            hd_t rel = hd_addc(s.vel[c], -dist[3 + c] * 0.5);
+                            f = hd_add(f, hd_scale(hd_mul(rel, hd_abs(rel)), cd * (-fabs(dist[2]) / (1.5 * 1.5))));
+                        }
+                    }
+                    fn[c] = f;
+                }
+            } else
+                hd_disturb_next(&s, time + k, dist ? dist : zero9, draws ? draws + 3 * k : zero9 + 3, fn); /* free.py:147 (pre-step state) */
             hd_dyn_step(&s, act, prm);
             for (int c = 0; c < 3; ++c) s.f[c] = fn[c];
             int idx = time + k + 1;
@@ -297,5 +315,5 @@ void oracle_hessian_ex_f64(const double *prm, const double *state22, int time, c
 void oracle_hessian_f64(const double *prm, const double *state22, int time, const double *pos_traj, const double *vel_traj,
                         int T, const double *a_mean, int H, double *R)
 {
-    oracle_hessian_ex_f64(prm, state22, time, pos_traj, vel_traj, T, a_mean, H, R, 0, NULL, NULL);
+    oracle_hessian_ex_f64(prm, state22, time, pos_traj, vel_traj, T, a_mean, H, R, 0, NULL, NULL, NULL);
 }

@@ -37,3 +37,27 @@ def make_problem(seed=0, time=37, dtype=np.float64, task="zigzag"):
 @pytest.fixture
 def problem():
     return make_problem()
+
+
+def table_ref(p, s, kind, draws, H=32):
+    """The table of csrc/disturb.hip from the oracle's model functions: row k = {g_k, c_k},
+    f_k = c_drag drag(vel_{k-1}) + c_k f_{k-1} + g_k."""
+    from oracle import ref_np as R
+    tab = np.zeros((H, 4))
+    f = np.asarray(s.f_disturb, dtype=np.float64)
+    for k in range(H - 1):
+        sk = s.replace(time=s.time + k, f_disturb=f)
+        hit = (s.time + k) % p.disturb_period == 0
+        if kind == "periodic":
+            g = R.period_disturb(draws[k], p, sk)
+            f = g
+            c = 0.0
+        elif kind == "sin":
+            g, c = R.sin_disturb(p, sk), 0.0
+        elif kind == "mixed":
+            g = (R.sin_disturb(p, sk) + (draws[k] if hit else 0.0)) / 3.0
+            c = 0.0 if hit else 1.0 / 3.0
+        else:
+            g, c = np.zeros(3), 0.0
+        tab[k + 1, :3], tab[k + 1, 3] = g, c
+    return tab

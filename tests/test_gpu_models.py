@@ -19,11 +19,12 @@ from covo_mpc_amd.controllers._core import SamplingCore  # noqa: E402
 from covo_mpc_amd.dynamics.dataclass import EnvParams3D  # noqa: E402
 from oracle import c_oracle as CO  # noqa: E402
 from oracle import ref_np as R  # noqa: E402
-from tests.conftest import make_problem  # noqa: E402
+from tests.conftest import make_problem, table_ref  # noqa: E402
 from tests.test_gpu_parity import DEV, dev_state, rel_err, sample_actions, to_stripes  # noqa: E402
 
 KINDS = ["periodic", "sin", "drag", "mixed"]
-DP = (0.7, -0.4, 0.9, 0.15, -0.35, 0.6)  # disturb_params: every component live (dataclass.py:88; DR / reset draw them)
+# disturb_params: every component live (dataclass.py:88; DR / reset draw them); fp32 numbers, like every parameter of the reference
+DP = tuple(float(np.float32(x)) for x in (0.7, -0.4, 0.9, 0.15, -0.35, 0.6))
 
 
 def params_c(p: R.Params, kind="none", reward="penyaw", rollover=False):
@@ -58,29 +59,6 @@ def uniform_draws(p, key, mode, H=32):
     return np.stack([cr.uniform(disturb_key(k), (3,), -p.disturb_scale, p.disturb_scale) for k in step_keys(key, mode, H)])
 
 
-def table_ref(p, s, kind, draws, H=32):
-    """The table of csrc/disturb.hip from the oracle's model functions: row k = {g_k, c_k},
-    f_k = c_drag drag(vel_{k-1}) + c_k f_{k-1} + g_k."""
-    tab = np.zeros((H, 4))
-    f = np.asarray(s.f_disturb, dtype=np.float64)
-    for k in range(H - 1):
-        sk = s.replace(time=s.time + k, f_disturb=f)
-        hit = (s.time + k) % p.disturb_period == 0
-        if kind == "periodic":
-            g = R.period_disturb(draws[k], p, sk)
-            f = g
-            c = 0.0
-        elif kind == "sin":
-            g, c = R.sin_disturb(p, sk), 0.0
-        elif kind == "mixed":
-            g = (R.sin_disturb(p, sk) + (draws[k] if hit else 0.0)) / 3.0
-            c = 0.0 if hit else 1.0 / 3.0
-        else:
-            g, c = np.zeros(3), 0.0
-        tab[k + 1, :3], tab[k + 1, 3] = g, c
-    return tab
-
-
 # ------------------------------------------------------------------------------------------ the table
 @pytest.mark.parametrize("kind", KINDS + ["gaussian"])
 @pytest.mark.parametrize("mode", [_lib.DISTURB_KEYS_SHARED, _lib.DISTURB_KEYS_HESSIAN, _lib.DISTURB_KEYS_NOMINAL])
@@ -99,7 +77,8 @@ def test_disturb_table_vs_model_functions(kind, mode):
         return
     draws = uniform_draws(p, key, mode)
     ref = table_ref(p, s, kind, draws)
-    assert np.abs(tab - ref).max() < 2e-7, np.abs(tab - ref).max()
+    # fp32 sin of an argument of ~15 rad (the host env's own arithmetic, free.py:27-38 in fp32): ~2e-7 on a 0.1 N force
+    assert np.abs(tab - ref).max() < 1e-6, np.abs(tab - ref).max()
     hits = [(s.time + k) % p.disturb_period == 0 for k in range(31)]
     assert sum(hits) == (3 if mode == _lib.DISTURB_KEYS_HESSIAN else 1)
     # batch: per-entry keys from a device array, per-entry states
@@ -109,7 +88,7 @@ def test_disturb_table_vs_model_functions(kind, mode):
     kd = torch.from_numpy(keys.view(np.int32)).to(DEV)
     tb = core.disturb_table(params_c(p, kind), packed, keys_dev=kd, key_mode=mode, deterministic=True, batch=2).cpu().numpy()
     assert np.array_equal(tb[0], tab)
-    assert np.abs(tb[1] - table_ref(p, s2, kind, uniform_draws(p, keys[1], mode))).max() < 2e-7
+    assert np.abs(tb[1] - table_ref(p, s2, kind, uniform_draws(p, keys[1], mode))).max() < 1e-6
 
 
 # ------------------------------------------------------------------------------------------ rollout
@@ -151,7 +130,7 @@ def test_rollout_reward_and_disturbance_variants_vs_fp64_oracle(kind, reward):
     pm, ps = R.pos_stats(poses)
     assert np.abs(info["pos_mean"].cpu().numpy() - pm).max() < 2e-5 and np.abs(info["pos_std"].cpu().numpy() - ps).max() < 2e-5
     assert np.array_equal(core.blockmin.cpu().numpy(), np.array([cost[i:i + 64].min() for i in range(0, N, 64)], dtype=np.float32))
-    # no statistics: same costs bit for bit
+    # no statistics: the same arithmetic (the rollout TUs are compiled with -ffp-contract=off so that template variants agree)
     cost2 = _rollout_dev(core, s, pc, a, f_shared=(0.02, -0.03, 0.01), tab=tab if kind in KINDS else None)
     assert np.array_equal(cost, cost2)
 
@@ -204,8 +183,15 @@ def test_hessian_reward_and_disturbance_variants_vs_ad_oracle(kind, reward, meth
     Rm = core.hessian(ds.packed, ds, pc, torch.from_numpy(a.reshape(-1)).to(DEV), method=method, f_steps=tab)[0].cpu().numpy()
     ref = CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32, reward=reward, kind=kind, draws=draws)
     assert np.abs(Rm - Rm.T).max() == 0.0 and np.abs(Rm[124:]).max() == 0.0
-    tol = 1e-9 if kind == "none" else 2e-8
-    assert np.abs(Rm - ref).max() < tol * max(1.0, np.abs(ref).max()), np.abs(Rm - ref).max()
+    if kind == "none":
+        assert np.abs(Rm - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), np.abs(Rm - ref).max()
+    else:
+        # (i) the kernel given ITS table (fp32 entries, like the reference's fp32 f_disturb): the oracle fed the same rows, 1e-9
+        ref_t = CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32, reward=reward, kind=kind, table=tab[0].cpu().numpy())
+        assert np.abs(Rm - ref_t).max() < 1e-9 * max(1.0, np.abs(ref_t).max()), np.abs(Rm - ref_t).max()
+        # (ii) against the model functions evaluated in fp64: what the table's fp32 rounding (sin of a ~15 rad argument: 2e-7 N)
+        # moves the curvature of the log-shaped reward by
+        assert np.abs(Rm - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), np.abs(Rm - ref).max()
     other = CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32)  # penyaw, no force: a different matrix
     assert np.abs(other - ref).max() > 1e-6
 
@@ -232,7 +218,7 @@ def test_hessian_batched_with_force_tables():
     tab = core.disturb_table(pc, packed, keys_dev=kd, key_mode=_lib.DISTURB_KEYS_HESSIAN, deterministic=True, batch=B)
     Rm = core.hessian(packed, dev_state(s), pc, am, batch=B, f_steps=tab).cpu().numpy()
     for b in range(B):
-        assert np.abs(Rm[b] - refs[b]).max() < 2e-8 * max(1.0, np.abs(refs[b]).max()), b
+        assert np.abs(Rm[b] - refs[b]).max() < 1e-6 * max(1.0, np.abs(refs[b]).max()), b  # fp32 table entries, see above
 
 
 # ------------------------------------------------------------------------------------------ env step / nominal / fused step
@@ -293,7 +279,7 @@ def test_offline_nominal_and_table_with_disturbance_models(kind):
     # the table rows (batch-300 Hessian + Sigma) against the oracle on the DEVICE's nominal states / means
     cp2 = controller.reset(state, params, cp, cr.PRNGKey(32))
     p = R.Params().fp32().replace(disturb_params=DP)
-    for t in (0, 49, 50, 137, 299):
+    for t in (1, 49, 50, 137, 299):  # (not row 0: err_pos is exactly 0 at reset, where norm'(0) is NaN in JAX's and the oracle's AD)
         st = pd[t]
         so = R.State(pos=st[0:3], vel=st[3:6], quat=st[6:10], omega=st[10:13], f_disturb=st[13:16], pos_tar=st[16:19],
                      vel_tar=st[19:22], acc_tar=st[22:25], time=int(st[25:26].view(np.int32)[0]), pos_traj=state.pos_traj,
@@ -336,8 +322,16 @@ def test_fused_step_with_models_equals_kernel_by_kernel_and_oracle(name, task, k
         outs.append((cp.a_mean.cpu().numpy().copy(), controller.core.cost.cpu().numpy().copy(),
                      controller.core.a.permute(1, 0, 2).contiguous().cpu().numpy().copy(),
                      cinfo["pos_mean"].cpu().numpy().copy(), ns, k_act))
-    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][3], outs[1][3])
+    if task != "tracking_slow":
+        assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][3], outs[1][3])
+    else:
+        # The quadratic reward keeps the costs within ~0.5 of each other: at lambda = 0.01 hundreds of samples carry weight
+        # (penyaw: one or two, the rest underflow to exactly 0), and the two paths sum them in different orders -- per-workgroup
+        # online-softmax records merged (fused) vs one global-minimum pass (kernel by kernel): equal to fp32 rounding, and the
+        # closed loop carries the last-ulp difference of the mean through the five steps
+        assert np.abs(outs[0][2] - outs[1][2]).max() < 5e-6 and np.abs(outs[0][0] - outs[1][0]).max() < 5e-6
+        assert rel_err(outs[0][1], outs[1][1]).max() < 1e-5 and np.abs(outs[0][3] - outs[1][3]).max() < 2e-5
     # oracle: the last step's costs on the device's own actions
     a_dev, cost_dev, ns, k_act = outs[0][2], outs[0][1], outs[0][4], outs[0][5]
     so = R.State(pos=ns.pos, vel=ns.vel, quat=ns.quat, omega=ns.omega, f_disturb=ns.f_disturb, pos_tar=ns.pos_tar,

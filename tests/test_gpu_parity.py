@@ -664,7 +664,7 @@ def test_offline_nominal_trajectory_device_vs_host():
     params = env.default_params
     obs, info, state = env.reset(cr.PRNGKey(31), params)
     ph, ah = controller._nominal_host(state, params, cr.PRNGKey(32))
-    pd, ad = controller._nominal_device(state, params, cr.PRNGKey(32))
+    pd, ad, _ = controller._nominal_device(state, params, cr.PRNGKey(32))
     pd, ad = pd.cpu().numpy(), ad.cpu().numpy()
     assert np.array_equal(pd[:, 25].view(np.int32), ph[:, 25].view(np.int32))      # time
     assert np.abs(pd[:, :25] - ph[:, :25]).max() < 5e-5, np.abs(pd[:, :25] - ph[:, :25]).max()

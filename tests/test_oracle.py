@@ -9,7 +9,7 @@ import pytest
 from oracle import c_oracle as CO
 from oracle import ref_np as R
 from oracle import rng_np
-from tests.conftest import make_problem
+from tests.conftest import make_problem, table_ref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
@@ -267,3 +267,18 @@ def test_c_hessian_with_disturbance_models_matches_torch_ad(kind, reward):
     import torch
     f_t = RT.make_objective(s, p, H, reward, kind, draws)(torch.as_tensor(a)).item()
     assert abs(f_np - f_t) < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["periodic", "sin", "drag", "mixed"])
+def test_force_table_semantics_equal_the_model_functions(kind):
+    """The per-step table of include/covo_hip.h (row k = {g_k, c_k}: f_k = c_drag drag(vel_{k-1}) + c_k f_{k-1} + g_k) is
+    a re-bracketing of free.py:10-58: the oracle Hessian fed the fp64 table equals the oracle Hessian on the model functions."""
+    s, p, rng = make_problem(seed=13, time=44)
+    p = p.replace(disturb_params=tuple(float(np.float32(x)) for x in rng.uniform(-1, 1, 6)), disturb_period=6)
+    H = 12
+    a = (R.hover_action(p, H, np.float64) + 0.2 * rng.normal(size=(H, 4))).reshape(-1)
+    draws = rng.uniform(-p.disturb_scale, p.disturb_scale, (H, 3))
+    tab = table_ref(p, s, kind, draws, H)
+    R1 = CO.hessian(s, p, a, H, kind=kind, draws=draws)
+    R2 = CO.hessian(s, p, a, H, kind=kind, table=tab)
+    assert np.abs(R1 - R2).max() < 1e-12 * max(1.0, np.abs(R1).max())
