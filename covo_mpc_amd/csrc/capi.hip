@@ -398,6 +398,12 @@ int covo_debug_set_ns_tail(int n_squarings, int n_iters)
     return 0;
 }
 
+int covo_debug_set_ns_deflate(int on)
+{
+    g_ns_deflate = on ? 1 : 0;
+    return 0;
+}
+
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)
 {
     REQUIRE(h && out, "covo_debug_sigma_workspace: bad argument");

@@ -36,7 +36,7 @@ void covo_set_error(const char *fmt, ...);
 // many stages of the Sigma pipeline (1 prep+squarings, 2 +Ritz, 3 +Newton-Schulz, 4 +finalize) are enqueued.
 // Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
-extern int g_ns_tail_iters, g_ns_tail_squarings;  // sigma_ns.hip
+extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_deflate;  // sigma_ns.hip
 
 #define COVO_CHECK_HIP(expr)                                                         \
     do {                                                                             \
@@ -90,6 +90,7 @@ struct CovDeferred {
     const double *Z[2], *Zt[2];  // the two Newton-Schulz buffers of Z and of its stored transpose
     const double *zbuf;          // != 0: buffer 1 holds the final iterate
     const double *cz;            // Sigma = cz sym(Z) (NaN when a grid barrier of the chain timed out)
+    const double *zcoef, *u;     // deflated chain (sigma_ns.hip): Z = Z~ + zcoef u u^T (*zcoef == 0: off)
     float *out;                  // a_cov [128][128]; null: nothing deferred
 };
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,

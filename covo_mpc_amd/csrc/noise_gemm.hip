@@ -227,14 +227,20 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
     __builtin_amdgcn_sched_barrier(0);
     // a_cov = cz sym(Z), left over by the Sigma chain's single-workgroup finalize launch (CovDeferred): the first 64
     // workgroups take 256 elements each; the loads ride with the epsilon request above, the stores leave after the staging of L
-    double cov_z = 0.0, cov_zt = 0.0, cov_cz = 0.0;
+    double cov_z = 0.0, cov_zt = 0.0, cov_cz = 0.0, cov_zc = 0.0, cov_ur = 0.0, cov_uc = 0.0;
     const bool cov_on = cov.out != nullptr && blockIdx.y == 0 && blockIdx.x < 64;
     const int cov_zb = cov_on ? ((*cov.zbuf != 0.0) ? 1 : 0) : 0;
     if (cov_on) {
         cov_cz = *cov.cz;
+        cov_zc = *cov.zcoef;  // deflated chain: Z = Z~ + zc u u^T (sigma_ns.hip)
         if (gridDim.x >= 64) {
-            cov_z = cov.Z[cov_zb][blockIdx.x * NG_BLOCK + tid];
-            cov_zt = cov.Zt[cov_zb][blockIdx.x * NG_BLOCK + tid];
+            const int e = blockIdx.x * NG_BLOCK + tid;
+            cov_z = cov.Z[cov_zb][e];
+            cov_zt = cov.Zt[cov_zb][e];
+            if (cov_zc != 0.0) {
+                cov_ur = cov_zc * cov.u[e / COVO_NA];
+                cov_uc = cov.u[e % COVO_NA];
+            }
         }
     }
 
@@ -272,10 +278,16 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
     if (tid < COVO_NA) mus[tid] = mu[tid];
     if (cov_on) {
         if (gridDim.x >= 64) {
-            cov.out[blockIdx.x * NG_BLOCK + tid] = (float)(cov_cz * 0.5 * (cov_z + cov_zt));  // covo.py:132 symmetrise; a_cov is fp32
+            // covo.py:132 symmetrise (+ the deflated eigenpair, the same expression as ns_finalize_kernel's); a_cov is fp32
+            double v = 0.5 * (cov_z + cov_zt);
+            if (cov_zc != 0.0) v = fma(cov_ur, cov_uc, v);
+            cov.out[blockIdx.x * NG_BLOCK + tid] = (float)(cov_cz * v);
         } else {  // small launches (N < 16 384): the workgroups there are stride over the matrix
-            for (int e = blockIdx.x * NG_BLOCK + tid; e < COVO_NA * COVO_NA; e += gridDim.x * NG_BLOCK)
-                cov.out[e] = (float)(cov_cz * 0.5 * (cov.Z[cov_zb][e] + cov.Zt[cov_zb][e]));
+            for (int e = blockIdx.x * NG_BLOCK + tid; e < COVO_NA * COVO_NA; e += gridDim.x * NG_BLOCK) {
+                double v = 0.5 * (cov.Z[cov_zb][e] + cov.Zt[cov_zb][e]);
+                if (cov_zc != 0.0) v = fma(cov_zc * cov.u[e / COVO_NA], cov.u[e % COVO_NA], v);
+                cov.out[e] = (float)(cov_cz * v);
+            }
         }
     }
     __syncthreads();

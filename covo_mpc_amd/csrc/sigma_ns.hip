@@ -35,6 +35,14 @@
 //      transpose (both MFMA operands are then read as 128-B runs); symmetry is neither assumed nor forced
 //      (mirroring the lower triangle makes the coupled iteration blow up after convergence).
 //      Iteration 0 needs no Z.Y product (Z0 = I): one launch forms Y1 = a0 Y0 + b0 Y0^2, Z1 = a0 I + b0 Y0.
+//      DEFLATION of the bottom eigenpair (round 3).  By construction B's smallest eigenvalue is 1e-2 -- but only ONE eigenvalue
+//      sits there: CoVO Hessians have ~58 negative eigenvalues spread over [lambda_min, 0) with bottom gaps
+//      lambda_2 - lambda_1 = 0.04 .. 1.7 (scripts/dump_hessians.py), i.e. the rest of B's spectrum starts 5 .. 170 times
+//      higher, and the iteration count is set by that single eigenvalue.  The Ritz step already holds its eigenvector u
+//      (residual <= 1e-12) and the filter's norm history gives a LOWER bound of the gap for free (ns_ritz_kernel), so the
+//      iteration runs on  B~ = B + (tau - 1e-2) u u^T  (spectrum in [1e-2 + gap, s]: 2 iterations = 4 launches fewer on
+//      closed-loop and on the bench's Hessians) and  B^(-1/2) = B~^(-1/2) + ((1e-2)^(-1/2) - tau^(-1/2)) u u^T  is put back
+//      where Z is consumed (finalize launch, CovDeferred).  Not taken when the bound is small or the residual is not.
 //   3. one workgroup: ONE Cholesky of Z (every update on the matrix cores, chol_lds.hpp) gives both
 //      log det B and, scaled by sqrt(c/sqrt(s)), the factor L of Sigma.
 // All reductions go through per-workgroup slots summed in a fixed order: results are bit-reproducible.
@@ -71,6 +79,11 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_BAR = 24,            // grid-barrier counters of the two persistent launches (unsigned in slots 24, 25; zeroed with the scalars)
        SC_BARFAIL = 26,        // != 0: a grid barrier timed out -> the finalize launch poisons Sigma and L with NaN
        SC_CZ = 27,             // Sigma = cz sym(Z): read by the noise GEMM when it writes a_cov for the finalize launch (CovDeferred)
+       SC_LO = 28,             // lower end of the spectrum the Newton-Schulz table is built for: 1e-2, or 1e-2 + gap bound (deflation)
+       SC_GAM = 29,            // deflation: Y0 = (B + (tau - 1e-2) u u^T) / s = B/s + gam u u^T (0: off)
+       SC_ZCOEF = 30,          // deflation: Z = Z~ + zcoef u u^T, zcoef = sqrt(s) ((1e-2)^(-1/2) - tau^(-1/2)) (0: off)
+       SC_GAPEST = 31,         // the gap bound lambda_2 - lambda_1 >= ... (diagnostics)
+       SC_RESID = 15,          // |A u - theta u| of the bottom Ritz pair (diagnostics)
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
@@ -79,7 +92,11 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_ERR = SC_SQN + (NS_SQUARINGS + 1) * 64,  // |Z_k Y_k - I|_F^2 partials: NS_ITERS x 64
        SC_RPART = SC_ERR + NS_ITERS * 64,          // sym_stats.hpp: per-row, per-column-block |.|-sums (128 x 8)
        SC_FPART = SC_RPART + 128 * 8,              // per-tile sums of squares (36)
-       SC_COUNT = SC_FPART + 64 };
+       SC_U = SC_FPART + 64,                       // the bottom Ritz vector u (128)
+       SC_COUNT = SC_U + 128 };
+constexpr double NS_DEFL_SAFETY = 0.7;   // the NS table assumes 1e-2 + 0.7 x (gap bound): the bound's linearisation is good to ~3 %
+constexpr double NS_DEFL_MIN_GAP = 2e-2; // below this the interval shrinks by < 3x: not worth a rank-1 correction
+constexpr double NS_DEFL_RESID = 1e-8;   // |A u - theta u| <= 1e-8 gap: eigenvector angle <= 1e-8, Sigma error <= 1e-7 relative
 static_assert(SC_COEF + 2 * NS_ITERS <= SC_ROWABS, "scalar slots");
 
 // ---- one 256-thread workgroup = one 16x16 tile of C = At^T . B  (At, B row-major 128x128); wave q takes
@@ -98,6 +115,14 @@ struct LoadAffine {  // alpha I - beta A
 struct LoadScaledB {
     double delta, inv;
     __device__ __forceinline__ double operator()(double v, int r, int c) const { return (v + ((r == c) ? delta : 0.0)) * inv; }
+};
+struct LoadScaledBDefl {  // (A + delta I)/s + gam u u^T  (deflated bottom eigenpair)
+    double delta, inv, gam;
+    const double *u;
+    __device__ __forceinline__ double operator()(double v, int r, int c) const
+    {
+        return fma(gam * u[r], u[c], (v + ((r == c) ? delta : 0.0)) * inv);
+    }
 };
 
 // COH: the access is an agent-scope relaxed atomic (sc1): coherent across the XCDs' L2s without cache-wide fences.  Used by
@@ -327,13 +352,16 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
 // B = A + delta I (min of its Gershgorin and Frobenius bounds, from the per-row data of prep) and the
 // Newton-Schulz coefficient table.
 __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__ Aall, const double *__restrict__ X0all,
-                                                      const double *__restrict__ X1all, double *__restrict__ scall)
+                                                      const double *__restrict__ X1all, double *__restrict__ scall,
+                                                      const int g_ns_deflate_dev)
 {
     __shared__ double V[RITZ][SN];
     __shared__ double AVp[4][RITZ][SN];  // partial A V over the four column quarters
     __shared__ double H[RITZ][RITZ];
     __shared__ double red[2];
     __shared__ double sh_delta;
+    __shared__ double sh_nrm[NS_SQUARINGS + 1];  // |X_j|_F^2 of every filter step
+    __shared__ double sh_cvec[RITZ], sh_lmin, sh_gap, sh_md[2], sh_r2[2];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *A = Aall + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -347,6 +375,16 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     // the per-row data of the Gershgorin bound at the end: requested now, one round trip to HBM less on the serial tail
     const double pre_dg = (tid < SN) ? s[SC_DIAG + tid] : 0.0, pre_ra = (tid < SN) ? s[SC_ROWABS + tid] : 0.0;
     const double pre_tr = s[SC_TRACE], pre_f2 = s[SC_FRO2];
+    // the filter's norm history (rows 1 .. squarings done: 36 partials each, fixed order) for the gap bound below
+    const int n_sq = (int)s[SC_SQ];
+    for (int j = 1 + wave; j <= NS_SQUARINGS; j += 8) {
+        const double v = (j <= n_sq) ? slot_sum(s + SC_SQN + j * 64, NS_TILES, lane) : 1.0;
+        if (lane == 0) sh_nrm[j] = v;
+    }
+    if (tid < SN) {
+        const double m = -wr::wave64_allmax(-pre_dg);
+        if (lane == 0) sh_md[wave] = m;
+    }
     if (tid < 64) {
         // ---- wave 0: pick the RITZ largest diagonal entries, orthonormalise those columns (two-pass MGS,
         // everything in registers: lane l owns rows l and l+64; reductions on the VALU)
@@ -414,12 +452,40 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         if (lane == 0) H[i][j] = d;
     }
     __syncthreads();
+    if (tid == 64) {
+        // ---- a LOWER bound of the bottom gap lambda_2 - lambda_1 from the filter's norm history, on another wave while lane 0
+        // diagonalises H.  X_k = sigma_k (v1 v1^T + sum_(i>=2) r_i v_i v_i^T), r_i = T_(2^k)(y_i) / T_(2^k)(y_1) (y = alpha -
+        // beta lambda; eigenvalues inside [cut, hi] have |T| <= 1, negligible), and one squaring gives |X_(k+1)|_F^2 =
+        // (1 + sum r_i^4) / (1 + sum r_i^2)^2 ~ 1 - 2 sum r_i^2.  With e = (1 - |X_j|_F^2) / 2 >= r_2^2 = exp(-2^j D),
+        // D = acosh y_1 - acosh y_2:  D >= -ln(e) / 2^j, hence y_2 <= cosh(acosh y_1 - D_est) and lambda_2 >= (alpha - y_2) / beta.
+        // lambda_1 enters through y_1 only to ~1 %: the Rayleigh quotient H[0][0] of the dominant column serves.
+        double gap = 0.0;
+        const double hi = s[SC_SHIFT], md = fmin(sh_md[0], sh_md[1]);
+        const double cut = fma(NS_CUT_MARGIN, hi - md, md), inv = 1.0 / (hi - cut);
+        const double alpha = (hi + cut) * inv, beta = 2.0 * inv, l1 = H[0][0];
+        const double y1 = fma(-beta, l1, alpha);
+        for (int j = 1; j <= n_sq && j <= NS_SQUARINGS; ++j) {
+            const double e = 0.5 * (1.0 - sh_nrm[j]);
+            if (e > 1e-13 && e < 0.05 && y1 > 1.0) {  // the earliest step at which the linearisation holds
+                const double D = -log(e) * exp2(-(double)j);
+                const double ac = log(y1 + sqrt(fma(y1, y1, -1.0))) - D;
+                const double ex = exp(fmax(ac, 0.0));
+                const double y2 = 0.5 * (ex + 1.0 / ex);
+                gap = fmax((alpha - y2) / beta - l1, 0.0);
+                break;
+            }
+        }
+        sh_gap = gap;
+    }
     if (tid == 0) {
-        // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, eigenvalues only, exits when diagonal);
-        // reciprocals / square roots by hardware seed + Newton (qm::rcp64_, qm::rsq64_), not libm
-        double h[RITZ][RITZ];
+        // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, exits when diagonal), the rotations accumulated for the
+        // bottom Ritz vector; reciprocals / square roots by hardware seed + Newton (qm::rcp64_, qm::rsq64_), not libm
+        double h[RITZ][RITZ], jv[RITZ][RITZ];
         for (int i = 0; i < RITZ; ++i)
-            for (int j = 0; j < RITZ; ++j) h[i][j] = 0.5 * (H[i][j] + H[j][i]);
+            for (int j = 0; j < RITZ; ++j) {
+                h[i][j] = 0.5 * (H[i][j] + H[j][i]);
+                jv[i][j] = (i == j) ? 1.0 : 0.0;
+            }
         for (int sweep = 0; sweep < 12; ++sweep) {
             double off = 0.0, dia = 0.0;
             for (int p = 0; p < RITZ; ++p)
@@ -448,16 +514,38 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
                         h[k][q2] = nq_;
                         h[q2][k] = nq_;
                     }
+                    for (int k = 0; k < RITZ; ++k) {  // eigenvectors: columns p, q2 of the accumulated rotation
+                        const double jp = jv[k][p], jq = jv[k][q2];
+                        jv[k][p] = c * jp - sn * jq;
+                        jv[k][q2] = sn * jp + c * jq;
+                    }
                 }
         }
         double lmin = h[0][0];
-        for (int i = 1; i < RITZ; ++i) lmin = fmin(lmin, h[i][i]);
+        int imin = 0;
+        for (int i = 1; i < RITZ; ++i)
+            if (h[i][i] < lmin) { lmin = h[i][i]; imin = i; }
+        for (int k = 0; k < RITZ; ++k) sh_cvec[k] = jv[k][imin];
+        sh_lmin = lmin;
         s[SC_LMIN] = lmin;
         s[SC_DELTA] = -lmin + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
         sh_delta = -lmin + 1e-2;
     }
     __syncthreads();
     const double delta = sh_delta;
+    // the bottom Ritz pair (theta, u = V c) and its residual |A u - theta u| (A V is in the partials of H)
+    if (tid < SN) {
+        double u = 0.0, au = 0.0;
+#pragma unroll
+        for (int k = 0; k < RITZ; ++k) {
+            u = fma(sh_cvec[k], V[k][tid], u);
+            au = fma(sh_cvec[k], (AVp[0][k][tid] + AVp[1][k][tid]) + (AVp[2][k][tid] + AVp[3][k][tid]), au);
+        }
+        s[SC_U + tid] = u;
+        const double d = fma(-sh_lmin, u, au);
+        const double r2 = wr::wave64_allsum(d * d);
+        if (lane == 0) sh_r2[wave] = r2;
+    }
     // Gershgorin bound of B = A + delta I from the row sums of A: only the diagonal term changes
     if (tid < SN) {
         const double m = wr::wave64_allmax(pre_ra - fabs(pre_dg) + fabs(pre_dg + delta));
@@ -468,6 +556,21 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, pre_tr, pre_f2));  // |A + delta I|_F^2
         const double scale = fmin(fmax(red[0], red[1]), sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
         s[SC_SCALE] = scale;  // the Newton-Schulz coefficient table follows from it: ns_first_kernel's extra workgroup
+        // deflate the bottom eigenpair when its gap bound is worth it and the pair is converged (see the header)
+        const double gap = NS_DEFL_SAFETY * sh_gap, resid = sqrt(sh_r2[0] + sh_r2[1]);
+        const bool defl = g_ns_deflate_dev && gap > NS_DEFL_MIN_GAP && resid <= NS_DEFL_RESID * gap && 1e-2 + gap < 0.25 * scale;
+        double lo = 1e-2, gam = 0.0, zc = 0.0;
+        if (defl) {
+            lo = 1e-2 + gap;
+            const double tau = sqrt(lo * scale);  // anywhere inside [lo, scale]
+            gam = (tau - 1e-2) / scale;
+            zc = sqrt(scale) * (10.0 - qm::rsq64_(tau));  // (1e-2)^(-1/2) = 10
+        }
+        s[SC_LO] = lo;
+        s[SC_GAM] = gam;
+        s[SC_ZCOEF] = zc;
+        s[SC_GAPEST] = sh_gap;
+        s[SC_RESID] = resid;
     }
 }
 
@@ -492,11 +595,12 @@ __global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict_
     double *s = scall + (size_t)b * SC_COUNT;
     const double scale = s[SC_SCALE];
     const double delta = s[SC_DELTA], inv = 1.0 / scale;
+    const double lo = s[SC_LO], gam = s[SC_GAM];  // deflation (ns_ritz_kernel): table from lo, Y0 = B/s + gam u u^T
     if (w == 64) {
         // the extra workgroup: the coefficient table of the iterations to come (a serial recurrence, ~1 us on one lane -- under
         // this launch's GEMM instead of on the tail of the single-workgroup Ritz launch before it)
         if (tid == 0) {
-            double l = sqrt(1e-2 / scale);
+            double l = sqrt(lo / scale);
             for (int k = 0; k < NS_ITERS; ++k) {
                 double a, bq;
                 ns_coef(l, a, bq);
@@ -508,17 +612,25 @@ __global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict_
         return;
     }
     double a0, b0;
-    ns_coef(sqrt(1e-2 / scale), a0, b0);
+    ns_coef(sqrt(lo / scale), a0, b0);
     if (w == 0 && tid == 0) {
         s[SC_ZBUF] = (double)zbuf_out;
         s[SC_ITERS] = 1.0;
     }
     const int ti = w >> 3, tj = w & 7;
-    const LoadScaledB ld{delta, inv};
-    const f64x4 acc = tile_mm_q(A, A, ti, tj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
-    const double y2 = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-    const double y0 = ld(A[(size_t)row * SN + col], row, col);
+    double y2, y0;
+    if (gam != 0.0) {  // (uniform)
+        const LoadScaledBDefl ld{delta, inv, gam, s + SC_U};
+        const f64x4 acc = tile_mm_q(A, A, ti, tj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
+        y2 = tile_reduce(acc, red, wv, lane);
+        y0 = ld(A[(size_t)row * SN + col], row, col);
+    } else {
+        const LoadScaledB ld{delta, inv};
+        const f64x4 acc = tile_mm_q(A, A, ti, tj, lane, wv, ld);
+        y2 = tile_reduce(acc, red, wv, lane);
+        y0 = ld(A[(size_t)row * SN + col], row, col);
+    }
     store_both(Yout + off, Ytout + off, row, col, fma(b0, y2, a0 * y0));
     store_both(Zout + off, Ztout + off, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
 }
@@ -731,6 +843,8 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     const int b = blockIdx.x, tid = threadIdx.x;
     double *s = scall + (size_t)b * SC_COUNT;
     const bool z1 = s[SC_ZBUF] != 0.0;
+    const double zc = s[SC_ZCOEF];         // deflation: Z = Z~ + zc u u^T (0: off)
+    const double *__restrict__ uv = s + SC_U;
     const double2 *Z = reinterpret_cast<const double2 *>((z1 ? Z1all : Z0all) + (size_t)b * SN * SN);
     const double2 *Zt = reinterpret_cast<const double2 *>((z1 ? Zt1all : Zt0all) + (size_t)b * SN * SN);
     constexpr int LD = SN + 1;
@@ -758,7 +872,12 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
             int ti, tj;
             tri_tile(w, ti, tj);
             const int r = 16 * ti + (in >> 3), c = 16 * tj + 2 * (in & 7);
-            const double v0 = 0.5 * (za[t].x + zt[t].x), v1 = 0.5 * (za[t].y + zt[t].y);  // covo.py:132 symmetrise
+            double v0 = 0.5 * (za[t].x + zt[t].x), v1 = 0.5 * (za[t].y + zt[t].y);  // covo.py:132 symmetrise
+            if (zc != 0.0) {
+                const double ur = zc * uv[r];
+                v0 = fma(ur, uv[c], v0);
+                v1 = fma(ur, uv[c + 1], v1);
+            }
             sm[c * LD + r] = v0;        // column-major element (r, c), r >= c up to the diagonal block: what the factorisation reads
             sm[(c + 1) * LD + r] = v1;
             if (ti == tj) {             // diagonal blocks are read as stored: both triangles
@@ -813,8 +932,16 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     if (Sigma_out) {
         float2 *So = reinterpret_cast<float2 *>(Sigma_out + (size_t)b * SN * SN);
 #pragma unroll
-        for (int t = 0; t < TRS; ++t)  // a_cov is fp32
-            So[tid + 512 * t] = make_float2((float)(cz * 0.5 * (za[t].x + zt[t].x)), (float)(cz * 0.5 * (za[t].y + zt[t].y)));
+        for (int t = 0; t < TRS; ++t) {  // a_cov is fp32
+            const int e = 2 * (tid + 512 * t), r = e / SN, c = e % SN;
+            double v0 = 0.5 * (za[t].x + zt[t].x), v1 = 0.5 * (za[t].y + zt[t].y);
+            if (zc != 0.0) {
+                const double ur = zc * uv[r];
+                v0 = fma(ur, uv[c], v0);
+                v1 = fma(ur, uv[c + 1], v1);
+            }
+            So[tid + 512 * t] = make_float2((float)(cz * v0), (float)(cz * v1));
+        }
     }
     tk[4] = clock64();
     if (tid == 0) {
@@ -830,7 +957,11 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // folded: squarings 8..13 (live on 98 .. 17 % of closed-loop Hessians, on almost none of the bench's teacher-forced ones)
 // and iterations 10..12 (68 / 4 / 0 %).  Measured (scripts/tail_bench.py, N = 65 536): bench 4 411 -> 4 615 steps/s,
 // closed loop unchanged (4 126 -> 4 120); folding everything: 4 550 / 4 078.
-int g_ns_tail_iters = 3, g_ns_tail_squarings = 6;
+// Round 3: with the bottom eigenpair deflated the iteration needs 3..6 (bench) / 4..9 (closed loop) steps instead of 6..10, so
+// iterations 6..11 are folded (same box, bench / closed loop steps/s: tail 3: 5 029 / 4 644, 5: 5 192 / 4 734, 6: 5 227 / 4 675,
+// 7: 5 238 / 4 697, 8: 5 180 / 4 645; without deflation, tail 3: 4 949 / 4 505).
+int g_ns_tail_iters = 6, g_ns_tail_squarings = 6;
+int g_ns_deflate = 1;  // COVO_NS_DEFLATE=0 / covo_debug_set_ns_deflate(0): the undeflated iteration (A/B measurements, tests)
 
 SymStatsOut sigma_ns_stats_out(void *workspace)
 {
@@ -875,7 +1006,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     }
     if (sq_tail > 0) hipLaunchKernelGGL(ns_square_tail_kernel, dim3(NS_TILES), dim3(256), 0, s, X0, X1, sc, sq_sep, NS_SQUARINGS - 1);
     if (g_dbg_sigma_stages < 2) return 0;
-    hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc);
+    hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
     if (g_dbg_sigma_stages < 3) return 0;
     hipLaunchKernelGGL(ns_first_kernel, dim3(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);  // 64 tiles + the table
     int n_tail = (batch == 1 && persistent_ok) ? g_ns_tail_iters : 0;
@@ -921,6 +1052,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
             }
             cov->zbuf = sc + SC_ZBUF;
             cov->cz = sc + SC_CZ;
+            cov->zcoef = sc + SC_ZCOEF;
+            cov->u = sc + SC_U;
             cov->out = Sigma;
             Sigma = nullptr;
         }

@@ -1,9 +1,17 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+"""bench.py with another split of the Sigma chain's phases between separate launches and the two persistent tail launches
+(covo_debug_set_ns_tail) and with / without the deflation (covo_debug_set_ns_deflate).
+usage: tail_bench.py <tail squarings> <tail iterations> <deflate 0|1> [bench.py flags]"""
+import sys, os, json, io, contextlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from covo_mpc_amd import _lib
-sq, it = int(sys.argv[1]), int(sys.argv[2])
+sq, it, defl = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 lib = _lib.load_library()
 _lib.check(lib.covo_debug_set_ns_tail(sq, it))
-sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[3:]
+_lib.check(lib.covo_debug_set_ns_deflate(defl))
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-info-leg"] + sys.argv[4:]
 import bench
-bench.main()
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    bench.main()
+d = json.loads(buf.getvalue().strip().splitlines()[-1])
+print(f"tail sq={sq} it={it} deflate={defl}: value {d['value']:.0f} steps/s ({1e3*d['ms_per_step']:.1f} us)  closed loop {d['closed_loop']['device_env']:.0f}")

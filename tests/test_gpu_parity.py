@@ -880,3 +880,59 @@ def test_errors_are_reported_through_the_abi():
     cfg = _lib.ConfigC(0, 32, 4, 0.01, 1.0, 0)
     h = C.c_void_p()
     assert core.lib.covo_create(C.byref(cfg), C.byref(h)) == -1 and b"n_local" in core.lib.covo_last_error()
+
+
+def _sigma_chain_iters(core):
+    """(squarings, Newton-Schulz iterations, deflated?) of the LAST batch-1 covo_sigma call, from the chain's scalar slots"""
+    out = torch.zeros(32, dtype=torch.float64, device=DEV)
+    _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out), 11 * 128 * 128, 32, core.stream()))
+    o = out.cpu().numpy()
+    return int(o[8]), int(o[6]), bool(o[29] != 0.0)  # SC_SQ, SC_ITERS, SC_GAM
+
+
+def test_sigma_deflation_on_real_hessians():
+    """The deflated Newton-Schulz chain (sigma_ns.hip: bottom eigenpair moved into the spectrum, put back at the end) on
+    Hessians of closed-loop and teacher-forced episodes (tests/golden/hessians_r03.npz: dumped by scripts/dump_hessians.py from
+    this build's Hessian kernel) and on synthetic spectra: Sigma <= 1e-6 of LAPACK eigh with and without it, fewer iterations
+    with it, and the cases it must decline (degenerate bottom, isolated bottom far below, identity)."""
+    g = np.load(os.path.join(HERE, "golden", "hessians_r03.npz"))
+    mats = [m for k in g.files for m in g[k]]
+    rng = np.random.default_rng(4)
+    A = rng.normal(size=(128, 128))
+    w, U = np.linalg.eigh(0.05 * (A + A.T))
+    for w01 in (1e-9, 1e-3, 0.05, 3.0):  # bottom gap from degenerate to isolated
+        ww = w.copy()
+        ww[0] = ww[1] - w01
+        mats.append((U * ww) @ U.T)
+    ww = w.copy()
+    ww[-1] = ww[0] + 4000.0  # cond 4e5 before deflation
+    mats.append((U * ww) @ U.T)
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    saved, n_defl = [], 0
+    try:
+        for i, Rm in enumerate(mats):
+            ref = R.optimize_sigma(Rm, 0.5, 32, 4)
+            res = {}
+            for on in (1, 0):
+                core.lib.covo_debug_set_ns_deflate(on)
+                Sigma, L = core.sigma(torch.from_numpy(Rm[None].copy()).to(DEV), 0.5)
+                Sigma, L = Sigma[0].cpu().numpy(), L[0].cpu().numpy().astype(np.float64)
+                err = np.linalg.norm(Sigma - ref) / np.linalg.norm(ref)
+                assert err < 1e-6, (i, on, err)
+                assert np.array_equal(Sigma, Sigma.T)
+                assert np.linalg.norm(L @ L.T - Sigma) / np.linalg.norm(Sigma) < 2e-7, (i, on)
+                res[on] = _sigma_chain_iters(core)
+            assert res[0][2] is False and res[1][1] <= res[0][1], (i, res)
+            if i < len(mats) - 5:  # the real Hessians: deflated, and it pays
+                assert res[1][2], (i, res)
+                saved.append(res[0][1] - res[1][1])
+            n_defl += res[1][2]
+    finally:
+        core.lib.covo_debug_set_ns_deflate(1)
+    assert np.mean(saved) >= 1.5, saved
+    # batched (covo-offline's table path): same matrices in one call, per-matrix deflation state
+    Rb = np.stack(mats)
+    Sb, Lb = core.sigma(torch.from_numpy(Rb).to(DEV), 0.5, batch=len(mats))
+    for i, Rm in enumerate(mats):
+        ref = R.optimize_sigma(Rm, 0.5, 32, 4)
+        assert np.linalg.norm(Sb[i].cpu().numpy() - ref) / np.linalg.norm(ref) < 1e-6, i
