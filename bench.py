@@ -9,8 +9,9 @@ A "step" is one controller __call__ (quadjax/controllers/covo.py:187-283) on one
 state of a tracking_zigzag episode, teacher-forced (states resident in HBM before the timed region,
 a_mean carried from step to step).  Workload (BASELINE.json north_star / configs[3]):
 covo-online, tracking_zigzag, N = 65536 samples x H = 32, lambda = 0.01, sigma = 0.5; with G > 1 ranks
-the sample axis is sharded (N/G per GPU, "strong" scaling: total work fixed) and ONE all-gather of the
-132-float online-softmax records crosses xGMI per step.
+the sample axis is sharded (N/G per GPU, "strong" scaling: total work fixed) and ONE exchange of the
+516-float rank records (online-softmax partial + position sums) crosses xGMI per step (RCCL all-gather; COVO_EXCHANGE=peer:
+direct peer writes, csrc/exchange.hip).
 
 Rank 0 prints ONE JSON line with `roofline` (the fused rollout kernel in the variant the timed step runs -- it also
 leaves the softmax records --, HBM bound, 516 B/sample algorithmic, mean launch duration measured live with events on
@@ -353,7 +354,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.controller} tracking_zigzag N={args.N} H={H} lam={args.lam} sigma=0.5 "
                                    f"(teacher-forced noisy states of one 300-step episode; samples sharded {world}x"
-                                   f"{n_local}, one 132-float all-gather per step)",
+                                   f"{n_local}, one exchange of the 516-float rank records per step: {core.exchange})",
                        "controller": args.controller, "N_global": args.N, "N_local": n_local, "H": H,
                        "pos_stats_info": bool(args.info)},
             "roofline": {"bound": "hbm", "kernel": kernel_name,

@@ -18,6 +18,8 @@ COVO_NA = COVO_H * COVO_DU
 COVO_STATE_FLOATS = 32
 COVO_PARTIAL_FLOATS = 132
 COVO_POS_STATS_DOUBLES = COVO_H * 6
+COVO_RANK_RECORD_FLOATS = COVO_PARTIAL_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 516: {m, s, v[128], pad} + 192 fp64 position sums
+COVO_EXCHANGE_HANDLE_BYTES = 64
 ABI_VERSION = 3
 COVO_FLAG_ACTIONS_CLIPPED = 1
 
@@ -73,6 +75,7 @@ COVO_FLAG_NO_GRAPH = 2
 COVO_FLAG_SHARED_DEVICE = 4
 COVO_E_DEVICE = -4
 COVO_DEVSTAT_GRID_BARRIER = 1
+COVO_DEVSTAT_EXCHANGE = 2
 _SIGS = {
     "covo_last_error": (C.c_char_p, []),
     "covo_abi_version": (C.c_int, []),
@@ -96,6 +99,10 @@ _SIGS = {
     "covo_softmax_reduce": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "covo_softmax_update": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_float, _P, _P]),
     "covo_merge": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P]),
+    "covo_merge_ranks": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P, _P]),
+    "covo_exchange_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "covo_exchange_connect": (C.c_int, [_P, _P]),
+    "covo_exchange_records": (C.c_int, [_P, _P, _P, _P]),
     "covo_shift_mean": (C.c_int, [_P, _P, _P, _P]),
     "covo_hessian": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, _P, C.c_int32, _P, _P]),
     "covo_hessian_pairs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, _P, C.c_int32, _P, _P]),

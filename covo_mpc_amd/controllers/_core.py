@@ -3,9 +3,12 @@
 Owns the libcovo_hip handle and the HBM buffers of one control step and issues the kernels of
 include/covo_hip.h on torch's current stream.  When a torch.distributed process group with more
 than one rank is given, the sample axis N is sharded: rank g owns global sample ids
-[g*N/G, (g+1)*N/G), epsilon is keyed by global id, every rank reduces its shard to one
-online-softmax record and ONE all-gather (RCCL over xGMI when the backend is nccl) exchanges the
-records; all ranks then merge identically.
+[g*N/G, (g+1)*N/G), epsilon is keyed by global id, every rank reduces its shard to ONE rank record
+(online-softmax partial + the position sums of covo.py:281 when they are wanted: 2 064 bytes) and ONE
+exchange per control step makes all G records known to all ranks, which then merge identically
+(SURVEY.md 5.8 / 8e).  The exchange is an all-gather (RCCL over xGMI under the nccl backend; the default)
+or, `exchange="peer"` / COVO_EXCHANGE=peer, direct peer writes into hipIpc-mapped buffers (csrc/exchange.hip:
+no collective library and no host round trip, so whole sharded episodes can be enqueued from C).
 """
 from __future__ import annotations
 
@@ -14,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
-from .._lib import COVO_H, COVO_NA, COVO_PARTIAL_FLOATS, COVO_POS_STATS_DOUBLES, check, ptr
+from .._lib import (COVO_H, COVO_NA, COVO_PARTIAL_FLOATS, COVO_POS_STATS_DOUBLES, COVO_RANK_RECORD_FLOATS, check, ptr)
 
 
 def shard_range(N: int, rank: int, world: int):
@@ -44,7 +47,7 @@ def exchange_records(record, gathered_flat, process_group=None):
 
 class SamplingCore:
     def __init__(self, N: int, H: int, lam: float, discount: float, device=None, process_group=None,
-                 compute_info: bool = True, trust_clipped: bool = False, use_graph=None, shared_device=None):
+                 compute_info: bool = True, trust_clipped: bool = False, use_graph=None, shared_device=None, exchange=None):
         import torch
         if H != COVO_H:
             raise NotImplementedError(f"the fused kernels are built for H={COVO_H}, got H={H}")
@@ -111,9 +114,21 @@ class SamplingCore:
         self.a = torch.empty((COVO_H, n, 4), **f32)
         self.cost = torch.empty((n,), **f32)
         self.blockmin = torch.empty(((n + 63) // 64,), **f32)  # per-64-sample cost minima
-        self.stats = torch.zeros((COVO_POS_STATS_DOUBLES,), dtype=torch.float64, device=self.device)
-        self.partial = torch.zeros((COVO_PARTIAL_FLOATS,), **f32)
-        self.gathered = torch.zeros((self.world * COVO_PARTIAL_FLOATS,), **f32) if self.world > 1 else None
+        # the rank record of a sharded step: {m, s, v[128], pad[2]} + the 192 fp64 position sums, ONE message per step; on a
+        # single rank the same buffer simply holds the two parts
+        self.record = torch.zeros((COVO_RANK_RECORD_FLOATS,), **f32)
+        self.partial = self.record[:COVO_PARTIAL_FLOATS]
+        self.stats = self.record[COVO_PARTIAL_FLOATS:].view(torch.float64)  # this shard's sums (528-byte offset: 8-aligned)
+        self.gathered = torch.zeros((self.world * COVO_RANK_RECORD_FLOATS,), **f32) if self.world > 1 else None
+        self.stats_total = torch.zeros((COVO_POS_STATS_DOUBLES,), dtype=torch.float64, device=self.device) if self.world > 1 else self.stats
+        self.exchange = "collective"
+        if self.world > 1:
+            mode = exchange if exchange is not None else os.environ.get("COVO_EXCHANGE", "collective")
+            if mode not in ("collective", "peer"):
+                raise ValueError(f"exchange={mode!r} (collective | peer)")
+            if mode == "peer":
+                self._connect_peer_exchange()
+            self.exchange = mode
 
     def __del__(self):
         try:
@@ -122,6 +137,32 @@ class SamplingCore:
                 self.h = None
         except Exception:
             pass
+
+    def _connect_peer_exchange(self):
+        """csrc/exchange.hip setup: every rank exports its exchange buffer (hipIpc), the 64-byte handles are all-gathered once
+        over the process group, every rank maps all peers' buffers."""
+        import torch.distributed as dist
+        hb = (C.c_char * _lib.COVO_EXCHANGE_HANDLE_BYTES)()
+        with self.torch.cuda.device(self.device):
+            check(self.lib.covo_exchange_create(self.h, self.world, self.rank, hb), "covo_exchange_create")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(hb), group=self.pg)
+            blob = (C.c_char * (self.world * _lib.COVO_EXCHANGE_HANDLE_BYTES)).from_buffer_copy(b"".join(handles))
+            check(self.lib.covo_exchange_connect(self.h, blob), "covo_exchange_connect")
+        dist.barrier(group=self.pg)  # nobody pushes before everybody has mapped
+
+    def exchange_rank_records(self):
+        """THE one exchange of a sharded control step: this rank's record -> self.gathered (world x COVO_RANK_RECORD_FLOATS)."""
+        if self.exchange == "peer":
+            check(self.lib.covo_exchange_records(self.h, ptr(self.record), ptr(self.gathered), self.stream()), "covo_exchange_records")
+        else:
+            exchange_records(self.record, self.gathered, self.pg)
+        return self.gathered
+
+    def merge_rank_records(self, a_mean_shifted, gamma_mean, out):
+        check(self.lib.covo_merge_ranks(self.h, ptr(self.gathered), self.world, ptr(a_mean_shifted), float(gamma_mean), ptr(out),
+                                        ptr(self.stats_total) if self.compute_info else None, self.stream()), "covo_merge_ranks")
+        return out
 
     def device_status(self, clear: bool = False) -> int:
         """Sticky COVO_DEVSTAT_* bits raised by kernels of earlier calls (0 = fine); no synchronisation."""
@@ -298,17 +339,17 @@ class SamplingCore:
               "covo_mpc_step")
         self._last_step = (params_c, args)
         if self.world > 1:
-            exchange_records(self.partial, self.gathered, self.pg)  # the ONE collective per step
-            check(self.lib.covo_merge(self.h, ptr(self.gathered), self.world, ptr(am_shift), float(gamma_mean), ptr(am),
-                                      self.stream()), "covo_merge")
+            self.exchange_rank_records()  # the ONE exchange per step (partial + position sums in one record)
+            self.merge_rank_records(am_shift, gamma_mean, am)
         return am, cov_out
 
     def run_episode(self, mode, episode, params_c, a_mean, rng, n_steps, **kw):
         """covo_run_episode: n_steps x (fused control step on episode.noisy -> env step on the device) enqueued by ONE
         C call, keys threaded like eval_env's run_one_step (quadrotor.py:520-538).  -> (a_mean buffer, a_cov buffer,
         rng after the segment).  Asynchronous; episode.read_log() synchronises."""
-        if self.world > 1:
-            raise NotImplementedError("run_episode: a sample-sharded step needs its all-gather between the launches")
+        if self.world > 1 and self.exchange != "peer":
+            raise NotImplementedError("run_episode on sample-sharded ranks needs the peer-write exchange (exchange='peer' / "
+                                      "COVO_EXCHANGE=peer): a torch.distributed collective cannot be enqueued from C")
         args, am, _, cov_out = self._prepare_step(mode, episode.noisy_state, a_mean, derive_keys=True, **kw)
         key = (C.c_uint32 * 2)(int(rng[0]), int(rng[1]))
         env = episode.env
@@ -340,19 +381,13 @@ class SamplingCore:
             return out
         check(self.lib.covo_softmax_reduce(self.h, ptr(self.cost), ptr(self.a), self.n_local, ptr(self.blockmin),
                                            ptr(self.partial), self.stream()), "covo_softmax_reduce")
-        exchange_records(self.partial, self.gathered, self.pg)  # the ONE collective per step
-        check(self.lib.covo_merge(self.h, ptr(self.gathered), self.world, ptr(a_mean_shifted), float(gamma_mean),
-                                  ptr(out), self.stream()), "covo_merge")
-        return out
+        self.exchange_rank_records()  # the ONE exchange per step
+        return self.merge_rank_records(a_mean_shifted, gamma_mean, out)
 
     def info(self, dstate):
         """{"pos_mean","pos_std"} (H,3) from the per-step sums (controllers/covo.py:281): covo_pos_info, one launch."""
         torch = self.torch
-        stats = self.stats
-        if self.world > 1:
-            import torch.distributed as dist
-            stats = stats.clone()
-            dist.all_reduce(stats, group=self.pg)
+        stats = self.stats_total  # sharded: the ranks' sums arrived in the rank records and were added by covo_merge_ranks
         out = torch.empty((2, COVO_H, 3), dtype=torch.float32, device=self.device)
         check(self.lib.covo_pos_info(self.h, ptr(stats), ptr(dstate.packed), int(self.N), ptr(out[0]), ptr(out[1]), self.stream()),
               "covo_pos_info")

@@ -27,7 +27,8 @@ void covo_set_error(const char *fmt, ...)
     do {                                                                                                                     \
         const int st_ = *(volatile int *)(h)->status_host;                                                                   \
         if (st_ != 0) {                                                                                                      \
-            covo_set_error("%s: device status 0x%x from an earlier call%s (covo_device_status)", what, st_,                 \
+            covo_set_error("%s: device status 0x%x from an earlier call%s%s (covo_device_status)", what, st_,               \
+                           (st_ & COVO_DEVSTAT_EXCHANGE) ? ": a peer's rank record did not arrive (covo_exchange_records)" : "", \
                            (st_ & COVO_DEVSTAT_GRID_BARRIER)                                                                 \
                                ? ": a grid barrier of the Sigma chain timed out -- the GPU is shared with other work; that " \
                                  "call's Sigma / L / mean are NaN.  Create the handle with COVO_FLAG_SHARED_DEVICE"        \
@@ -81,6 +82,7 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     h->cfg = *cfg;
     COVO_CHECK_HIP(hipGetDevice(&h->device));
     h->max_red_blocks = 256;
+    h->exchange = nullptr;
     const int nb = (cfg->n_local + 255) / 256, ng = (cfg->n_local + 63) / 64;
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
@@ -104,6 +106,7 @@ int covo_destroy(covo_handle_t h)
     if (!h) return COVO_E_NOHANDLE;
     step_state_destroy(h);
     batch_state_destroy(h);
+    exchange_destroy(h);
     int rc = 0;
 #define DESTROY(expr)                                                                                   \
     do {                                                                                                \
@@ -326,6 +329,38 @@ int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a
     return launch_merge(partials, G, h->cfg.lam, a_mean_old, gamma_mean, a_mean_out, (hipStream_t)stream);
 }
 
+int covo_merge_ranks(covo_handle_t h, const float *records, int32_t G, const float *a_mean_old, float gamma_mean,
+                     float *a_mean_out, double *pos_stats_out, void *stream)
+{
+    REQUIRE(h, "covo_merge_ranks: null handle");
+    CHECK_DEVICE(h, "covo_merge_ranks");
+    REQUIRE(records && a_mean_old && a_mean_out && G > 0, "covo_merge_ranks: bad argument");
+    int rc = launch_merge(records, G, h->cfg.lam, a_mean_old, gamma_mean, a_mean_out, (hipStream_t)stream, nullptr, 1,
+                          COVO_RANK_RECORD_FLOATS);
+    if (rc) return rc;
+    if (pos_stats_out != nullptr) rc = launch_rank_stats_sum(records, G, pos_stats_out, (hipStream_t)stream);
+    return rc;
+}
+
+int covo_exchange_create(covo_handle_t h, int32_t world, int32_t rank, void *handle_out)
+{
+    REQUIRE(h && handle_out, "covo_exchange_create: null argument");
+    return exchange_create(h, world, rank, handle_out);
+}
+
+int covo_exchange_connect(covo_handle_t h, const void *handles)
+{
+    REQUIRE(h && handles, "covo_exchange_connect: null argument");
+    return exchange_connect(h, handles);
+}
+
+int covo_exchange_records(covo_handle_t h, const float *record, float *gathered_out, void *stream)
+{
+    REQUIRE(h && record && gathered_out, "covo_exchange_records: null argument");
+    CHECK_DEVICE(h, "covo_exchange_records");
+    return exchange_records(h, record, gathered_out, nullptr, (hipStream_t)stream);
+}
+
 int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, void *stream)
 {
     REQUIRE(h, "covo_shift_mean: null handle");
@@ -465,7 +500,9 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
     REQUIRE(params && args && state_true && acc_traj && rng && n_steps > 0, "covo_run_episode: bad argument");
     REQUIRE(args->derive_keys == 1, "covo_run_episode: args->derive_keys must be 1 (the controller key is the raw rng_act)");
     CHECK_MODEL(params, "covo_run_episode");
-    REQUIRE(args->partial_out == nullptr, "covo_run_episode: a sample-sharded step needs its all-gather between the calls");
+    REQUIRE(args->partial_out == nullptr || (exchange_ready(h) && args->a_mean_shift != nullptr),
+            "covo_run_episode: a sample-sharded step (partial_out != NULL) needs the peer-write exchange (covo_exchange_create / "
+            "covo_exchange_connect) and a_mean_shift");
     REQUIRE(args->state && args->pos_traj && args->vel_traj && args->a_mean && args->a && args->cost && args->groupmin &&
                 args->T > 0 && args->mode >= 0 && args->mode <= 2,
             "covo_run_episode: bad step arguments");
@@ -479,6 +516,15 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
         host_philox_split(key, 2u, rng_step);
         int rc = covo_step_impl(h, params, args, rng_act[0], rng_act[1], nullptr, s);
         if (rc) return rc;
+        if (args->partial_out != nullptr) {
+            // sample-sharded: every rank's record to every rank (peer writes, exchange.hip), then the same merge on all of them.
+            // partial_out is this rank's RANK record: {m, s, v} there, its position sums (if any) at + COVO_PARTIAL_FLOATS
+            const float *gathered = nullptr;
+            if ((rc = exchange_records(h, args->partial_out, nullptr, &gathered, s))) return rc;
+            if ((rc = launch_merge(gathered, exchange_world(h), h->cfg.lam, args->a_mean_shift, args->gamma_mean, args->a_mean, s,
+                                   nullptr, 1, COVO_RANK_RECORD_FLOATS)))
+                return rc;
+        }
         rc = launch_env_step(state_true, const_cast<float *>(args->state), args->pos_traj, args->vel_traj, acc_traj, args->T,
                              *params, args->a_mean, rng_step, noisy_on, obs_noise_scale, log, t, s);
         if (rc) return rc;

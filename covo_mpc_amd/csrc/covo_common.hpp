@@ -28,6 +28,7 @@ struct covo_ctx {
     int max_red_blocks;
     int *status_host;         // host-mapped sticky status word (COVO_DEVSTAT_* bits written by kernels), see covo_device_status
     int *status_dev;          // its device address
+    void *exchange;           // Exchange (exchange.hip): peer-write exchange of the rank records, or null
 };
 
 void covo_set_error(const char *fmt, ...);
@@ -120,7 +121,15 @@ int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N,
                           hipStream_t s, float *partials_ws = nullptr, int batch = 1);  // batch > 1: dense per-instance slices, own partials_ws
 // a_mean_out == null: the merged record goes to partial_out (sample-sharded step); batch > 1: dense per-instance slices
 int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
-                 hipStream_t s, float *partial_out = nullptr, int batch = 1);
+                 hipStream_t s, float *partial_out = nullptr, int batch = 1, int stride = COVO_PARTIAL_FLOATS);
+// exchange.hip: the rank records of a sample-sharded step and their peer-write exchange
+int launch_rank_stats_sum(const float *records, int G, double *out, hipStream_t s);
+int exchange_create(covo_ctx *h, int world, int rank, void *handle_out);
+int exchange_connect(covo_ctx *h, const void *handles);
+void exchange_destroy(covo_ctx *h);
+bool exchange_ready(const covo_ctx *h);
+int exchange_world(const covo_ctx *h);
+int exchange_records(covo_ctx *h, const float *record, float *gathered_dst, const float **gathered_out, hipStream_t s);
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
 size_t hessian_workspace_bytes(int batch);
 struct SymStatsOut;  // sym_stats.hpp

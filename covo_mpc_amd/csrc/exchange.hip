@@ -1,0 +1,193 @@
+// exchange.hip -- the ONE exchange of a sample-sharded control step as direct peer writes.
+//
+// A sharded step (quadjax has none: its N samples live in one XLA program) leaves one RANK RECORD per GPU --
+// the online-softmax partial {m, s, v[128]} of controllers/covo.py:266-272 and, when the caller wants covo.py:281's
+// pos_mean / pos_std, the 192 fp64 position sums -- COVO_RANK_RECORD_FLOATS * 4 = 2 064 bytes.  Every rank needs all G records
+// before it can merge.  Through RCCL that is an all-gather whose cost is pure latency (10-20 us for 2 KB); the xGMI mesh
+// is fully connected and the payload fits one store burst, so here every rank WRITES its record straight into a slot of
+// every peer's exchange buffer (hipIpc-mapped device memory) and raises a per-(step parity, source rank) sequence flag;
+// the receiving side spins on its OWN memory until all G flags carry this step's sequence number, then copies the slots
+// out.  No collective library, no host round trip: the whole control step, exchange included, can be enqueued from C
+// (covo_run_episode on sharded ranks).
+//   buffer (per rank):  float  slot[2][G][COVO_RANK_RECORD_FLOATS]   two parities: a rank can run at most one step ahead
+//                       uint64 flag[2][G]                            of the slowest (it needs everybody's record to finish)
+// Visibility: payload stores, then a system-scope fence, then the flag as a system-scope release store; the reader
+// acquires the flag and reads the payload with system-scope (sc0 sc1) loads -- nothing depends on a cache being flushed at
+// a kernel boundary.  The spin is bounded (2 s): a missing peer surfaces as COVO_DEVSTAT_EXCHANGE + NaN records, never a hang.
+// Validated functionally with two processes sharing one GPU (tests/test_gpu_parity.py); NOT measured over xGMI (the pool
+// has single-GPU boxes only), which is why torch.distributed (RCCL) stays the default exchange.
+#include <cstring>
+#include "covo_common.hpp"
+
+constexpr int EX_MAX_WORLD = 16;
+
+struct ExPeers {
+    float *base[EX_MAX_WORLD];
+};
+
+struct Exchange {
+    int world, rank;
+    float *local;                      // this rank's buffer (slots + flags)
+    float *peer[EX_MAX_WORLD];         // everybody's buffer as mapped here (peer[rank] = local)
+    float *gathered;                   // [world][COVO_RANK_RECORD_FLOATS] local staging the merge reads
+    unsigned long long seq;            // exchanges done
+    bool connected;
+    hipIpcMemHandle_t handle;
+};
+
+__host__ __device__ inline size_t ex_slot_floats(int world) { return (size_t)2 * world * COVO_RANK_RECORD_FLOATS; }
+static size_t ex_bytes(int world) { return ex_slot_floats(world) * sizeof(float) + (size_t)2 * world * sizeof(unsigned long long); }
+
+// workgroup p: this rank's record -> slot [parity][rank] of rank p's buffer, then the flag
+__global__ __launch_bounds__(256) void exchange_push_kernel(const float *__restrict__ record, const ExPeers peers, int world, int rank,
+                                                            int parity, unsigned long long seq)
+{
+    const int p = blockIdx.x;
+    float *base = peers.base[p];
+    float *dst = base + ((size_t)parity * world + rank) * COVO_RANK_RECORD_FLOATS;
+    for (int i = threadIdx.x; i < COVO_RANK_RECORD_FLOATS; i += 256)
+        __hip_atomic_store(dst + i, record[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *flags = reinterpret_cast<unsigned long long *>(base + ex_slot_floats(world));
+        __hip_atomic_store(flags + (size_t)parity * world + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// one workgroup: wait until all `world` flags of this parity carry `seq`, then copy the slots to `gathered`
+__global__ __launch_bounds__(512) void exchange_wait_kernel(float *__restrict__ local, int world, int parity, unsigned long long seq,
+                                                            float *__restrict__ gathered, int *status)
+{
+    __shared__ int ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    if (tid < world) {
+        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(local + ex_slot_floats(world)) +
+                                         (size_t)parity * world + tid;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 200000000LL) {  // 2 s of the 100 MHz wall clock: a peer is gone
+                ok = 0;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    const bool good = ok != 0;
+    if (!good && tid == 0 && status != nullptr)
+        __hip_atomic_fetch_or(status, COVO_DEVSTAT_EXCHANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const float *src = local + (size_t)parity * world * COVO_RANK_RECORD_FLOATS;
+    for (int i = tid; i < world * COVO_RANK_RECORD_FLOATS; i += 512)
+        gathered[i] = good ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __builtin_nanf("");
+}
+
+// sum_g of the fp64 position sums riding in the rank records (covo.py:281 over all shards)
+__global__ __launch_bounds__(256) void rank_stats_sum_kernel(const float *__restrict__ records, int G, double *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= COVO_POS_STATS_DOUBLES) return;
+    double acc = 0.0;
+    for (int g = 0; g < G; ++g)
+        acc += reinterpret_cast<const double *>(records + (size_t)g * COVO_RANK_RECORD_FLOATS + COVO_PARTIAL_FLOATS)[i];
+    out[i] = acc;
+}
+
+int launch_rank_stats_sum(const float *records, int G, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(rank_stats_sum_kernel, dim3(1), dim3(256), 0, s, records, G, out);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+void exchange_destroy(covo_ctx *h)
+{
+    Exchange *x = reinterpret_cast<Exchange *>(h->exchange);
+    if (!x) return;
+    for (int p = 0; p < x->world; ++p)
+        if (x->connected && p != x->rank && x->peer[p]) (void)hipIpcCloseMemHandle(x->peer[p]);
+    (void)hipFree(x->local);
+    (void)hipFree(x->gathered);
+    delete x;
+    h->exchange = nullptr;
+}
+
+int exchange_create(covo_ctx *h, int world, int rank, void *handle_out)
+{
+    if (world < 2 || world > EX_MAX_WORLD || rank < 0 || rank >= world) {
+        covo_set_error("covo_exchange_create: world=%d rank=%d (2 <= world <= %d)", world, rank, EX_MAX_WORLD);
+        return COVO_E_BADARG;
+    }
+    exchange_destroy(h);
+    Exchange *x = new Exchange();
+    std::memset(x, 0, sizeof(*x));
+    x->world = world;
+    x->rank = rank;
+    COVO_CHECK_HIP(hipMalloc(&x->local, ex_bytes(world)));
+    COVO_CHECK_HIP(hipMemset(x->local, 0, ex_bytes(world)));  // flags = 0 < every sequence number (they start at 1)
+    COVO_CHECK_HIP(hipMalloc(&x->gathered, (size_t)world * COVO_RANK_RECORD_FLOATS * sizeof(float)));
+    COVO_CHECK_HIP(hipDeviceSynchronize());
+    COVO_CHECK_HIP(hipIpcGetMemHandle(&x->handle, x->local));
+    static_assert(sizeof(hipIpcMemHandle_t) <= COVO_EXCHANGE_HANDLE_BYTES, "handle size");
+    std::memset(handle_out, 0, COVO_EXCHANGE_HANDLE_BYTES);
+    std::memcpy(handle_out, &x->handle, sizeof(hipIpcMemHandle_t));
+    h->exchange = x;
+    return 0;
+}
+
+int exchange_connect(covo_ctx *h, const void *handles)
+{
+    Exchange *x = reinterpret_cast<Exchange *>(h->exchange);
+    if (!x) {
+        covo_set_error("covo_exchange_connect: covo_exchange_create first");
+        return COVO_E_BADARG;
+    }
+    for (int p = 0; p < x->world; ++p) {
+        if (p == x->rank) {
+            x->peer[p] = x->local;
+            continue;
+        }
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, reinterpret_cast<const char *>(handles) + (size_t)p * COVO_EXCHANGE_HANDLE_BYTES, sizeof(hd));
+        void *ptr = nullptr;
+        COVO_CHECK_HIP(hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess));
+        x->peer[p] = reinterpret_cast<float *>(ptr);
+    }
+    x->connected = true;
+    return 0;
+}
+
+bool exchange_ready(const covo_ctx *h)
+{
+    const Exchange *x = reinterpret_cast<const Exchange *>(h->exchange);
+    return x != nullptr && x->connected;
+}
+int exchange_world(const covo_ctx *h)
+{
+    const Exchange *x = reinterpret_cast<const Exchange *>(h->exchange);
+    return x ? x->world : 1;
+}
+
+// enqueue: push this rank's record to every peer, wait for everybody's, leave them in *gathered_out (the handle's staging
+// buffer when gathered_dst == null)
+int exchange_records(covo_ctx *h, const float *record, float *gathered_dst, const float **gathered_out, hipStream_t s)
+{
+    Exchange *x = reinterpret_cast<Exchange *>(h->exchange);
+    if (!x || !x->connected) {
+        covo_set_error("covo_exchange_records: the exchange is not connected (covo_exchange_create / covo_exchange_connect)");
+        return COVO_E_BADARG;
+    }
+    const unsigned long long seq = ++x->seq;
+    const int parity = (int)(seq & 1ull);
+    ExPeers peers;
+    std::memset(&peers, 0, sizeof(peers));
+    for (int p = 0; p < x->world; ++p) peers.base[p] = x->peer[p];
+    float *dst = gathered_dst ? gathered_dst : x->gathered;
+    hipLaunchKernelGGL(exchange_push_kernel, dim3(x->world), dim3(256), 0, s, record, peers, x->world, x->rank, parity, seq);
+    hipLaunchKernelGGL(exchange_wait_kernel, dim3(1), dim3(512), 0, s, x->local, x->world, parity, seq, dst, h->status_dev);
+    COVO_CHECK_HIP(hipGetLastError());
+    if (gathered_out) *gathered_out = dst;
+    return 0;
+}

@@ -117,10 +117,12 @@ __global__ __launch_bounds__(RD_BLOCK) void softmax_partial_kernel(const float *
 constexpr int MG_THREADS = 1024;
 constexpr int MG_SLICES = MG_THREADS / COVO_NA;  // 8
 constexpr int MG_MAXG = 1024;
+// stride: floats between consecutive records (COVO_PARTIAL_FLOATS, or COVO_RANK_RECORD_FLOATS for the all-gathered rank records
+// that also carry the position sums)
 template <bool FINAL>
 __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restrict__ partials, int G, float inv_lam,
                                                            const float *__restrict__ a_mean_old, float gamma_mean,
-                                                           float *__restrict__ out)
+                                                           float *__restrict__ out, int stride)
 {
     __shared__ float scale[MG_MAXG];
     __shared__ float redm[MG_THREADS / 64];
@@ -129,13 +131,13 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {   // blockIdx.x (env-batched step): instance x merges its own G records into its own mean
         const size_t x = blockIdx.x;
-        partials += x * G * COVO_PARTIAL_FLOATS;
+        partials += x * G * stride;
         if (FINAL) a_mean_old += x * COVO_NA;
         out += x * (FINAL ? COVO_NA : COVO_PARTIAL_FLOATS);
     }
     // phase 1: m = min_g m_g
     float m = __builtin_inff();
-    for (int g = tid; g < G; g += MG_THREADS) m = fminf(m, partials[(size_t)g * COVO_PARTIAL_FLOATS]);
+    for (int g = tid; g < G; g += MG_THREADS) m = fminf(m, partials[(size_t)g * stride]);
     m = wave_min(m);
     if (lane == 0) redm[wave] = m;
     __syncthreads();
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
     // phase 2: per-record scale and s = sum_g s_g scale_g
     float s = 0.0f;
     for (int g = tid; g < G; g += MG_THREADS) {
-        const float *rec = partials + (size_t)g * COVO_PARTIAL_FLOATS;
+        const float *rec = partials + (size_t)g * stride;
         const float sg = rec[1];
         const float sc = (sg > 0.0f) ? expf((m - rec[0]) * inv_lam) : 0.0f;  // empty shard -> 0
         scale[g] = sc;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
     const int col = tid & (COVO_NA - 1), slice = tid >> 7;
     float v = 0.0f;
 #pragma unroll 4
-    for (int g = slice; g < G; g += MG_SLICES) v = fmaf(partials[(size_t)g * COVO_PARTIAL_FLOATS + 2 + col], scale[g], v);
+    for (int g = slice; g < G; g += MG_SLICES) v = fmaf(partials[(size_t)g * stride + 2 + col], scale[g], v);
     sv[slice][col] = v;
     __syncthreads();
     if (tid < COVO_NA) {
@@ -204,24 +206,24 @@ int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N,
                        reinterpret_cast<const float4 *>(a), N, blockmin, n_blockmin, inv_lam, partials_ws);
     if (a_mean_out != nullptr)
         hipLaunchKernelGGL(merge_kernel<true>, dim3(batch), dim3(MG_THREADS), 0, s, partials_ws, grid, inv_lam, a_mean_old,
-                           gamma_mean, a_mean_out);
+                           gamma_mean, a_mean_out, COVO_PARTIAL_FLOATS);
     else
         hipLaunchKernelGGL(merge_kernel<false>, dim3(batch), dim3(MG_THREADS), 0, s, partials_ws, grid, inv_lam,
-                           (const float *)nullptr, 1.0f, partial_out);
+                           (const float *)nullptr, 1.0f, partial_out, COVO_PARTIAL_FLOATS);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
-                 hipStream_t s, float *partial_out, int batch)
+                 hipStream_t s, float *partial_out, int batch, int stride)
 {
     if (G > MG_MAXG) { covo_set_error("covo_merge: G=%d > %d", G, MG_MAXG); return COVO_E_BADARG; }
     if (a_mean_out != nullptr)
         hipLaunchKernelGGL(merge_kernel<true>, dim3(batch), dim3(MG_THREADS), 0, s, partials, G, 1.0f / lam, a_mean_old, gamma_mean,
-                           a_mean_out);
+                           a_mean_out, stride);
     else
         hipLaunchKernelGGL(merge_kernel<false>, dim3(batch), dim3(MG_THREADS), 0, s, partials, G, 1.0f / lam,
-                           (const float *)nullptr, 1.0f, partial_out);
+                           (const float *)nullptr, 1.0f, partial_out, stride);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -67,6 +67,12 @@ extern "C" {
 #define COVO_E_UNSUPPORTED (-3)
 #define COVO_E_DEVICE (-4)           /* a kernel of an EARLIER call on this handle reported a failure (covo_device_status) */
 
+#define COVO_RANK_RECORD_FLOATS (COVO_PARTIAL_FLOATS + 2 * COVO_POS_STATS_DOUBLES) /* 516: the record one rank of a sample-sharded
+                                        step contributes to the exchange: {m, s, v[128], pad[2]} + the 192 fp64 position sums of
+                                        covo.py:281 (zeros when not requested): ONE message of 2 064 bytes per rank and step */
+#define COVO_EXCHANGE_HANDLE_BYTES 64 /* opaque inter-process handle of a rank's exchange buffer (covo_exchange_create) */
+
+#define COVO_DEVSTAT_EXCHANGE 2      /* covo_exchange_records: a peer's record did not arrive within 2 s; the gathered records are NaN */
 #define COVO_DEVSTAT_GRID_BARRIER 1  /* a grid barrier of the Sigma chain's persistent launches timed out (its workgroups were not
                                         co-resident within 0.2 s: GPU shared with other work); that call's Sigma / L are NaN */
 
@@ -233,6 +239,24 @@ int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int3
  *              + (1-gamma_mean) * a_mean_old.         a_mean_*: float[128] (index 4t+d). */
 int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a_mean_old, float gamma_mean,
                float *a_mean_out, void *stream);
+
+/* Sample-sharded step: merge the all-gathered RANK records (float[G][COVO_RANK_RECORD_FLOATS]: rank g's
+ * covo_mpc_step wrote its {m, s, v} to partial_out = record and its position sums to pos_stats = record + COVO_PARTIAL_FLOATS)
+ * like covo_merge, and (pos_stats_out != NULL) sum the ranks' position sums into pos_stats_out [double[COVO_POS_STATS_DOUBLES]]
+ * for covo_pos_info -- the statistics travel in the same message as the softmax partial, not in a second collective. */
+int covo_merge_ranks(covo_handle_t h, const float *records, int32_t G, const float *a_mean_old, float gamma_mean,
+                     float *a_mean_out, double *pos_stats_out, void *stream);
+
+/* The exchange of the rank records as direct peer writes instead of a collective (exchange.hip).  Setup, once:
+ * every rank calls covo_exchange_create (allocates its buffer, returns its inter-process handle), the G handles are
+ * all-gathered by the caller (any transport: they are 64 opaque bytes), every rank calls covo_exchange_connect with all G of
+ * them (rank order).  Per step: covo_exchange_records enqueues, on `stream`, the push of this rank's record into every peer's
+ * buffer and the wait for all G records, which land in gathered_out [float[G][COVO_RANK_RECORD_FLOATS], device]; no host
+ * synchronisation.  A peer that does not deliver within 2 s raises COVO_DEVSTAT_EXCHANGE and leaves NaN records.  With a
+ * connected exchange covo_run_episode also runs on sample-sharded handles (args->partial_out = this rank's record). */
+int covo_exchange_create(covo_handle_t h, int32_t world, int32_t rank, void *handle_out /* [host COVO_EXCHANGE_HANDLE_BYTES] */);
+int covo_exchange_connect(covo_handle_t h, const void *handles /* [host world x COVO_EXCHANGE_HANDLE_BYTES] */);
+int covo_exchange_records(covo_handle_t h, const float *record, float *gathered_out, void *stream);
 
 /* a_mean <- [a_mean[1:], a_mean[-1]] (controllers/covo.py:201-203).  in != out. */
 int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, void *stream);

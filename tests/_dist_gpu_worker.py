@@ -1,6 +1,9 @@
 """world_size-2 worker for tests/test_gpu_parity.py::test_two_ranks_one_gpu: two processes share cuda:0 and run the
-sample-sharded controller (covo_mpc_step with partial_out -> all-gather of the 132-float records -> covo_merge) over
-gloo; every rank checks the sharded result against an unsharded controller fed the same keys."""
+sample-sharded controller (covo_mpc_step writing this shard's rank record -> ONE exchange of the 516-float records -> covo_merge_ranks);
+every rank checks the sharded result (new mean AND covo.py:281's pos_mean / pos_std, which ride in the same record) against an
+unsharded controller fed the same keys.  argv: controller name, exchange ("collective": all-gather over gloo, staged through
+the host; "peer": direct writes into hipIpc-mapped buffers, csrc/exchange.hip -- then also a whole sharded episode segment
+enqueued from C by covo_run_episode)."""
 import os
 import sys
 
@@ -12,7 +15,8 @@ import torch.distributed as dist
 
 
 def main():
-    name = sys.argv[1]
+    name, exchange = sys.argv[1], sys.argv[2]
+    os.environ["COVO_EXCHANGE"] = exchange
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import covo_mpc_amd as cm
@@ -23,7 +27,7 @@ def main():
     N = 4096
     cs, cps = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0", process_group=dist.group.WORLD)
     c1, cp1 = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0")
-    assert cs.core.n_local == N // world and cs.core.offset == rank * (N // world)
+    assert cs.core.n_local == N // world and cs.core.offset == rank * (N // world) and cs.core.exchange == exchange
     params = env.default_params
     obs, info, state = env.reset(cr.PRNGKey(4), params)
     cps = cs.reset(state, params, cs.init_control_params, cr.PRNGKey(5))
@@ -31,14 +35,34 @@ def main():
     key = cr.PRNGKey(6)
     for step in range(5):  # eager, capture, replays
         key, k_act, k_step = cr.split(key, 3)
-        us, cps, _ = cs(obs, state, params, k_act, cps, info)
-        u1, cp1, _ = c1(obs, state, params, k_act, cp1, info)
+        us, cps, infs = cs(obs, state, params, k_act, cps, info)
+        u1, cp1, inf1 = c1(obs, state, params, k_act, cp1, info)
         err = (cps.a_mean - cp1.a_mean).abs().max().item()
         assert err < 2e-6, (name, rank, step, err)  # online-softmax merge: fp32 reassociation only
+        for k in ("pos_mean", "pos_std"):  # the shards' position sums travelled in the rank records (no second collective)
+            e = (infs[k] - inf1[k]).abs().max().item()
+            assert e < 2e-6, (name, rank, step, k, e)
         obs, state, reward, done, info = env.step(k_step, state, u1.cpu().numpy(), params)
     out = [None] * world
     dist.all_gather_object(out, cps.a_mean.cpu().numpy().tobytes())
     assert out[0] == out[1]  # every rank merges identically
+    if exchange == "peer":
+        # a sharded episode segment enqueued by ONE C call per rank (covo_run_episode: step -> peer-write exchange -> merge ->
+        # env step, no host in between) against the unsharded controller's
+        n = 12
+        logs = []
+        for ctrl in (cs, c1):
+            ctrl.alias_outputs = True
+            ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(41), params, (ctrl.core.lib, ctrl.core.h), "cuda:0")
+            cp = ctrl.reset(ep.state0, params, ctrl.init_control_params, cr.PRNGKey(42))
+            cp, rng = ctrl.run_episode(ep, params, cp, cr.PRNGKey(43), n)
+            logs.append((ep.read_log().copy(), cp.a_mean.cpu().numpy().copy(), ep.true.cpu().numpy().copy()))
+        assert logs[0][0].shape == (n, 4)
+        assert np.abs(logs[0][0] - logs[1][0]).max() < 1e-4 and np.abs(logs[0][1] - logs[1][1]).max() < 1e-4, \
+            (np.abs(logs[0][0] - logs[1][0]).max(), np.abs(logs[0][1] - logs[1][1]).max())
+        out = [None] * world
+        dist.all_gather_object(out, logs[0][2].tobytes())
+        assert out[0] == out[1]  # both ranks drove their replicated env to the same state
     dist.barrier()
     if rank == 0:
         print("DIST_GPU_OK")

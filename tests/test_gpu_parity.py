@@ -754,11 +754,13 @@ def test_closed_loop_on_device():
     assert err.shape == (1,) and err[0] < 0.15, err
 
 
+@pytest.mark.parametrize("exchange", ["collective", "peer"])
 @pytest.mark.parametrize("name", ["covo-online", "mppi"])
-def test_two_ranks_one_gpu(name):
+def test_two_ranks_one_gpu(name, exchange):
     """SURVEY.md 8e through the PRODUCT path: two processes (gloo rendezvous, both on cuda:0) run the sample-sharded
-    controller -- fused step writing this shard's record, ONE all-gather, device merge -- and each checks it against
-    the unsharded controller on the same keys (tests/_dist_gpu_worker.py)."""
+    controller -- fused step writing this shard's rank record (softmax partial + position sums), ONE exchange (all-gather, or
+    csrc/exchange.hip's peer writes into hipIpc-mapped buffers), device merge -- and each checks it against the unsharded
+    controller on the same keys; with the peer exchange also a sharded episode segment enqueued from C (tests/_dist_gpu_worker.py)."""
     import os
     import subprocess
     import sys
@@ -766,7 +768,7 @@ def test_two_ranks_one_gpu(name):
     script = os.path.join(root, "tests", "_dist_gpu_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", script, name],
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", script, name, exchange],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "DIST_GPU_OK" in r.stdout
