@@ -55,7 +55,8 @@ class StepArgsC(C.Structure):
                 ("state", _P), ("pos_traj", _P), ("vel_traj", _P), ("a_mean", _P), ("a_mean_shift", _P), ("a_cov", _P),
                 ("L_table", _P), ("a", _P), ("cost", _P), ("groupmin", _P), ("pos_stats", _P), ("partial_out", _P),
                 ("sample_offset", C.c_int64), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float),
-                ("derive_keys", C.c_int32), ("rollout_deterministic", C.c_int32)]
+                ("derive_keys", C.c_int32), ("rollout_deterministic", C.c_int32), ("gamma_sigma", C.c_float),
+                ("pad_", C.c_int32)]
 
 
 class BatchArgsC(C.Structure):
@@ -98,6 +99,7 @@ _SIGS = {
                                           C.c_int32, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_softmax_reduce": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "covo_softmax_update": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_float, _P, _P]),
+    "covo_softmax_update_cov": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_float, _P, C.c_float, _P, _P, _P]),
     "covo_merge": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P]),
     "covo_merge_ranks": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P, _P]),
     "covo_exchange_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),

@@ -284,7 +284,7 @@ class SamplingCore:
         return t
 
     def _prepare_step(self, mode, dstate, a_mean, *, a_cov=None, L_table=None, gamma_mean=1.0, sample_sigma=0.5,
-                      want_stats=False, derive_keys=False, rollout_deterministic=True):
+                      want_stats=False, derive_keys=False, rollout_deterministic=True, gamma_sigma=0.0):
         """Fixed-address buffers + struct covo_step_args of the fused step -> (args, a_mean buffer, shifted-mean
         buffer, a_cov buffer or None)."""
         torch = self.torch
@@ -306,7 +306,8 @@ class SamplingCore:
         # the argument block only changes when a buffer does (new episode -> new trajectory tensors): it is rebuilt
         # then, otherwise only the state pointer is refreshed (this call sits on the per-step host path)
         sig = (mode, dstate.pos_traj.data_ptr(), dstate.vel_traj.data_ptr(), L_table.data_ptr() if L_table is not None else 0,
-               bool(want_stats), float(gamma_mean), float(sample_sigma), bool(derive_keys), bool(rollout_deterministic))
+               bool(want_stats), float(gamma_mean), float(sample_sigma), bool(derive_keys), bool(rollout_deterministic),
+               float(gamma_sigma))
         cached = self._args_cache
         if cached is not None and cached[0] == sig:
             args = cached[1]
@@ -325,6 +326,7 @@ class SamplingCore:
             args.partial_out = self.partial.data_ptr() if self.world > 1 else None
             args.sample_offset, args.gamma_mean, args.sample_sigma = self.offset, float(gamma_mean), float(sample_sigma)
             args.derive_keys, args.rollout_deterministic = (1 if derive_keys else 0), (1 if rollout_deterministic else 0)
+            args.gamma_sigma = float(gamma_sigma)
             self._args_cache = (sig, args, (dstate.pos_traj, dstate.vel_traj, L_table))  # keep the tensors alive
         args.state = packed.data_ptr()
         return args, am, am_shift, cov_out
@@ -383,6 +385,18 @@ class SamplingCore:
                                            ptr(self.partial), self.stream()), "covo_softmax_reduce")
         self.exchange_rank_records()  # the ONE exchange per step
         return self.merge_rank_records(a_mean_shifted, gamma_mean, out)
+
+    def update_cov(self, a_mean_shifted, gamma_mean, a_cov_shifted, gamma_sigma):
+        """MPPI's update with covariance adaptation (mppi.py:109-125) -> (new mean (128,), new a_cov (H,4,4)); single shard."""
+        if self.world > 1:
+            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0) on sample-sharded ranks: the rank record "
+                                      "carries no second moments")
+        mean = self.torch.empty_like(a_mean_shifted)
+        cov = self.torch.empty_like(a_cov_shifted)
+        check(self.lib.covo_softmax_update_cov(self.h, ptr(self.cost), ptr(self.a), self.n_local, ptr(self.blockmin),
+                                               ptr(a_mean_shifted), float(gamma_mean), ptr(a_cov_shifted), float(gamma_sigma),
+                                               ptr(mean), ptr(cov), self.stream()), "covo_softmax_update_cov")
+        return mean, cov
 
     def info(self, dstate):
         """{"pos_mean","pos_std"} (H,3) from the per-step sums (controllers/covo.py:281): covo_pos_info, one launch."""

@@ -40,15 +40,21 @@ class MPPIController(BaseController):
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
                                  compute_info=compute_info, trust_clipped=True)
 
+    def _check_gamma_sigma(self, control_params):
+        """mppi.py:119-125's covariance adaptation (gamma_sigma != 0; quadjax's own factory fixes 0, envs/quadrotor.py:715) runs
+        on one shard only: the rank record of a sample-sharded step carries no second moments."""
+        if control_params.gamma_sigma != 0.0 and self.core.world > 1:
+            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0) on sample-sharded ranks")
+
     def run_episode(self, episode, env_params, control_params, rng, n_steps):
         """n_steps closed-loop steps (this controller + the device env step) enqueued by one C call; keys threaded like
         eval_env's run_one_step.  -> (control_params with the final mean / shifted covariances, rng)."""
         from .. import _lib
-        if control_params.gamma_sigma != 0.0:
-            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0, mppi.py:119-125) is not built")
+        self._check_gamma_sigma(control_params)
         am, cov, rng = self.core.run_episode(_lib.MODE_MPPI, episode, self._params_c(env_params), control_params.a_mean, rng,
                                              n_steps, a_cov=control_params.a_cov, gamma_mean=control_params.gamma_mean,
-                                             sample_sigma=control_params.sample_sigma, rollout_deterministic=False)
+                                             sample_sigma=control_params.sample_sigma, rollout_deterministic=False,
+                                             gamma_sigma=control_params.gamma_sigma)
         a_mean = am.view(self.H, 4)
         if not self.alias_outputs:
             a_mean, cov = a_mean.clone(), cov.clone()
@@ -58,9 +64,7 @@ class MPPIController(BaseController):
         from .. import random as crandom
         core = self.core
         torch = core.torch
-        if control_params.gamma_sigma != 0.0:
-            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0, mppi.py:119-125) is not built; "
-                                      "quadjax's own factory fixes gamma_sigma = 0 (envs/quadrotor.py:715)")
+        self._check_gamma_sigma(control_params)
         dstate = as_device_state(info["noisy_state"], core.device)  # mppi.py:40
         if self.noise_stream not in ("philox", "jax"):
             raise ValueError(f"noise_stream={self.noise_stream!r}")
@@ -74,7 +78,7 @@ class MPPIController(BaseController):
             am, cov = core.step(_lib.MODE_MPPI, dstate, self._params_c(env_params), control_params.a_mean, rng_act,
                                 a_cov=control_params.a_cov, gamma_mean=control_params.gamma_mean,
                                 sample_sigma=control_params.sample_sigma, want_stats=core.compute_info,
-                                derive_keys=True, rollout_deterministic=False)
+                                derive_keys=True, rollout_deterministic=False, gamma_sigma=control_params.gamma_sigma)
             a_mean_new = am.view(self.H, 4)
             if not self.alias_outputs:
                 a_mean_new, cov = a_mean_new.clone(), cov.clone()
@@ -112,7 +116,12 @@ class MPPIController(BaseController):
             else:
                 f_shared, tab = self.env.rollout_disturbance(step_key, env_params, deterministic=False), None
         core.rollout(dstate, params_c, f_shared, core.compute_info, f_steps=tab)
-        a_mean_new = core.update(a_mean.reshape(-1), control_params.gamma_mean).view(self.H, 4)  # mppi.py:109-125
-        control_params = control_params.replace(a_mean=a_mean_new)
+        if control_params.gamma_sigma != 0.0:  # mppi.py:109-125: mean, then the covariance about the NEW mean
+            a_mean_new, a_cov_new = core.update_cov(a_mean.reshape(-1), control_params.gamma_mean, a_cov, control_params.gamma_sigma)
+            control_params = control_params.replace(a_mean=a_mean_new.view(self.H, 4), a_cov=a_cov_new)
+            a_mean_new = a_mean_new.view(self.H, 4)
+        else:
+            a_mean_new = core.update(a_mean.reshape(-1), control_params.gamma_mean).view(self.H, 4)  # mppi.py:109-118
+            control_params = control_params.replace(a_mean=a_mean_new)
         out_info = core.info(dstate) if core.compute_info else {}
         return a_mean_new[0], control_params, out_info

@@ -85,6 +85,7 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     h->exchange = nullptr;
     const int nb = (cfg->n_local + 255) / 256, ng = (cfg->n_local + 63) / 64;
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&h->ws_partials_cov, softmax_cov_workspace_floats(h->max_red_blocks) * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)(nb > 256 ? nb : 256) * COVO_H * 6 * sizeof(double)));  // one row per rollout workgroup
     h->ws_sigma_bytes = sigma_ns_workspace_bytes(1);
@@ -117,6 +118,7 @@ int covo_destroy(covo_handle_t h)
         }                                                                                               \
     } while (0)
     DESTROY(hipFree(h->ws_partials));
+    DESTROY(hipFree(h->ws_partials_cov));
     DESTROY(hipFree(h->ws_blockmin));
     DESTROY(hipFree(h->ws_stats));
     DESTROY(hipFree(h->ws_sigma));
@@ -318,6 +320,18 @@ int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int3
     REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_update: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
     return launch_softmax_reduce(h, cost, a, N, groupmin, (N + 63) / 64, nullptr, a_mean_old, gamma_mean, a_mean_out,
                                  (hipStream_t)stream);
+}
+
+int covo_softmax_update_cov(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
+                            const float *a_mean_old, float gamma_mean, const float *a_cov_old, float gamma_sigma,
+                            float *a_mean_out, float *a_cov_out, void *stream)
+{
+    REQUIRE(h, "covo_softmax_update_cov: null handle");
+    CHECK_DEVICE(h, "covo_softmax_update_cov");
+    REQUIRE(cost && a && a_mean_old && a_cov_old && a_mean_out && a_cov_out, "covo_softmax_update_cov: bad argument");
+    REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_update_cov: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    return launch_softmax_update_cov(h, cost, a, N, groupmin, (N + 63) / 64, a_mean_old, gamma_mean, a_cov_old, gamma_sigma,
+                                     a_mean_out, a_cov_out, (hipStream_t)stream);
 }
 
 int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a_mean_old, float gamma_mean,
@@ -605,6 +619,8 @@ int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_ste
     REQUIRE(args->mode != COVO_MODE_COVO_OFFLINE || (args->L_table && args->n_table > 0), "covo_mpc_step: offline needs L_table");
     REQUIRE(args->mode != COVO_MODE_MPPI || args->a_cov, "covo_mpc_step: mppi needs a_cov");
     CHECK_MODEL(params, "covo_mpc_step");
+    REQUIRE(args->gamma_sigma == 0.0f || (args->mode == COVO_MODE_MPPI && args->partial_out == nullptr),
+            "covo_mpc_step: gamma_sigma != 0 is MPPI's covariance adaptation (mppi.py:119-125), single shard only");
     REQUIRE(!needs_table(params) || args->derive_keys == 1, "covo_mpc_step: disturb_kind=%d needs derive_keys = 1 (the per-step "
             "disturbance tables are derived from the raw controller key on the device)", params->disturb_kind);
     return covo_step_impl(h, params, args, key0, key1, f_disturb_shared, (hipStream_t)stream);

@@ -15,6 +15,7 @@ struct covo_ctx {
     int device;
     // workspace (device)
     float *ws_partials;   // [max_blocks][COVO_PARTIAL_FLOATS] stage-1 records of the softmax reduce
+    float *ws_partials_cov;  // [max_blocks][452] stage-1 records with second moments (MPPI covariance adaptation, reduce.hip)
     float *ws_blockmin;   // [ceil(n_local/64)] per-wave cost minima when the caller passes none
     double *ws_stats;     // [ceil(n_local/256)][H*6] per-block position statistics
     void *ws_sigma;       // scratch of the eigh-free Sigma pipeline (grown on demand, outside graph capture)
@@ -130,6 +131,10 @@ void exchange_destroy(covo_ctx *h);
 bool exchange_ready(const covo_ctx *h);
 int exchange_world(const covo_ctx *h);
 int exchange_records(covo_ctx *h, const float *record, float *gathered_dst, const float **gathered_out, hipStream_t s);
+size_t softmax_cov_workspace_floats(int max_blocks);
+int launch_softmax_update_cov(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
+                              const float *a_mean_old, float gamma_mean, const float *a_cov_old, float gamma_sigma,
+                              float *a_mean_out, float *a_cov_out, hipStream_t s);
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
 size_t hessian_workspace_bytes(int batch);
 struct SymStatsOut;  // sym_stats.hpp

@@ -262,12 +262,17 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     // the rollout's workgroups leave the softmax update's stage-1 records themselves when they fit the merge (rollout.hip:
     // rollout_record); otherwise the stand-alone stage-1 kernel runs over the costs
     const int G = rollout_workgroups(N, a.pos_stats != nullptr);
-    const bool records = G <= h->max_red_blocks;
+    // MPPI's covariance adaptation needs second moments the in-rollout records do not carry: its own stage 1 (reduce.hip)
+    const bool cov_adapt = a.mode == COVO_MODE_MPPI && a.gamma_sigma != 0.0f;
+    const bool records = G <= h->max_red_blocks && !cov_adapt;
     if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
                                          records ? nullptr : a.groupmin, a.pos_stats, h->ws_stats, s, fdev,
                                          records ? h->ws_partials : nullptr, h->cfg.lam, tables ? st->f_tab_rollout : nullptr)))
         return rc;
     if (!(M & 32)) return 0;
+    if (cov_adapt)  // mppi.py:109-125: new mean, then a_cov (already shifted by the begin launch) adapted in place
+        return launch_softmax_update_cov(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, am_shift, a.gamma_mean, a.a_cov, a.gamma_sigma,
+                                         a.a_mean, a.a_cov, s);
     if (records) {
         if (a.partial_out != nullptr) return launch_merge(h->ws_partials, G, h->cfg.lam, nullptr, 1.0f, nullptr, s, a.partial_out);
         return launch_merge(h->ws_partials, G, h->cfg.lam, am_shift, a.gamma_mean, a.a_mean, s);

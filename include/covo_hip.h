@@ -233,6 +233,15 @@ int covo_softmax_reduce(covo_handle_t h, const float *cost, const float *a, int3
 int covo_softmax_update(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
                         const float *a_mean_old, float gamma_mean, float *a_mean_out, void *stream);
 
+/* MPPI with covariance adaptation (controllers/mppi.py:109-125, gamma_sigma != 0; quadjax's own factory fixes gamma_sigma = 0,
+ * envs/quadrotor.py:715): the update of covo_softmax_update plus
+ *   a_cov_out[t] = gamma_sigma sum_n w_n (a_n[t] - a_mean_out[t]) (a_n[t] - a_mean_out[t])^T + (1 - gamma_sigma) a_cov_old[t]
+ * with the NEW mean, as the reference does.  a_cov_*: float[H][4][4] (a_cov_old already shifted, mppi.py:43-49); in place allowed.
+ * The weighted second moments are accumulated about a_mean_old (the mean the samples were drawn around).  Single shard. */
+int covo_softmax_update_cov(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
+                            const float *a_mean_old, float gamma_mean, const float *a_cov_old, float gamma_sigma,
+                            float *a_mean_out, float *a_cov_out, void *stream);
+
 /* Merge G shard records (this GPU's, or the all-gathered records of all ranks), normalise,
  * blend with the old mean (controllers/covo.py:270-275):
  *   a_mean_out = gamma_mean * (sum_g v_g e^{-(m_g-m)/lam}) / (sum_g s_g e^{-(m_g-m)/lam})
@@ -358,6 +367,9 @@ typedef struct covo_step_args {
                               *    derive_keys = 1 */
     int32_t rollout_deterministic; /* step_env's `deterministic` in the sampling rollouts: 1 for CoVO (covo.py:231), 0 for MPPI
                               *    (mppi.py:74): switches the GAUSSIAN model off (quadrotor.py:234-235) */
+    float gamma_sigma;       /* MPPI: != 0 adapts a_cov in place after the mean update (mppi.py:119-125, covo_softmax_update_cov);
+                              *    single shard */
+    int32_t pad_;
 } covo_step_args;
 
 int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, uint32_t key0,

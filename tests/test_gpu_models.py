@@ -486,3 +486,52 @@ def test_pid_nominal_vs_oracle_pid_action():
         worst_mean = max(worst_mean, np.abs(ad[t] - np.concatenate(mean)).max())
     assert worst_chain < 5e-6, worst_chain
     assert worst_mean < 2e-4, worst_mean  # the attitude gain amplifies fp32 rounding of the 32-step roll-out (cf. the host-env test)
+
+
+# ------------------------------------------------------------------------------------------ MPPI covariance adaptation
+@pytest.mark.parametrize("lam,N,gs,gm", [(1.0, 3000, 0.4, 1.0), (0.05, 8192, 1.0, 0.7), (0.01, 257, 0.25, 1.0)])
+def test_mppi_covariance_adaptation_vs_oracle(lam, N, gs, gm):
+    """covo_softmax_update_cov (mppi.py:109-125 with gamma_sigma != 0) against oracle/ref_np.py::softmax_update +
+    mppi_cov_update (fp64) on the same costs and samples: new mean and the H 4x4 covariances about the NEW mean."""
+    s, p, rng = make_problem(seed=N, time=60)
+    mu = R.hover_action(p, 32, np.float64) + 0.05 * rng.normal(size=(32, 4))
+    a = np.clip(mu[None] + 0.3 * rng.normal(size=(N, 32, 4)), -1, 1).astype(np.float32)
+    cov_old = np.stack([(lambda B: B @ B.T * 0.05 + 0.02 * np.eye(4))(rng.normal(size=(4, 4))) for _ in range(32)]).astype(np.float32)
+    core = SamplingCore(N, 32, lam, 1.0, device=DEV)
+    core.a.copy_(to_stripes(a))
+    cost = core.rollout(dev_state(s), params_c(p), (0.0, 0.0, 0.0), False).cpu().numpy().astype(np.float64)
+    mean_d, cov_d = core.update_cov(torch.from_numpy(mu.reshape(-1).astype(np.float32)).to(DEV), gm,
+                                    torch.from_numpy(cov_old).to(DEV), gs)
+    mu32 = mu.astype(np.float32).astype(np.float64)
+    a_new, w = R.softmax_update(cost, a.astype(np.float64), lam, gm, mu32)
+    cov_ref = R.mppi_cov_update(w, a.astype(np.float64), a_new, cov_old.astype(np.float64), gs)
+    assert np.abs(mean_d.cpu().numpy().reshape(32, 4) - a_new).max() < 1e-5
+    assert np.abs(cov_d.cpu().numpy() - cov_ref).max() < 1e-5, np.abs(cov_d.cpu().numpy() - cov_ref).max()
+    assert np.abs(cov_ref - cov_old).max() > 1e-3  # the adaptation moved it
+
+
+@pytest.mark.parametrize("graph", ["graph", "eager"])
+def test_mppi_step_with_covariance_adaptation(graph, monkeypatch):
+    """The fused MPPI step with gamma_sigma != 0 (covariances shifted, sampled from, adapted in place) equals the
+    kernel-by-kernel path, and a few closed-loop steps keep the covariances symmetric positive definite."""
+    import covo_mpc_amd as cm
+    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params
+    outs = []
+    for fused in (True, False):
+        controller, cp = cm.envs.get_controller(env, "mppi", "N4096_H32_lam0.5", device=DEV)
+        cp = cp.replace(gamma_sigma=0.3)
+        controller.materialize_eps = not fused
+        obs, info, state = env.reset(cr.PRNGKey(3), params)
+        key = cr.PRNGKey(6)
+        for i in range(6):
+            key, k_act, k_step = cr.split(key, 3)
+            u, cp, _ = controller(obs, state, params, k_act, cp, info)
+            obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+        outs.append((cp.a_mean.cpu().numpy().copy(), cp.a_cov.cpu().numpy().copy()))
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-6 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-6
+    cov = outs[0][1].astype(np.float64)
+    assert np.abs(cov - np.transpose(cov, (0, 2, 1))).max() < 1e-7
+    assert all(np.linalg.eigvalsh(c).min() > 0 for c in cov) and np.abs(cov - 0.25 * np.eye(4)).max() > 1e-3
