@@ -106,6 +106,7 @@ void exchange_destroy(covo_ctx *h)
 {
     Exchange *x = reinterpret_cast<Exchange *>(h->exchange);
     if (!x) return;
+    (void)hipDeviceSynchronize();  // nothing of this rank still reads or writes the buffers (peers: the caller tears ranks down together)
     for (int p = 0; p < x->world; ++p)
         if (x->connected && p != x->rank && x->peer[p]) (void)hipIpcCloseMemHandle(x->peer[p]);
     (void)hipFree(x->local);
@@ -125,15 +126,20 @@ int exchange_create(covo_ctx *h, int world, int rank, void *handle_out)
     std::memset(x, 0, sizeof(*x));
     x->world = world;
     x->rank = rank;
-    COVO_CHECK_HIP(hipMalloc(&x->local, ex_bytes(world)));
-    COVO_CHECK_HIP(hipMemset(x->local, 0, ex_bytes(world)));  // flags = 0 < every sequence number (they start at 1)
-    COVO_CHECK_HIP(hipMalloc(&x->gathered, (size_t)world * COVO_RANK_RECORD_FLOATS * sizeof(float)));
-    COVO_CHECK_HIP(hipDeviceSynchronize());
-    COVO_CHECK_HIP(hipIpcGetMemHandle(&x->handle, x->local));
+    h->exchange = x;  // owned by the handle from here on: a failure below is cleaned up by exchange_destroy / covo_destroy
+    hipError_t e = hipMalloc(&x->local, ex_bytes(world));
+    if (e == hipSuccess) e = hipMemset(x->local, 0, ex_bytes(world));  // flags = 0 < every sequence number (they start at 1)
+    if (e == hipSuccess) e = hipMalloc(&x->gathered, (size_t)world * COVO_RANK_RECORD_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&x->handle, x->local);
+    if (e != hipSuccess) {
+        covo_set_error("covo_exchange_create: %s", hipGetErrorString(e));
+        exchange_destroy(h);
+        return (int)e;
+    }
     static_assert(sizeof(hipIpcMemHandle_t) <= COVO_EXCHANGE_HANDLE_BYTES, "handle size");
     std::memset(handle_out, 0, COVO_EXCHANGE_HANDLE_BYTES);
     std::memcpy(handle_out, &x->handle, sizeof(hipIpcMemHandle_t));
-    h->exchange = x;
     return 0;
 }
 
