@@ -58,9 +58,11 @@
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SN = COVO_NA;  // 128
-constexpr int NS_SQUARINGS = 13;   // Chebyshev degree 2^13: at least as selective as X^(2^16) was (numpy study on closed-loop
-                                   // Hessians and synthetic spectra); RITZ = 4 near-degenerate bottom
-                                   // eigenvalues are resolved exactly by the Ritz step
+constexpr int NS_SQUARINGS = 16;   // cap: Chebyshev degree 2^16.  Real CoVO Hessians stop at 6..12; the cap matters for bottoms
+                                   // that sit within 1e-5 of the spectrum's width of the next eigenvalues (round 3's fuzz sweep:
+                                   // lambda_min = -0.015 next to the exact zeros of the null block, width 1.7e3: 15 squarings);
+                                   // squarings beyond the 7th run inside the persistent tail launch and cost nothing once
+                                   // stationary.  RITZ = 4 near-degenerate bottom eigenvalues are resolved exactly by the Ritz step
 constexpr double NS_CUT_MARGIN = 1.0 / 1024.0;  // cut = min diag + margin * (hi - min diag): lambda_min is strictly amplified
 constexpr double NS_SQ_TOL = 1e-7;     // squaring k+1 is skipped once |X_k|_F^2 moved by < 1e-7 relative ...
 constexpr double NS_SQ_TGUARD = 1e10;  // ... and t_k > 1e10 (the bounded part of the spectrum is down at 1e-10)
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
     __shared__ double sh_delta;
     __shared__ double sh_nrm[NS_SQUARINGS + 1];  // |X_j|_F^2 of every filter step
     __shared__ double sh_cvec[RITZ], sh_lmin, sh_gap, sh_md[2], sh_r2[2];
+    __shared__ int sh_has_null, sh_null_is_min;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *A = Aall + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -389,6 +392,18 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         // ---- wave 0: pick the RITZ largest diagonal entries, orthonormalise those columns (two-pass MGS,
         // everything in registers: lane l owns rows l and l+64; reductions on the VALU)
         double d0 = X[(size_t)lane * SN + lane], d1 = X[(size_t)(lane + 64) * SN + lane + 64];
+        // Rows of A that are exactly zero (always the last four of a CoVO Hessian: a_(H-1) never reaches a reward) are unit
+        // eigenvectors of eigenvalue 0.  While the filter has not yet separated lambda_min < 0 from them they own the largest
+        // diagonal entries of X and would take all RITZ picks (round 3's fuzz sweep: lambda_min = -0.015 reported as 0, B
+        // indefinite, NaN): they are left out of the picks and enter as the known eigenvalue 0 below.
+        const bool null0 = s[SC_ROWABS + lane] == 0.0, null1 = s[SC_ROWABS + lane + 64] == 0.0;
+        const int n_null = __builtin_popcountll(__ballot(null0)) + __builtin_popcountll(__ballot(null1));
+        const bool skip_null = n_null > 0 && n_null <= SN - RITZ;
+        if (skip_null) {
+            if (null0) d0 = -1e300;
+            if (null1) d1 = -1e300;
+        }
+        if (lane == 0) sh_has_null = skip_null ? 1 : 0;
         double v[RITZ][2];
         int pick_k[RITZ];
 #pragma unroll
@@ -526,7 +541,12 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         for (int i = 1; i < RITZ; ++i)
             if (h[i][i] < lmin) { lmin = h[i][i]; imin = i; }
         for (int k = 0; k < RITZ; ++k) sh_cvec[k] = jv[k][imin];
-        sh_lmin = lmin;
+        sh_lmin = lmin;  // (the Ritz pair's own value: what its residual is taken against)
+        sh_null_is_min = 0;
+        if (sh_has_null && lmin > 0.0) {  // the exact zeros of the null rows are the bottom of the spectrum
+            lmin = 0.0;
+            sh_null_is_min = 1;
+        }
         s[SC_LMIN] = lmin;
         s[SC_DELTA] = -lmin + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
         sh_delta = -lmin + 1e-2;
@@ -558,7 +578,8 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         s[SC_SCALE] = scale;  // the Newton-Schulz coefficient table follows from it: ns_first_kernel's extra workgroup
         // deflate the bottom eigenpair when its gap bound is worth it and the pair is converged (see the header)
         const double gap = NS_DEFL_SAFETY * sh_gap, resid = sqrt(sh_r2[0] + sh_r2[1]);
-        const bool defl = g_ns_deflate_dev && gap > NS_DEFL_MIN_GAP && resid <= NS_DEFL_RESID * gap && 1e-2 + gap < 0.25 * scale;
+        const bool defl = g_ns_deflate_dev && !sh_null_is_min && gap > NS_DEFL_MIN_GAP && resid <= NS_DEFL_RESID * gap &&
+                          1e-2 + gap < 0.25 * scale;
         double lo = 1e-2, gam = 0.0, zc = 0.0;
         if (defl) {
             lo = 1e-2 + gap;
@@ -960,7 +981,7 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // Round 3: with the bottom eigenpair deflated the iteration needs 3..6 (bench) / 4..9 (closed loop) steps instead of 6..10, so
 // iterations 6..11 are folded (same box, bench / closed loop steps/s: tail 3: 5 029 / 4 644, 5: 5 192 / 4 734, 6: 5 227 / 4 675,
 // 7: 5 238 / 4 697, 8: 5 180 / 4 645; without deflation, tail 3: 4 949 / 4 505).
-int g_ns_tail_iters = 6, g_ns_tail_squarings = 6;
+int g_ns_tail_iters = 6, g_ns_tail_squarings = 9;
 int g_ns_deflate = 1;  // COVO_NS_DEFLATE=0 / covo_debug_set_ns_deflate(0): the undeflated iteration (A/B measurements, tests)
 
 SymStatsOut sigma_ns_stats_out(void *workspace)

@@ -315,7 +315,7 @@ int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sam
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 /* Test hook (process-wide): how many of the eigh-free Sigma chain's last Chebyshev squarings / Newton-Schulz iterations
  * run inside the two persistent launches (phases separated by grid barriers) instead of as one / two launches each.
- * Default (6, 6): the last six squarings and six iterations; (64, 64) = all but the first of each; (0, 0) = every phase its own launch.  The result does not
+ * Default (9, 6): the last nine squarings (of a cap of sixteen) and six iterations; (64, 64) = all but the first of each; (0, 0) = every phase its own launch.  The result does not
  * depend on it bit for bit; graphs captured before the call keep their launch sequence; batch > 1 never uses them. */
 int covo_debug_set_ns_tail(int n_squarings, int n_iters);
 /* Test hook (process-wide): 0 switches the deflation of the bottom eigenpair in the eigh-free Sigma chain off (sigma_ns.hip: the

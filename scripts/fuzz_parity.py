@@ -99,6 +99,14 @@ for trial in range(int(sys.argv[4]) if len(sys.argv) > 4 else 24):
         ok = err < 1e-6 and errL < 2e-7 and np.all(np.isfinite(S))
         if not ok:
             print("FAIL sigma", trial, "batch", batch, "lmin %.3f width %g mult %d gap %g" % (lmin, width, mult, gap), "err", err, "errL", errL, flush=True)
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.save(f"gpurun_out/fail_sigma_{trial}.npy", Rm)
+            for on in (1, 0):  # with / without the deflation (sigma_ns.hip)
+                core.lib.covo_debug_set_ns_deflate(on)
+                S2, _ = core.sigma(torch.from_numpy(Rm[None].copy()).to(T.DEV), 0.5)
+                e2 = np.linalg.norm(S2[0].cpu().numpy() - ref) / np.linalg.norm(ref)
+                print("    deflate", on, "err", e2, "chain (squarings, iterations, deflated)", T._sigma_chain_iters(core), flush=True)
+            core.lib.covo_debug_set_ns_deflate(1)
         else:
             n3 += 1
 print("sigma:", n3, "passed, worst rel err", worst)
@@ -124,3 +132,36 @@ for trial in range(int(sys.argv[5]) if len(sys.argv) > 5 else 16):
     else:
         n4 += 1
 print("hessian:", n4, "passed, worst", worst)
+
+# ---- round 3: rollout with random disturbance model / reward / key / period / size against the fp64 oracle with the same draws
+import test_gpu_models as M
+from covo_mpc_amd import _lib as L_
+n5 = 0
+worst = 0.0
+for trial in range(int(sys.argv[6]) if len(sys.argv) > 6 else 24):
+    kind = rnd.choice(M.KINDS)
+    reward = rnd.choice(["penyaw", "realworld"])
+    time = rnd.choice([0, 7, 37, 49, 50, 150, 268, 290, 299, 305])
+    N = rnd.choice([1, 63, 65, 257, 1000, 4096, 16448, 40001])
+    period = rnd.choice([1, 3, 7, 50])
+    rollover = rnd.random() < 0.3
+    s, p, rng = T.make_problem(seed=rnd.randrange(10000), time=time)
+    p = p.replace(disturb_params=tuple(float(np.float32(x)) for x in rng.uniform(-1, 1, 6)), disturb_period=period)
+    a = T.sample_actions(p, rng, N, sigma=rnd.choice([0.2, 0.5, 1.0]))
+    key = M.cr.PRNGKey(rnd.randrange(1 << 30))
+    disc = rnd.choice([1.0, 0.97])
+    core = T.SamplingCore(N, 32, 0.01, disc, device=T.DEV)
+    pc = M.params_c(p, kind, reward, rollover=rollover)
+    tab = core.disturb_table(pc, T.dev_state(s).packed, key=key, key_mode=L_.DISTURB_KEYS_SHARED, deterministic=True)
+    cost = M._rollout_dev(core, s, pc, a, tab=tab, want_stats=rnd.random() < 0.5)
+    draw = M.cr.uniform(M.disturb_key(key), (3,), -p.disturb_scale, p.disturb_scale).astype(np.float64)
+    d = T.R.Disturb(kind, draw, True)
+    ref = T.CO.rollout(s, p, a.astype(np.float64), disc, dtype=np.float64, rollover=rollover, reward=reward, disturb=d)
+    ref32 = T.CO.rollout(s.astype(np.float32), p, a, disc, dtype=np.float32, rollover=rollover, reward=reward, disturb=d)
+    err = np.minimum(T.rel_err(cost, ref), T.rel_err(cost, ref32.astype(np.float64)))
+    worst = max(worst, float(np.median(err)))
+    if (err < 1.3e-5).mean() > 0.995:
+        n5 += 1
+    else:
+        print("FAIL model rollout", kind, reward, time, N, period, rollover, disc, "max err", err.max(), "frac ok", (err < 1.3e-5).mean(), flush=True)
+print("model rollouts:", n5, "passed, worst median err", worst)

@@ -909,6 +909,12 @@ def test_sigma_deflation_on_real_hessians():
     ww = w.copy()
     ww[-1] = ww[0] + 4000.0  # cond 4e5 before deflation
     mats.append((U * ww) @ U.T)
+    # found by scripts/fuzz_parity.py (seed 3): lambda_min = -0.015 next to the four exact zeros of the null block, width 1.7e3 --
+    # round 2's chain reported lambda_min = 0 (the null rows' unit vectors took all Ritz picks after 13 squarings) and returned NaN
+    mats.append(np.load(os.path.join(HERE, "golden", "sigma_nullblock_small_lmin.npy")))
+    Z = np.zeros((128, 128))
+    Z[:120, :120] = (lambda B: B @ B.T / 120 + 0.3 * np.eye(120))(rng.normal(size=(120, 120)))  # PSD with an 8-dim null block: lambda_min = 0 exactly
+    mats.append(Z)
     core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
     saved, n_defl = [], 0
     try:
@@ -925,7 +931,7 @@ def test_sigma_deflation_on_real_hessians():
                 assert np.linalg.norm(L @ L.T - Sigma) / np.linalg.norm(Sigma) < 2e-7, (i, on)
                 res[on] = _sigma_chain_iters(core)
             assert res[0][2] is False and res[1][1] <= res[0][1], (i, res)
-            if i < len(mats) - 5:  # the real Hessians: deflated, and it pays
+            if i < len(mats) - 7:  # the real Hessians: deflated, and it pays
                 assert res[1][2], (i, res)
                 saved.append(res[0][1] - res[1][1])
             n_defl += res[1][2]
