@@ -85,7 +85,7 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_GAM = 29,            // deflation: Y0 = (B + (tau - 1e-2) u u^T) / s = B/s + gam u u^T (0: off)
        SC_ZCOEF = 30,          // deflation: Z = Z~ + zcoef u u^T, zcoef = sqrt(s) ((1e-2)^(-1/2) - tau^(-1/2)) (0: off)
        SC_GAPEST = 31,         // the gap bound lambda_2 - lambda_1 >= ... (diagnostics)
-       SC_RESID = 15,          // |A u - theta u| of the bottom Ritz pair (diagnostics)
+       SC_RESID = 15,          // |A u - theta u|^2 of the bottom Ritz pair (diagnostics)
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
@@ -492,15 +492,15 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         }
         sh_gap = gap;
     }
-    if (tid == 0) {
-        // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, exits when diagonal), the rotations accumulated for the
-        // bottom Ritz vector; reciprocals / square roots by hardware seed + Newton (qm::rcp64_, qm::rsq64_), not libm
-        double h[RITZ][RITZ], jv[RITZ][RITZ];
-        for (int i = 0; i < RITZ; ++i)
-            for (int j = 0; j < RITZ; ++j) {
-                h[i][j] = 0.5 * (H[i][j] + H[j][i]);
-                jv[i][j] = (i == j) ? 1.0 : 0.0;
-            }
+    if (tid < RITZ) {
+        // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, exits when diagonal); reciprocals / square roots by hardware seed +
+        // Newton (qm::rcp64_, qm::rsq64_), not libm.  Lanes 0..3 run it in lockstep (the same issue slots as one lane): each also
+        // carries ONE row of the accumulated rotation -- the eigenvectors for 4 extra operations per rotation instead of 16
+        double h[RITZ][RITZ], jrow[RITZ];
+        for (int i = 0; i < RITZ; ++i) {
+            for (int j = 0; j < RITZ; ++j) h[i][j] = 0.5 * (H[i][j] + H[j][i]);
+            jrow[i] = (i == tid) ? 1.0 : 0.0;
+        }
         for (int sweep = 0; sweep < 12; ++sweep) {
             double off = 0.0, dia = 0.0;
             for (int p = 0; p < RITZ; ++p)
@@ -529,27 +529,28 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
                         h[k][q2] = nq_;
                         h[q2][k] = nq_;
                     }
-                    for (int k = 0; k < RITZ; ++k) {  // eigenvectors: columns p, q2 of the accumulated rotation
-                        const double jp = jv[k][p], jq = jv[k][q2];
-                        jv[k][p] = c * jp - sn * jq;
-                        jv[k][q2] = sn * jp + c * jq;
+                    {   // this lane's row of the accumulated rotation: columns p, q2
+                        const double jp = jrow[p], jq = jrow[q2];
+                        jrow[p] = c * jp - sn * jq;
+                        jrow[q2] = sn * jp + c * jq;
                     }
                 }
         }
-        double lmin = h[0][0];
-        int imin = 0;
+        double lmin = h[0][0], cmin = jrow[0];
         for (int i = 1; i < RITZ; ++i)
-            if (h[i][i] < lmin) { lmin = h[i][i]; imin = i; }
-        for (int k = 0; k < RITZ; ++k) sh_cvec[k] = jv[k][imin];
-        sh_lmin = lmin;  // (the Ritz pair's own value: what its residual is taken against)
-        sh_null_is_min = 0;
-        if (sh_has_null && lmin > 0.0) {  // the exact zeros of the null rows are the bottom of the spectrum
-            lmin = 0.0;
-            sh_null_is_min = 1;
+            if (h[i][i] < lmin) { lmin = h[i][i]; cmin = jrow[i]; }
+        sh_cvec[tid] = cmin;  // component `tid` of the bottom eigenvector of H
+        if (tid == 0) {
+            sh_lmin = lmin;  // (the Ritz pair's own value: what its residual is taken against)
+            sh_null_is_min = 0;
+            if (sh_has_null && lmin > 0.0) {  // the exact zeros of the null rows are the bottom of the spectrum
+                lmin = 0.0;
+                sh_null_is_min = 1;
+            }
+            s[SC_LMIN] = lmin;
+            s[SC_DELTA] = -lmin + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
+            sh_delta = -lmin + 1e-2;
         }
-        s[SC_LMIN] = lmin;
-        s[SC_DELTA] = -lmin + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
-        sh_delta = -lmin + 1e-2;
     }
     __syncthreads();
     const double delta = sh_delta;
@@ -577,21 +578,22 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         const double scale = fmin(fmax(red[0], red[1]), sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
         s[SC_SCALE] = scale;  // the Newton-Schulz coefficient table follows from it: ns_first_kernel's extra workgroup
         // deflate the bottom eigenpair when its gap bound is worth it and the pair is converged (see the header)
-        const double gap = NS_DEFL_SAFETY * sh_gap, resid = sqrt(sh_r2[0] + sh_r2[1]);
-        const bool defl = g_ns_deflate_dev && !sh_null_is_min && gap > NS_DEFL_MIN_GAP && resid <= NS_DEFL_RESID * gap &&
+        const double gap = NS_DEFL_SAFETY * sh_gap, resid2 = sh_r2[0] + sh_r2[1], rtol = NS_DEFL_RESID * gap;
+        const bool defl = g_ns_deflate_dev && !sh_null_is_min && gap > NS_DEFL_MIN_GAP && resid2 <= rtol * rtol &&
                           1e-2 + gap < 0.25 * scale;
         double lo = 1e-2, gam = 0.0, zc = 0.0;
         if (defl) {
             lo = 1e-2 + gap;
-            const double tau = sqrt(lo * scale);  // anywhere inside [lo, scale]
+            const double ls = lo * scale;
+            const double tau = ls * qm::rsq64_(ls);  // sqrt(lo scale): anywhere inside [lo, scale] serves
             gam = (tau - 1e-2) / scale;
-            zc = sqrt(scale) * (10.0 - qm::rsq64_(tau));  // (1e-2)^(-1/2) = 10
+            zc = scale * qm::rsq64_(scale) * (10.0 - qm::rsq64_(tau));  // sqrt(scale) ((1e-2)^(-1/2) - tau^(-1/2))
         }
         s[SC_LO] = lo;
         s[SC_GAM] = gam;
         s[SC_ZCOEF] = zc;
         s[SC_GAPEST] = sh_gap;
-        s[SC_RESID] = resid;
+        s[SC_RESID] = resid2;  // squared
     }
 }
 
