@@ -262,39 +262,6 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(cp.a_mean).all(), "non-finite a_mean after the timed region"
 
-    # ---- the same steps with covo.py:281's pos_mean / pos_std (a22) computed: a second controller, same inputs, same keys,
-    # same barrier + sync bracket; reported NEXT to `value` (the reference's jitted eval loop drops the info as dead code,
-    # a plain controller __call__ returns it)
-    elapsed_other = None
-    if not args.no_info_leg:
-        ctrl2, cp2 = cm.envs.get_controller(env, args.controller, f"N{args.N}_H{H}_lam{args.lam}", device=device,
-                                            process_group=pg, compute_info=not args.info)
-        cp2 = ctrl2.reset(s_reset, params, ctrl2.init_control_params, cr.PRNGKey(7))
-        ctrl2.alias_outputs = True
-
-        def step2(i, cp2):
-            u, cp2, _ = ctrl2(None, None, params, act_keys[i], cp2, {"noisy_state": dstates[i % n_states]})
-            return cp2
-
-        for i in range(args.warmup):
-            cp2 = step2(i, cp2)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            cp2 = step2(args.warmup + i, cp2)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed_other = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed_other], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed_other = float(t.item())
-        del ctrl2, cp2
-
     # The rollout kernel of the timed steps runs inside the fused step and cannot be bracketed individually from the host.
     # `launch_us` = MEAN duration of back-to-back launches of the SAME kernel variant the step runs (with the softmax
     # records; with the position statistics under --info) on the SAME buffers, measured right here with events on the launch
@@ -336,8 +303,51 @@ def main():
         except Exception:
             in_step_us = gemm_in_step_us = None
 
+    n_local, exchange_name = core.n_local, core.exchange
+    closed = closed_loop(env, controller, params, n_states) if (world == 1 and rank == 0 and not args.no_closed_loop) else None
+
+    # ---- the same steps with covo.py:281's pos_mean / pos_std (a22) computed: a second controller, same inputs, same keys,
+    # same barrier + sync bracket; reported NEXT to `value` (the reference's jitted eval loop drops the info as dead code,
+    # a plain controller __call__ returns it)
+    # The first controller is destroyed first: two live handles per process are harmless on a GPU of one's own, but with
+    # several ranks SHARING one GPU (the single-box rehearsal of --gpus N) every launch of the second handle ran 2.3x
+    # slower (hardware-queue oversubscription) -- r03 measurement, DESIGN.md 6.
+    elapsed_other = None
+    if not args.no_info_leg:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()  # peers map this rank's exchange buffer: everybody is done with it before anybody frees it
+        core.close()
+        del controller, core, cp
+        ctrl2, cp2 = cm.envs.get_controller(env, args.controller, f"N{args.N}_H{H}_lam{args.lam}", device=device,
+                                            process_group=pg, compute_info=not args.info)
+        cp2 = ctrl2.reset(s_reset, params, ctrl2.init_control_params, cr.PRNGKey(7))
+        ctrl2.alias_outputs = True
+
+        def step2(i, cp2):
+            u, cp2, _ = ctrl2(None, None, params, act_keys[i], cp2, {"noisy_state": dstates[i % n_states]})
+            return cp2
+
+        for i in range(args.warmup):
+            cp2 = step2(i, cp2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            cp2 = step2(args.warmup + i, cp2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_other = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed_other], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_other = float(t.item())
+        del ctrl2, cp2
+
     if rank == 0:
-        n_local = core.n_local
         alg_bytes = n_local * ROLLOUT_BYTES_PER_SAMPLE
         # the judged duration is the kernel's IN-STEP duration (what the timed region ran and what the rocprofv3 kernel trace
         # of this command averages, cold stripes fresh from the GEMM); the warm back-to-back figure rides along
@@ -354,7 +364,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.controller} tracking_zigzag N={args.N} H={H} lam={args.lam} sigma=0.5 "
                                    f"(teacher-forced noisy states of one 300-step episode; samples sharded {world}x"
-                                   f"{n_local}, one exchange of the 516-float rank records per step: {core.exchange})",
+                                   f"{n_local}, one exchange of the 516-float rank records per step: {exchange_name})",
                        "controller": args.controller, "N_global": args.N, "N_local": n_local, "H": H,
                        "pos_stats_info": bool(args.info)},
             "roofline": {"bound": "hbm", "kernel": kernel_name,
@@ -386,8 +396,8 @@ def main():
                                     "flop_per_sample": {"dense_equivalent": GEMM_FLOP_PER_SAMPLE_DENSE,
                                                         "issued": GEMM_FLOP_PER_SAMPLE_ISSUED},
                                     "counters": (kin.get("noise_gemm") or {}).get("derived")}
-        if world == 1 and not args.no_closed_loop:
-            out["closed_loop"] = closed_loop(env, controller, params, n_states)
+        if closed is not None:
+            out["closed_loop"] = closed
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_states, params, args.N, H, args.lam, args.cpu_budget)
         print(json.dumps(out))

@@ -130,11 +130,16 @@ class SamplingCore:
                 self._connect_peer_exchange()
             self.exchange = mode
 
+    def close(self):
+        """covo_destroy now (workspaces, step graphs, side stream, exchange buffers) instead of at garbage collection.
+        On sample-sharded ranks every rank closes at the same point: peers hold hipIpc mappings of the exchange buffer."""
+        if getattr(self, "h", None):
+            self.lib.covo_destroy(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            if getattr(self, "h", None):
-                self.lib.covo_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
 
