@@ -564,10 +564,10 @@ int covo_mpc_step_batched(covo_handle_t h, const covo_batch_args *args, const co
             "covo_mpc_step_batched: null buffer");
     for (int e = 0; e < args->n_envs; ++e) {
         CHECK_MODEL(&params[e], "covo_mpc_step_batched");
-        REQUIRE(!needs_table(&params[e]), "covo_mpc_step_batched: disturb_kind=%d of instance %d: the env-batched step takes "
-                "COVO_DISTURB_NONE / GAUSSIAN only (the per-step tables are per control step)", params[e].disturb_kind, e);
-        REQUIRE(params[e].reward_kind == params[0].reward_kind && params[e].rollover_terminate == params[0].rollover_terminate,
-                "covo_mpc_step_batched: all instances must share reward_kind and rollover_terminate");
+        REQUIRE(params[e].reward_kind == params[0].reward_kind && params[e].rollover_terminate == params[0].rollover_terminate &&
+                    params[e].disturb_kind == params[0].disturb_kind,
+                "covo_mpc_step_batched: all instances must share reward_kind, rollover_terminate and disturb_kind (one kernel "
+                "variant per launch); disturb_params / period / scale may differ");
     }
     return covo_step_batched_impl(h, args, params, keys, (hipStream_t)stream);
 }

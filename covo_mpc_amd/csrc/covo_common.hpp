@@ -110,11 +110,18 @@ int launch_disturb_table(const covo_env_params &p, const float *state, int batch
                          uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s);
 int launch_disturb_tables_step(const covo_env_params &p, const float *state, const uint32_t *dyn, int rollout_deterministic,
                                float *tab_rollout, float *tab_hess, hipStream_t s);
+// env-batched step: per-instance models (dm::Model[n], host-filled, copied to the device by the caller) and both tables of
+// every instance in one launch ([n][H][4] each; raw keys at dyn[12 e + 10..11])
+size_t disturb_models_bytes(int n);
+void disturb_fill_models(const covo_env_params *params, int n, void *out);
+int launch_disturb_tables_batched(const void *models_dev, const float *states, const uint32_t *dyn, int n_envs,
+                                  int rollout_deterministic, float *tab_rollout, float *tab_hess, hipStream_t s);
 int rollout_workgroups(int N, bool stats, int nbatch = 1);
 size_t rollout_args_bytes(int n);
 void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
                        const covo_env_params &p, const float *a, int N, float discount, float *cost, float *groupmin,
-                       const float *f_shared_dev, float *records = nullptr, float lam = 0.0f, bool trust_clipped = true);
+                       const float *f_shared_dev, float *records = nullptr, float lam = 0.0f, bool trust_clipped = true,
+                       const float *f_tab = nullptr);
 int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, hipStream_t s);
 // a_mean_out != null: finish on this GPU (normalise + blend); else write the merged record to partial_out
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
@@ -142,7 +149,8 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev = nullptr,
                    size_t traj_stride = 0,
                    const SymStatsOut *stats = nullptr,   // batch 1: KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
-                   const float *f_tab = nullptr);        // [batch][H][4] per-step disturbance table (disturb.hip), device
+                   const float *f_tab = nullptr,         // [batch][H][4] per-step disturbance table (disturb.hip), device
+                   const void *models_dev = nullptr);    // dm::Model[batch] next to consts_dev (drag / mixed with per-instance parameters)
 // true: launch_hessian leaves R's Sigma-chain statistics when asked to (the adjoint kernels; the per-pair kernel that takes
 // the drag / mixed models does not)
 inline bool hessian_leaves_stats(const covo_env_params &p)
@@ -153,7 +161,8 @@ size_t hessian_consts_bytes(int n);
 void hessian_fill_consts(const covo_env_params *params, int n, void *out);
 // the per-pair hyper-dual rollout version (hessian.hip): slower, independent derivation, kept as a cross-check
 int launch_hessian_pairs(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                         const float *a_mean, int batch, double *R, hipStream_t s, const float *f_tab = nullptr);
+                         const float *a_mean, int batch, double *R, hipStream_t s, const float *f_tab = nullptr,
+                         const void *consts_dev = nullptr, size_t traj_stride = 0, const void *models_dev = nullptr);
 int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, unsigned long long *prof,
                  hipStream_t s);
 size_t sigma_ns_workspace_bytes(int batch);

@@ -97,6 +97,45 @@ __global__ __launch_bounds__(64) void disturb_tables_step_kernel(const float *__
     }
 }
 
+// env-batched step (step.hip: covo_mpc_step_batched): the same two tables for every instance -- workgroup (e, 0) the rollouts',
+// (e, 1) the Hessian's; instance e has its own state, raw key (dyn[12 e + 10..11]) and, under domain randomisation, its own
+// disturb_params (quadrotor.py:152)
+__global__ __launch_bounds__(64) void disturb_tables_batched_kernel(const float *__restrict__ states, const uint32_t *__restrict__ dyn,
+                                                                    const dm::Model *__restrict__ models, int rollout_deterministic,
+                                                                    float4 *__restrict__ tab_rollout, float4 *__restrict__ tab_hess)
+{
+    if (threadIdx.x != 0) return;
+    const int e = blockIdx.x;
+    const dm::Model m = models[e];
+    const float *st = states + (size_t)e * COVO_STATE_FLOATS;
+    const uint32_t raw[2] = {dyn[12 * e + 10], dyn[12 * e + 11]};
+    if (blockIdx.y == 0) {
+        uint32_t rng1[2], step_key[2];
+        dm::split(raw, 0u, rng1);
+        dm::split(rng1, 1u, step_key);
+        disturb_table_row_loop(m, st, step_key, COVO_DISTURB_KEYS_SHARED, rollout_deterministic != 0, tab_rollout + (size_t)e * COVO_H);
+    } else {
+        disturb_table_row_loop(m, st, raw, COVO_DISTURB_KEYS_HESSIAN, true, tab_hess + (size_t)e * COVO_H);
+    }
+}
+
+size_t disturb_models_bytes(int n) { return (size_t)n * sizeof(dm::Model); }
+void disturb_fill_models(const covo_env_params *params, int n, void *out)
+{
+    dm::Model *m = reinterpret_cast<dm::Model *>(out);
+    for (int i = 0; i < n; ++i) m[i] = dm::make_model(params[i]);
+}
+
+int launch_disturb_tables_batched(const void *models_dev, const float *states, const uint32_t *dyn, int n_envs,
+                                  int rollout_deterministic, float *tab_rollout, float *tab_hess, hipStream_t s)
+{
+    hipLaunchKernelGGL(disturb_tables_batched_kernel, dim3(n_envs, 2), dim3(64), 0, s, states, dyn,
+                       reinterpret_cast<const dm::Model *>(models_dev), rollout_deterministic,
+                       reinterpret_cast<float4 *>(tab_rollout), reinterpret_cast<float4 *>(tab_hess));
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_disturb_table(const covo_env_params &p, const float *state, int batch, const uint32_t *keys_dev, uint32_t key0,
                          uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s)
 {

@@ -42,8 +42,12 @@ __device__ __forceinline__ void split(const uint32_t (&key)[2], uint32_t i, uint
     child[0] = r[0];
     child[1] = r[1];
 }
+// (fp contraction is switched off inside the model functions: they are inlined into several kernels -- the fused step's table
+// launch, the env-batched one, covo_disturb_table, the env step -- and left to itself hipcc fuses a different subset of their
+// a * b + c per call site, so that the same model gave tables differing in the last ulp)
 __device__ __forceinline__ float uniform3(const uint32_t (&key)[2], int i, float lo, float hi)
 {
+#pragma clang fp contract(off)
     uint32_t b[4];
     rngd::philox4x32_10(0u, 0u, 0u, 0xB175u, key[0], key[1], b);
     const double u = ((double)(b[i] >> 8) + 0.5) / 16777216.0;
@@ -51,6 +55,7 @@ __device__ __forceinline__ float uniform3(const uint32_t (&key)[2], int i, float
 }
 __device__ __forceinline__ float normal3(const uint32_t (&key)[2], int i)
 {
+#pragma clang fp contract(off)
     uint32_t b1[4], b2[4];
     rngd::philox4x32_10(0u, 0u, 0u, 0xB175u, key[0], key[1], b1);
     rngd::philox4x32_10((uint32_t)((3 + i) >> 2), 0u, 0u, 0xB175u, key[0], key[1], b2);
@@ -71,6 +76,7 @@ __device__ __forceinline__ void disturb_key(const uint32_t (&k)[2], uint32_t (&o
 // component i of free.py:27-38 at `time` (fp32, like the host env)
 __device__ __forceinline__ float sin_term(const Model &m, int time, int i)
 {
+#pragma clang fp contract(off)
     const float scale = m.dp[i] * m.scale;
     const float period = m.dp[i] * (float)((double)m.period / 3.0) + (float)m.period;
     const float phase = m.dp[3 + i] * 6.2831853071795864769f;
@@ -79,6 +85,7 @@ __device__ __forceinline__ float sin_term(const Model &m, int time, int i)
 // component i of free.py:41-47
 __device__ __forceinline__ float drag_term(const Model &m, float vel_i, int i)
 {
+#pragma clang fp contract(off)
     const float rel = vel_i - m.dp[i] * 0.5f;
     return -fabsf(m.scale) * rel * fabsf(rel) / 2.25f;
 }
@@ -93,6 +100,7 @@ __host__ __device__ inline float drag_coeff(const Model &m)
 __device__ __forceinline__ float next_force(const Model &m, const uint32_t (&dkey)[2], int time, float vel_i, float f_i, int i,
                                             bool deterministic)
 {
+#pragma clang fp contract(off)
     switch (m.kind) {
     case COVO_DISTURB_GAUSSIAN: return deterministic ? 0.0f : m.noise_scale * normal3(dkey, i);
     case COVO_DISTURB_PERIODIC: return (time % m.period == 0) ? uniform3(dkey, i, -m.scale, m.scale) : f_i;

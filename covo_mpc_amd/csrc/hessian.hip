@@ -32,12 +32,24 @@ struct HessArgs {
     int reward;           // COVO_REWARD_*
     double drag_k;        // c_drag * (-|disturb_scale| / 1.5^2): != 0 makes the force part of the differentiated state (free.py:41-56)
     double drag_off[3];   // disturb_params[:3] / 2
+    // env-batched step: per-instance constants / trajectories / disturbance parameters (null / 0: the shared ones above)
+    const qm::Consts<double> *cs;
+    size_t traj_stride;
+    const dm::Model *models;
+};
+
+__host__ __device__ inline double hs_drag_k(const dm::Model &m)
+{
+    return -(m.kind == COVO_DISTURB_DRAG ? 1.0 : (m.kind == COVO_DISTURB_MIXED ? 1.0 / 3.0 : 0.0)) * fabs((double)m.scale) / 2.25;
+}
+struct HsDrag {
+    double k, off[3];
 };
 
 // The force of step k+1 from the PRE-step state of step k (free.py:147): f' = drag_k rel |rel| + c f + g with row k+1 = {g, c} of
 // the table (disturb.hip); S = double (primal prefix) or HD.  Without a table: zero.
 template <class S>
-__device__ __forceinline__ void hs_next_force(const HessArgs &A, int b, int k, const qm::State<S> &s, S (&f)[3])
+__device__ __forceinline__ void hs_next_force(const HessArgs &A, const HsDrag &D, int b, int k, const qm::State<S> &s, S (&f)[3])
 {
     if (A.f_tab == nullptr || k + 1 >= COVO_H) {
         f[0] = f[1] = f[2] = S{};
@@ -49,7 +61,7 @@ __device__ __forceinline__ void hs_next_force(const HessArgs &A, int b, int k, c
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         S n = f[i] * c + g[i];
-        if (A.drag_k != 0.0) n = n + qm::drag_force<S, double>(v[i], A.drag_off[i], A.drag_k);
+        if (D.k != 0.0) n = n + qm::drag_force<S, double>(v[i], D.off[i], D.k);
         f[i] = n;
     }
 }
@@ -66,14 +78,15 @@ __host__ __device__ constexpr int hs_total_waves()
 }
 
 template <class S>
-__device__ __forceinline__ void hs_targets(const float *__restrict__ st, const HessArgs &A, int time0, int k, double (&tar)[6])
+__device__ __forceinline__ void hs_targets(const float *__restrict__ st, const HessArgs &A, int b, int time0, int k, double (&tar)[6])
 {
     if (k == 0) {
         for (int i = 0; i < 3; ++i) { tar[i] = st[ST_POSTAR + i]; tar[3 + i] = st[ST_VELTAR + i]; }
     } else {
         int idx = time0 + k;
         idx = idx < 0 ? 0 : (idx > A.T - 1 ? A.T - 1 : idx);
-        for (int i = 0; i < 3; ++i) { tar[i] = A.pos_traj[3 * idx + i]; tar[3 + i] = A.vel_traj[3 * idx + i]; }
+        const float *pt = A.pos_traj + (size_t)b * A.traj_stride, *vt = A.vel_traj + (size_t)b * A.traj_stride;
+        for (int i = 0; i < 3; ++i) { tar[i] = pt[3 * idx + i]; tar[3 + i] = vt[3 * idx + i]; }
     }
 }
 
@@ -97,7 +110,13 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
         i = 4 * ti + d;
         j = i + q;
     }
-    const qm::Consts<double> c = A.c;
+    const qm::Consts<double> c = A.cs ? A.cs[b] : A.c;
+    HsDrag D = {A.drag_k, {A.drag_off[0], A.drag_off[1], A.drag_off[2]}};
+    if (A.models != nullptr) {
+        const dm::Model m = A.models[b];
+        D.k = hs_drag_k(m);
+        for (int q3 = 0; q3 < 3; ++q3) D.off[q3] = 0.5 * (double)m.dp[q3];
+    }
     const int time0 = __float_as_int(st[ST_TIME]);
 
     // ---- primal prefix: steps 0 .. t_i-1 in plain fp64
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
         const double a0 = qm::clip11_((double)am[4 * k + 0]), a1 = qm::clip11_((double)am[4 * k + 1]);
         const double a2 = qm::clip11_((double)am[4 * k + 2]), a3 = qm::clip11_((double)am[4 * k + 3]);
         double fn[3] = {fp[0], fp[1], fp[2]};
-        hs_next_force<double>(A, b, k, p, fn);  // from the PRE-step state
+        hs_next_force<double>(A, D, b, k, p, fn);  // from the PRE-step state
         qm::dyn_step<double, double>(p, a0, a1, a2, a3, c, fp[0], fp[1], fp[2]);
         fp[0] = fn[0]; fp[1] = fn[1]; fp[2] = fn[2];
     }
@@ -126,7 +145,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
     for (int k = ti; k < COVO_H; ++k) {
         if (k > ti) {  // s_k depends on the seeds only for k > t_i
             double tar[6];
-            hs_targets<double>(st, A, time0, k, tar);
+            hs_targets<double>(st, A, b, time0, k, tar);
             const qm::HD r = qm::reward_kind<qm::HD, double>(A.reward, s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
             acc += r.ab;
         }
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
             a[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
         }
         qm::HD fn[3] = {fh[0], fh[1], fh[2]};
-        hs_next_force<qm::HD>(A, b, k, s, fn);  // from the PRE-step state (free.py:147)
+        hs_next_force<qm::HD>(A, D, b, k, s, fn);  // from the PRE-step state (free.py:147)
         qm::dyn_step<qm::HD, double, true, qm::HD>(s, a[0], a[1], a[2], a[3], c, fh[0], fh[1], fh[2]);
         fh[0] = fn[0]; fh[1] = fn[1]; fh[2] = fn[2];
     }
@@ -150,7 +169,8 @@ __global__ __launch_bounds__(64) void hessian_kernel(const HessArgs A)
 }
 
 int launch_hessian_pairs(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
-                   const float *a_mean, int batch, double *R, hipStream_t s, const float *f_tab)
+                   const float *a_mean, int batch, double *R, hipStream_t s, const float *f_tab, const void *consts_dev,
+                   size_t traj_stride, const void *models_dev)
 {
     const bool needs_tab = p.disturb_kind >= COVO_DISTURB_PERIODIC && p.disturb_kind <= COVO_DISTURB_MIXED;
     if (needs_tab && f_tab == nullptr) {
@@ -168,8 +188,11 @@ int launch_hessian_pairs(const float *state, const float *pos_traj, const float 
     const dm::Model m = dm::make_model(p);
     A.f_tab = needs_tab ? reinterpret_cast<const float4 *>(f_tab) : nullptr;
     A.reward = p.reward_kind;
-    A.drag_k = -(m.kind == COVO_DISTURB_DRAG ? 1.0 : (m.kind == COVO_DISTURB_MIXED ? 1.0 / 3.0 : 0.0)) * fabs((double)m.scale) / 2.25;
+    A.drag_k = hs_drag_k(m);
     for (int i = 0; i < 3; ++i) A.drag_off[i] = 0.5 * (double)m.dp[i];
+    A.cs = reinterpret_cast<const qm::Consts<double> *>(consts_dev);
+    A.traj_stride = traj_stride;
+    A.models = reinterpret_cast<const dm::Model *>(models_dev);
     COVO_CHECK_HIP(hipMemsetAsync(R, 0, (size_t)batch * COVO_NA * COVO_NA * sizeof(double), s));
     hipLaunchKernelGGL(hessian_kernel, dim3(hs_total_waves(), batch), dim3(64), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());

@@ -549,16 +549,16 @@ size_t hessian_workspace_bytes(int batch) { return (size_t)batch * WS_COUNT * si
 
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev,
-                   size_t traj_stride, const SymStatsOut *stats, const float *f_tab)
+                   size_t traj_stride, const SymStatsOut *stats, const float *f_tab, const void *models_dev)
 {
     if (p.disturb_kind == COVO_DISTURB_DRAG || p.disturb_kind == COVO_DISTURB_MIXED) {
         // a velocity-dependent force is part of the differentiated state (16 components instead of the 13 this kernel's tiles
         // are laid out for): the per-pair hyper-dual rollout takes these two models (hessian.hip)
-        if (consts_dev != nullptr || traj_stride != 0) {
-            covo_set_error("hessian: drag / mixed disturbance with per-instance parameters is not built");
-            return COVO_E_UNSUPPORTED;
+        if ((consts_dev != nullptr) != (models_dev != nullptr)) {
+            covo_set_error("hessian: drag / mixed disturbance with per-instance constants needs the per-instance models too");
+            return COVO_E_BADARG;
         }
-        return launch_hessian_pairs(state, pos_traj, vel_traj, T, p, a_mean, batch, R, s, f_tab);
+        return launch_hessian_pairs(state, pos_traj, vel_traj, T, p, a_mean, batch, R, s, f_tab, consts_dev, traj_stride, models_dev);
     }
     if ((p.disturb_kind == COVO_DISTURB_PERIODIC || p.disturb_kind == COVO_DISTURB_SIN) && f_tab == nullptr) {
         covo_set_error("hessian: disturb_kind=%d needs the per-step disturbance table (covo_disturb_table)", p.disturb_kind);

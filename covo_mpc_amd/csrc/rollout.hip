@@ -143,17 +143,17 @@ size_t rollout_args_bytes(int n) { return (size_t)n * sizeof(RolloutArgs); }
 
 void rollout_fill_args(void *out, int index, const float *state, const float *pos_traj, const float *vel_traj, int T,
                        const covo_env_params &p, const float *a, int N, float discount, float *cost, float *groupmin,
-                       const float *f_shared_dev, float *records, float lam, bool trust_clipped)
+                       const float *f_shared_dev, float *records, float lam, bool trust_clipped, const float *f_tab)
 {
     RolloutArgs &A = reinterpret_cast<RolloutArgs *>(out)[index];
-    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost, groupmin, nullptr, f_shared_dev, nullptr);
-    A.fdist = 0;  // the env-batched step takes none / gaussian only (checked by the caller)
+    // f_tab: this instance's rows of the step's disturbance tables (periodic / sin / drag / mixed; all instances share the kind)
+    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost, groupmin, nullptr, f_shared_dev, f_tab);
     A.clip = trust_clipped ? 0 : 1;
     A.records = records;
     A.inv_lam = records ? 1.0f / lam : 0.0f;
 }
 
-// every instance must share instance 0's N, discount, clip and rollover settings (checked by the caller)
+// every instance must share instance 0's N, discount, clip, rollover, reward and disturbance kind (checked by the caller)
 int launch_rollout_batched(const void *args_host, const void *args_dev, int nbatch, hipStream_t s)
 {
     return dispatch_rollout<true>(reinterpret_cast<const RolloutArgs *>(args_host)[0],

@@ -5,7 +5,12 @@
 
 void launch_rollout_variant_r0(const RolloutArgs &A, const RolloutArgs *batch, int nb, bool batched, int groups, bool stats, hipStream_t s)
 {
-    (void)batched;  // per-step / per-sample disturbance tables are per control step: the env-batched step does not take them
-    if (A.fdist == 1) launch_pipe3_family<false, false, 0, 1>(A, batch, nb, groups, stats, s);
-    else launch_pipe3_family<false, false, 0, 2>(A, batch, nb, groups, stats, s);
+    if (batched) {  // env-batched step: instance y's table rides in its argument block
+        if (A.fdist == 1) launch_pipe3_family<false, true, 0, 1>(A, batch, nb, groups, false, s);
+        else launch_pipe3_family<false, true, 0, 2>(A, batch, nb, groups, false, s);
+    } else if (A.fdist == 1) {
+        launch_pipe3_family<false, false, 0, 1>(A, batch, nb, groups, stats, s);
+    } else {
+        launch_pipe3_family<false, false, 0, 2>(A, batch, nb, groups, stats, s);
+    }
 }

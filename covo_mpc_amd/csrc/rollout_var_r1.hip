@@ -9,8 +9,10 @@ void launch_rollout_variant_r1(const RolloutArgs &A, const RolloutArgs *batch, i
         if (batched) launch_pipe3_family<false, true, 1, 0>(A, batch, nb, groups, false, s);
         else launch_pipe3_family<false, false, 1, 0>(A, batch, nb, groups, stats, s);
     } else if (A.fdist == 1) {
-        launch_pipe3_family<false, false, 1, 1>(A, batch, nb, groups, stats, s);
+        if (batched) launch_pipe3_family<false, true, 1, 1>(A, batch, nb, groups, false, s);
+        else launch_pipe3_family<false, false, 1, 1>(A, batch, nb, groups, stats, s);
     } else {
-        launch_pipe3_family<false, false, 1, 2>(A, batch, nb, groups, stats, s);
+        if (batched) launch_pipe3_family<false, true, 1, 2>(A, batch, nb, groups, false, s);
+        else launch_pipe3_family<false, false, 1, 2>(A, batch, nb, groups, stats, s);
     }
 }

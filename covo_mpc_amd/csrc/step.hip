@@ -434,6 +434,8 @@ __global__ void batch_begin_kernel(const float *__restrict__ a_mean, float *__re
         d[0] = k[0];
         d[1] = k[1];
         d[2] = d[3] = d[4] = 0u;
+        d[10] = raw[0];  // the raw controller key, for the step's disturbance tables (disturb.hip)
+        d[11] = raw[1];
     }
 }
 
@@ -446,6 +448,9 @@ struct BatchState {
     void *consts = nullptr;         // qm::Consts<double>[E]   (Hessian)
     void *ro_args = nullptr;        // RolloutArgs[E]          (rollout)
     float *partials = nullptr;      // [E][max_red_blocks][COVO_PARTIAL_FLOATS]: the instances' softmax stage-1 records
+    void *models = nullptr;         // dm::Model[E]            (disturbance tables, per-pair Hessian)
+    float *tab_rollout = nullptr, *tab_hess = nullptr;  // [E][H][4] the step's disturbance tables (periodic / sin / drag / mixed)
+    bool tables = false;            // the instances' disturbance model needs them
     std::vector<char> ro_args_host;
     std::vector<covo_env_params> params;
     covo_batch_args key;
@@ -470,6 +475,10 @@ static void batch_state_free(BatchState *b)
     (void)hipFree(b->consts);
     (void)hipFree(b->ro_args);
     (void)hipFree(b->partials);
+    (void)hipFree(b->models);
+    (void)hipFree(b->tab_rollout);
+    (void)hipFree(b->tab_hess);
+    b->models = nullptr; b->tab_rollout = b->tab_hess = nullptr;
     b->dyn = nullptr; b->a_mean_shift = nullptr; b->R = nullptr; b->Sigma = b->L = nullptr; b->consts = nullptr;
     b->ro_args = nullptr; b->partials = nullptr;
 }
@@ -512,8 +521,10 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
     const int E = a.n_envs, N = a.n_samples;
     int rc;
     hipLaunchKernelGGL(batch_begin_kernel, dim3(E), dim3(COVO_NA + 64), 0, s, a.a_mean, b->a_mean_shift, b->dyn);
+    // covo.py:231: CoVO's sampling rollouts run step_env(deterministic=True); get_hessian likewise (covo.py:152)
+    if (b->tables && (rc = launch_disturb_tables_batched(b->models, a.states, b->dyn, E, 1, b->tab_rollout, b->tab_hess, s))) return rc;
     if ((rc = launch_hessian(a.states, a.pos_traj, a.vel_traj, a.T, b->params[0], b->a_mean_shift, E, b->R, h->ws_hess, s,
-                             b->consts, (size_t)a.T * 3)))
+                             b->consts, (size_t)a.T * 3, nullptr, b->tables ? b->tab_hess : nullptr, b->models)))
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
     if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
@@ -558,12 +569,19 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
             COVO_CHECK_HIP(hipMalloc(&b->consts, hessian_consts_bytes(E)));
             COVO_CHECK_HIP(hipMalloc(&b->ro_args, rollout_args_bytes(E)));
             COVO_CHECK_HIP(hipMalloc(&b->partials, (size_t)E * h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
+            COVO_CHECK_HIP(hipMalloc(&b->models, disturb_models_bytes(E)));
+            COVO_CHECK_HIP(hipMalloc(&b->tab_rollout, (size_t)E * COVO_H * 4 * sizeof(float)));
+            COVO_CHECK_HIP(hipMalloc(&b->tab_hess, (size_t)E * COVO_H * 4 * sizeof(float)));
             b->n_envs = E;
         }
         b->params.assign(params, params + E);
         std::vector<char> tmp(hessian_consts_bytes(E));
         hessian_fill_consts(params, E, tmp.data());
         COVO_CHECK_HIP(hipMemcpy(b->consts, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+        tmp.assign(disturb_models_bytes(E), 0);
+        disturb_fill_models(params, E, tmp.data());
+        COVO_CHECK_HIP(hipMemcpy(b->models, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+        b->tables = params[0].disturb_kind >= COVO_DISTURB_PERIODIC && params[0].disturb_kind <= COVO_DISTURB_MIXED;
         b->ro_args_host.assign(rollout_args_bytes(E), 0);
         const int N = args->n_samples, ng = (N + 63) / 64;
         const int bG = rollout_workgroups(N, false, E);
@@ -573,7 +591,8 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
                               args->pos_traj + (size_t)e * args->T * 3, args->vel_traj + (size_t)e * args->T * 3, args->T,
                               params[e], args->a + (size_t)e * COVO_H * N * 4, N, h->cfg.discount, args->cost + (size_t)e * N,
                               brec ? nullptr : args->groupmin + (size_t)e * ng, reinterpret_cast<const float *>(b->dyn + 12 * e + 2),
-                              brec ? b->partials + (size_t)e * bG * COVO_PARTIAL_FLOATS : nullptr, h->cfg.lam);
+                              brec ? b->partials + (size_t)e * bG * COVO_PARTIAL_FLOATS : nullptr, h->cfg.lam, true,
+                              b->tables ? b->tab_rollout + (size_t)e * COVO_H * 4 : nullptr);
         COVO_CHECK_HIP(hipMemcpy(b->ro_args, b->ro_args_host.data(), b->ro_args_host.size(), hipMemcpyHostToDevice));
         const size_t need_s = sigma_ns_workspace_bytes(E), need_h = hessian_workspace_bytes(E);
         if (need_s > h->ws_sigma_bytes || need_h > h->ws_hess_bytes) step_graphs_drop(h);  // captured launches point into them

@@ -380,7 +380,10 @@ int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_ste
  * (domain randomisation), mean and key; the Hessians and the Sigma chain of all instances run as ONE batched set of
  * launches, the sampling path (noise GEMM, rollout, softmax update) per instance.  Results per instance are bit-identical
  * to covo_mpc_step on that instance alone.  params: host array [n_envs]; keys: host uint32[n_envs][2], each the raw
- * rng_act of that instance's controller call (the sampling key is derived on the device, covo.py:212). */
+ * rng_act of that instance's controller call (the sampling key is derived on the device, covo.py:212).  All instances
+ * share reward_kind, rollover_terminate and disturb_kind (one kernel variant per launch); every disturbance model is
+ * taken -- for PERIODIC / SIN / DRAG / MIXED the call builds each instance's per-step tables (covo_disturb_table's, SHARED
+ * and HESSIAN key threading) from that instance's state, raw key and disturb_params inside the same graph. */
 #define COVO_MAX_ENVS 64
 typedef struct covo_batch_args {
     int32_t n_envs;          /* <= COVO_MAX_ENVS */

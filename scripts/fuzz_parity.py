@@ -8,30 +8,36 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import test_gpu_parity as T
 
 rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+import numpy as np
 n_ok = 0
+worst_abs = 0.0
 for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     time = rnd.choice([0, 1, 5, 37, 150, 268, 269, 285, 299, 300, 330])
     N = rnd.choice([1, 63, 64, 65, 200, 257, 1000, 4096, 8192, 16385, 33000, 70000])
     seed = rnd.randrange(1000)
-    try:
-        T.test_rollout_vs_fp64_oracle(time, seed, N)
+    # test_rollout_vs_fp64_oracle's body with the fp32 error model made explicit: a cost is a sum of 32 rewards of either sign
+    # (|r_k| up to ~10 when a sample flies off), so its fp32 error scales with sum_k |r_k|, not with |sum_k r_k| -- the test's
+    # rel_err (denominator max(|cost|, 1)) reads 1-3e-5 on the few samples of a large sweep whose rewards cancel
+    s_, p_, rng_ = T.make_problem(seed=seed, time=time)
+    a = T.sample_actions(p_, rng_, N)
+    fs = np.array([0.01, -0.02, 0.03], dtype=np.float32)
+    core = T.SamplingCore(N, 32, 0.01, 1.0, device=T.DEV)
+    cost = T._run_rollout(core, s_, p_, a, fs, want_stats=True)
+    ref, rew, poses = T.CO.rollout(s_, p_, a.astype(np.float64), 1.0, fs.astype(np.float64), dtype=np.float64, want_rewards=True, want_poses=True)
+    scale = np.maximum(np.abs(rew).sum(axis=-1), 1.0)
+    err = np.abs(cost - ref) / scale
+    info = core.info(T.dev_state(s_))
+    pm, ps = T.R.pos_stats(poses)
+    dm = np.abs(info["pos_mean"].cpu().numpy() - pm).max(); ds = np.abs(info["pos_std"].cpu().numpy() - ps).max()
+    bm = core.blockmin.cpu().numpy()
+    bm_ok = np.array_equal(bm, np.array([cost[j:j + 64].min() for j in range(0, N, 64)], dtype=np.float32))
+    worst_abs = max(worst_abs, float(err.max()))
+    if err.max() < 1e-5 and dm < 2e-5 and ds < 2e-5 and bm_ok:
         n_ok += 1
-        print("ok rollout", time, seed, N, flush=True)
-    except AssertionError as e:
-        print("FAIL rollout", time, seed, N, flush=True)
-        import numpy as np
-        s_, p_, rng_ = T.make_problem(seed=seed, time=time)
-        a = T.sample_actions(p_, rng_, N)
-        fs = np.array([0.01, -0.02, 0.03], dtype=np.float32)
-        core = T.SamplingCore(N, 32, 0.01, 1.0, device=T.DEV)
-        cost = T._run_rollout(core, s_, p_, a, fs, want_stats=True)
-        ref, rew, poses = T.CO.rollout(s_, p_, a.astype(np.float64), 1.0, fs.astype(np.float64), dtype=np.float64, want_rewards=True, want_poses=True)
-        info = core.info(T.dev_state(s_))
-        pm, ps = T.R.pos_stats(poses)
-        dm = np.abs(info["pos_mean"].cpu().numpy() - pm); ds = np.abs(info["pos_std"].cpu().numpy() - ps)
-        print("  cost rel", T.rel_err(cost, ref).max(), "mean err max", dm.max(), "at", np.unravel_index(dm.argmax(), dm.shape), "std err max", ds.max(), "at", np.unravel_index(ds.argmax(), ds.shape))
-        k = np.unravel_index(ds.argmax(), ds.shape)[0]
-        print("  std dev/ref at worst step", info["pos_std"].cpu().numpy()[k], ps[k], " step0:", info["pos_std"].cpu().numpy()[0], ps[0])
+        print("ok rollout", time, seed, N, "test-style rel err %.2e" % T.rel_err(cost, ref).max(), flush=True)
+    else:
+        print("FAIL rollout", time, seed, N, "err / sum|r|", err.max(), "pos_mean", dm, "pos_std", ds, "blockmin", bm_ok, flush=True)
+print("rollout worst |cost - ref| / max(1, sum_k |r_k|):", worst_abs)
 for N in (4097, 20000, 66000):
     T.test_rollout_workgroup_shapes(N)
 print("rollout:", n_ok, "passed", flush=True)

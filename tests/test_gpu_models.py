@@ -356,6 +356,43 @@ def test_fused_step_with_models_equals_kernel_by_kernel_and_oracle(name, task, k
         assert np.linalg.norm(S - Sref) / np.linalg.norm(Sref) < 2e-5
 
 
+@pytest.mark.parametrize("task,kind", [("tracking", "periodic"), ("tracking", "sin"), ("tracking_slow", "drag"), ("tracking", "mixed")])
+def test_batched_step_with_disturbance_models_equals_replicas(task, kind):
+    """covo_mpc_step_batched with the table-driven disturbance models: every instance's rollout and Hessian tables are built
+    inside the batched graph from that instance's state, raw controller key and (domain-randomised, quadrotor.py:152)
+    disturb_params; drag / mixed take the per-pair Hessian with per-instance constants.  Against one covo-online controller per
+    instance on the same states and keys: plans and Sigmas bit-identical (eager call, capture, replays)."""
+    import covo_mpc_amd as cm
+    N, E = 1024, 3
+    env = cm.envs.Quad3D(task=task, obs_type="quad_params", enable_randomizer=True, disturb_type=kind,
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+    inst = []
+    for e in range(E):
+        params = env.sample_params(cr.PRNGKey(100 + e)).replace(disturb_period=5 + 2 * e)
+        controller, cp = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV, compute_info=False)
+        obs, info, state = env.reset(cr.PRNGKey(200 + e), params)
+        cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(2))
+        inst.append(dict(params=params, controller=controller, cp=cp, obs=obs, info=info, state=state, key=cr.PRNGKey(300 + e)))
+    assert np.abs(np.asarray(inst[0]["params"].disturb_params) - np.asarray(inst[1]["params"].disturb_params)).max() > 1e-3
+    cp0 = inst[0]["cp"]
+    batched = cm.controllers.BatchedCoVOController(env, E, N, 32, 0.01, discount=cp0.discount, gamma_mean=cp0.gamma_mean,
+                                                   sample_sigma=cp0.sample_sigma, a_mean_init=cp0.a_mean, device=DEV)
+    batched.set_instances([i["state"] for i in inst], [i["params"] for i in inst])
+    for step in range(4):
+        k_acts = []
+        for i in inst:
+            i["key"], k_act, i["k_step"] = cr.split(i["key"], 3)
+            k_acts.append(np.asarray(k_act))
+        u_b = batched([i["info"]["noisy_state"] for i in inst], np.stack(k_acts)).clone()
+        for e, i in enumerate(inst):
+            u, i["cp"], _ = i["controller"](i["obs"], i["state"], i["params"], k_acts[e], i["cp"], i["info"])
+            assert torch.equal(batched.a_cov[e], i["cp"].a_cov), (step, e)
+            assert torch.equal(batched.a_mean[e].view(32, 4), i["cp"].a_mean), (step, e)
+            assert torch.equal(u_b[e], u), (step, e)
+            i["obs"], i["state"], _, _, i["info"] = env.step(i["k_step"], i["state"], u.cpu().numpy(), i["params"])
+    assert torch.isfinite(batched.a_mean).all() and (batched.a_mean[0] - batched.a_mean[1]).abs().max() > 1e-4
+
+
 @pytest.mark.parametrize("name,task,kind", [("covo-online", "tracking_slow", "periodic"), ("mppi", "tracking_zigzag", "mixed")])
 def test_run_episode_with_models_equals_python_loop(name, task, kind):
     import covo_mpc_amd as cm
