@@ -151,11 +151,12 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
                    const SymStatsOut *stats = nullptr,   // batch 1: KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
                    const float *f_tab = nullptr,         // [batch][H][4] per-step disturbance table (disturb.hip), device
                    const void *models_dev = nullptr);    // dm::Model[batch] next to consts_dev (drag / mixed with per-instance parameters)
-// true: launch_hessian leaves R's Sigma-chain statistics when asked to (the adjoint kernels; the per-pair kernel that takes
-// the drag / mixed models does not)
+// true: launch_hessian leaves R's Sigma-chain statistics when asked to (the adjoint kernels do, for every disturbance model;
+// launch_hessian_pairs does not)
 inline bool hessian_leaves_stats(const covo_env_params &p)
 {
-    return p.disturb_kind != COVO_DISTURB_DRAG && p.disturb_kind != COVO_DISTURB_MIXED;
+    (void)p;
+    return true;
 }
 size_t hessian_consts_bytes(int n);
 void hessian_fill_consts(const covo_env_params *params, int n, void *out);

@@ -21,79 +21,97 @@ struct DisturbTableArgs {
     dm::Model m;
 };
 
-// one lane per batch entry: the key chain of the per-step modes is serial (split after split); a horizon holds at most
-// ceil(H / period) + 1 redraw steps, so only those derive a disturb key and hash a draw
-__device__ __forceinline__ void disturb_table_row_loop(const dm::Model &m, const float *__restrict__ st, const uint32_t (&key0)[2],
-                                                       int key_mode, bool deterministic, float4 *__restrict__ out)
+// One WAVE per table, lane k = row k + 1 (round 3; the first version walked the 31 rows on one lane: 25-43 us per control step
+// of Philox splits and sinf -- more than the Hessian).  Only the key chain of the per-step modes is serial (split after split),
+// and it is walked by all lanes together only as far as the last row that draws: a horizon holds at most ceil(H / period)
+// redraw steps.  periodic's hold (g_k = f_{k-1} when the step does not redraw) resolves from the ballot of the redraw lanes.
+__device__ __forceinline__ void disturb_table_rows_wave(const dm::Model &m, const float *__restrict__ st, const uint32_t (&key0)[2],
+                                                        int key_mode, bool deterministic, float4 *__restrict__ out)
 {
-    const int time0 = __float_as_int(st[ST_TIME]);
-    float f[3] = {st[ST_FDIST + 0], st[ST_FDIST + 1], st[ST_FDIST + 2]};  // periodic's hold resolves from the state's own force
-    uint32_t key[2] = {key0[0], key0[1]};
-    out[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int k = 0; k < COVO_H - 1; ++k) {
-        // the key step_env receives at rollout step k
-        uint32_t sk[2] = {key[0], key[1]};
-        if (key_mode == COVO_DISTURB_KEYS_HESSIAN) {  // rng_act, key = split(key) (covo.py:151)
+    const int k = threadIdx.x & 63;
+    const bool act = k < COVO_H - 1;
+    const int time = __float_as_int(st[ST_TIME]) + k;
+    const bool hit = act && (time % m.period) == 0;
+    const bool need_draw = act && ((m.kind == COVO_DISTURB_GAUSSIAN && !deterministic) ||
+                                   ((m.kind == COVO_DISTURB_PERIODIC || m.kind == COVO_DISTURB_MIXED) && hit));
+    // the key step_env receives at rollout step k
+    uint32_t sk[2] = {key0[0], key0[1]};
+    const unsigned long long need = __ballot(need_draw);
+    if (key_mode != COVO_DISTURB_KEYS_SHARED && need != 0ull) {
+        const int last = 63 - __builtin_clzll(need);
+        uint32_t key[2] = {key0[0], key0[1]}, mine[2] = {key0[0], key0[1]};
+        for (int j = 0; j <= last; ++j) {  // (uniform)
             uint32_t nk[2];
-            dm::split(key, 0u, sk);
-            dm::split(key, 1u, nk);
-            key[0] = nk[0]; key[1] = nk[1];
-        } else if (key_mode == COVO_DISTURB_KEYS_NOMINAL) {  // rng_act, key = split(key); rng_step, key = split(key) (covo.py:60,66)
-            uint32_t k1[2], nk[2];
-            dm::split(key, 1u, k1);
-            dm::split(k1, 0u, sk);
-            dm::split(k1, 1u, nk);
-            key[0] = nk[0]; key[1] = nk[1];
-        }
-        const int time = time0 + k;
-        const bool hit = (time % m.period) == 0;
-        float g[3] = {0.0f, 0.0f, 0.0f}, c = 0.0f;
-        const bool need_draw = (m.kind == COVO_DISTURB_GAUSSIAN && !deterministic) ||
-                               ((m.kind == COVO_DISTURB_PERIODIC || m.kind == COVO_DISTURB_MIXED) && hit);
-        uint32_t dk[2] = {0u, 0u};
-        if (need_draw) dm::disturb_key(sk, dk);
-        for (int i = 0; i < 3; ++i) {
-            switch (m.kind) {
-            case COVO_DISTURB_GAUSSIAN: g[i] = deterministic ? 0.0f : m.noise_scale * dm::normal3(dk, i); break;
-            case COVO_DISTURB_PERIODIC: g[i] = hit ? dm::uniform3(dk, i, -m.scale, m.scale) : f[i]; break;
-            case COVO_DISTURB_SIN: g[i] = dm::sin_term(m, time, i); break;
-            case COVO_DISTURB_MIXED:
-                g[i] = (dm::sin_term(m, time, i) + (hit ? dm::uniform3(dk, i, -m.scale, m.scale) : 0.0f)) / 3.0f;
-                break;
-            default: break;  // none, drag
+            if (key_mode == COVO_DISTURB_KEYS_HESSIAN) {  // rng_act, key = split(key) (covo.py:151)
+                if (j == k) { mine[0] = key[0]; mine[1] = key[1]; }
+                dm::split(key, 1u, nk);
+            } else {  // rng_act, key = split(key); rng_step, key = split(key) (covo.py:60,66)
+                uint32_t k1[2];
+                dm::split(key, 1u, k1);
+                if (j == k) { mine[0] = k1[0]; mine[1] = k1[1]; }
+                dm::split(k1, 1u, nk);
             }
-            f[i] = g[i];  // (only periodic reads it back)
+            key[0] = nk[0]; key[1] = nk[1];
         }
-        if (m.kind == COVO_DISTURB_MIXED) c = hit ? 0.0f : 1.0f / 3.0f;
-        out[k + 1] = make_float4(g[0], g[1], g[2], c);
+        dm::split(mine, 0u, sk);
     }
+    uint32_t dk[2] = {0u, 0u};
+    if (need_draw) dm::disturb_key(sk, dk);
+    float draw[3] = {0.0f, 0.0f, 0.0f};
+    if (need_draw) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            draw[i] = (m.kind == COVO_DISTURB_GAUSSIAN) ? m.noise_scale * dm::normal3(dk, i) : dm::uniform3(dk, i, -m.scale, m.scale);
+    }
+    float g[3] = {0.0f, 0.0f, 0.0f}, c = 0.0f;
+    if (m.kind == COVO_DISTURB_PERIODIC) {
+        // the latest redraw at or before this row, else the state's own force (free.py:10-24)
+        const unsigned long long hm = __ballot(hit);
+        const unsigned long long upto = hm & ((k >= 63) ? ~0ull : ((2ull << k) - 1ull));
+        const int src = upto ? 63 - __builtin_clzll(upto) : 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float held = __shfl(draw[i], src);
+            g[i] = upto ? held : st[ST_FDIST + i];
+        }
+    } else if (m.kind == COVO_DISTURB_GAUSSIAN) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = draw[i];
+    } else if (m.kind == COVO_DISTURB_SIN) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = act ? dm::sin_term(m, time, i) : 0.0f;
+    } else if (m.kind == COVO_DISTURB_MIXED) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = act ? (dm::sin_term(m, time, i) + draw[i]) / 3.0f : 0.0f;  // draw = 0 unless the step redraws
+        c = hit ? 0.0f : 1.0f / 3.0f;
+    }  // none, drag: zeros
+    if (act) out[k + 1] = make_float4(g[0], g[1], g[2], c);
+    if (k == 0) out[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 __global__ __launch_bounds__(64) void disturb_table_kernel(const DisturbTableArgs A)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= A.batch) return;
+    const int b = blockIdx.x;
     const uint32_t key[2] = {A.keys ? A.keys[2 * b] : A.key[0], A.keys ? A.keys[2 * b + 1] : A.key[1]};
-    disturb_table_row_loop(A.m, A.state + (size_t)b * COVO_STATE_FLOATS, key, A.key_mode, A.deterministic != 0,
-                           A.out + (size_t)b * COVO_H);
+    disturb_table_rows_wave(A.m, A.state + (size_t)b * COVO_STATE_FLOATS, key, A.key_mode, A.deterministic != 0,
+                            A.out + (size_t)b * COVO_H);
 }
 
-// fused step (step.hip): both tables of one control step in one launch -- lane 0 of workgroup 0 the rollouts' (shared step key
-// = split(split(rng_act)[0])[1], covo.py:212,225 / mppi.py:53,69), lane 0 of workgroup 1 the Hessian's (per-step keys from the
+// fused step (step.hip): both tables of one control step in one launch -- workgroup 0 the rollouts' (shared step key
+// = split(split(rng_act)[0])[1], covo.py:212,225 / mppi.py:53,69), workgroup 1 the Hessian's (per-step keys from the
 // raw rng_act, covo.py:39,150-153); dyn = the step's device block {.., raw rng_act at [10], [11]} (step.hip: DynBlock)
 __global__ __launch_bounds__(64) void disturb_tables_step_kernel(const float *__restrict__ state, const uint32_t *__restrict__ dyn,
                                                                  dm::Model m, int rollout_deterministic, float4 *__restrict__ tab_rollout,
                                                                  float4 *__restrict__ tab_hess)
 {
-    if (threadIdx.x != 0) return;
     const uint32_t raw[2] = {dyn[10], dyn[11]};
     if (blockIdx.x == 0) {
         uint32_t rng1[2], step_key[2];
         dm::split(raw, 0u, rng1);
         dm::split(rng1, 1u, step_key);
-        disturb_table_row_loop(m, state, step_key, COVO_DISTURB_KEYS_SHARED, rollout_deterministic != 0, tab_rollout);
+        disturb_table_rows_wave(m, state, step_key, COVO_DISTURB_KEYS_SHARED, rollout_deterministic != 0, tab_rollout);
     } else if (tab_hess != nullptr) {
-        disturb_table_row_loop(m, state, raw, COVO_DISTURB_KEYS_HESSIAN, true, tab_hess);
+        disturb_table_rows_wave(m, state, raw, COVO_DISTURB_KEYS_HESSIAN, true, tab_hess);
     }
 }
 
@@ -104,7 +122,6 @@ __global__ __launch_bounds__(64) void disturb_tables_batched_kernel(const float 
                                                                     const dm::Model *__restrict__ models, int rollout_deterministic,
                                                                     float4 *__restrict__ tab_rollout, float4 *__restrict__ tab_hess)
 {
-    if (threadIdx.x != 0) return;
     const int e = blockIdx.x;
     const dm::Model m = models[e];
     const float *st = states + (size_t)e * COVO_STATE_FLOATS;
@@ -113,9 +130,9 @@ __global__ __launch_bounds__(64) void disturb_tables_batched_kernel(const float 
         uint32_t rng1[2], step_key[2];
         dm::split(raw, 0u, rng1);
         dm::split(rng1, 1u, step_key);
-        disturb_table_row_loop(m, st, step_key, COVO_DISTURB_KEYS_SHARED, rollout_deterministic != 0, tab_rollout + (size_t)e * COVO_H);
+        disturb_table_rows_wave(m, st, step_key, COVO_DISTURB_KEYS_SHARED, rollout_deterministic != 0, tab_rollout + (size_t)e * COVO_H);
     } else {
-        disturb_table_row_loop(m, st, raw, COVO_DISTURB_KEYS_HESSIAN, true, tab_hess + (size_t)e * COVO_H);
+        disturb_table_rows_wave(m, st, raw, COVO_DISTURB_KEYS_HESSIAN, true, tab_hess + (size_t)e * COVO_H);
     }
 }
 
@@ -149,7 +166,7 @@ int launch_disturb_table(const covo_env_params &p, const float *state, int batch
     A.key_mode = key_mode;
     A.deterministic = deterministic;
     A.m = dm::make_model(p);
-    hipLaunchKernelGGL(disturb_table_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(disturb_table_kernel, dim3(batch), dim3(64), 0, s, A);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

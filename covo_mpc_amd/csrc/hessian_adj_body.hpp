@@ -1,0 +1,596 @@
+// hessian_adj_body.hpp -- the four kernels of the second-order adjoint (see hessian_adj.hip), included TWICE by hessian_adj.hip:
+//   ADJ_NX 13, ADJ_FS 0 (namespace adj13): the force of a step is a constant of the step (none / gaussian / periodic / sin);
+//   ADJ_NX 16, ADJ_FS 1 (namespace adj16): the force is part of the differentiated state (drag / mixed: f_{k+1} depends on the
+//     PRE-step velocity and, for mixed, on f_k; free.py:41-56,147) -- x = (pos, vel, quat, omega, f) fills the 16 rows the tiles
+//     were padded to anyway, z = (x, u) has 20 entries, 210 pairs per step.
+// No include guard on purpose.
+constexpr int NX = ADJ_NX, NZ = NX + 4, NH = NX + 1, HH = COVO_H, NA = COVO_NA;  // state (13, or 16 with the force), step inputs, 1 + NX
+// per-matrix workspace (doubles)
+constexpr size_t WS_X = 0;                       // [32][16]       x_k
+constexpr size_t WS_JF = WS_X + 32 * 16;         // [32][NX][NZ]   df_k/dz (k = 31 unused)
+constexpr size_t WS_GL = WS_JF + 32 * NX * NZ;   // [32][16]       grad r_k (k = 0: zeros)
+constexpr size_t WS_LAM = WS_GL + 32 * 16;       // [33][16]       lam_k (lam_32 = 0)
+constexpr size_t WS_MXX = WS_LAM + 33 * 16;      // [32][16][16]   zero padded
+constexpr size_t WS_MXU = WS_MXX + 32 * 256;     // [32][16][4]
+constexpr size_t WS_MUU = WS_MXU + 32 * 64;      // [32][4][4]
+constexpr size_t WS_S = WS_MUU + 32 * 16;        // [32][16][128]  rows NX..15 zero
+constexpr int NPAIR = NZ * (NZ + 1) / 2;         // 153 (210) pairs a <= b of step inputs
+constexpr int PAIR_THREADS = (NPAIR + 63) / 64 * 64;
+constexpr size_t WS_H14 = WS_S + (size_t)32 * 16 * NA;  // [32][NH][NPAIR]  second derivatives of r_k and of the NX components of f_k per pair
+constexpr size_t WS_COUNT = WS_H14 + (size_t)32 * NH * NPAIR + 2;
+
+
+// the disturbance force acting during step k (free.py:91,98,147): the state's own for k = 0, then the table's row k (periodic /
+// sin resolved per step by disturb.hip; none / deterministic gaussian: no table, zero)
+__device__ __forceinline__ void adj_force(const float *__restrict__ st, const AdjArgs &A, int bi, int k, double (&f)[3])
+{
+    if (k == 0) {
+        f[0] = st[ST_FDIST + 0]; f[1] = st[ST_FDIST + 1]; f[2] = st[ST_FDIST + 2];
+    } else if (A.f_tab != nullptr) {
+        const float4 r = A.f_tab[(size_t)bi * HH + k];
+        f[0] = r.x; f[1] = r.y; f[2] = r.z;
+    } else {
+        f[0] = f[1] = f[2] = 0.0;
+    }
+}
+
+__device__ __forceinline__ void adj_targets(const float *__restrict__ st, const float *__restrict__ pos_traj,
+                                            const float *__restrict__ vel_traj, int T, int time0, int k, double (&tar)[6])
+{
+    if (k == 0) {
+        for (int i = 0; i < 3; ++i) { tar[i] = st[ST_POSTAR + i]; tar[3 + i] = st[ST_VELTAR + i]; }
+    } else {
+        int idx = time0 + k;
+        idx = idx < 0 ? 0 : (idx > T - 1 ? T - 1 : idx);
+        for (int i = 0; i < 3; ++i) { tar[i] = pos_traj[3 * idx + i]; tar[3 + i] = vel_traj[3 * idx + i]; }
+    }
+}
+
+// the step's 13 outputs / inputs in z order
+#define ADJ_FOR_STATE(OP) OP(px, 0) OP(py, 1) OP(pz, 2) OP(vx, 3) OP(vy, 4) OP(vz, 5) OP(qx, 6) OP(qy, 7) OP(qz, 8) OP(qw, 9) OP(ox, 10) OP(oy, 11) OP(oz, 12)
+
+__device__ __forceinline__ void adj_store_state(const qm::State<double> &p, double *__restrict__ x)
+{
+#define OP(m, i) x[i] = p.m;
+    ADJ_FOR_STATE(OP)
+#undef OP
+}
+__device__ __forceinline__ void adj_load_state(qm::State<double> &p, const double *__restrict__ x)
+{
+#define OP(m, i) p.m = x[i];
+    ADJ_FOR_STATE(OP)
+#undef OP
+}
+
+#if ADJ_FS
+// f_{k+1} from the PRE-step state of step k (free.py:147): drag_k rel |rel| + c f_k + g with row k+1 = {g, c} of the table
+// (disturb.hip); S = double (primal prefix), D1 or HD.  Beyond the horizon: zero (never integrated).
+struct AdjDrag {
+    double k, off[3];
+};
+__device__ __forceinline__ AdjDrag adj_drag(const AdjArgs &A, int bi)
+{
+    AdjDrag D = {A.drag_k, {A.drag_off[0], A.drag_off[1], A.drag_off[2]}};
+    if (A.models != nullptr) {
+        const dm::Model m = A.models[bi];
+        D.k = adj_drag_coeff(m);
+        for (int i = 0; i < 3; ++i) D.off[i] = 0.5 * (double)m.dp[i];
+    }
+    return D;
+}
+template <class S>
+__device__ __forceinline__ void adj_next_force(const AdjArgs &A, const AdjDrag &D, int bi, int k, const qm::State<S> &s, const S (&f)[3],
+                                               S (&fn)[3])
+{
+    if (k + 1 >= HH) {
+        fn[0] = fn[1] = fn[2] = S{};
+        return;
+    }
+    const float4 r = A.f_tab[(size_t)bi * HH + k + 1];
+    const double g[3] = {r.x, r.y, r.z}, c = r.w;
+    const S v[3] = {s.vx, s.vy, s.vz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fn[i] = (f[i] * c + g[i]) + qm::drag_force<S, double>(v[i], D.off[i], D.k);
+}
+#endif
+
+// one step on hyper-dual numbers: z_a carries e1, z_b carries e2 (an index outside 0..16 seeds nothing).
+// r = r_k(x) (0 for k = 0), s = f_k(z) (left at x_k for k = H-1, whose dynamics never reach a reward).
+__device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const float *__restrict__ am, const AdjArgs &A, int bi,
+                                            int time0, int k, const qm::State<double> &p, int a, int b, qm::HD &r,
+                                            qm::State<qm::HD> &s
+#if ADJ_FS
+                                            , const double (&pf)[3], qm::HD (&fn)[3]  // the force during step k; out: f_{k+1}
+#endif
+)
+{
+    const qm::Consts<double> c = A.cs ? A.cs[bi] : A.c;
+#define OP(m, i) s.m = qm::HD{p.m, a == i ? 1.0 : 0.0, b == i ? 1.0 : 0.0, 0.0};
+    ADJ_FOR_STATE(OP)
+#undef OP
+#if ADJ_FS
+    qm::HD fh[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fh[i] = qm::HD{pf[i], a == 13 + i ? 1.0 : 0.0, b == 13 + i ? 1.0 : 0.0, 0.0};
+        fn[i] = fh[i];
+    }
+#endif
+    r = qm::hd(0.0);
+    if (k >= 1) {
+        double tar[6];
+        adj_targets(st, A.pos_traj + bi * A.traj_stride, A.vel_traj + bi * A.traj_stride, A.T, time0, k, tar);
+        r = qm::reward_kind<qm::HD, double>(A.reward, s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
+    }
+    if (k <= HH - 2) {
+        qm::HD act[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const qm::HD x{(double)am[4 * k + d], a == NX + d ? 1.0 : 0.0, b == NX + d ? 1.0 : 0.0, 0.0};
+            act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
+        }
+#if ADJ_FS
+        adj_next_force<qm::HD>(A, adj_drag(A, bi), bi, k, s, fh, fn);  // from the PRE-step state
+        qm::dyn_step<qm::HD, double, true, qm::HD>(s, act[0], act[1], act[2], act[3], c, fh[0], fh[1], fh[2]);
+#else
+        double f[3];
+        adj_force(st, A, bi, k, f);
+        qm::dyn_step<qm::HD, double>(s, act[0], act[1], act[2], act[3], c, f[0], f[1], f[2]);
+#endif
+    }
+}
+
+// ---- KB: wave k: x_k by a plain fp64 rollout, then df_k/dz (13 x 17) and grad r_k from 17 first-order seeds
+// FT: a per-step force table is present (periodic / sin); without it the force of steps >= 1 is a literal zero and its three
+// adds per step drop out of the prefix's serial chain
+template <bool FT>
+__global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
+{
+    const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
+    const float *__restrict__ am = A.a_mean + (size_t)b * NA;
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    const int time0 = __float_as_int(st[ST_TIME]);
+    const qm::Consts<double> c = A.cs ? A.cs[b] : A.c;
+    qm::State<double> p;
+    p.px = st[ST_POS + 0]; p.py = st[ST_POS + 1]; p.pz = st[ST_POS + 2];
+    p.vx = st[ST_VEL + 0]; p.vy = st[ST_VEL + 1]; p.vz = st[ST_VEL + 2];
+    p.qx = st[ST_QUAT + 0]; p.qy = st[ST_QUAT + 1]; p.qz = st[ST_QUAT + 2]; p.qw = st[ST_QUAT + 3];
+    p.ox = st[ST_OMEGA + 0]; p.oy = st[ST_OMEGA + 1]; p.oz = st[ST_OMEGA + 2];
+    // The prefix is the launch's critical path: for wave 31, 31 steps of dependent-issue fp64 instructions, one per ~7 cycles
+    // whatever their dependencies.  What does not depend on the state -- clip, thrust and body-rate targets of every step's
+    // action (quadrotor.py:223,258-260; 16 of a step's 80 instructions) -- is computed by lane t for step t in ONE pass and
+    // read back per step (uniform LDS reads); from step 1 on the entry normalisation of the just-normalised quaternion is
+    // skipped (<= 1 ulp; the dual step below keeps both).  80 -> 52 instructions per step, 10.1 -> 7.8 us.  (Measured and
+    // dropped: the attitude / translation cascade as TWO waves through LDS, as in the rollout -- the three LDS writes per step
+    // on the attitude wave cost more issue time than the 13 instructions they move away: 9.3 us.)
+    __shared__ double sact[HH][4];
+    __shared__ double sfd[HH][3];  // the force of every step (adj_force), read back per step like the action terms
+    if (lane < HH) {
+        double f[3];
+        adj_force(st, A, b, lane, f);
+        sfd[lane][0] = f[0]; sfd[lane][1] = f[1]; sfd[lane][2] = f[2];
+    }
+    if (lane < HH) {
+        const double a0 = qm::clip11_((double)am[4 * lane + 0]), a1 = qm::clip11_((double)am[4 * lane + 1]);
+        const double a2 = qm::clip11_((double)am[4 * lane + 2]), a3 = qm::clip11_((double)am[4 * lane + 3]);
+        sact[lane][0] = (a0 + 1.0) * c.thrust_half;
+        sact[lane][1] = a1 * c.komega[0];
+        sact[lane][2] = a2 * c.komega[1];
+        sact[lane][3] = a3 * c.komega[2];
+    }
+    __syncthreads();
+#if ADJ_FS
+    const AdjDrag D = adj_drag(A, b);
+    double pf[3] = {sfd[0][0], sfd[0][1], sfd[0][2]};  // the force acting during the current step
+    for (int t = 0; t < k; ++t) {
+        const double th = sact[t][0], w0 = sact[t][1], w1 = sact[t][2], w2 = sact[t][3];
+        double fn[3];
+        adj_next_force<double>(A, D, b, t, p, pf, fn);  // from the PRE-step state
+        if (t == 0) qm::dyn_core<double, double>(p, th, w0, w1, w2, c, pf[0], pf[1], pf[2]);
+        else qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, pf[0], pf[1], pf[2]);
+        pf[0] = fn[0]; pf[1] = fn[1]; pf[2] = fn[2];
+    }
+    if (lane == 0) {
+        adj_store_state(p, ws + WS_X + 16 * k);
+        ws[WS_X + 16 * k + 13] = pf[0]; ws[WS_X + 16 * k + 14] = pf[1]; ws[WS_X + 16 * k + 15] = pf[2];
+    }
+#else
+    for (int t = 0; t < k; ++t) {
+        const double th = sact[t][0], w0 = sact[t][1], w1 = sact[t][2], w2 = sact[t][3];
+        if (t == 0) qm::dyn_core<double, double>(p, th, w0, w1, w2, c, sfd[0][0], sfd[0][1], sfd[0][2]);
+        else if (FT) qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, sfd[t][0], sfd[t][1], sfd[t][2]);
+        else qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, 0.0, 0.0, 0.0);
+    }
+    if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
+#endif
+    // the step with ONE first-order seed per lane (17 lanes): reward gradient and column `lane` of df/dz
+    qm::State<qm::D1> s;
+#define OP(m, i) s.m = qm::D1{p.m, lane == i ? 1.0 : 0.0};
+    ADJ_FOR_STATE(OP)
+#undef OP
+#if ADJ_FS
+    qm::D1 fd[3], fdn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fd[i] = qm::D1{pf[i], lane == 13 + i ? 1.0 : 0.0};
+        fdn[i] = fd[i];
+    }
+#endif
+    qm::D1 r{0.0, 0.0};
+    if (k >= 1) {
+        double tar[6];
+        adj_targets(st, A.pos_traj + b * A.traj_stride, A.vel_traj + b * A.traj_stride, A.T, time0, k, tar);
+        r = qm::reward_kind<qm::D1, double>(A.reward, s, tar[0], tar[1], tar[2], tar[3], tar[4], tar[5]);
+    }
+    if (k <= HH - 2) {
+        qm::D1 act[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const qm::D1 x{(double)am[4 * k + d], lane == NX + d ? 1.0 : 0.0};
+            act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
+        }
+#if ADJ_FS
+        adj_next_force<qm::D1>(A, D, b, k, s, fd, fdn);  // from the PRE-step state
+        qm::dyn_step<qm::D1, double, true, qm::D1>(s, act[0], act[1], act[2], act[3], c, fd[0], fd[1], fd[2]);
+#else
+        qm::dyn_step<qm::D1, double>(s, act[0], act[1], act[2], act[3], c, sfd[k][0], sfd[k][1], sfd[k][2]);
+#endif
+    }
+    if (lane < NZ) {
+        if (lane < NX) ws[WS_GL + 16 * k + lane] = r.a;  // 0 for k = 0 (the reward does not see the force: rows 13..15 are zeros)
+        if (k <= HH - 2) {
+            double *__restrict__ jf = ws + WS_JF + (size_t)k * NX * NZ;
+#define OP(m, i) jf[i * NZ + lane] = s.m.a;
+            ADJ_FOR_STATE(OP)
+#undef OP
+#if ADJ_FS
+            jf[13 * NZ + lane] = fdn[0].a; jf[14 * NZ + lane] = fdn[1].a; jf[15 * NZ + lane] = fdn[2].a;
+#endif
+        }
+    }
+}
+
+// ---- the lambda-independent 9/10 of KM: one hyper-dual step per pair a <= b of the 17 step inputs -> the mixed second derivative of
+// r_k and of each of the 13 components of f_k (14 numbers per pair).  M_k = Hess_z(r_k + lam_{k+1} . f_k) is their combination
+// with the costate -- which the chains of KC are still computing: these 32 workgroups ride in KC's launch on otherwise idle
+// CUs (5 us in the shadow of the 10 us recursions), and the launch after it only contracts (adj_hess_kernel).
+__device__ __forceinline__ void adj_hd_pairs(const AdjArgs &A, int k, int b, int tid)
+{
+    if (tid >= NPAIR) return;
+    const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
+    const float *__restrict__ am = A.a_mean + (size_t)b * NA;
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    const int time0 = __float_as_int(st[ST_TIME]);
+    int q = tid, a = 0;
+    while (q >= NZ - a) { q -= NZ - a; ++a; }
+    const int bb = a + q;
+    qm::State<double> p;
+    adj_load_state(p, ws + WS_X + 16 * k);
+    qm::HD r;
+    qm::State<qm::HD> s;
+#if ADJ_FS
+    const double pf[3] = {ws[WS_X + 16 * k + 13], ws[WS_X + 16 * k + 14], ws[WS_X + 16 * k + 15]};
+    qm::HD fn[3];
+    adj_hd_step(st, am, A, b, time0, k, p, a, bb, r, s, pf, fn);
+#else
+    adj_hd_step(st, am, A, b, time0, k, p, a, bb, r, s);
+#endif
+    double *__restrict__ H = ws + WS_H14 + (size_t)k * NH * NPAIR + tid;  // [component][pair]: coalesced over the pairs
+    H[0] = r.ab;
+#define OP(m, i) H[(size_t)(1 + i) * NPAIR] = s.m.ab;
+    ADJ_FOR_STATE(OP)
+#undef OP
+#if ADJ_FS
+    H[(size_t)14 * NPAIR] = fn[0].ab; H[(size_t)15 * NPAIR] = fn[1].ab; H[(size_t)16 * NPAIR] = fn[2].ab;
+#endif
+}
+
+// ---- KC: the two linear recursions on the matrix cores.
+// S_{k+1} = A_k S_k + B_k E_k is a (13x13).(13x128) product per step: wave w keeps a 16-column tile of S in
+// the MFMA C/D layout (lane (lo, hi), register g = row 4g + hi, column lo) -- which is exactly the B operand
+// of k-group g of the next step's v_mfma_f64_16x16x4_f64, so the tile never leaves its registers; A_k
+// (zero padded to 16x16) comes from LDS as the A operand.  The costate lam_k = grad r_k + A_k^T lam_{k+1} is
+// the same product with A^T and the vector in column 0 of a tile (wave 8).  ~330 cycles per step (four
+// dependent MFMAs + the MFMA -> operand hazard), 31 steps.  (One lane per column with the vector in
+// registers: 2000 cycles per step; 16-lane rows with ds_swizzle broadcasts: 1000.)
+__global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
+{
+    __shared__ double sjf[(HH - 1) * NX * NZ + 1];  // + one zero: what the lanes outside the 13 x 13 block read
+    __shared__ double sgl[HH * 16];
+    // one chain per WORKGROUP (the f64 MFMA pipe of a SIMD is not shared with another chain: nine chains in one
+    // workgroup put 76 steps on one SIMD); the four waves fill LDS together, wave 0 runs the chain
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, lo = lane & 15, hi = lane >> 4;
+    const int w = blockIdx.x;  // 0..7: column tile of S, 8: costate, 9..40: the hyper-dual steps of KM (see adj_hd_pairs)
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    if (w >= 9) {
+        adj_hd_pairs(A, w - 9, b, tid);
+        return;
+    }
+    {
+        // all global loads in flight before the first LDS store (a rolled loop pays one L2 latency per trip)
+        constexpr int NJ = (HH - 1) * NX * NZ, TJ = (NJ + 255) / 256;
+        double vj[TJ];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) vj[t] = (tid + 256 * t < NJ) ? ws[WS_JF + tid + 256 * t] : 0.0;
+        const double vg0 = ws[WS_GL + tid], vg1 = ws[WS_GL + 256 + tid];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t)
+            if (tid + 256 * t < NJ) sjf[tid + 256 * t] = vj[t];
+        sgl[tid] = vg0;
+        sgl[256 + tid] = vg1;
+        if (tid == 0) sjf[NJ] = 0.0;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // The chains are fully unrolled (k is a compile-time constant: every LDS / global address is base + immediate) and the lanes
+    // outside the 13 x 13 block read a zero slot instead of being masked off: as a rolled loop with `cond ? sjf[..] : 0` operands
+    // hipcc spent ~420 of a step's 755 cycles on exec-mask sequences, index arithmetic and accumulator copies around the four
+    // dependent MFMAs (KC_PROF stamps; the MFMAs + their result -> operand hazard are ~330).
+    constexpr int ZI = (HH - 1) * NX * NZ;
+    if (w == 8) {
+        // ---- costate: lam_31 = grad r_31, lam_k = grad r_k + A_k^T lam_{k+1}; the vector is column 0 of the tile
+        const double *__restrict__ G = sgl;  // grad r_k, staged in LDS: a global load per step would BE the step time
+        double *__restrict__ L = ws + WS_LAM;
+        f64x4 lam;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lam[r] = (lo == 0 && hi + 4 * r < NX) ? G[16 * (HH - 1) + hi + 4 * r] : 0.0;
+        if (lo == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                L[16 * (HH - 1) + hi + 4 * r] = lam[r];
+                L[16 * HH + hi + 4 * r] = 0.0;
+            }
+        }
+        int offA[4];  // A^T[lo][4g+hi] = df/dz[4g+hi][lo]
+        bool okA[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            okA[g] = lo < NX && 4 * g + hi < NX;
+            offA[g] = (4 * g + hi) * NZ + lo;
+        }
+        bool okG[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) okG[r] = lo == 0 && hi + 4 * r < NX;
+        double an[4];
+        f64x4 gn;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? (HH - 2) * NX * NZ + offA[g] : ZI];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gn[r] = okG[r] ? G[16 * (HH - 2) + hi + 4 * r] : 0.0;
+#pragma unroll
+        for (int k = HH - 2; k >= 1; --k) {
+            double ac[4];
+            f64x4 acc = gn;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = an[g];
+            if (k > 1) {  // next step's operands in flight
+#pragma unroll
+                for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? (k - 1) * NX * NZ + offA[g] : ZI];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gn[r] = okG[r] ? G[16 * (k - 1) + hi + 4 * r] : 0.0;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g], lam[g], acc, 0, 0, 0);
+            lam = acc;
+            if (lo == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L[16 * k + hi + 4 * r] = lam[r];
+            }
+        }
+        return;
+    }
+    // ---- sensitivities: tile w = columns 16w .. 16w+15 = the actions of steps 4w .. 4w+3; S_k tile = 0 for k <= 4w
+    const int col = 16 * w + lo, tcol = col >> 2, dcol = col & 3, k0 = 4 * w;
+    double *__restrict__ S = ws + WS_S;
+    for (int k = 0; k <= k0; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[((size_t)k * 16 + hi + 4 * r) * NA + col] = 0.0;
+    }
+    f64x4 sv = {0.0, 0.0, 0.0, 0.0};
+    int offA[4];  // A[lo][4g+hi]
+    bool okA[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        okA[g] = lo < NX && 4 * g + hi < NX;
+        offA[g] = lo * NZ + 4 * g + hi;
+    }
+    double an[4];
+    f64x4 bn;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? k0 * NX * NZ + offA[g] : ZI];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bn[r] = (tcol == k0 && hi + 4 * r < NX) ? sjf[(k0 * NX + hi + 4 * r) * NZ + NX + dcol] : 0.0;  // B_k E_k
+    double *__restrict__ Sp = S + (size_t)hi * NA + col;
+#pragma unroll
+    for (int k = 0; k < HH - 1; ++k) {
+        if (k < k0) continue;  // (uniform)
+        double ac[4];
+        f64x4 acc = bn;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ac[g] = an[g];
+        if (k + 1 < HH - 1) {  // next step's operands in flight
+#pragma unroll
+            for (int g = 0; g < 4; ++g) an[g] = sjf[okA[g] ? (k + 1) * NX * NZ + offA[g] : ZI];
+            // B_k E_k is non-zero only while the tile's own four steps enter (uniform branch)
+            if (k + 1 <= k0 + 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bn[r] = (tcol == k + 1 && hi + 4 * r < NX) ? sjf[((k + 1) * NX + hi + 4 * r) * NZ + NX + dcol] : 0.0;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bn[r] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g], sv[g], acc, 0, 0, 0);
+        sv = acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sp[((size_t)(k + 1) * 16 + 4 * r) * NA] = sv[r];
+    }
+}
+
+// ---- KM: M_k = Hess_z( r_k(x) + lam_{k+1} . f_k(z) ) = (second derivatives of r_k) + sum_i lam_{k+1,i} (second derivatives of f_k^i):
+// the contraction of what adj_hd_pairs left behind (KC's launch) with the costate -- 15 loads and 13 FMAs per pair
+__global__ __launch_bounds__(PAIR_THREADS) void adj_hess_kernel(const AdjArgs A)
+{
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    double *__restrict__ Mxx = ws + WS_MXX + (size_t)k * 256, *__restrict__ Mxu = ws + WS_MXU + (size_t)k * 64;
+    double *__restrict__ Muu = ws + WS_MUU + (size_t)k * 16;
+    const int pr = tid < NPAIR ? tid : 0;
+    const double *__restrict__ H = ws + WS_H14 + (size_t)k * NH * NPAIR + pr;
+    double h[NH], lam[NX];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) h[i] = H[(size_t)i * NPAIR];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lam[i] = (k <= HH - 2) ? ws[WS_LAM + 16 * (k + 1) + i] : 0.0;
+    // zero padding of the x block (rows / columns 13..15)
+    for (int e = tid; e < 256; e += PAIR_THREADS)
+        if ((e >> 4) >= NX || (e & 15) >= NX) Mxx[e] = 0.0;
+    if (tid < (16 - NX) * 4) Mxu[NX * 4 + tid] = 0.0;
+    int q = pr, a = 0;
+    while (q >= NZ - a) { q -= NZ - a; ++a; }
+    const int bb = a + q;
+    double g = h[0];
+    if (k <= HH - 2) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) g = fma(lam[i], h[1 + i], g);
+    }
+    if (tid < NPAIR) {
+        if (bb < NX) {
+            Mxx[a * 16 + bb] = g;
+            Mxx[bb * 16 + a] = g;
+        } else if (a < NX) {
+            Mxu[a * 4 + (bb - NX)] = g;
+        } else {
+            Muu[(a - NX) * 4 + (bb - NX)] = g;
+            Muu[(bb - NX) * 4 + (a - NX)] = g;
+        }
+    }
+}
+
+// ---- KD: R = -( sum_k S_k^T Mxx_k S_k  +  action blocks ), one lower 16x16 tile per workgroup, k split over 8 waves
+__device__ __forceinline__ void adj_tri_tile(int w, int &ti, int &tj)
+{
+    ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= w) ++ti;
+    tj = w - ti * (ti + 1) / 2;
+}
+
+__global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
+{
+    __shared__ double red[8][4][64];
+    __shared__ double sMu[4][64];  // Mxu of the four step indices 4I .. 4I+3 the rows (and, on diagonal tiles, columns) of this tile have
+    __shared__ double sMuu[64];    // Muu of the same four steps
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    const double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    double *__restrict__ R = A.R + (size_t)b * NA * NA;
+    int I, J;
+    adj_tri_tile(blockIdx.x, I, J);
+    const double *__restrict__ S = ws + WS_S, *__restrict__ Mxx = ws + WS_MXX;
+    // S_k[:, 16 I ..] is zero for k <= 4 I (I >= J): k = 4I+1 .. 31, round-robin over the 8 waves.
+    // MFMA f64 16x16x4: A[m = lo][kk = hi], B[kk = hi][n = lo]; C/D: column lo, rows hi + 4 r.
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#ifdef KD_PROF
+    const long long kp0 = clock64();
+#endif
+    // A wave keeps at most 63 loads in flight (vmcnt); one more and the launch pays a second memory round trip to data the
+    // previous launch has just written from other XCDs (round 1's order -- 26 epilogue loads, then 48 operands, in every
+    // wave -- took 8.6 us for ~1 us of MFMA).  So: the <= 48 MFMA operands first, then the 13 sensitivities of the epilogue
+    // (finishing waves only); the action blocks Mxu / Muu travel through LDS, one load per thread.
+    // at most 4 values of k per wave
+    // The contraction index of the FIRST product runs as kk = 4 hi + g (any order serves, A and B agree): a lane then owns
+    // 32 contiguous bytes of the row-major Mxx_k and a wave reads each of its 16 lines once (as Mxx[lo][4g + hi] every one of the
+    // four loads touched all 16 lines for 8 bytes each -- 2 KiB through the L1 per instruction, and the L1's 64 B/clk is what
+    // this kernel waits for: 8 waves x ~55 KiB).  The second product contracts over the C/D row order 4g + hi of Q.
+    double ma[4][4], sj[4][4], si[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = 4 * I + 1 + wv + 8 * it;
+        const bool on = k < HH;
+        const double *__restrict__ Sk = S + (size_t)(on ? k : 0) * 16 * NA, *__restrict__ Mk = Mxx + (size_t)(on ? k : 0) * 256;
+        const double2 *__restrict__ Mk2 = reinterpret_cast<const double2 *>(Mk + lo * 16 + 4 * hi);
+        const double2 m01 = on ? Mk2[0] : make_double2(0.0, 0.0), m23 = on ? Mk2[1] : make_double2(0.0, 0.0);
+        ma[it][0] = m01.x;  // Mxx[m = lo][4 hi + g]
+        ma[it][1] = m01.y;
+        ma[it][2] = m23.x;
+        ma[it][3] = m23.y;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sj[it][g] = on ? Sk[(size_t)(4 * hi + g) * NA + 16 * J + lo] : 0.0;  // S[4 hi + g][n = 16J + lo]
+            si[it][g] = on ? Sk[(size_t)(4 * g + hi) * NA + 16 * I + lo] : 0.0;  // S^T: A[m = lo][kk = hi] = S[4g + hi][16I + lo]
+        }
+    }
+    // epilogue operands of the element this lane will finish (waves 0..3: register wv of the tile)
+    const int i = 16 * I + hi + 4 * (wv & 3), j = 16 * J + lo;
+    const int ti = i >> 2, di = i & 3, tj = j >> 2, dj = j & 3;
+    const int tk = ti > tj ? ti : tj, dk = ti > tj ? di : dj;
+    double es[NX];
+    if (wv < 4) {
+        const int col = ti > tj ? j : i;
+        const double *__restrict__ Sk = S + (size_t)tk * 16 * NA;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) es[m] = Sk[(size_t)m * NA + col];
+    } else if (wv == 4) {
+        sMuu[lane] = ws[WS_MUU + (size_t)(4 * I) * 16 + lane];
+    }
+    if (tid < 256) sMu[wv][lane] = ws[WS_MXU + (size_t)(4 * I + wv) * 64 + lane];  // [step][m * 4 + d], m < 16 (rows 13..15 zero)
+#ifdef KD_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long kp1 = clock64();
+#endif
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (4 * I + 1 + wv + 8 * it >= HH) break;
+        f64x4 Q = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Q = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[it][g], sj[it][g], Q, 0, 0, 0);
+        // Q = Mxx S_J in C layout: register g of lane (lo, hi) is row 4g + hi -- the B operand of k-group g as is
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(si[it][g], Q[g], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][r][lane] = acc[r];
+#ifdef KD_PROF
+    const long long kp2 = clock64();
+#endif
+    __syncthreads();
+#ifdef KD_PROF
+    const long long kp3 = clock64();
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 35)) printf("KD wg %d: loads %lld mfma %lld barrier %lld\n", (int)blockIdx.x, kp1 - kp0, kp2 - kp1, kp3 - kp2);
+#endif
+    double v = 0.0;
+    if (wv < 4) {
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += red[w8][wv][lane];
+        // action blocks: u_i enters at step t_i where column j has sensitivity S_{t_i}[:, j] (t_j < t_i), and vice versa
+        if (ti != tj) {
+            const double *mu = sMu[tk - 4 * I];
+#pragma unroll
+            for (int m = 0; m < NX; ++m) v = fma(es[m], mu[m * 4 + dk], v);
+        } else {
+            v += sMuu[(ti - 4 * I) * 16 + di * 4 + dj];
+        }
+        // C = -J.  Off-diagonal tiles mirror; in diagonal tiles the lower half writes both copies (exactly symmetric R)
+        if (I != J || i >= j) {
+            R[(size_t)i * NA + j] = -v;
+            R[(size_t)j * NA + i] = -v;
+        }
+    }
+    if (A.stats.rpart != nullptr && b == 0) {
+        // the Sigma chain's input statistics of R = -v, tile by tile (sym_stats.hpp): the chain then needs no prep launch.  In a
+        // diagonal tile R holds the lower half and its mirror image, so the statistics take the mirrored values too
+        __shared__ double st_tmp[16][17];
+        __shared__ double st_part[4];
+        __shared__ double st_diag[16][17];
+        double rv = -v;
+        if (I == J) {
+            if (wv < 4) st_diag[hi + 4 * wv][lo] = rv;
+            __syncthreads();
+            if (wv < 4 && i < j) rv = st_diag[lo][hi + 4 * wv];
+        }
+        sym_tile_stats(wv < 4, rv, I, J, (int)blockIdx.x, lane, wv & 3, A.stats, st_tmp, st_part);
+    }
+}
+#undef ADJ_FOR_STATE

@@ -448,7 +448,7 @@ struct BatchState {
     void *consts = nullptr;         // qm::Consts<double>[E]   (Hessian)
     void *ro_args = nullptr;        // RolloutArgs[E]          (rollout)
     float *partials = nullptr;      // [E][max_red_blocks][COVO_PARTIAL_FLOATS]: the instances' softmax stage-1 records
-    void *models = nullptr;         // dm::Model[E]            (disturbance tables, per-pair Hessian)
+    void *models = nullptr;         // dm::Model[E]            (disturbance tables, drag / mixed Hessian)
     float *tab_rollout = nullptr, *tab_hess = nullptr;  // [E][H][4] the step's disturbance tables (periodic / sin / drag / mixed)
     bool tables = false;            // the instances' disturbance model needs them
     std::vector<char> ro_args_host;

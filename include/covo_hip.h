@@ -280,7 +280,7 @@ int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, 
  * f_disturb_steps [DEVICE float[batch][COVO_H][4], nullable]: covo_disturb_table(COVO_DISTURB_KEYS_HESSIAN, deterministic = 1)
  * -- required for params->disturb_kind PERIODIC / SIN / DRAG / MIXED (get_hessian's deterministic=True only switches the
  * gaussian model off, quadrotor.py:234-235); NULL = no force after step 0.  DRAG / MIXED make the force part of the
- * differentiated state (16 instead of 13 components): those two run the per-pair kernel (covo_hessian_pairs). */
+ * differentiated state: those two run the kernels' 16-component instantiation (state + force; hessian_adj.hip adj16). */
 int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
                  const covo_env_params *params, const float *a_mean, const float *f_disturb_steps, int32_t batch,
                  double *R_out, void *stream);

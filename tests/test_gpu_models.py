@@ -163,10 +163,11 @@ def test_rollout_variants_shapes_rollover_and_freeze(kind, reward, N):
                                                 ("periodic", "penyaw", "adjoint"), ("periodic", "realworld", "pairs"),
                                                 ("sin", "realworld", "adjoint"), ("sin", "penyaw", "pairs"),
                                                 ("drag", "penyaw", "adjoint"), ("mixed", "realworld", "adjoint"),
-                                                ("mixed", "penyaw", "pairs")])
+                                                ("mixed", "penyaw", "pairs"), ("drag", "realworld", "pairs")])
 def test_hessian_reward_and_disturbance_variants_vs_ad_oracle(kind, reward, method):
-    """covo_hessian for every model against the fp64 hyper-dual C oracle (itself equal to torch forward-over-forward AD:
-    tests/test_oracle.py).  drag / mixed: covo_hessian routes to the per-pair kernel (the force is differentiated state)."""
+    """covo_hessian (second-order adjoint) and covo_hessian_pairs for every model against the fp64 hyper-dual C oracle (itself
+    equal to torch forward-over-forward AD: tests/test_oracle.py).  drag / mixed: the force is part of the differentiated state
+    -- the adjoint kernels' 16-component instantiation (hessian_adj.hip: adj16)."""
     s, p, rng = make_problem(seed=3, time=41)  # step 9 (time 50) redraws
     p = p.replace(disturb_params=DP)
     a = (R.hover_action(p, 32, np.float64) + 0.1 * rng.normal(size=(32, 4))).astype(np.float32)
