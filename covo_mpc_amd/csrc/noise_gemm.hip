@@ -373,6 +373,9 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
 
 // MPPI: a[t] = clip(mu[t] + Ls[t] eps[t]) with 4x4 lower factors; eps [N][H][4] -> a [H][N][4].
 // HBM-bound streaming kernel (1 KiB per sample); fmaf chains in ascending k like the oracle.
+// PHILOX (the product path: nothing is read): workgroup row y = step t, consecutive lanes = consecutive samples -- a wave stores
+// 1 KiB contiguous runs of stripe t.  (Round 3; the first mapping, consecutive lanes = consecutive t of one sample, suits the eps
+// READ of the other variant but scattered the stores as 64 partial lines per wave: 19.2 us at N = 65 536.)
 template <bool PHILOX>
 __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__restrict__ Ls, const float *__restrict__ mu,
                                                               const float4 *__restrict__ eps, uint32_t k0, uint32_t k1,
@@ -380,27 +383,37 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
                                                               const uint32_t *__restrict__ dyn)
 {
     if (dyn != nullptr) { k0 = dyn[0]; k1 = dyn[1]; }
-    __shared__ float sL[COVO_H * 16];
-    __shared__ float sm[COVO_NA];
-    for (int i = threadIdx.x; i < COVO_H * 16; i += 256) sL[i] = Ls[i];
-    if (threadIdx.x < COVO_NA) sm[threadIdx.x] = mu[threadIdx.x];
-    __syncthreads();
-    // thread -> (sample, t): consecutive threads take consecutive t of one sample (coalesced reads);
-    // writes are 16-B scattered by t but each (t) stripe is filled by neighbouring blocks.
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)N * COVO_H;
-    if (gid >= total) return;
-    const int t = (int)(gid % COVO_H);
-    const size_t n = gid / COVO_H;
-    const float4 e = PHILOX ? rngd::normal4((uint32_t)t, (uint64_t)(sample_offset + (int64_t)n), k0, k1) : eps[gid];
+    int t;
+    size_t n;
+    float Lt[16], mt[4];
+    if (PHILOX) {
+        t = blockIdx.y;
+        n = (size_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Lt[i] = Ls[t * 16 + i];  // (uniform: scalar loads)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mt[i] = mu[t * 4 + i];
+        if (n >= (size_t)N) return;
+    } else {
+        // thread -> (sample, t): consecutive threads take consecutive t of one sample (coalesced eps reads)
+        const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (gid >= (size_t)N * COVO_H) return;
+        t = (int)(gid % COVO_H);
+        n = gid / COVO_H;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Lt[i] = Ls[t * 16 + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mt[i] = mu[t * 4 + i];
+    }
+    const float4 e = PHILOX ? rngd::normal4((uint32_t)t, (uint64_t)(sample_offset + (int64_t)n), k0, k1) : eps[n * COVO_H + t];
     const float ev[4] = {e.x, e.y, e.z, e.w};
     float o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc = fmaf((k <= i) ? sL[t * 16 + i * 4 + k] : 0.0f, ev[k], acc);
-        o[i] = qm::clip11_(sm[t * 4 + i] + acc);
+        for (int k = 0; k < 4; ++k) acc = fmaf((k <= i) ? Lt[i * 4 + k] : 0.0f, ev[k], acc);
+        o[i] = qm::clip11_(mt[i] + acc);
     }
     a_out[(size_t)t * N + n] = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -450,8 +463,8 @@ int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, u
                            reinterpret_cast<const float4 *>(eps), 0u, 0u, (int64_t)0, N, reinterpret_cast<float4 *>(a),
                            (const uint32_t *)nullptr);
     else
-        hipLaunchKernelGGL(noise_blockdiag_kernel<true>, dim3(grid), dim3(256), 0, s, Ls, mu, (const float4 *)nullptr, k0,
-                           k1, sample_offset, N, reinterpret_cast<float4 *>(a), dyn);
+        hipLaunchKernelGGL(noise_blockdiag_kernel<true>, dim3((N + 255) / 256, COVO_H), dim3(256), 0, s, Ls, mu,
+                           (const float4 *)nullptr, k0, k1, sample_offset, N, reinterpret_cast<float4 *>(a), dyn);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -208,13 +208,27 @@ __global__ __launch_bounds__(MG_THREADS) void merge_cov_kernel(const float *__re
 #pragma unroll
     for (int i = 0; i < MG_THREADS / 64; ++i) s += reds[i];
     const int col = tid & (COVO_NA - 1), slice = tid >> 7;
+    // one workgroup reads all G records (G x 1.8 KB): the loads of a thread's G / 8 records are independent, only the fmaf chain
+    // is ordered -- unrolled so that eight are in flight (rolled, every trip paid its own memory round trip: 37 us at G = 256)
     float v = 0.0f;
+#pragma unroll 8
     for (int g = slice; g < G; g += MG_SLICES) v = fmaf(partials[(size_t)g * REC + 2 + col], scale[g], v);
     sv[slice][col] = v;
-    for (int c2 = col; c2 < RD_COV_FLOATS; c2 += COVO_NA) {
-        float v2 = 0.0f;
-        for (int g = slice; g < G; g += MG_SLICES) v2 = fmaf(partials[(size_t)g * REC + COVO_PARTIAL_FLOATS + c2], scale[g], v2);
-        sv2[slice][c2] = v2;
+    {
+        // the 320 second-moment columns: columns col, col + 128 and (col < 64) col + 256 side by side
+        const bool third = col + 2 * COVO_NA < RD_COV_FLOATS;
+        float va = 0.0f, vb = 0.0f, vc = 0.0f;
+#pragma unroll 4
+        for (int g = slice; g < G; g += MG_SLICES) {
+            const float *rec = partials + (size_t)g * REC + COVO_PARTIAL_FLOATS + col;
+            const float sc = scale[g];
+            va = fmaf(rec[0], sc, va);
+            vb = fmaf(rec[COVO_NA], sc, vb);
+            if (third) vc = fmaf(rec[2 * COVO_NA], sc, vc);
+        }
+        sv2[slice][col] = va;
+        sv2[slice][col + COVO_NA] = vb;
+        if (third) sv2[slice][col + 2 * COVO_NA] = vc;
     }
     __syncthreads();
     const float inv_s = 1.0f / s;
