@@ -38,7 +38,10 @@ __device__ __forceinline__ void eps_tiles_generate(const EpsGenArgs &G, int wave
 #ifndef EPS_STORE_PLAIN
             typedef float f4v __attribute__((ext_vector_type(4)));
             const f4v vv = {v.x, v.y, v.z, v.w};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out + q * 64), "v"(vv) : "memory");
+            // s_nop 1: a VALU write to the data registers of a > 64-bit store needs two wait states on gfx940+ (the store reads its
+            // upper dwords late); hipcc's hazard recognizer inserts them for its own stores but cannot see into inline asm -- without
+            // them the next draw's arithmetic clobbered z / w of a few samples whenever the scheduler put it right behind the store
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(out + q * 64), "v"(vv) : "memory");
 #else
             out[q * 64] = v;
 #endif

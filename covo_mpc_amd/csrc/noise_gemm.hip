@@ -334,7 +334,8 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
 #ifdef NG_STORE_WT
                     typedef float f4v __attribute__((ext_vector_type(4)));
                     const f4v vv = {v.x, v.y, v.z, v.w};
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a_out + (size_t)t * N + n), "v"(vv) : "memory");
+                    // (s_nop 1: the > 64-bit-store data hazard the compiler cannot see inside inline asm, eps_tiles.hpp)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(a_out + (size_t)t * N + n), "v"(vv) : "memory");
 #elif defined(NG_STORE_NT)
                     __builtin_nontemporal_store(v.x, &a_out[(size_t)t * N + n].x);
                     __builtin_nontemporal_store(v.y, &a_out[(size_t)t * N + n].y);
