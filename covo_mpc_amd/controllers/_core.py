@@ -123,12 +123,16 @@ class SamplingCore:
         self.stats_total = torch.zeros((COVO_POS_STATS_DOUBLES,), dtype=torch.float64, device=self.device) if self.world > 1 else self.stats
         self.exchange = "collective"
         if self.world > 1:
-            mode = exchange if exchange is not None else os.environ.get("COVO_EXCHANGE", "collective")
-            if mode not in ("collective", "peer"):
-                raise ValueError(f"exchange={mode!r} (collective | peer)")
+            # "auto" (default): the peer-write exchange (csrc/exchange.hip) when its construction-time self-test passes on EVERY
+            # rank, else the torch.distributed all-gather -- the peer path is validated on shared-GPU boxes only
+            mode = exchange if exchange is not None else os.environ.get("COVO_EXCHANGE", "auto")
+            if mode not in ("collective", "peer", "auto"):
+                raise ValueError(f"exchange={mode!r} (auto | collective | peer)")
             if mode == "peer":
                 self._connect_peer_exchange()
-            self.exchange = mode
+                self.exchange = "peer"
+            elif mode == "auto":
+                self.exchange = "peer" if self._try_peer_exchange() else "collective"
 
     def close(self):
         """covo_destroy now (workspaces, step graphs, side stream, exchange buffers) instead of at garbage collection.
@@ -155,6 +159,44 @@ class SamplingCore:
             blob = (C.c_char * (self.world * _lib.COVO_EXCHANGE_HANDLE_BYTES)).from_buffer_copy(b"".join(handles))
             check(self.lib.covo_exchange_connect(self.h, blob), "covo_exchange_connect")
         dist.barrier(group=self.pg)  # nobody pushes before everybody has mapped
+
+    def _all_agree(self, ok: bool) -> bool:
+        import torch.distributed as dist
+        seen = [None] * self.world
+        dist.all_gather_object(seen, bool(ok), group=self.pg)
+        return all(seen)
+
+    def _try_peer_exchange(self) -> bool:
+        """exchange="auto": map the peers' buffers and run two exchanges (both parities) of a known record; the peer path is taken
+        only if every rank mapped every buffer and read back every rank's record bit for bit.  A failure costs the wait kernel's
+        bounded spin (2 s) once, leaves the handle clean (status cleared) and the collective in charge."""
+        torch = self.torch
+        try:
+            self._connect_peer_exchange()
+            ok = True
+        except Exception:
+            ok = False
+        # a rank that could not map must not leave the others spinning on its flag: agree BEFORE anybody pushes
+        if not self._all_agree(ok):
+            return False
+        keep = self.record.clone()
+        try:
+            for rnd in range(2):
+                probe = torch.arange(COVO_RANK_RECORD_FLOATS, dtype=torch.float32, device=self.device) + 1000.0 * self.rank + 0.5 * rnd
+                self.record.copy_(probe)
+                check(self.lib.covo_exchange_records(self.h, ptr(self.record), ptr(self.gathered), self.stream()),
+                      "covo_exchange_records")
+                torch.cuda.synchronize(self.device)
+                got = self.gathered.view(self.world, COVO_RANK_RECORD_FLOATS).cpu()
+                want = torch.stack([torch.arange(COVO_RANK_RECORD_FLOATS, dtype=torch.float32) + 1000.0 * r + 0.5 * rnd
+                                    for r in range(self.world)])
+                ok = ok and bool(torch.equal(got, want))
+            ok = ok and self.device_status() == 0
+        except Exception:
+            ok = False
+        self.device_status(clear=True)
+        self.record.copy_(keep)
+        return self._all_agree(ok)
 
     def exchange_rank_records(self):
         """THE one exchange of a sharded control step: this rank's record -> self.gathered (world x COVO_RANK_RECORD_FLOATS)."""

@@ -15,7 +15,8 @@
 // acquires the flag and reads the payload with system-scope (sc0 sc1) loads -- nothing depends on a cache being flushed at
 // a kernel boundary.  The spin is bounded (2 s): a missing peer surfaces as COVO_DEVSTAT_EXCHANGE + NaN records, never a hang.
 // Validated functionally with two processes sharing one GPU (tests/test_gpu_parity.py); NOT measured over xGMI (the pool
-// has single-GPU boxes only), which is why torch.distributed (RCCL) stays the default exchange.
+// has single-GPU boxes only), which is why the host side takes this path only after a construction-time self-test on every rank
+// (controllers/_core.py: exchange="auto") and otherwise keeps torch.distributed (RCCL).
 #include <cstring>
 #include "covo_common.hpp"
 
@@ -127,7 +128,14 @@ int exchange_create(covo_ctx *h, int world, int rank, void *handle_out)
     x->world = world;
     x->rank = rank;
     h->exchange = x;  // owned by the handle from here on: a failure below is cleaned up by exchange_destroy / covo_destroy
-    hipError_t e = hipMalloc(&x->local, ex_bytes(world));
+    // fine-grained device memory (uncached in this GPU's L2): the peers' writes arrive over xGMI behind the L2's back, and the
+    // wait kernel must see them; plain hipMalloc is the fallback (ranks sharing one GPU share its L2 anyway)
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void **>(&x->local), ex_bytes(world), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        x->local = nullptr;
+        e = hipMalloc(&x->local, ex_bytes(world));
+    }
     if (e == hipSuccess) e = hipMemset(x->local, 0, ex_bytes(world));  // flags = 0 < every sequence number (they start at 1)
     if (e == hipSuccess) e = hipMalloc(&x->gathered, (size_t)world * COVO_RANK_RECORD_FLOATS * sizeof(float));
     if (e == hipSuccess) e = hipDeviceSynchronize();

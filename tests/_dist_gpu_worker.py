@@ -27,7 +27,10 @@ def main():
     N = 4096
     cs, cps = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0", process_group=dist.group.WORLD)
     c1, cp1 = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0")
-    assert cs.core.n_local == N // world and cs.core.offset == rank * (N // world) and cs.core.exchange == exchange
+    # "auto": the construction-time self-test picks the peer path when it works on every rank (here: two ranks, one GPU)
+    want_exchange = "peer" if exchange == "auto" else exchange
+    assert cs.core.n_local == N // world and cs.core.offset == rank * (N // world) and cs.core.exchange == want_exchange
+    assert cs.core.device_status() == 0
     params = env.default_params
     obs, info, state = env.reset(cr.PRNGKey(4), params)
     cps = cs.reset(state, params, cs.init_control_params, cr.PRNGKey(5))
@@ -46,7 +49,7 @@ def main():
     out = [None] * world
     dist.all_gather_object(out, cps.a_mean.cpu().numpy().tobytes())
     assert out[0] == out[1]  # every rank merges identically
-    if exchange == "peer":
+    if want_exchange == "peer":
         # a sharded episode segment enqueued by ONE C call per rank (covo_run_episode: step -> peer-write exchange -> merge ->
         # env step, no host in between) against the unsharded controller's
         n = 12
