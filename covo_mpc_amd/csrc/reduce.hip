@@ -279,6 +279,17 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
         if (FINAL) a_mean_old += x * COVO_NA;
         out += x * (FINAL ? COVO_NA : COVO_PARTIAL_FLOATS);
     }
+    // phase 3's operands first (the first 256 records: every launch of the product's steps): they depend on nothing, so their
+    // memory round trip overlaps those of phases 1 and 2 (three dependent round trips to records other XCDs have just written
+    // were most of this launch)
+    const int col = tid & (COVO_NA - 1), slice = tid >> 7;
+    constexpr int MG_PRE = 32;
+    float vals[MG_PRE];
+#pragma unroll
+    for (int i = 0; i < MG_PRE; ++i) {
+        const int g = slice + MG_SLICES * i;
+        vals[i] = (g < G) ? partials[(size_t)g * stride + 2 + col] : 0.0f;
+    }
     // phase 1: m = min_g m_g
     float m = __builtin_inff();
     for (int g = tid; g < G; g += MG_THREADS) m = fminf(m, partials[(size_t)g * stride]);
@@ -303,11 +314,15 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
     s = 0.0f;
 #pragma unroll
     for (int i = 0; i < MG_THREADS / 64; ++i) s += reds[i];
-    // phase 3: v[col] = sum_g v_g[col] scale_g, record slices in parallel
-    const int col = tid & (COVO_NA - 1), slice = tid >> 7;
+    // phase 3: v[col] = sum_g v_g[col] scale_g, record slices in parallel (ascending g within a slice, as before)
     float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MG_PRE; ++i) {
+        const int g = slice + MG_SLICES * i;
+        if (g < G) v = fmaf(vals[i], scale[g], v);
+    }
 #pragma unroll 4
-    for (int g = slice; g < G; g += MG_SLICES) v = fmaf(partials[(size_t)g * stride + 2 + col], scale[g], v);
+    for (int g = slice + MG_SLICES * MG_PRE; g < G; g += MG_SLICES) v = fmaf(partials[(size_t)g * stride + 2 + col], scale[g], v);
     sv[slice][col] = v;
     __syncthreads();
     if (tid < COVO_NA) {
