@@ -865,9 +865,14 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     }
     const int b = blockIdx.x, tid = threadIdx.x;
     double *s = scall + (size_t)b * SC_COUNT;
+    // the deflation vector goes to LDS with the launch's FIRST round trip (beside the two scalars the Z loads depend on): read
+    // from global memory where it is used, behind `zc != 0`, it was a third dependent round trip of this one-workgroup launch
+    __shared__ double suv[SN];
+    const double uv_mine = (tid < SN) ? s[SC_U + tid] : 0.0;
     const bool z1 = s[SC_ZBUF] != 0.0;
     const double zc = s[SC_ZCOEF];         // deflation: Z = Z~ + zc u u^T (0: off)
-    const double *__restrict__ uv = s + SC_U;
+    if (tid < SN) suv[tid] = uv_mine;
+    const double *uv = suv;
     const double2 *Z = reinterpret_cast<const double2 *>((z1 ? Z1all : Z0all) + (size_t)b * SN * SN);
     const double2 *Zt = reinterpret_cast<const double2 *>((z1 ? Zt1all : Zt0all) + (size_t)b * SN * SN);
     constexpr int LD = SN + 1;
@@ -889,6 +894,7 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
             za[t] = Z[e2];
             zt[t] = Zt[e2];
         }
+        __syncthreads();  // suv
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
             const int w = __builtin_amdgcn_readfirstlane((tid >> 7) + 4 * t), in = tid & 127;
