@@ -171,3 +171,38 @@ for trial in range(int(sys.argv[6]) if len(sys.argv) > 6 else 24):
     else:
         print("FAIL model rollout", kind, reward, time, N, period, rollover, disc, "max err", err.max(), "frac ok", (err < 1.3e-5).mean(), flush=True)
 print("model rollouts:", n5, "passed, worst median err", worst)
+
+# ---- round 3: adjoint Hessian (13- and 16-component instantiations) with random disturbance model / reward / period / time / keys
+n6 = 0
+worst = 0.0
+hcore = T.SamplingCore(256, 32, 0.01, 1.0, device=T.DEV)
+for trial in range(int(sys.argv[7]) if len(sys.argv) > 7 else 16):
+    kind = rnd.choice(M.KINDS + ["none"])
+    reward = rnd.choice(["penyaw", "realworld"])
+    time = rnd.choice([0, 3, 37, 49, 150, 268, 275, 290, 299])
+    period = rnd.choice([1, 3, 7, 50])
+    s, p, rng = T.make_problem(seed=rnd.randrange(10000), time=time)
+    p = p.replace(disturb_params=tuple(float(np.float32(x)) for x in rng.uniform(-1, 1, 6)), disturb_period=period)
+    a = (T.R.hover_action(p, 32, np.float64) + rnd.choice([0.02, 0.1, 0.5]) * rng.normal(size=(32, 4))).astype(np.float32)
+    if rnd.random() < 0.5:
+        a[rnd.randrange(32), rnd.randrange(4)] = 1.0
+    key = M.cr.PRNGKey(rnd.randrange(1 << 30))
+    ds = T.dev_state(s)
+    pc = M.params_c(p, kind, reward)
+    tab = None
+    if kind in M.KINDS:
+        tab = hcore.disturb_table(pc, ds.packed, key=key, key_mode=L_.DISTURB_KEYS_HESSIAN, deterministic=True)
+    Rm = hcore.hessian(ds.packed, ds, pc, torch.from_numpy(a.reshape(-1)).to(T.DEV), f_steps=tab)[0].cpu().numpy()
+    Rp = hcore.hessian(ds.packed, ds, pc, torch.from_numpy(a.reshape(-1)).to(T.DEV), method="pairs", f_steps=tab)[0].cpu().numpy()
+    ref = T.CO.hessian(s, p, a.reshape(-1).astype(np.float64), 32, reward=reward, kind=kind,
+                       table=None if tab is None else tab[0].cpu().numpy())
+    sc = max(1.0, np.abs(ref).max())
+    err, errp = np.abs(Rm - ref).max() / sc, np.abs(Rp - ref).max() / sc
+    worst = max(worst, err, errp)
+    if np.all(np.isfinite(ref)) and err < 1e-9 and errp < 1e-9 and np.abs(Rm - Rm.T).max() == 0.0:
+        n6 += 1
+    elif not np.all(np.isfinite(ref)):  # norm'(0) = NaN in the reference's AD: both must be NaN at the same places
+        n6 += int(np.array_equal(np.isnan(ref), np.isnan(Rm)))
+    else:
+        print("FAIL model hessian", kind, reward, time, period, "adjoint", err, "pairs", errp, flush=True)
+print("model hessians:", n6, "passed, worst", worst)
