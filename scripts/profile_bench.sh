@@ -26,6 +26,12 @@ cd "$R"
 python3 scripts/phase_times.py > gpurun_out/phase_times.log 2>/dev/null
 python3 scripts/kbench.py > gpurun_out/kbench.log 2>/dev/null
 python3 scripts/pmc_summary.py gpurun_out "$RND" > gpurun_out/pmc_summary.log 2>&1
-find gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b -name "*.csv" | head -30
+# gpurun merges at most 64 MiB back: the per-dispatch counter dumps (4 x ~14 MB) and the kernel trace stay on the box, their
+# per-kernel means (profiles/<round>_bench_pmc_*.csv, *_summary.json: written above) and the kernel stats travel
+mkdir -p gpurun_out/profiles_out
+cp profiles/"$RND"_bench_pmc_* gpurun_out/profiles_out/
+cp gpurun_out/prof_stats/bench_kernel_stats.csv gpurun_out/profiles_out/"$RND"_bench_kernel_stats.csv
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b gpurun_out/prof_stats
+ls gpurun_out/profiles_out
 tail -c 1500 gpurun_out/bench_line.json
 tail -5 gpurun_out/pmc_summary.log
