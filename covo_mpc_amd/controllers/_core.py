@@ -13,6 +13,7 @@ no collective library and no host round trip, so whole sharded episodes can be e
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -147,18 +148,36 @@ class SamplingCore:
         except Exception:
             pass
 
-    def _connect_peer_exchange(self):
+    def _connect_peer_exchange(self, must: bool = True) -> bool:
         """csrc/exchange.hip setup: every rank exports its exchange buffer (hipIpc), the 64-byte handles are all-gathered once
-        over the process group, every rank maps all peers' buffers."""
+        over the process group, every rank maps all peers' buffers.  Every rank runs the SAME sequence of collectives whatever
+        fails locally (a rank that raised between two of them would leave the others waiting in the next one); a failure
+        anywhere makes every rank return False (must = False) or raise (must = True)."""
         import torch.distributed as dist
         hb = (C.c_char * _lib.COVO_EXCHANGE_HANDLE_BYTES)()
+        err = None
         with self.torch.cuda.device(self.device):
-            check(self.lib.covo_exchange_create(self.h, self.world, self.rank, hb), "covo_exchange_create")
+            try:
+                if os.environ.get("COVO_DEBUG_FAIL_EXCHANGE_RANK") == str(self.rank):  # tests: one rank cannot export its buffer
+                    raise RuntimeError("covo_exchange_create: injected failure (COVO_DEBUG_FAIL_EXCHANGE_RANK)")
+                check(self.lib.covo_exchange_create(self.h, self.world, self.rank, hb), "covo_exchange_create")
+            except Exception as e:  # noqa: BLE001 - reported below, after the collective
+                err = e
             handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(hb), group=self.pg)
-            blob = (C.c_char * (self.world * _lib.COVO_EXCHANGE_HANDLE_BYTES)).from_buffer_copy(b"".join(handles))
-            check(self.lib.covo_exchange_connect(self.h, blob), "covo_exchange_connect")
-        dist.barrier(group=self.pg)  # nobody pushes before everybody has mapped
+            dist.all_gather_object(handles, None if err else bytes(hb), group=self.pg)
+            if all(x is not None for x in handles):
+                try:
+                    blob = (C.c_char * (self.world * _lib.COVO_EXCHANGE_HANDLE_BYTES)).from_buffer_copy(b"".join(handles))
+                    check(self.lib.covo_exchange_connect(self.h, blob), "covo_exchange_connect")
+                except Exception as e:  # noqa: BLE001
+                    err = e
+            elif err is None:
+                err = RuntimeError("covo_exchange_create failed on another rank")
+        # nobody pushes before everybody has mapped -- and everybody learns whether everybody has
+        ok = self._all_agree(err is None)
+        if not ok and must:
+            raise err if err is not None else RuntimeError("covo_exchange_connect failed on another rank")
+        return ok
 
     def _all_agree(self, ok: bool) -> bool:
         import torch.distributed as dist
@@ -171,14 +190,10 @@ class SamplingCore:
         only if every rank mapped every buffer and read back every rank's record bit for bit.  A failure costs the wait kernel's
         bounded spin (2 s) once, leaves the handle clean (status cleared) and the collective in charge."""
         torch = self.torch
-        try:
-            self._connect_peer_exchange()
-            ok = True
-        except Exception:
-            ok = False
-        # a rank that could not map must not leave the others spinning on its flag: agree BEFORE anybody pushes
-        if not self._all_agree(ok):
+        # a rank that could not map must not leave the others spinning on its flag: all agree BEFORE anybody pushes
+        if not self._connect_peer_exchange(must=False):
             return False
+        ok = True
         keep = self.record.clone()
         try:
             for rnd in range(2):

@@ -16,6 +16,10 @@ import torch.distributed as dist
 
 def main():
     name, exchange = sys.argv[1], sys.argv[2]
+    inject = exchange == "auto_fail"  # rank 1 cannot export its exchange buffer: every rank must fall back, nobody may hang
+    if inject:
+        exchange = "auto"
+        os.environ["COVO_DEBUG_FAIL_EXCHANGE_RANK"] = "1"
     os.environ["COVO_EXCHANGE"] = exchange
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -28,7 +32,7 @@ def main():
     cs, cps = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0", process_group=dist.group.WORLD)
     c1, cp1 = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0")
     # "auto": the construction-time self-test picks the peer path when it works on every rank (here: two ranks, one GPU)
-    want_exchange = "peer" if exchange == "auto" else exchange
+    want_exchange = ("collective" if inject else "peer") if exchange == "auto" else exchange
     assert cs.core.n_local == N // world and cs.core.offset == rank * (N // world) and cs.core.exchange == want_exchange
     assert cs.core.device_status() == 0
     params = env.default_params

@@ -755,7 +755,7 @@ def test_closed_loop_on_device():
 
 
 @pytest.mark.parametrize("name,exchange", [("covo-online", "collective"), ("covo-online", "peer"), ("mppi", "collective"),
-                                           ("mppi", "peer"), ("covo-online", "auto")])
+                                           ("mppi", "peer"), ("covo-online", "auto"), ("mppi", "auto_fail")])
 def test_two_ranks_one_gpu(name, exchange):
     """SURVEY.md 8e through the PRODUCT path: two processes (gloo rendezvous, both on cuda:0) run the sample-sharded
     controller -- fused step writing this shard's rank record (softmax partial + position sums), ONE exchange (all-gather, or
