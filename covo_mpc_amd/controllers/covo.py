@@ -210,9 +210,24 @@ class CoVOController(BaseController):
         a_mean = core.shift_mean(control_params.a_mean.reshape(-1))  # covo.py:201-203
         control_params = control_params.replace(a_mean=a_mean.view(self.H, 4))
         tables = self._needs_table(params_c)
+        jax_stream = self.noise_stream == "jax"
+
+        def table(key, key_mode):
+            # Philox stream: built on the device (disturb.hip); jax stream: the same table on the host with jax.random's own key
+            # splits and uniform draws (envs/quadrotor.py: rollout_disturbance_table), uploaded (128 floats)
+            if not tables:
+                return None
+            if not jax_stream:
+                return core.disturb_table(params_c, dstate.packed, key=key, key_mode=key_mode, deterministic=True)
+            from .. import random_jax
+            ns = info["noisy_state"]
+            t0 = int(ns.time) if hasattr(ns, "pos") else int(dstate.packed[25:26].view(core.torch.int32).item())
+            f0 = np.asarray(ns.f_disturb) if hasattr(ns, "pos") else dstate.packed[13:16].cpu().numpy()
+            tab = self.env.rollout_disturbance_table(key, env_params, t0, f0, key_mode, True, rng=random_jax, H=self.H)
+            return core.torch.from_numpy(tab[None]).to(core.device)
+
         if self.mode == "online":  # optimal Sigma (covo.py:205-208); get_hessian receives the RAW rng_act (covo.py:205)
-            tab_h = core.disturb_table(params_c, dstate.packed, key=rng_act, key_mode=_lib.DISTURB_KEYS_HESSIAN,
-                                       deterministic=True) if tables else None
+            tab_h = table(rng_act, _lib.DISTURB_KEYS_HESSIAN)
             R = core.hessian(dstate.packed, dstate, params_c, a_mean, f_steps=tab_h)
             Sigma, L = core.sigma(R, control_params.sample_sigma)
             a_cov, L = Sigma[0], L[0]
@@ -230,9 +245,9 @@ class CoVOController(BaseController):
             rng_act, act_key = crandom.split(rng_act)  # covo.py:212-224
             core.randn(act_key)
         core.noise_gemm(L, a_mean)
-        rng_act, step_key = crandom.split(rng_act)  # covo.py:225-263: deterministic=True -> the gaussian model is off
-        tab_r = core.disturb_table(params_c, dstate.packed, key=step_key, key_mode=_lib.DISTURB_KEYS_SHARED,
-                                   deterministic=True) if tables else None
+        # covo.py:225-263: deterministic=True -> the gaussian model is off; periodic / mixed still draw from step_key
+        rng_act, step_key = random_jax.split(rng_act) if jax_stream else crandom.split(rng_act)
+        tab_r = table(step_key, _lib.DISTURB_KEYS_SHARED)
         core.rollout(dstate, params_c, (0.0, 0.0, 0.0), core.compute_info, f_steps=tab_r)
         a_mean_new = core.update(a_mean, control_params.gamma_mean).view(self.H, 4)  # covo.py:266-278
         control_params = control_params.replace(a_mean=a_mean_new)

@@ -5,6 +5,8 @@ Same constructor / __call__ arguments and return triple; the body is the HIP pip
 """
 from __future__ import annotations
 
+import numpy as np
+
 import dataclasses
 from dataclasses import dataclass
 from typing import Any
@@ -104,9 +106,16 @@ class MPPIController(BaseController):
         if self.noise_stream == "jax":  # the step key and the shared gaussian draw from jax's bitstream too (mppi.py:69,74)
             rng_act, step_key = random_jax.split(rng_act)
             if params_c.disturb_kind in _lib.TABLE_DISTURB_KINDS:
-                raise NotImplementedError("noise_stream='jax' with a periodic / sin / drag / mixed disturbance: the table kernel "
-                                          "draws from the Philox stream")
-            f_shared, tab = self.env.rollout_disturbance(step_key, env_params, deterministic=False, rng=random_jax), None
+                # the device table kernel draws from the Philox stream: under jax's stream the same table is built on the host
+                # with jax.random's key splits and uniforms (envs/quadrotor.py: rollout_disturbance_table) and uploaded
+                ns = info["noisy_state"]
+                t0 = int(ns.time) if hasattr(ns, "pos") else int(dstate.packed[25:26].view(torch.int32).item())
+                f0 = np.asarray(ns.f_disturb) if hasattr(ns, "pos") else dstate.packed[13:16].cpu().numpy()
+                f_shared = (0.0, 0.0, 0.0)
+                tab = torch.from_numpy(self.env.rollout_disturbance_table(step_key, env_params, t0, f0, _lib.DISTURB_KEYS_SHARED,
+                                                                          False, rng=random_jax, H=self.H)[None]).to(core.device)
+            else:
+                f_shared, tab = self.env.rollout_disturbance(step_key, env_params, deterministic=False, rng=random_jax), None
         else:
             rng_act, step_key = crandom.split(rng_act)  # mppi.py:69-106
             if params_c.disturb_kind in _lib.TABLE_DISTURB_KINDS:  # periodic / sin / drag / mixed (free.py:10-58)

@@ -132,6 +132,63 @@ class Quad3D(BaseEnvironment):
             return (f32(scale) * np.asarray(rng.normal(disturb_key, (3,)), dtype=f32)).astype(f32)
         raise NotImplementedError(f"disturb_type={self.disturb_type!r}: no single shared vector (use SamplingCore.disturb_table)")
 
+    def rollout_disturbance_table(self, key, params, time: int, f_disturb0, key_mode: int, deterministic: bool, rng=crandom,
+                                  H: int = 32):
+        """Host restatement of csrc/disturb.hip: the per-step disturbance table of a controller rollout, float32 [H][4] with
+        row k = {g_k[3], c_k}, f_k = c_drag drag(vel_{k-1}) + c_k f_{k-1} + g_k for k >= 1 (row 0 unused: step 0 integrates the
+        state's own f_disturb).  `rng`: the key module -- covo_mpc_amd.random (then the rows are the device kernel's), or
+        random_jax for jax's own bitstream (noise_stream = "jax": keys split and uniforms / normals drawn as jax.random does).
+        key_mode (covo_mpc_amd._lib.DISTURB_KEYS_*): who calls step_env with which key -- SHARED: every step the same `key`
+        (covo.py:225,231; mppi.py:69,74); HESSIAN: rng_k, key = split(key) per step (covo.py:150-153); NOMINAL: _, key = split(key);
+        rng_step, key = split(key) (covo.py:58-70)."""
+        from .. import _lib
+        kind = self.disturb_type
+        tab = np.zeros((H, 4), dtype=f32)
+        dp = np.asarray(params.disturb_params, dtype=f32)
+        period = int(params.disturb_period) if int(params.disturb_period) > 0 else 1
+        scale = f32(params.disturb_scale)
+        held = np.asarray(f_disturb0, dtype=f32).copy()
+        key = np.asarray(key)
+
+        def disturb_key(k):  # raw_step: key, step_key = split(k); step_fn: key, key_dyn = split(step_key); disturb_key, key = split(key)
+            _, a = rng.split(k)
+            b, _ = rng.split(a)
+            d, _ = rng.split(b)
+            return d
+
+        def sin_term(t):  # free.py:27-38 in fp32, like the env
+            amp = dp[:3] * scale
+            per = dp[:3] * f32(period / 3) + f32(period)
+            return (amp * np.sin(f32(2 * np.pi) / per * f32(t) + dp[3:6] * f32(2 * np.pi))).astype(f32)
+
+        for k in range(H - 1):
+            if key_mode == _lib.DISTURB_KEYS_HESSIAN:
+                sk, key = rng.split(key)
+            elif key_mode == _lib.DISTURB_KEYS_NOMINAL:
+                _, key = rng.split(key)
+                sk, key = rng.split(key)
+            else:
+                sk = key
+            t = int(time) + k
+            hit = t % period == 0
+            g, c = np.zeros(3, dtype=f32), f32(0.0)
+            if kind == "gaussian":
+                if not deterministic:
+                    g = (f32(params.dyn_noise_scale) * np.asarray(rng.normal(disturb_key(sk), (3,)), dtype=f32)).astype(f32)
+            elif kind == "periodic":
+                if hit:
+                    held = np.asarray(rng.uniform(disturb_key(sk), (3,), -scale, scale), dtype=f32)
+                g = held.copy()
+            elif kind == "sin":
+                g = sin_term(t)
+            elif kind == "mixed":
+                u = np.asarray(rng.uniform(disturb_key(sk), (3,), -scale, scale), dtype=f32) if hit else np.zeros(3, dtype=f32)
+                g = ((sin_term(t) + u) / f32(3)).astype(f32)
+                c = f32(0.0) if hit else f32(1.0) / f32(3.0)
+            tab[k + 1, :3] = g
+            tab[k + 1, 3] = c
+        return tab
+
     def get_zero_state(self, key, params) -> EnvState3D:
         """quadrotor.py:265-312."""
         traj_key, disturb_key, key = crandom.split(key, 3)

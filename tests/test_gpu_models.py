@@ -91,6 +91,64 @@ def test_disturb_table_vs_model_functions(kind, mode):
     assert np.abs(tb[1] - table_ref(p, s2, kind, uniform_draws(p, keys[1], mode))).max() < 1e-6
 
 
+@pytest.mark.parametrize("kind", KINDS + ["gaussian"])
+@pytest.mark.parametrize("mode", [_lib.DISTURB_KEYS_SHARED, _lib.DISTURB_KEYS_HESSIAN, _lib.DISTURB_KEYS_NOMINAL])
+def test_host_table_builder_equals_the_device_table(kind, mode):
+    """Quad3D.rollout_disturbance_table (the host restatement the jax-stream path uses with random_jax) fed the library's own
+    key module must reproduce the device kernel's table: same key threading, same draws (bit-equal), sin to fp32 rounding."""
+    import covo_mpc_amd as cm
+    s, p, rng = make_problem(seed=5, time=93)
+    p = p.replace(disturb_params=DP, disturb_period=10)
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    ep = env.default_params.replace(disturb_params=np.asarray(DP, dtype=np.float32), disturb_period=10)
+    core = SamplingCore(64, 32, 0.01, 1.0, device=DEV)
+    key = cr.PRNGKey(77)
+    for det in (False, True):
+        dev = core.disturb_table(params_c(p, kind), dev_state(s).packed, key=key, key_mode=mode, deterministic=det)[0].cpu().numpy()
+        host = env.rollout_disturbance_table(key, ep, s.time, s.f_disturb, mode, det, rng=cr)
+        assert host.shape == dev.shape == (32, 4)
+        if kind in ("sin", "mixed"):
+            assert np.abs(host - dev).max() < 1e-6
+        else:
+            assert np.array_equal(host, dev), (kind, mode, det)
+    assert np.any(dev != 0) or kind in ("gaussian", "drag")
+
+
+@pytest.mark.parametrize("name,kind", [("covo-online", "periodic"), ("mppi", "mixed")])
+def test_jax_stream_with_table_models(name, kind):
+    """noise_stream = "jax" with a table-driven disturbance model: step key and the models' uniform draws come from jax.random's
+    bitstream (host-built table, random_jax) -- the rollout costs equal the oracle's with exactly those draws, and differ from the
+    run on the library's own stream."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random_jax as rj
+    N = 512
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params.replace(disturb_params=np.asarray(DP, dtype=np.float32), disturb_period=4)
+    c, cp = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
+    c.noise_stream = "jax"
+    obs, info, state = env.reset(cr.PRNGKey(3), params)
+    rng_act = rj.PRNGKey(11)
+    u, cp2, _ = c(obs, state, params, rng_act, cp, info)
+    assert np.all(np.isfinite(cp2.a_mean.cpu().numpy()))
+    cost_jax = c.core.cost.cpu().numpy().copy()
+    a_dev = c.core.a.permute(1, 0, 2).contiguous().cpu().numpy()
+    ns = info["noisy_state"]
+    so = R.State(pos=ns.pos, vel=ns.vel, quat=ns.quat, omega=ns.omega, f_disturb=ns.f_disturb, pos_tar=ns.pos_tar,
+                 vel_tar=ns.vel_tar, acc_tar=ns.acc_tar, time=ns.time, pos_traj=ns.pos_traj, vel_traj=ns.vel_traj,
+                 acc_traj=ns.acc_traj).astype(np.float64)
+    p = R.Params().fp32().replace(disturb_params=DP, disturb_period=4)
+    step_key = rj.split(rj.split(rng_act)[0])[1]  # rng, act_key = split(rng_act); rng, step_key = split(rng) on jax's stream
+    dk = rj.split(rj.split(rj.split(step_key)[1])[0])[0]  # quadrotor.py:262, free.py:136,144
+    draw = np.asarray(rj.uniform(dk, (3,), -p.disturb_scale, p.disturb_scale), dtype=np.float64)
+    ref = CO.rollout(so, p, a_dev.astype(np.float64), 1.0, dtype=np.float64, disturb=R.Disturb(kind, draw, name != "mppi"))
+    assert rel_err(cost_jax, ref).max() < 1e-5, rel_err(cost_jax, ref).max()
+    # the library's own stream on the same key bits draws another force: other costs
+    draw_philox = np.asarray(cr.uniform(disturb_key(cr.split(cr.split(rng_act)[0])[1]), (3,), -p.disturb_scale, p.disturb_scale))
+    assert np.abs(draw - draw_philox).max() > 1e-3
+
+
 # ------------------------------------------------------------------------------------------ rollout
 def _rollout_dev(core, s, pc, a, f_shared=(0.0, 0.0, 0.0), tab=None, want_stats=False):
     core.a.copy_(to_stripes(a))
