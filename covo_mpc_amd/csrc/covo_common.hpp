@@ -88,6 +88,12 @@ int launch_randn_jax(uint32_t k0, uint32_t k1, int64_t n_total, int64_t off, int
 // cov != null (fused covo-online step): a_cov = cz sym(Z) is NOT written by the chain's finalize launch -- one workgroup that
 // everything after it waits for -- but by the first workgroups of the noise GEMM that follows (same expression, same bits);
 // launch_sigma_ns fills *cov with where Z, its transpose and the scalars live.
+// threads per workgroup of the noise GEMM (noise_gemm.hip): 512 = one workgroup per CU, the factor staged into LDS once per CU
+// (256: two per CU, staged twice; round 3: 20.2 -> 17.8 us in the step).  The rollout's XCD-affine sample mapping follows it
+// (rollout.hip: xcd_remap = 64-sample groups per GEMM workgroup).
+#ifndef NG_BLOCK_THREADS
+#define NG_BLOCK_THREADS 512
+#endif
 struct CovDeferred {
     const double *Z[2], *Zt[2];  // the two Newton-Schulz buffers of Z and of its stored transpose
     const double *zbuf;          // != 0: buffer 1 holds the final iterate

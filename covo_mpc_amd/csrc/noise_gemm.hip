@@ -39,7 +39,8 @@ __device__ unsigned long long *g_ng_probe;
 #define NG_STAMP(i)
 #endif
 
-constexpr int NG_BLOCK = 256;
+constexpr int NG_BLOCK = NG_BLOCK_THREADS;   // 256: two workgroups per CU; 512: one, staging L once per CU
+constexpr int NG_ROWS_PER_TRIP = NG_BLOCK / 32;
 constexpr int NG_LDA = COVO_NA + 1;  // padded leading dimension of the LDS image of L
 
 
@@ -151,7 +152,7 @@ __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup 
 // PHILOX = false: epsilon is read from `eps` (TILED: in the tile order of eps_tiles.hpp, else row-major (N, 128));
 // true: drawn in registers from (k0, k1, sample_offset + n).
 template <bool PHILOX, bool TILED = false>
-__global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
+__global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
                                                               const float *__restrict__ eps, uint32_t k0, uint32_t k1,
                                                               int64_t sample_offset, int N, int ntiles,
                                                               float4 *__restrict__ a_out, const uint32_t *__restrict__ dyn,
@@ -228,12 +229,12 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
     // a_cov = cz sym(Z), left over by the Sigma chain's single-workgroup finalize launch (CovDeferred): the first 64
     // workgroups take 256 elements each; the loads ride with the epsilon request above, the stores leave after the staging of L
     double cov_z = 0.0, cov_zt = 0.0, cov_cz = 0.0, cov_zc = 0.0, cov_ur = 0.0, cov_uc = 0.0;
-    const bool cov_on = cov.out != nullptr && blockIdx.y == 0 && blockIdx.x < 64;
+    const bool cov_on = cov.out != nullptr && blockIdx.y == 0 && blockIdx.x < COVO_NA * COVO_NA / NG_BLOCK;
     const int cov_zb = cov_on ? ((*cov.zbuf != 0.0) ? 1 : 0) : 0;
     if (cov_on) {
         cov_cz = *cov.cz;
         cov_zc = *cov.zcoef;  // deflated chain: Z = Z~ + zc u u^T (sigma_ns.hip)
-        if (gridDim.x >= 64) {
+        if (gridDim.x >= COVO_NA * COVO_NA / NG_BLOCK) {
             const int e = blockIdx.x * NG_BLOCK + tid;
             cov_z = cov.Z[cov_zb][e];
             cov_zt = cov.Zt[cov_zb][e];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
         float4 v[TRIPS];
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = i0 + 8 * it;
+            const int i = i0 + NG_ROWS_PER_TRIP * it;
             v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (k4 <= i) v[it] = reinterpret_cast<const float4 *>(L)[tid + NG_BLOCK * it];
         }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
 #endif
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = i0 + 8 * it;
+            const int i = i0 + NG_ROWS_PER_TRIP * it;
             if (k4 < 32 * (i / 32 + 1)) {
                 float *d = Ls + i * NG_LDA + k4;
                 d[0] = (k4 + 0 <= i) ? v[it].x : 0.0f;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NG_BLOCK, 2) void noise_gemm_kernel(const float *__
     }
     if (tid < COVO_NA) mus[tid] = mu[tid];
     if (cov_on) {
-        if (gridDim.x >= 64) {
+        if (gridDim.x >= COVO_NA * COVO_NA / NG_BLOCK) {
             // covo.py:132 symmetrise (+ the deflated eigenpair, the same expression as ns_finalize_kernel's); a_cov is fp32
             double v = 0.5 * (cov_z + cov_zt);
             if (cov_zc != 0.0) v = fma(cov_ur, cov_uc, v);
@@ -429,7 +430,7 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
     const int ntiles = (N + 31) / 32;
     const int waves_per_block = NG_BLOCK / 64;
     int grid = (ntiles + waves_per_block - 1) / waves_per_block;
-    if (grid > 512) grid = 512;  // persistent: two workgroups per CU (2 waves/SIMD), waves stride over tiles
+    if (grid > 2048 / waves_per_block) grid = 2048 / waves_per_block;  // persistent: 2 waves/SIMD chip-wide, waves stride over tiles
     const size_t lds = (size_t)(COVO_NA * NG_LDA + COVO_NA) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

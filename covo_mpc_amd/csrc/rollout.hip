@@ -63,7 +63,9 @@ static void fill_rollout_args(RolloutArgs &A, const float *state, const float *p
     A.discount = discount;
     for (int i = 0; i < 3; ++i) A.f_shared[i] = f_shared ? f_shared[i] : 0.0f;
     A.f_shared_dev = f_shared_dev;
-    A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? 1 : 0;  // the GEMM runs one 32-sample tile per wave up to 512 workgroups
+    // the GEMM runs one 32-sample tile per wave up to N = 65 536: its workgroup g (NG_BLOCK_THREADS / 64 tiles = NG_BLOCK_THREADS / 128
+    // groups of 64 samples) sits on XCD g % 8, and the rollout's workgroups take the groups their own XCD's L2 has just been written with
+    A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? NG_BLOCK_THREADS / 128 : 0;
     A.records = nullptr;
     A.inv_lam = 0.0f;
     A.clip = 1;

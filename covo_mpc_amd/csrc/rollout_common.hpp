@@ -16,7 +16,7 @@ struct RolloutArgs {
     float discount;
     float f_shared[3];
     const float *f_shared_dev;  // nullable: {fx, fy, fz} in device memory (graph replays), overrides f_shared
-    int xcd_remap;              // 1: workgroup -> sample chunks follow the noise GEMM's XCD placement (see kernel)
+    int xcd_remap;              // > 0: workgroup -> sample chunks follow the noise GEMM's XCD placement; = 64-sample groups per GEMM workgroup
     float *records;             // nullable: [workgroups][COVO_PARTIAL_FLOATS] online-softmax records (rollout_record below)
     float inv_lam;
     int clip;      // 1: re-apply step_env's clip to the stripes (quadrotor.py:223,258); 0: the producer guarantees clipped stripes

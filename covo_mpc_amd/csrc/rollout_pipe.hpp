@@ -120,9 +120,9 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
     const float *__restrict__ st = A.state;
 
     int group = blockIdx.x * GROUPS + gsub;  // XCD affinity as in the two-stage kernel (speed only)
-    if (A.xcd_remap) {
-        const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + gsub;
-        group = 2 * (x + 8 * (m >> 1)) + (m & 1);
+    if (A.xcd_remap) {  // q = 64-sample groups per GEMM workgroup: group = q * (GEMM workgroup on this XCD) + (its m % q-th group)
+        const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + gsub, q = A.xcd_remap;
+        group = q * (x + 8 * (m / q)) + (m % q);
     }
     const int n_raw = group * COVO_WAVE + lane;
     const bool valid = n_raw < A.N;
@@ -429,8 +429,8 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
             for (int g = 0; g < GROUPS; ++g) {
                 int grp = blockIdx.x * GROUPS + g;
                 if (A.xcd_remap) {
-                    const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + g;
-                    grp = 2 * (x + 8 * (m >> 1)) + (m & 1);
+                    const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + g, q = A.xcd_remap;
+                    grp = q * (x + 8 * (m / q)) + (m % q);
                 }
                 int nv = A.N - grp * COVO_WAVE;
                 nv = nv < 0 ? 0 : (nv > COVO_WAVE ? COVO_WAVE : nv);
