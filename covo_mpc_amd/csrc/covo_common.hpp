@@ -88,12 +88,9 @@ int launch_randn_jax(uint32_t k0, uint32_t k1, int64_t n_total, int64_t off, int
 // cov != null (fused covo-online step): a_cov = cz sym(Z) is NOT written by the chain's finalize launch -- one workgroup that
 // everything after it waits for -- but by the first workgroups of the noise GEMM that follows (same expression, same bits);
 // launch_sigma_ns fills *cov with where Z, its transpose and the scalars live.
-// threads per workgroup of the noise GEMM (noise_gemm.hip): 512 = one workgroup per CU, the factor staged into LDS once per CU
-// (256: two per CU, staged twice; round 3: 20.2 -> 17.8 us in the step).  The rollout's XCD-affine sample mapping follows it
-// (rollout.hip: xcd_remap = 64-sample groups per GEMM workgroup).
-#ifndef NG_BLOCK_THREADS
-#define NG_BLOCK_THREADS 512
-#endif
+// threads per workgroup the noise GEMM launches with for (N, batch) (noise_gemm.hip: 512 once a launch fills the chip, else 256);
+// the rollout's XCD-affine sample mapping follows it (rollout.hip: xcd_remap = 64-sample groups per GEMM workgroup)
+int noise_gemm_block_threads(int N, int batch);
 struct CovDeferred {
     const double *Z[2], *Zt[2];  // the two Newton-Schulz buffers of Z and of its stored transpose
     const double *zbuf;          // != 0: buffer 1 holds the final iterate
@@ -111,7 +108,8 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr,
                    float *records = nullptr, float lam = 0.0f,   // records: one online-softmax record per workgroup (rollout.hip)
-                   const float *f_tab = nullptr);                // [H][4] per-step disturbance table (disturb.hip), device
+                   const float *f_tab = nullptr,                 // [H][4] per-step disturbance table (disturb.hip), device
+                   int xcd_groups = 0);   // 64-sample groups per workgroup of the kernel that wrote `a` (0: the noise GEMM's for this N)
 int launch_disturb_table(const covo_env_params &p, const float *state, int batch, const uint32_t *keys_dev, uint32_t key0,
                          uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s);
 int launch_disturb_tables_step(const covo_env_params &p, const float *state, const uint32_t *dyn, int rollout_deterministic,

@@ -39,8 +39,6 @@ __device__ unsigned long long *g_ng_probe;
 #define NG_STAMP(i)
 #endif
 
-constexpr int NG_BLOCK = NG_BLOCK_THREADS;   // 256: two workgroups per CU; 512: one, staging L once per CU
-constexpr int NG_ROWS_PER_TRIP = NG_BLOCK / 32;
 constexpr int NG_LDA = COVO_NA + 1;  // padded leading dimension of the LDS image of L
 
 
@@ -151,7 +149,11 @@ __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup 
 
 // PHILOX = false: epsilon is read from `eps` (TILED: in the tile order of eps_tiles.hpp, else row-major (N, 128));
 // true: drawn in registers from (k0, k1, sample_offset + n).
-template <bool PHILOX, bool TILED = false>
+// NG_BLOCK threads per workgroup: 512 = one workgroup per CU, the factor staged into LDS once per CU -- the choice once a launch
+// fills the chip (>= 2 048 tiles: 20.2 -> 17.8 us at N = 65 536); 256 = two per CU: smaller launches spread over twice as many
+// CUs (N = 8 192: 64 workgroups with one wave per SIMD instead of 32 with two; covo-offline 36.2k against 29.5k steps/s).
+// noise_gemm_block_threads() below decides; the rollout's XCD-affine mapping follows it.
+template <bool PHILOX, bool TILED = false, int NG_BLOCK = 256>
 __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
                                                               const float *__restrict__ eps, uint32_t k0, uint32_t k1,
                                                               int64_t sample_offset, int N, int ntiles,
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
         float4 v[TRIPS];
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = i0 + NG_ROWS_PER_TRIP * it;
+            const int i = i0 + (NG_BLOCK / 32) * it;
             v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (k4 <= i) v[it] = reinterpret_cast<const float4 *>(L)[tid + NG_BLOCK * it];
         }
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
 #endif
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = i0 + NG_ROWS_PER_TRIP * it;
+            const int i = i0 + (NG_BLOCK / 32) * it;
             if (k4 < 32 * (i / 32 + 1)) {
                 float *d = Ls + i * NG_LDA + k4;
                 d[0] = (k4 + 0 <= i) ? v[it].x : 0.0f;
@@ -420,6 +422,8 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
     a_out[(size_t)t * N + n] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+int noise_gemm_block_threads(int N, int batch) { return (batch == 1 && (N + 31) / 32 >= 2048) ? 512 : 256; }
+
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table, int batch,
                       bool eps_tiled, const CovDeferred *cov)
@@ -428,29 +432,37 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
     std::memset(&cv, 0, sizeof(cv));
     if (cov != nullptr) cv = *cov;
     const int ntiles = (N + 31) / 32;
-    const int waves_per_block = NG_BLOCK / 64;
+    const int block = noise_gemm_block_threads(N, batch);
+    const int waves_per_block = block / 64;
     int grid = (ntiles + waves_per_block - 1) / waves_per_block;
     if (grid > 2048 / waves_per_block) grid = 2048 / waves_per_block;  // persistent: 2 waves/SIMD chip-wide, waves stride over tiles
     const size_t lds = (size_t)(COVO_NA * NG_LDA + COVO_NA) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<false, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define NG_ATTR(...) COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<__VA_ARGS__>), \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+        NG_ATTR(false, false, 256); NG_ATTR(true, false, 256); NG_ATTR(false, true, 256);
+        NG_ATTR(false, false, 512); NG_ATTR(true, false, 512); NG_ATTR(false, true, 512);
+#undef NG_ATTR
         attr_set = true;
     }
-    if (eps != nullptr && eps_tiled)
-        hipLaunchKernelGGL((noise_gemm_kernel<false, true>), dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
-                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv);
-    else if (eps != nullptr)
-        hipLaunchKernelGGL(noise_gemm_kernel<false>, dim3(grid), dim3(NG_BLOCK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, N,
-                           ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv);
-    else
-        hipLaunchKernelGGL(noise_gemm_kernel<true>, dim3(grid, batch), dim3(NG_BLOCK), lds, s, L, mu, (const float *)nullptr, k0,
-                           k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn, state_for_time, n_table, cv);
+#define NG_GO(BLK)                                                                                                              \
+    do {                                                                                                                         \
+        if (eps != nullptr && eps_tiled)                                                                                         \
+            hipLaunchKernelGGL((noise_gemm_kernel<false, true, BLK>), dim3(grid), dim3(BLK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, \
+                               N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv); \
+        else if (eps != nullptr)                                                                                                 \
+            hipLaunchKernelGGL((noise_gemm_kernel<false, false, BLK>), dim3(grid), dim3(BLK), lds, s, L, mu, eps, 0u, 0u,          \
+                               (int64_t)0, N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time,  \
+                               n_table, cv);                                                                                     \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((noise_gemm_kernel<true, false, BLK>), dim3(grid, batch), dim3(BLK), lds, s, L, mu,                 \
+                               (const float *)nullptr, k0, k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn,     \
+                               state_for_time, n_table, cv);                                                                     \
+    } while (0)
+    if (block == 512) NG_GO(512);
+    else NG_GO(256);
+#undef NG_GO
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

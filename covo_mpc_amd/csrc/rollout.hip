@@ -48,8 +48,10 @@ static void launch_rollout_pf(const RolloutArgs &A, const RolloutArgs *batch, in
 
 static void fill_rollout_args(RolloutArgs &A, const float *state, const float *pos_traj, const float *vel_traj, int T,
                               const covo_env_params &p, const float *f_shared, const float *a, int N, float discount,
-                              float *cost, float *groupmin, double *stats_ws, const float *f_shared_dev, const float *f_tab)
+                              float *cost, float *groupmin, double *stats_ws, const float *f_shared_dev, const float *f_tab,
+                              int xcd_groups = 0, int nbatch = 1)
 {
+    if (xcd_groups <= 0) xcd_groups = noise_gemm_block_threads(N, nbatch) / 128;  // the producer is the noise GEMM unless told otherwise
     A.state = state;
     A.pos_traj = pos_traj;
     A.vel_traj = vel_traj;
@@ -63,9 +65,10 @@ static void fill_rollout_args(RolloutArgs &A, const float *state, const float *p
     A.discount = discount;
     for (int i = 0; i < 3; ++i) A.f_shared[i] = f_shared ? f_shared[i] : 0.0f;
     A.f_shared_dev = f_shared_dev;
-    // the GEMM runs one 32-sample tile per wave up to N = 65 536: its workgroup g (NG_BLOCK_THREADS / 64 tiles = NG_BLOCK_THREADS / 128
-    // groups of 64 samples) sits on XCD g % 8, and the rollout's workgroups take the groups their own XCD's L2 has just been written with
-    A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? NG_BLOCK_THREADS / 128 : 0;
+    // the producers run one 32-sample tile per wave up to N = 65 536: workgroup g of the noise GEMM (noise_gemm_block_threads / 128
+    // groups of 64 samples; MPPI's block-diagonal kernel: 256 samples = 4 groups per workgroup row) sits on XCD g % 8, and the
+    // rollout's workgroups take the groups their own XCD's L2 has just been written with (a mismatch costs MPPI's rollout 11 us)
+    A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? xcd_groups : 0;
     A.records = nullptr;
     A.inv_lam = 0.0f;
     A.clip = 1;
@@ -113,10 +116,11 @@ static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int 
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev,
-                   float *records, float lam, const float *f_tab)
+                   float *records, float lam, const float *f_tab, int xcd_groups)
 {
     RolloutArgs A;
-    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev, f_tab);
+    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev, f_tab,
+                      xcd_groups);
     if (A.fdist != 0 && f_tab == nullptr) {
         covo_set_error("rollout: disturb_kind=%d needs the per-step disturbance table (covo_disturb_table)", p.disturb_kind);
         return COVO_E_BADARG;
@@ -149,7 +153,7 @@ void rollout_fill_args(void *out, int index, const float *state, const float *po
 {
     RolloutArgs &A = reinterpret_cast<RolloutArgs *>(out)[index];
     // f_tab: this instance's rows of the step's disturbance tables (periodic / sin / drag / mixed; all instances share the kind)
-    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost, groupmin, nullptr, f_shared_dev, f_tab);
+    fill_rollout_args(A, state, pos_traj, vel_traj, T, p, nullptr, a, N, discount, cost, groupmin, nullptr, f_shared_dev, f_tab, 0, 2);
     A.clip = trust_clipped ? 0 : 1;
     A.records = records;
     A.inv_lam = records ? 1.0f / lam : 0.0f;

@@ -267,7 +267,8 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     const bool records = G <= h->max_red_blocks && !cov_adapt;
     if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
                                          records ? nullptr : a.groupmin, a.pos_stats, h->ws_stats, s, fdev,
-                                         records ? h->ws_partials : nullptr, h->cfg.lam, tables ? st->f_tab_rollout : nullptr)))
+                                         records ? h->ws_partials : nullptr, h->cfg.lam, tables ? st->f_tab_rollout : nullptr,
+                                         a.mode == COVO_MODE_MPPI ? 4 : 0)))  // MPPI's block-diagonal kernel: 256 samples per workgroup
         return rc;
     if (!(M & 32)) return 0;
     if (cov_adapt)  // mppi.py:109-125: new mean, then a_cov (already shifted by the begin launch) adapted in place
