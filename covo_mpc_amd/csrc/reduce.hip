@@ -290,10 +290,12 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
         const int g = slice + MG_SLICES * i;
         vals[i] = (g < G) ? partials[(size_t)g * stride + 2 + col] : 0.0f;
     }
-    // phase 1: m = min_g m_g
-    float m = __builtin_inff();
-    for (int g = tid; g < G; g += MG_THREADS) m = fminf(m, partials[(size_t)g * stride]);
-    m = wave_min(m);
+    // phase 1: m = min_g m_g; a thread's record header {m_g, s_g} (G <= 1 024 = one record per thread) stays in registers for
+    // phase 2 -- with the operands above, every load of this launch is in flight before the first is used
+    const bool mine = tid < G;
+    const float my_m = mine ? partials[(size_t)tid * stride] : __builtin_inff();
+    const float my_s = mine ? partials[(size_t)tid * stride + 1] : 0.0f;
+    float m = wave_min(my_m);
     if (lane == 0) redm[wave] = m;
     __syncthreads();
     m = redm[0];
@@ -301,12 +303,10 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
     for (int i = 1; i < MG_THREADS / 64; ++i) m = fminf(m, redm[i]);
     // phase 2: per-record scale and s = sum_g s_g scale_g
     float s = 0.0f;
-    for (int g = tid; g < G; g += MG_THREADS) {
-        const float *rec = partials + (size_t)g * stride;
-        const float sg = rec[1];
-        const float sc = (sg > 0.0f) ? expf((m - rec[0]) * inv_lam) : 0.0f;  // empty shard -> 0
-        scale[g] = sc;
-        s = fmaf(sg, sc, s);
+    if (mine) {
+        const float sc = (my_s > 0.0f) ? expf((m - my_m) * inv_lam) : 0.0f;  // empty shard -> 0
+        scale[tid] = sc;
+        s = my_s * sc;
     }
     s = wave_sum(s);
     if (lane == 0) reds[wave] = s;
