@@ -91,6 +91,7 @@ int launch_randn_jax(uint32_t k0, uint32_t k1, int64_t n_total, int64_t off, int
 // threads per workgroup the noise GEMM launches with for (N, batch) (noise_gemm.hip: 512 once a launch fills the chip, else 256);
 // the rollout's XCD-affine sample mapping follows it (rollout.hip: xcd_remap = 64-sample groups per GEMM workgroup)
 int noise_gemm_block_threads(int N, int batch);
+int noise_gemm_groups_per_workgroup(int N, int batch);
 struct CovDeferred {
     const double *Z[2], *Zt[2];  // the two Newton-Schulz buffers of Z and of its stored transpose
     const double *zbuf;          // != 0: buffer 1 holds the final iterate

@@ -97,12 +97,14 @@ __device__ __forceinline__ BGroup gen_group(uint64_t id, int g, int kh, uint32_t
     return b;
 }
 
-// A fragments of one float4 chunk of k's (4 k-steps x the row tiles G..3), read from the LDS image of L
+// A fragments of one float4 chunk of k's (4 k-steps x the row tiles rt >= G of the wave's set MASK), read from the LDS image of L.
+// MASK: which row tiles (32 actions each) this wave multiplies -- 15: all (a whole tile per wave); 9 / 6: {0, 3} / {1, 2}, the two
+// halves of a tile with 80 of its 160 MFMAs each (small launches: a tile split over two waves, see the kernel)
 template <int G>
 struct AFrag {
-    float v[4][4 - G];  // [q][rt - G]
+    float v[4][4];  // [q][rt] (entries outside the set are never touched)
 };
-template <int G>
+template <int G, int MASK>
 __device__ __forceinline__ AFrag<G> load_afrag(const float *__restrict__ La, int i)
 {
     AFrag<G> f;
@@ -110,7 +112,8 @@ __device__ __forceinline__ AFrag<G> load_afrag(const float *__restrict__ La, int
     for (int q = 0; q < 4; ++q) {
         const int ks = 16 * G + 4 * i + q;  // k-step (k0 = 2 ks)
 #pragma unroll
-        for (int rt = G; rt < 4; ++rt) f.v[q][rt - G] = La[32 * rt * NG_LDA + 2 * ks];
+        for (int rt = G; rt < 4; ++rt)
+            if ((MASK >> rt) & 1) f.v[q][rt] = La[32 * rt * NG_LDA + 2 * ks];
     }
     return f;
 }
@@ -119,14 +122,15 @@ __device__ __forceinline__ AFrag<G> load_afrag(const float *__restrict__ La, int
 // i are issued (a ds_read -> s_waitcnt -> 2 dependent MFMAs sequence, as hipcc schedules the naive loop, leaves the
 // matrix pipe idle for an LDS round trip per pair: 26.8 us; with the fragments one chunk ahead the MFMAs of a chunk
 // go out back to back on four independent accumulators).
-template <int G>
+template <int G, int MASK = 15>
 __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup b, f32x16 (&acc)[4])
 {
-    AFrag<G> cur = load_afrag<G>(La, 0);
+    if ((MASK >> G) == 0) return;  // no row tile of the set reaches this k-group (L is lower triangular)
+    AFrag<G> cur = load_afrag<G, MASK>(La, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         AFrag<G> nxt = cur;
-        if (i < 3) nxt = load_afrag<G>(La, i + 1);
+        if (i < 3) nxt = load_afrag<G, MASK>(La, i + 1);
         float x = b.c[i].x, y = b.c[i].y, z = b.c[i].z, w = b.c[i].w;
         // lanes 32-63 of vdst <-> lanes 0-31 of src
         auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -141,7 +145,7 @@ __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup 
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int rt = G; rt < 4; ++rt)
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[q][rt - G], bb[q], acc[rt], 0, 0, 0);
+                if ((MASK >> rt) & 1) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[q][rt], bb[q], acc[rt], 0, 0, 0);
         }
         cur = nxt;
     }
@@ -153,7 +157,14 @@ __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup 
 // fills the chip (>= 2 048 tiles: 20.2 -> 17.8 us at N = 65 536); 256 = two per CU: smaller launches spread over twice as many
 // CUs (N = 8 192: 64 workgroups with one wave per SIMD instead of 32 with two; covo-offline 36.2k against 29.5k steps/s).
 // noise_gemm_block_threads() below decides; the rollout's XCD-affine mapping follows it.
-template <bool PHILOX, bool TILED = false, int NG_BLOCK = 256>
+// SPLIT (launches of <= 512 tiles, i.e. N <= 16 384: fewer tiles than half the chip's SIMDs): a tile is shared by TWO waves -- row
+// tiles {0, 3} and {1, 2}, 80 of the 160 MFMAs each -- so that twice as many SIMDs work and a wave's serial MFMA time halves
+// (N = 8 192: 256 tiles on 1 024 SIMDs).  Same dot products, same order: bit-identical to the unsplit kernel.
+template <int M>
+struct RtMask {
+    static constexpr int value = M;
+};
+template <bool PHILOX, bool TILED = false, int NG_BLOCK = 256, bool SPLIT = false>
 __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(const float *__restrict__ L, const float *__restrict__ mu,
                                                               const float *__restrict__ eps, uint32_t k0, uint32_t k1,
                                                               int64_t sample_offset, int N, int ntiles,
@@ -194,7 +205,9 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
         row = row < N ? row : N - 1;
         return reinterpret_cast<const float4 *>(eps + (size_t)row * COVO_NA);
     };
-    int tile = wave_global;
+    int item = wave_global;  // work item: a tile, or (SPLIT) half of one
+    const int nitems = SPLIT ? 2 * ntiles : ntiles;
+    auto tile_id = [&](int it) { return SPLIT ? (it >> 1) : it; };
     // the first tile's epsilon rows are requested before anything else: their HBM latency hides
     // behind the staging of L below
     auto tile_of = [&](int t) {
@@ -225,8 +238,8 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
         return b;
     };
     BTile cur;
-    if (STREAM) cur.g[0] = fetch_group(tile < ntiles ? tile : 0, 0);
-    else cur = tile_of(tile < ntiles ? tile : 0);
+    if (STREAM) cur.g[0] = fetch_group(item < nitems ? tile_id(item) : 0, 0);
+    else cur = tile_of(item < nitems ? tile_id(item) : 0);
     __builtin_amdgcn_sched_barrier(0);
     // a_cov = cz sym(Z), left over by the Sigma chain's single-workgroup finalize launch (CovDeferred): the first 64
     // workgroups take 256 elements each; the loads ride with the epsilon request above, the stores leave after the staging of L
@@ -298,20 +311,23 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
     const float *__restrict__ La = Ls + j * NG_LDA + kh;  // this lane's row / k-parity of every A fragment
     NG_STAMP(1);
 
-    if (tile >= ntiles) return;
+    if (item >= nitems) return;
 
-    for (; tile < ntiles; tile += wave_stride) {
+    for (; item < nitems; item += wave_stride) {
+        const int tile = tile_id(item);
         f32x16 acc[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rt][e] = 0.0f;
 
-        const int next_tile = tile + wave_stride;
+        const int next_item = item + wave_stride;
+        const bool has_next = next_item < nitems;
+        const int next_tile = has_next ? tile_id(next_item) : tile;
         BTile nxt;
         if (!STREAM) {
             // whole next tile in flight while this one is multiplied (10 240 MFMA cycles of cover)
-            nxt = tile_of(next_tile < ntiles ? next_tile : tile);
+            nxt = tile_of(next_tile);
             __builtin_amdgcn_sched_barrier(0);
         }
         // L is lower triangular: row tile rt (actions of steps 8 rt .. 8 rt + 7) is complete after k-group rt, so its
@@ -350,27 +366,35 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
                 }
             }
         };
-        if (TILED) cur.g[1] = fetch_group(tile, 1);  // loads: requested BEFORE the MFMAs that hide them
-        mfma_group<0>(La, cur.g[0], acc);
-        NG_STAMP(2);
-        store_rt(0);
-        if (PHILOX) cur.g[1] = fetch_group(tile, 1);  // draws: issued BEHIND the MFMAs they overlap with
-        if (TILED) cur.g[2] = fetch_group(tile, 2);
-        mfma_group<1>(La, cur.g[1], acc);
-        NG_STAMP(3);
-        store_rt(1);
-        if (PHILOX) cur.g[2] = fetch_group(tile, 2);
-        if (TILED) cur.g[3] = fetch_group(tile, 3);
-        mfma_group<2>(La, cur.g[2], acc);
-        NG_STAMP(4);
-        store_rt(2);
-        if (PHILOX) cur.g[3] = fetch_group(tile, 3);
-        if (TILED && next_tile < ntiles) cur.g[0] = fetch_group(next_tile, 0);
-        mfma_group<3>(La, cur.g[3], acc);
-        NG_STAMP(5);
-        store_rt(3);
-        NG_STAMP(6);
-        if (PHILOX && next_tile < ntiles) cur.g[0] = fetch_group(next_tile, 0);
+        // the sequence for the row-tile set M of this work item (15: the whole tile); k-group g is fetched / multiplied only if a
+        // row tile >= g is in the set, row tile g stored right after k-group g if it is in the set
+        auto seq = [&](auto mtag) {
+            constexpr int M = decltype(mtag)::value;
+            if (TILED && (M >> 1)) cur.g[1] = fetch_group(tile, 1);  // loads: requested BEFORE the MFMAs that hide them
+            mfma_group<0, M>(La, cur.g[0], acc);
+            NG_STAMP(2);
+            if (M & 1) store_rt(0);
+            if (PHILOX && (M >> 1)) cur.g[1] = fetch_group(tile, 1);  // draws: issued BEHIND the MFMAs they overlap with
+            if (TILED && (M >> 2)) cur.g[2] = fetch_group(tile, 2);
+            mfma_group<1, M>(La, cur.g[1], acc);
+            NG_STAMP(3);
+            if (M & 2) store_rt(1);
+            if (PHILOX && (M >> 2)) cur.g[2] = fetch_group(tile, 2);
+            if (TILED && (M >> 3)) cur.g[3] = fetch_group(tile, 3);
+            mfma_group<2, M>(La, cur.g[2], acc);
+            NG_STAMP(4);
+            if (M & 4) store_rt(2);
+            if (PHILOX && (M >> 3)) cur.g[3] = fetch_group(tile, 3);
+            if (TILED && has_next) cur.g[0] = fetch_group(next_tile, 0);
+            mfma_group<3, M>(La, cur.g[3], acc);
+            NG_STAMP(5);
+            if (M & 8) store_rt(3);
+            NG_STAMP(6);
+            if (PHILOX && has_next) cur.g[0] = fetch_group(next_tile, 0);
+        };
+        if (!SPLIT) seq(RtMask<15>());
+        else if (item & 1) seq(RtMask<6>());
+        else seq(RtMask<9>());
         if (!STREAM) cur = nxt;
     }
 }
@@ -423,6 +447,13 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
 }
 
 int noise_gemm_block_threads(int N, int batch) { return (batch == 1 && (N + 31) / 32 >= 2048) ? 512 : 256; }
+// launches of <= 512 tiles share every tile between two waves (the kernel's SPLIT)
+static bool noise_gemm_split(int N, int batch) { return (long long)((N + 31) / 32) * batch <= 512; }
+// 64-sample groups per workgroup (the rollout's XCD-affine mapping, rollout.hip)
+int noise_gemm_groups_per_workgroup(int N, int batch)
+{
+    return noise_gemm_split(N, batch) ? 1 : noise_gemm_block_threads(N, batch) / 128;
+}
 
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table, int batch,
@@ -433,8 +464,9 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
     if (cov != nullptr) cv = *cov;
     const int ntiles = (N + 31) / 32;
     const int block = noise_gemm_block_threads(N, batch);
+    const bool split = noise_gemm_split(N, batch);
     const int waves_per_block = block / 64;
-    int grid = (ntiles + waves_per_block - 1) / waves_per_block;
+    int grid = ((split ? 2 * ntiles : ntiles) + waves_per_block - 1) / waves_per_block;
     if (grid > 2048 / waves_per_block) grid = 2048 / waves_per_block;  // persistent: 2 waves/SIMD chip-wide, waves stride over tiles
     const size_t lds = (size_t)(COVO_NA * NG_LDA + COVO_NA) * sizeof(float);
     static bool attr_set = false;
@@ -443,24 +475,26 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
         NG_ATTR(false, false, 256); NG_ATTR(true, false, 256); NG_ATTR(false, true, 256);
         NG_ATTR(false, false, 512); NG_ATTR(true, false, 512); NG_ATTR(false, true, 512);
+        NG_ATTR(false, false, 256, true); NG_ATTR(true, false, 256, true); NG_ATTR(false, true, 256, true);
 #undef NG_ATTR
         attr_set = true;
     }
-#define NG_GO(BLK)                                                                                                              \
+#define NG_GO(...)                                                                                                             \
     do {                                                                                                                         \
         if (eps != nullptr && eps_tiled)                                                                                         \
-            hipLaunchKernelGGL((noise_gemm_kernel<false, true, BLK>), dim3(grid), dim3(BLK), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, \
+            hipLaunchKernelGGL((noise_gemm_kernel<false, true, __VA_ARGS__>), dim3(grid), dim3(block), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, \
                                N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv); \
         else if (eps != nullptr)                                                                                                 \
-            hipLaunchKernelGGL((noise_gemm_kernel<false, false, BLK>), dim3(grid), dim3(BLK), lds, s, L, mu, eps, 0u, 0u,          \
+            hipLaunchKernelGGL((noise_gemm_kernel<false, false, __VA_ARGS__>), dim3(grid), dim3(block), lds, s, L, mu, eps, 0u, 0u,          \
                                (int64_t)0, N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time,  \
                                n_table, cv);                                                                                     \
         else                                                                                                                     \
-            hipLaunchKernelGGL((noise_gemm_kernel<true, false, BLK>), dim3(grid, batch), dim3(BLK), lds, s, L, mu,                 \
+            hipLaunchKernelGGL((noise_gemm_kernel<true, false, __VA_ARGS__>), dim3(grid, batch), dim3(block), lds, s, L, mu,                 \
                                (const float *)nullptr, k0, k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn,     \
                                state_for_time, n_table, cv);                                                                     \
     } while (0)
     if (block == 512) NG_GO(512);
+    else if (split) NG_GO(256, true);
     else NG_GO(256);
 #undef NG_GO
     COVO_CHECK_HIP(hipGetLastError());

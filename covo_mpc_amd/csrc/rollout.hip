@@ -51,7 +51,7 @@ static void fill_rollout_args(RolloutArgs &A, const float *state, const float *p
                               float *cost, float *groupmin, double *stats_ws, const float *f_shared_dev, const float *f_tab,
                               int xcd_groups = 0, int nbatch = 1)
 {
-    if (xcd_groups <= 0) xcd_groups = noise_gemm_block_threads(N, nbatch) / 128;  // the producer is the noise GEMM unless told otherwise
+    if (xcd_groups <= 0) xcd_groups = noise_gemm_groups_per_workgroup(N, nbatch);  // the producer is the noise GEMM unless told otherwise
     A.state = state;
     A.pos_traj = pos_traj;
     A.vel_traj = vel_traj;
