@@ -22,6 +22,9 @@
 //   * the D layout (col = lane&31 -> sample, rows 8g+4h+i -> (t, d)) makes every lane own whole
 //     float4 actions, so the epilogue (+mu, clip) stores 512-B contiguous runs of the stripe
 //     layout a[H][N][4] the rollout kernel reads.
+//   * launch shapes (round 3): 512-thread workgroups once the launch fills the chip (>= 2 048 tiles: the factor is staged once per
+//     CU), 256-thread ones below, and for <= 512 tiles every tile is shared by two waves (row tiles {0, 3} / {1, 2}: 80 MFMAs
+//     each) -- noise_gemm_block_threads / noise_gemm_split below; all shapes give the same bits.
 // fp32 MFMA roofline: 2*128*128 flop per sample (dense-equivalent), 157.3 TFLOP/s peak.
 #include "covo_common.hpp"
 #include <cstring>
