@@ -14,12 +14,13 @@
 //     d^2 J/da^2 = sum_k [S_k; E_k]^T  Hess_z( r_k(x) + lam_{k+1} . f_k(z) )  [S_k; E_k]
 // (E_k selects the four actions of step k).  All derivatives of the step come from evaluating the SAME
 // templated model (quad_model.hpp) on hyper-dual numbers, so every JAX AD convention it mirrors (clip ties,
-// |x|', the double clip of quadrotor.py:223/:258) carries over.  Four launches:
+// |x|', the double clip of quadrotor.py:223/:258) carries over.  Three launches (KM rides in KC's):
 //   KB  32 waves: primal rollout to step k (plain fp64), then the step on first-order duals (17 seeds) -> A_k, B_k, grad r_k
 //   KC  9 waves: the sensitivity recursion (8 column tiles of S held in MFMA C/D layout, which IS the B operand
 //       of the next step: four dependent v_mfma_f64_16x16x4_f64 per step, nothing leaves the registers) and
 //       the costate recursion (the same product with A^T) -- no barriers, no sparsity assumptions
-//   KM  32 x 153 lanes: one hyper-dual step per pair (a <= b) of step inputs -> M_k = Hess_z(r_k + lam_{k+1}.f_k)
+//   KM  32 x 153 lanes, 32 more workgroups of KC's launch: one hyper-dual step per pair (a <= b) of step inputs, contracted with
+//       lam_{k+1} as soon as the costate chain of the same launch has stored it -> M_k = Hess_z(r_k + lam_{k+1}.f_k)
 //   KD  36 lower 16x16 tiles: sum_k S_k^T Mxx_k S_k on the matrix cores (v_mfma_f64_16x16x4_f64; the product
 //       Mxx S leaves the MFMA in exactly the register layout the next MFMA wants as its B operand), the
 //       action blocks Mxu, Muu added in the epilogue.
@@ -118,12 +119,11 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.stats.fpart = nullptr;
     A.stats.diag = nullptr;
     if (stats != nullptr && batch == 1) A.stats = *stats;
-    // launch shapes: KB 32 waves; KC 9 chains + KM's 32 hyper-dual workgroups; KM contraction; KD 36 tiles
+    // launch shapes: KB 32 waves; KC 9 chains + KM's 32 hyper-dual workgroups (which also contract with the costate); KD 36 tiles
 #define ADJ_LAUNCH(NS, JAC)                                                                                                      \
     do {                                                                                                                          \
         if (g_dbg_hess_mask & 1) hipLaunchKernelGGL(JAC, dim3(NS::HH, batch), dim3(64), 0, s, A);                                 \
         if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(NS::adj_chain_kernel, dim3(9 + NS::HH, batch), dim3(256), 0, s, A);           \
-        if (g_dbg_hess_mask & 4) hipLaunchKernelGGL(NS::adj_hess_kernel, dim3(NS::HH, batch), dim3(NS::PAIR_THREADS), 0, s, A);   \
         if (g_dbg_hess_mask & 8) hipLaunchKernelGGL(NS::adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);                    \
     } while (0)
     if (fs) ADJ_LAUNCH(adj16, adj16::adj_jac_kernel<true>);

@@ -16,8 +16,11 @@ constexpr size_t WS_MUU = WS_MXU + 32 * 64;      // [32][4][4]
 constexpr size_t WS_S = WS_MUU + 32 * 16;        // [32][16][128]  rows NX..15 zero
 constexpr int NPAIR = NZ * (NZ + 1) / 2;         // 153 (210) pairs a <= b of step inputs
 constexpr int PAIR_THREADS = (NPAIR + 63) / 64 * 64;
-constexpr size_t WS_H14 = WS_S + (size_t)32 * 16 * NA;  // [32][NH][NPAIR]  second derivatives of r_k and of the NX components of f_k per pair
-constexpr size_t WS_COUNT = WS_H14 + (size_t)32 * NH * NPAIR + 2;
+constexpr size_t WS_COUNT = WS_S + (size_t)32 * 16 * NA + 2;
+// what KB leaves in WS_LAM before KC runs: the hyper-dual workgroups of KC's launch contract their second derivatives with lam_{k+1}
+// as soon as the costate chain of the SAME launch has stored it, and recognise "not yet" by this pattern (a NaN payload no arithmetic
+// produces; a NaN costate -- norm'(0) -- is a different bit pattern and passes through)
+constexpr unsigned long long ADJ_LAM_UNSET = 0xFFF7ADEADBEEF000ull;
 
 
 // the disturbance force acting during step k (free.py:91,98,147): the state's own for k = 0, then the table's row k (periodic /
@@ -150,6 +153,10 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
     const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
     const float *__restrict__ am = A.a_mean + (size_t)b * NA;
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    if (lane < 16) {  // rows k (and 32, by the last wave) of the costate buffer: "not yet stored" for KC's launch (ADJ_LAM_UNSET)
+        reinterpret_cast<unsigned long long *>(ws + WS_LAM)[16 * k + lane] = ADJ_LAM_UNSET;
+        if (k == HH - 1) reinterpret_cast<unsigned long long *>(ws + WS_LAM)[16 * HH + lane] = ADJ_LAM_UNSET;
+    }
     const int time0 = __float_as_int(st[ST_TIME]);
     const qm::Consts<double> c = A.cs ? A.cs[b] : A.c;
     qm::State<double> p;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
 // ---- the lambda-independent 9/10 of KM: one hyper-dual step per pair a <= b of the 17 step inputs -> the mixed second derivative of
 // r_k and of each of the 13 components of f_k (14 numbers per pair).  M_k = Hess_z(r_k + lam_{k+1} . f_k) is their combination
 // with the costate -- which the chains of KC are still computing: these 32 workgroups ride in KC's launch on otherwise idle
-// CUs (5 us in the shadow of the 10 us recursions), and the launch after it only contracts (adj_hess_kernel).
+// CUs (5 us in the shadow of the 10 us recursions) and contract as soon as their lam_{k+1} is there (below).
 __device__ __forceinline__ void adj_hd_pairs(const AdjArgs &A, int k, int b, int tid)
 {
     if (tid >= NPAIR) return;
@@ -276,14 +283,59 @@ __device__ __forceinline__ void adj_hd_pairs(const AdjArgs &A, int k, int b, int
 #else
     adj_hd_step(st, am, A, b, time0, k, p, a, bb, r, s);
 #endif
-    double *__restrict__ H = ws + WS_H14 + (size_t)k * NH * NPAIR + tid;  // [component][pair]: coalesced over the pairs
-    H[0] = r.ab;
-#define OP(m, i) H[(size_t)(1 + i) * NPAIR] = s.m.ab;
+    // the pair's second derivatives: of r_k and of the NX components of f_k
+    double h[NH];
+    h[0] = r.ab;
+#define OP(m, i) h[1 + i] = s.m.ab;
     ADJ_FOR_STATE(OP)
 #undef OP
 #if ADJ_FS
-    H[(size_t)14 * NPAIR] = fn[0].ab; H[(size_t)15 * NPAIR] = fn[1].ab; H[(size_t)16 * NPAIR] = fn[2].ab;
+    h[14] = fn[0].ab; h[15] = fn[1].ab; h[16] = fn[2].ab;
 #endif
+    // ---- KM: M_k = Hess_z( r_k(x) + lam_{k+1} . f_k(z) ), contracted right here as soon as the costate chain of this launch
+    // (workgroup 8, dispatched before this one) has stored lam_{k+1}: row k + 1 of WS_LAM still holding KB's "unset" pattern means
+    // not yet.  lam_31 is stored first and the chain runs down at ~0.16 us per step, the hyper-dual step above takes ~5 us: only
+    // the first few steps wait at all, and none longer than the chain itself (round 3; the contraction used to be a launch of
+    // its own, 3 us, with these 14 numbers per pair going through memory).  The spin is bounded (0.2 s -> NaN).
+    double g = h[0];
+    if (k <= HH - 2) {
+        const double *__restrict__ Lk = ws + WS_LAM + 16 * (k + 1);
+        double lam[NX];
+        const long long t0 = wall_clock64();
+        for (;;) {
+            bool unset = false;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                lam[i] = __hip_atomic_load(Lk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unset |= (unsigned long long)__double_as_longlong(lam[i]) == ADJ_LAM_UNSET;
+            }
+            if (!unset || wall_clock64() - t0 > 20000000LL) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) g = fma(lam[i], h[1 + i], g);
+    }
+    double *__restrict__ Mxx = ws + WS_MXX + (size_t)k * 256, *__restrict__ Mxu = ws + WS_MXU + (size_t)k * 64;
+    double *__restrict__ Muu = ws + WS_MUU + (size_t)k * 16;
+    if (bb < NX) {
+        Mxx[a * 16 + bb] = g;
+        Mxx[bb * 16 + a] = g;
+    } else if (a < NX) {
+        Mxu[a * 4 + (bb - NX)] = g;
+    } else {
+        Muu[(a - NX) * 4 + (bb - NX)] = g;
+        Muu[(bb - NX) * 4 + (a - NX)] = g;
+    }
+}
+
+// zero padding of the x block of M_k (rows / columns NX..15): by the hyper-dual workgroup of step k, all of its threads
+__device__ __forceinline__ void adj_hd_padding(const AdjArgs &A, int k, int b, int tid, int nthreads)
+{
+    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
+    double *__restrict__ Mxx = ws + WS_MXX + (size_t)k * 256, *__restrict__ Mxu = ws + WS_MXU + (size_t)k * 64;
+    for (int e = tid; e < 256; e += nthreads)
+        if ((e >> 4) >= NX || (e & 15) >= NX) Mxx[e] = 0.0;
+    if (tid < (16 - NX) * 4) Mxu[NX * 4 + tid] = 0.0;
 }
 
 // ---- KC: the two linear recursions on the matrix cores.
@@ -304,6 +356,7 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
     const int w = blockIdx.x;  // 0..7: column tile of S, 8: costate, 9..40: the hyper-dual steps of KM (see adj_hd_pairs)
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
     if (w >= 9) {
+        adj_hd_padding(A, w - 9, b, tid, 256);
         adj_hd_pairs(A, w - 9, b, tid);
         return;
     }
@@ -335,11 +388,12 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
         f64x4 lam;
 #pragma unroll
         for (int r = 0; r < 4; ++r) lam[r] = (lo == 0 && hi + 4 * r < NX) ? G[16 * (HH - 1) + hi + 4 * r] : 0.0;
+        // (agent-scope write-through stores: the hyper-dual workgroups of this launch poll these rows, adj_hd_pairs)
         if (lo == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                L[16 * (HH - 1) + hi + 4 * r] = lam[r];
-                L[16 * HH + hi + 4 * r] = 0.0;
+                __hip_atomic_store(&L[16 * (HH - 1) + hi + 4 * r], lam[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&L[16 * HH + hi + 4 * r], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         int offA[4];  // A^T[lo][4g+hi] = df/dz[4g+hi][lo]
@@ -375,7 +429,7 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
             lam = acc;
             if (lo == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) L[16 * k + hi + 4 * r] = lam[r];
+                for (int r = 0; r < 4; ++r) __hip_atomic_store(&L[16 * k + hi + 4 * r], lam[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -427,46 +481,6 @@ __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
         sv = acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Sp[((size_t)(k + 1) * 16 + 4 * r) * NA] = sv[r];
-    }
-}
-
-// ---- KM: M_k = Hess_z( r_k(x) + lam_{k+1} . f_k(z) ) = (second derivatives of r_k) + sum_i lam_{k+1,i} (second derivatives of f_k^i):
-// the contraction of what adj_hd_pairs left behind (KC's launch) with the costate -- 15 loads and 13 FMAs per pair
-__global__ __launch_bounds__(PAIR_THREADS) void adj_hess_kernel(const AdjArgs A)
-{
-    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
-    double *__restrict__ Mxx = ws + WS_MXX + (size_t)k * 256, *__restrict__ Mxu = ws + WS_MXU + (size_t)k * 64;
-    double *__restrict__ Muu = ws + WS_MUU + (size_t)k * 16;
-    const int pr = tid < NPAIR ? tid : 0;
-    const double *__restrict__ H = ws + WS_H14 + (size_t)k * NH * NPAIR + pr;
-    double h[NH], lam[NX];
-#pragma unroll
-    for (int i = 0; i < NH; ++i) h[i] = H[(size_t)i * NPAIR];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) lam[i] = (k <= HH - 2) ? ws[WS_LAM + 16 * (k + 1) + i] : 0.0;
-    // zero padding of the x block (rows / columns 13..15)
-    for (int e = tid; e < 256; e += PAIR_THREADS)
-        if ((e >> 4) >= NX || (e & 15) >= NX) Mxx[e] = 0.0;
-    if (tid < (16 - NX) * 4) Mxu[NX * 4 + tid] = 0.0;
-    int q = pr, a = 0;
-    while (q >= NZ - a) { q -= NZ - a; ++a; }
-    const int bb = a + q;
-    double g = h[0];
-    if (k <= HH - 2) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) g = fma(lam[i], h[1 + i], g);
-    }
-    if (tid < NPAIR) {
-        if (bb < NX) {
-            Mxx[a * 16 + bb] = g;
-            Mxx[bb * 16 + a] = g;
-        } else if (a < NX) {
-            Mxu[a * 4 + (bb - NX)] = g;
-        } else {
-            Muu[(a - NX) * 4 + (bb - NX)] = g;
-            Muu[(bb - NX) * 4 + (a - NX)] = g;
-        }
     }
 }
 

@@ -27,8 +27,8 @@ for i in range(45):
 torch.cuda.synchronize()
 core = controller.core
 T = core.time_phases
-rows = [("whole step (graph)", T()), ("hessian (4 kernels)", T(2)),
-        ("  jac", T(2, 1)), ("  chain", T(2, 2)), ("  hess", T(2, 4)), ("  gemm", T(2, 8)),
+rows = [("whole step (graph)", T()), ("hessian (3 kernels)", T(2)),
+        ("  jac", T(2, 1)), ("  chain + hyper-dual pairs + contraction", T(2, 2)), ("  gemm", T(2, 8)),
         ("sigma (all)", T(4)), ("  prep+squarings", T(4, 15, 1)), ("  +ritz", T(4, 15, 2)), ("  +newton-schulz", T(4, 15, 3)),
         ("sigma + gemm (product: eps drawn under finalize, tiled GEMM)", T(12)),
         ("noise gemm, in-kernel Philox (offline/MPPI path)", T(8)), ("rollout (+ softmax records)", T(16)),
