@@ -134,9 +134,13 @@ def closed_loop(env, controller, params, T):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r03_bench_pmc_summary.json")
-KERNEL_SRCS = ["covo_mpc_amd/csrc/rollout_pipe.hpp", "covo_mpc_amd/csrc/rollout.hip", "covo_mpc_amd/csrc/quad_model.hpp",
-               "covo_mpc_amd/csrc/noise_gemm.hip", "covo_mpc_amd/csrc/eps_tiles.hpp"]  # = scripts/pmc_summary.py
+PMC_SUMMARY = os.path.join("profiles", "r04_bench_pmc_summary.json")
+# every file the rollout kernel and the noise GEMM are built from: the hash that decides whether committed PMC counters still
+# describe the kernels of this tree (scripts/pmc_summary.py imports this list)
+KERNEL_SRCS = ["covo_mpc_amd/csrc/" + f for f in (
+    "rollout_pipe.hpp", "rollout_common.hpp", "rollout_launch.hpp", "rollout.hip", "rollout_var_r0.hip", "rollout_var_r1.hip",
+    "quad_model.hpp", "disturb_model.hpp", "covo_common.hpp", "wave_reduce.hpp", "noise_gemm.hip", "eps_tiles.hpp",
+    "rng_device.hpp", "Makefile")]
 
 
 def kernel_src_sha():
@@ -288,27 +292,41 @@ def main():
         launch_us, launch_us_min = core.time_rollout(dstates[40], pc, reps=100, with_records=True)
         standalone = core.time_rollout(dstates[40], pc, reps=100, with_records=False)
         kernel_name = "rollout_pipe3_kernel<..., REC = true>"
-    in_step_us = gemm_in_step_us = None
+    in_step_us = gemm_in_step_us = in_step_rounds = gemm_in_step_rounds = in_step_rejected = None
     if world == 1:
         try:
             # every figure is a DIFFERENCE of two graph-replay times; for covo-online both carry the ~135 us Sigma chain, so 1 % of
             # clock wander between the two replays would move the 10 us rollout by 1.4 us (r03: the driver's 20-step command read
             # frac 0.34 ... 0.43 run to run).  The selections are therefore replayed interleaved, four times each, and the
             # fastest replay of each is used: both then sit at the same (highest) clock.
-            def fastest(*masks, rounds=4):
-                best = [float("inf")] * len(masks)
-                for _ in range(rounds):
-                    for i, m in enumerate(masks):
-                        best[i] = min(best[i], core.time_phases(m))
-                return best
+            def rounds_of(*masks, rounds=4):
+                return [[core.time_phases(m) for m in masks] for _ in range(rounds)]
+
+            def spread(v):
+                v = sorted(v)
+                return {"min": v[0], "median": 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2]), "max": v[-1]}
             if args.controller == "covo-online":
                 # the product order: the Sigma chain's last launch draws epsilon, the GEMM streams it (tiled variant)
-                t_sig, t_sig_gemm, t_all = fastest(4, 4 | 8, 4 | 8 | 16)
+                rr = rounds_of(4, 4 | 8, 4 | 8 | 16)
+                t_sig, t_sig_gemm, t_all = (min(r[i] for r in rr) for i in range(3))
                 gemm_in_step_us = t_sig_gemm - t_sig
                 in_step_us = t_all - t_sig_gemm
+                in_step_rounds = spread([r[2] - r[1] for r in rr])       # the same difference WITHIN each round
+                gemm_in_step_rounds = spread([r[1] - r[0] for r in rr])
             else:
-                gemm_in_step_us, t_both = fastest(8, 8 | 16)
+                rr = rounds_of(8, 8 | 16)
+                gemm_in_step_us, t_both = (min(r[i] for r in rr) for i in range(2))
                 in_step_us = t_both - gemm_in_step_us
+                in_step_rounds = spread([r[1] - r[0] for r in rr])
+                gemm_in_step_rounds = spread([r[0] for r in rr])
+            # a difference of two independently minimised ~150 us replays standing in for a ~10 us kernel: only accepted when it is
+            # positive AND agrees with the per-round differences (else the warm back-to-back figure is the judged duration)
+            if not (in_step_us > 0 and in_step_rounds["min"] > 0 and
+                    0.7 * in_step_rounds["median"] <= in_step_us <= 1.3 * in_step_rounds["median"]):
+                in_step_rejected = in_step_us
+                in_step_us = None
+            if not (gemm_in_step_us and gemm_in_step_us > 0):
+                gemm_in_step_us = None
         except Exception:
             in_step_us = gemm_in_step_us = None
 
@@ -381,8 +399,11 @@ def main():
                          "traffic": (pmc or {}).get("traffic_bytes_per_launch"), "counters_source": pmc_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_us": launch_us, "launch_us_statistic":
                          ("in-step: graph replay of 20 x (Sigma chain, GEMM, rollout) minus 20 x (Sigma chain, GEMM), events around "
-                          "the replay, fastest of 4 interleaved rounds x 3 replays each" if in_step_us else "mean of 3 x 100 back-to-back launches (events on the launch stream)"),
-                         "in_step_us": in_step_us,
+                          "the replay, fastest replay of each selection over 4 interleaved rounds; in_step_us_per_round = the "
+                          "same difference within each round (min / median / max)" if in_step_us
+                          else "mean of 3 x 100 back-to-back launches (events on the launch stream)"),
+                         "in_step_us": in_step_us, "in_step_us_per_round": in_step_rounds,
+                         "in_step_us_rejected": in_step_rejected,
                          "back_to_back": {"launch_us": b2b_us, "launch_us_min": b2b_min_us,
                                           "frac": alg_bytes / (b2b_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                           "statistic": "mean / fastest batch of 3 x 100 back-to-back launches on warm stripes"},
@@ -399,7 +420,8 @@ def main():
             dense = n_local * GEMM_FLOP_PER_SAMPLE_DENSE / (gemm_in_step_us * 1e-6) / 1e12
             issued = n_local * GEMM_FLOP_PER_SAMPLE_ISSUED / (gemm_in_step_us * 1e-6) / 1e12
             out["roofline_gemm"] = {"bound": "mfma", "kernel": "noise_gemm_kernel", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "in_step_us": gemm_in_step_us, "achieved_dense_equivalent": dense,
+                                    "in_step_us": gemm_in_step_us, "in_step_us_per_round": gemm_in_step_rounds,
+                                    "achieved_dense_equivalent": dense,
                                     "frac_dense_equivalent": dense / MFMA_F32_PEAK_TFLOPS, "achieved": issued,
                                     "frac": issued / MFMA_F32_PEAK_TFLOPS,
                                     "flop_per_sample": {"dense_equivalent": GEMM_FLOP_PER_SAMPLE_DENSE,

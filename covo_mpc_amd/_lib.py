@@ -19,8 +19,10 @@ COVO_STATE_FLOATS = 32
 COVO_PARTIAL_FLOATS = 132
 COVO_POS_STATS_DOUBLES = COVO_H * 6
 COVO_RANK_RECORD_FLOATS = COVO_PARTIAL_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 516: {m, s, v[128], pad} + 192 fp64 position sums
-COVO_EXCHANGE_HANDLE_BYTES = 64
-ABI_VERSION = 3
+COVO_COV_FLOATS = COVO_H * 10
+COVO_RANK_RECORD_COV_FLOATS = COVO_PARTIAL_FLOATS + COVO_COV_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 836: with MPPI's second moments
+COVO_EXCHANGE_HANDLE_BYTES = 128
+ABI_VERSION = 4
 COVO_FLAG_ACTIONS_CLIPPED = 1
 
 
@@ -74,9 +76,11 @@ COVO_MAX_ENVS = 64
 MODE_MPPI, MODE_COVO_ONLINE, MODE_COVO_OFFLINE = 0, 1, 2
 COVO_FLAG_NO_GRAPH = 2
 COVO_FLAG_SHARED_DEVICE = 4
+COVO_FLAG_PROPAGATE_NAN = 8
 COVO_E_DEVICE = -4
 COVO_DEVSTAT_GRID_BARRIER = 1
 COVO_DEVSTAT_EXCHANGE = 2
+COVO_DEVSTAT_ADJOINT = 4
 _SIGS = {
     "covo_last_error": (C.c_char_p, []),
     "covo_abi_version": (C.c_int, []),
@@ -104,7 +108,12 @@ _SIGS = {
     "covo_merge_ranks": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P, _P]),
     "covo_exchange_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "covo_exchange_connect": (C.c_int, [_P, _P]),
+    "covo_exchange_set_timeout": (C.c_int, [_P, C.c_double]),
+    "covo_device_bus_id": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "covo_exchange_records": (C.c_int, [_P, _P, _P, _P]),
+    "covo_exchange_records_cov": (C.c_int, [_P, _P, _P, _P]),
+    "covo_softmax_reduce_cov": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "covo_merge_ranks_cov": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, C.c_float, _P, _P, _P, _P]),
     "covo_shift_mean": (C.c_int, [_P, _P, _P, _P]),
     "covo_hessian": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, _P, C.c_int32, _P, _P]),
     "covo_hessian_pairs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, _P, C.c_int32, _P, _P]),

@@ -6,9 +6,11 @@ than one rank is given, the sample axis N is sharded: rank g owns global sample 
 [g*N/G, (g+1)*N/G), epsilon is keyed by global id, every rank reduces its shard to ONE rank record
 (online-softmax partial + the position sums of covo.py:281 when they are wanted: 2 064 bytes) and ONE
 exchange per control step makes all G records known to all ranks, which then merge identically
-(SURVEY.md 5.8 / 8e).  The exchange is an all-gather (RCCL over xGMI under the nccl backend; the default)
-or, `exchange="peer"` / COVO_EXCHANGE=peer, direct peer writes into hipIpc-mapped buffers (csrc/exchange.hip:
-no collective library and no host round trip, so whole sharded episodes can be enqueued from C).
+(SURVEY.md 5.8 / 8e).  The exchange is an all-gather (RCCL over xGMI under the nccl backend; the DEFAULT)
+or -- opt-in: `exchange="peer"` / "auto", COVO_EXCHANGE=peer|auto -- direct peer writes into hipIpc-mapped buffers
+(csrc/exchange.hip: no collective library and no host round trip, so whole sharded episodes can be enqueued from C).
+The peer path has only ever run with ranks sharing ONE GPU (the build pool has single-GPU boxes): it stays opt-in
+until it has been measured over xGMI.
 """
 from __future__ import annotations
 
@@ -18,7 +20,8 @@ import os
 import numpy as np
 
 from .. import _lib
-from .._lib import (COVO_H, COVO_NA, COVO_PARTIAL_FLOATS, COVO_POS_STATS_DOUBLES, COVO_RANK_RECORD_FLOATS, check, ptr)
+from .._lib import (COVO_COV_FLOATS, COVO_H, COVO_NA, COVO_PARTIAL_FLOATS, COVO_POS_STATS_DOUBLES, COVO_RANK_RECORD_COV_FLOATS,
+                    COVO_RANK_RECORD_FLOATS, check, ptr)
 
 
 def shard_range(N: int, rank: int, world: int):
@@ -48,7 +51,8 @@ def exchange_records(record, gathered_flat, process_group=None):
 
 class SamplingCore:
     def __init__(self, N: int, H: int, lam: float, discount: float, device=None, process_group=None,
-                 compute_info: bool = True, trust_clipped: bool = False, use_graph=None, shared_device=None, exchange=None):
+                 compute_info: bool = True, trust_clipped: bool = False, use_graph=None, shared_device=None, exchange=None,
+                 cov_records: bool = False, propagate_nan=None):
         import torch
         if H != COVO_H:
             raise NotImplementedError(f"the fused kernels are built for H={COVO_H}, got H={H}")
@@ -92,16 +96,24 @@ class SamplingCore:
             shared_device = os.environ.get("COVO_SHARED_DEVICE") == "1"
             if not shared_device and self.world > 1:
                 # ranks of this group that sit on the SAME physical device compete for its CUs: detected here (one
-                # object all-gather at construction), not left to the caller
+                # object all-gather at construction), not left to the caller.  The identity is the PCI bus id, not the device
+                # index: under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES every isolated rank sees its own GPU as index 0, and
+                # comparing indices would put every real multi-GPU run on the slower one-launch-per-phase Sigma chain.
                 import socket
                 import torch.distributed as dist
-                mine = (socket.gethostname(), int(self._dev_index))
+                mine = (socket.gethostname(), self.device_bus_id())
                 seen = [None] * self.world
                 dist.all_gather_object(seen, mine, group=process_group)
                 shared_device = seen.count(mine) > 1
         self.shared_device = bool(shared_device)
+        # propagate_nan (or COVO_PROPAGATE_NAN=1): jnp.clip's NaN semantics in the action clips (COVO_FLAG_PROPAGATE_NAN) -- quadjax's
+        # behaviour, where one NaN sample makes every later mean NaN; the default keeps the kernels' maxNum / minNum clip (NaN -> -1)
+        if propagate_nan is None:
+            propagate_nan = os.environ.get("COVO_PROPAGATE_NAN") == "1"
+        self.propagate_nan = bool(propagate_nan)
         flags = ((_lib.COVO_FLAG_ACTIONS_CLIPPED if trust_clipped else 0) | (_lib.COVO_FLAG_NO_GRAPH if eager else 0) |
-                 (_lib.COVO_FLAG_SHARED_DEVICE if self.shared_device else 0))
+                 (_lib.COVO_FLAG_SHARED_DEVICE if self.shared_device else 0) |
+                 (_lib.COVO_FLAG_PROPAGATE_NAN if self.propagate_nan else 0))
         cfg = _lib.ConfigC(self.n_local, self.H, 4, self.lam, self.discount, flags)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -116,17 +128,22 @@ class SamplingCore:
         self.cost = torch.empty((n,), **f32)
         self.blockmin = torch.empty(((n + 63) // 64,), **f32)  # per-64-sample cost minima
         # the rank record of a sharded step: {m, s, v[128], pad[2]} + the 192 fp64 position sums, ONE message per step; on a
-        # single rank the same buffer simply holds the two parts
-        self.record = torch.zeros((COVO_RANK_RECORD_FLOATS,), **f32)
-        self.partial = self.record[:COVO_PARTIAL_FLOATS]
-        self.stats = self.record[COVO_PARTIAL_FLOATS:].view(torch.float64)  # this shard's sums (528-byte offset: 8-aligned)
-        self.gathered = torch.zeros((self.world * COVO_RANK_RECORD_FLOATS,), **f32) if self.world > 1 else None
+        # single rank the same buffer simply holds the two parts.  cov_records (MPPI with gamma_sigma != 0, mppi.py:119-125): the
+        # record also carries the 320 weighted second moments between the two (COVO_RANK_RECORD_COV_FLOATS = 836 floats)
+        self.cov_records = bool(cov_records)
+        self.rec_floats = COVO_RANK_RECORD_COV_FLOATS if self.cov_records else COVO_RANK_RECORD_FLOATS
+        n_part = COVO_PARTIAL_FLOATS + (COVO_COV_FLOATS if self.cov_records else 0)
+        self.record = torch.zeros((self.rec_floats,), **f32)
+        self.partial = self.record[:n_part]
+        self.stats = self.record[n_part:].view(torch.float64)  # this shard's sums (528- / 1 808-byte offset: 8-aligned)
+        self.gathered = torch.zeros((self.world * self.rec_floats,), **f32) if self.world > 1 else None
         self.stats_total = torch.zeros((COVO_POS_STATS_DOUBLES,), dtype=torch.float64, device=self.device) if self.world > 1 else self.stats
         self.exchange = "collective"
         if self.world > 1:
-            # "auto" (default): the peer-write exchange (csrc/exchange.hip) when its construction-time self-test passes on EVERY
-            # rank, else the torch.distributed all-gather -- the peer path is validated on shared-GPU boxes only
-            mode = exchange if exchange is not None else os.environ.get("COVO_EXCHANGE", "auto")
+            # "collective" (default): torch.distributed's all-gather = RCCL over xGMI.  "peer": the peer-write exchange
+            # (csrc/exchange.hip), raising if it cannot be set up.  "auto": peer when its construction-time self-test passes on EVERY
+            # rank, else the collective.  Peer stays opt-in: it is validated on shared-GPU boxes only, never measured over xGMI.
+            mode = exchange if exchange is not None else os.environ.get("COVO_EXCHANGE", "collective")
             if mode not in ("collective", "peer", "auto"):
                 raise ValueError(f"exchange={mode!r} (auto | collective | peer)")
             if mode == "peer":
@@ -147,6 +164,13 @@ class SamplingCore:
             self.close()
         except Exception:
             pass
+
+    def device_bus_id(self) -> str:
+        """PCI bus id of this core's GPU (covo_device_bus_id): the physical identity ranks compare, independent of
+        HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumbering."""
+        buf = C.create_string_buffer(32)
+        check(self.lib.covo_device_bus_id(int(self._dev_index), buf, 32), "covo_device_bus_id")
+        return buf.value.decode()
 
     def _connect_peer_exchange(self, must: bool = True) -> bool:
         """csrc/exchange.hip setup: every rank exports its exchange buffer (hipIpc), the 64-byte handles are all-gathered once
@@ -188,7 +212,8 @@ class SamplingCore:
     def _try_peer_exchange(self) -> bool:
         """exchange="auto": map the peers' buffers and run two exchanges (both parities) of a known record; the peer path is taken
         only if every rank mapped every buffer and read back every rank's record bit for bit.  A failure costs the wait kernel's
-        bounded spin (2 s) once, leaves the handle clean (status cleared) and the collective in charge."""
+        bounded spin once (2 s for this probe; the product exchanges then wait COVO_EXCHANGE_TIMEOUT_S, default 60 s, like a
+        collective that simply waits), leaves the handle clean (status cleared) and the collective in charge."""
         torch = self.torch
         # a rank that could not map must not leave the others spinning on its flag: all agree BEFORE anybody pushes
         if not self._connect_peer_exchange(must=False):
@@ -196,14 +221,14 @@ class SamplingCore:
         ok = True
         keep = self.record.clone()
         try:
+            check(self.lib.covo_exchange_set_timeout(self.h, 2.0), "covo_exchange_set_timeout")
             for rnd in range(2):
-                probe = torch.arange(COVO_RANK_RECORD_FLOATS, dtype=torch.float32, device=self.device) + 1000.0 * self.rank + 0.5 * rnd
+                probe = torch.arange(self.rec_floats, dtype=torch.float32, device=self.device) + 1000.0 * self.rank + 0.5 * rnd
                 self.record.copy_(probe)
-                check(self.lib.covo_exchange_records(self.h, ptr(self.record), ptr(self.gathered), self.stream()),
-                      "covo_exchange_records")
+                self._peer_exchange()
                 torch.cuda.synchronize(self.device)
-                got = self.gathered.view(self.world, COVO_RANK_RECORD_FLOATS).cpu()
-                want = torch.stack([torch.arange(COVO_RANK_RECORD_FLOATS, dtype=torch.float32) + 1000.0 * r + 0.5 * rnd
+                got = self.gathered.view(self.world, self.rec_floats).cpu()
+                want = torch.stack([torch.arange(self.rec_floats, dtype=torch.float32) + 1000.0 * r + 0.5 * rnd
                                     for r in range(self.world)])
                 ok = ok and bool(torch.equal(got, want))
             ok = ok and self.device_status() == 0
@@ -211,12 +236,21 @@ class SamplingCore:
             ok = False
         self.device_status(clear=True)
         self.record.copy_(keep)
+        try:
+            check(self.lib.covo_exchange_set_timeout(self.h, float(os.environ.get("COVO_EXCHANGE_TIMEOUT_S", "60"))),
+                  "covo_exchange_set_timeout")
+        except Exception:
+            ok = False
         return self._all_agree(ok)
 
+    def _peer_exchange(self):
+        fn = self.lib.covo_exchange_records_cov if self.cov_records else self.lib.covo_exchange_records
+        check(fn(self.h, ptr(self.record), ptr(self.gathered), self.stream()), "covo_exchange_records")
+
     def exchange_rank_records(self):
-        """THE one exchange of a sharded control step: this rank's record -> self.gathered (world x COVO_RANK_RECORD_FLOATS)."""
+        """THE one exchange of a sharded control step: this rank's record -> self.gathered (world x rec_floats)."""
         if self.exchange == "peer":
-            check(self.lib.covo_exchange_records(self.h, ptr(self.record), ptr(self.gathered), self.stream()), "covo_exchange_records")
+            self._peer_exchange()
         else:
             exchange_records(self.record, self.gathered, self.pg)
         return self.gathered
@@ -225,6 +259,15 @@ class SamplingCore:
         check(self.lib.covo_merge_ranks(self.h, ptr(self.gathered), self.world, ptr(a_mean_shifted), float(gamma_mean), ptr(out),
                                         ptr(self.stats_total) if self.compute_info else None, self.stream()), "covo_merge_ranks")
         return out
+
+    def merge_rank_records_cov(self, a_mean_shifted, gamma_mean, a_cov_shifted, gamma_sigma, out_mean, out_cov):
+        """MPPI with gamma_sigma != 0 on sharded ranks (mppi.py:109-125): the gathered 836-float records -> new mean and the
+        covariances adapted about it, identically on every rank (in place on a_cov_shifted is allowed)."""
+        check(self.lib.covo_merge_ranks_cov(self.h, ptr(self.gathered), self.world, ptr(a_mean_shifted), float(gamma_mean),
+                                            ptr(a_cov_shifted), float(gamma_sigma), ptr(out_mean), ptr(out_cov),
+                                            ptr(self.stats_total) if self.compute_info else None, self.stream()),
+              "covo_merge_ranks_cov")
+        return out_mean, out_cov
 
     def device_status(self, clear: bool = False) -> int:
         """Sticky COVO_DEVSTAT_* bits raised by kernels of earlier calls (0 = fine); no synchronisation."""
@@ -403,8 +446,13 @@ class SamplingCore:
               "covo_mpc_step")
         self._last_step = (params_c, args)
         if self.world > 1:
-            self.exchange_rank_records()  # the ONE exchange per step (partial + position sums in one record)
-            self.merge_rank_records(am_shift, gamma_mean, am)
+            self.exchange_rank_records()  # the ONE exchange per step (partial (+ second moments) + position sums in one record)
+            gs = float(kw.get("gamma_sigma", 0.0))
+            if mode == _lib.MODE_MPPI and gs != 0.0:
+                self._need_cov_records()
+                self.merge_rank_records_cov(am_shift, gamma_mean, cov_out, gs, am, cov_out)  # a_cov was shifted by the begin launch
+            else:
+                self.merge_rank_records(am_shift, gamma_mean, am)
         return am, cov_out
 
     def run_episode(self, mode, episode, params_c, a_mean, rng, n_steps, **kw):
@@ -414,6 +462,8 @@ class SamplingCore:
         if self.world > 1 and self.exchange != "peer":
             raise NotImplementedError("run_episode on sample-sharded ranks needs the peer-write exchange (exchange='peer' / "
                                       "COVO_EXCHANGE=peer): a torch.distributed collective cannot be enqueued from C")
+        if self.world > 1 and mode == _lib.MODE_MPPI and float(kw.get("gamma_sigma", 0.0)) != 0.0:
+            self._need_cov_records()
         args, am, _, cov_out = self._prepare_step(mode, episode.noisy_state, a_mean, derive_keys=True, **kw)
         key = (C.c_uint32 * 2)(int(rng[0]), int(rng[1]))
         env = episode.env
@@ -448,13 +498,23 @@ class SamplingCore:
         self.exchange_rank_records()  # the ONE exchange per step
         return self.merge_rank_records(a_mean_shifted, gamma_mean, out)
 
+    def _need_cov_records(self):
+        if not self.cov_records:
+            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0) on sample-sharded ranks needs the 836-float rank "
+                                      "records: build the controller with control_params.gamma_sigma != 0 "
+                                      "(SamplingCore(cov_records=True))")
+
     def update_cov(self, a_mean_shifted, gamma_mean, a_cov_shifted, gamma_sigma):
-        """MPPI's update with covariance adaptation (mppi.py:109-125) -> (new mean (128,), new a_cov (H,4,4)); single shard."""
-        if self.world > 1:
-            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0) on sample-sharded ranks: the rank record "
-                                      "carries no second moments")
+        """MPPI's update with covariance adaptation (mppi.py:109-125) -> (new mean (128,), new a_cov (H,4,4)).  Sharded ranks:
+        this shard's record with its second moments -> the ONE exchange -> the same merge on every rank."""
         mean = self.torch.empty_like(a_mean_shifted)
         cov = self.torch.empty_like(a_cov_shifted)
+        if self.world > 1:
+            self._need_cov_records()
+            check(self.lib.covo_softmax_reduce_cov(self.h, ptr(self.cost), ptr(self.a), self.n_local, ptr(self.blockmin),
+                                                   ptr(a_mean_shifted), ptr(self.partial), self.stream()), "covo_softmax_reduce_cov")
+            self.exchange_rank_records()
+            return self.merge_rank_records_cov(a_mean_shifted, gamma_mean, a_cov_shifted, gamma_sigma, mean, cov)
         check(self.lib.covo_softmax_update_cov(self.h, ptr(self.cost), ptr(self.a), self.n_local, ptr(self.blockmin),
                                                ptr(a_mean_shifted), float(gamma_mean), ptr(a_cov_shifted), float(gamma_sigma),
                                                ptr(mean), ptr(cov), self.stream()), "covo_softmax_update_cov")

@@ -41,7 +41,7 @@ class CoVOParams:
 
 class CoVOController(BaseController):
     def __init__(self, env, control_params, N: int, H: int, lam: float, mode: str = "online", *, device=None,
-                 process_group=None, compute_info: bool = True) -> None:
+                 process_group=None, compute_info: bool = True, propagate_nan=None) -> None:
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
         self.materialize_eps = False  # True: epsilon is written to HBM and the kernels are called one by one (parity)
@@ -58,8 +58,9 @@ class CoVOController(BaseController):
             self.expansion_controller = PIDController(env, control_params=control_params)
             self.reset = self.reset_a_cov_offline  # covo.py:112
         self.mode = mode
+        # propagate_nan: jnp.clip's NaN semantics in the sampling clip (covo.py:224) -- see SamplingCore
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
-                                 compute_info=compute_info, trust_clipped=True)
+                                 compute_info=compute_info, trust_clipped=True, propagate_nan=propagate_nan)
 
     def _needs_table(self, params_c) -> bool:
         """periodic / sin / drag / mixed (free.py:10-58): quadjax's deterministic=True only zeroes dyn_noise_scale

@@ -32,21 +32,24 @@ class MPPIParams:
 
 class MPPIController(BaseController):
     def __init__(self, env, control_params, N: int, H: int, lam: float, *, device=None, process_group=None,
-                 compute_info: bool = True) -> None:
+                 compute_info: bool = True, propagate_nan=None) -> None:
         super().__init__(env, control_params)
         self.N, self.H, self.lam = N, H, lam
         self.materialize_eps = False  # True: epsilon is written to HBM and the kernels are called one by one (parity)
         self.noise_stream = "philox"  # "jax": sampling keys / epsilon from jax.random's own bitstream (random_jax.py)
         self.alias_outputs = False    # True: returned a_mean / a_cov alias the controller's buffers (no clones)
         self._params_c(env.default_params)  # raises now if env.reward_fn / disturb_type is not one the kernels evaluate
+        # mppi.py:119-125's covariance adaptation (gamma_sigma != 0; quadjax's own factory fixes 0, envs/quadrotor.py:715): on
+        # sample-sharded ranks the rank record then also carries the weighted second moments (still ONE exchange per step)
         self.core = SamplingCore(N, H, lam, control_params.discount, device=device, process_group=process_group,
-                                 compute_info=compute_info, trust_clipped=True)
+                                 compute_info=compute_info, trust_clipped=True,
+                                 cov_records=float(getattr(control_params, "gamma_sigma", 0.0)) != 0.0, propagate_nan=propagate_nan)
 
     def _check_gamma_sigma(self, control_params):
-        """mppi.py:119-125's covariance adaptation (gamma_sigma != 0; quadjax's own factory fixes 0, envs/quadrotor.py:715) runs
-        on one shard only: the rank record of a sample-sharded step carries no second moments."""
+        """A controller built with gamma_sigma = 0 exchanges the 516-float records: on sharded ranks a later gamma_sigma != 0 needs
+        a controller built for it (the record size is fixed at construction: exchange buffers, captured graphs)."""
         if control_params.gamma_sigma != 0.0 and self.core.world > 1:
-            raise NotImplementedError("MPPI covariance adaptation (gamma_sigma != 0) on sample-sharded ranks")
+            self.core._need_cov_records()
 
     def run_episode(self, episode, env_params, control_params, rng, n_steps):
         """n_steps closed-loop steps (this controller + the device env step) enqueued by one C call; keys threaded like

@@ -28,7 +28,8 @@ void covo_set_error(const char *fmt, ...)
         const int st_ = *(volatile int *)(h)->status_host;                                                                   \
         if (st_ != 0) {                                                                                                      \
             covo_set_error("%s: device status 0x%x from an earlier call%s%s (covo_device_status)", what, st_,               \
-                           (st_ & COVO_DEVSTAT_EXCHANGE) ? ": a peer's rank record did not arrive (covo_exchange_records)" : "", \
+                           (st_ & COVO_DEVSTAT_EXCHANGE) ? ": a peer's rank record did not arrive (covo_exchange_records)"    \
+                           : (st_ & COVO_DEVSTAT_ADJOINT) ? ": the adjoint Hessian's costate wait timed out (that call's R / Sigma / L are NaN)" : "", \
                            (st_ & COVO_DEVSTAT_GRID_BARRIER)                                                                 \
                                ? ": a grid barrier of the Sigma chain timed out -- the GPU is shared with other work; that " \
                                  "call's Sigma / L / mean are NaN.  Create the handle with COVO_FLAG_SHARED_DEVICE"        \
@@ -79,6 +80,7 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     REQUIRE(cfg->n_local > 0, "covo_create: n_local=%d", cfg->n_local);
     REQUIRE(cfg->lam > 0.0f, "covo_create: lam=%g", (double)cfg->lam);
     covo_ctx *h = new covo_ctx();
+    h->dbg_epoch = g_dbg_epoch;
     h->cfg = *cfg;
     COVO_CHECK_HIP(hipGetDevice(&h->device));
     h->max_red_blocks = 256;
@@ -172,7 +174,8 @@ int covo_noise_gemm(covo_handle_t h, const float *L, const float *mu, const floa
     REQUIRE(h, "covo_noise_gemm: null handle");
     CHECK_DEVICE(h, "covo_noise_gemm");
     REQUIRE(L && mu && eps && a_out && N > 0, "covo_noise_gemm: bad argument");
-    return launch_noise_gemm(L, mu, eps, 0u, 0u, 0, N, a_out, (hipStream_t)stream);
+    return launch_noise_gemm(L, mu, eps, 0u, 0u, 0, N, a_out, (hipStream_t)stream, nullptr, nullptr, 0, 1, false, nullptr,
+                             covo_propagate_nan(h));
 }
 
 int covo_noise_gemm_philox(covo_handle_t h, const float *L, const float *mu, uint32_t key0, uint32_t key1,
@@ -181,7 +184,8 @@ int covo_noise_gemm_philox(covo_handle_t h, const float *L, const float *mu, uin
     REQUIRE(h, "covo_noise_gemm_philox: null handle");
     CHECK_DEVICE(h, "covo_noise_gemm_philox");
     REQUIRE(L && mu && a_out && N > 0, "covo_noise_gemm_philox: bad argument");
-    return launch_noise_gemm(L, mu, nullptr, key0, key1, sample_offset, N, a_out, (hipStream_t)stream);
+    return launch_noise_gemm(L, mu, nullptr, key0, key1, sample_offset, N, a_out, (hipStream_t)stream, nullptr, nullptr, 0, 1, false,
+                             nullptr, covo_propagate_nan(h));
 }
 
 int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, const float *eps, int32_t N, float *a_out,
@@ -189,7 +193,7 @@ int covo_noise_blockdiag(covo_handle_t h, const float *Ls, const float *mu, cons
 {
     REQUIRE(h, "covo_noise_blockdiag: null handle");
     REQUIRE(Ls && mu && eps && a_out && N > 0, "covo_noise_blockdiag: bad argument");
-    return launch_noise_blockdiag(Ls, mu, eps, 0u, 0u, 0, N, a_out, (hipStream_t)stream);
+    return launch_noise_blockdiag(Ls, mu, eps, 0u, 0u, 0, N, a_out, (hipStream_t)stream, nullptr, covo_propagate_nan(h));
 }
 
 int covo_noise_blockdiag_philox(covo_handle_t h, const float *Ls, const float *mu, uint32_t key0, uint32_t key1,
@@ -197,7 +201,8 @@ int covo_noise_blockdiag_philox(covo_handle_t h, const float *Ls, const float *m
 {
     REQUIRE(h, "covo_noise_blockdiag_philox: null handle");
     REQUIRE(Ls && mu && a_out && N > 0, "covo_noise_blockdiag_philox: bad argument");
-    return launch_noise_blockdiag(Ls, mu, nullptr, key0, key1, sample_offset, N, a_out, (hipStream_t)stream);
+    return launch_noise_blockdiag(Ls, mu, nullptr, key0, key1, sample_offset, N, a_out, (hipStream_t)stream, nullptr,
+                                  covo_propagate_nan(h));
 }
 
 int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
@@ -213,7 +218,7 @@ int covo_rollout_cost(covo_handle_t h, const float *state, const float *pos_traj
             params->disturb_kind);
     return launch_rollout(state, pos_traj, vel_traj, T, *params, f_disturb_shared, a, N, h->cfg.discount,
                           (h->cfg.flags & COVO_FLAG_ACTIONS_CLIPPED) != 0, cost_out, groupmin, pos_stats, h->ws_stats,
-                          (hipStream_t)stream, nullptr, nullptr, 0.0f, f_disturb_steps);
+                          (hipStream_t)stream, nullptr, nullptr, 0.0f, f_disturb_steps, 0, covo_propagate_nan(h));
 }
 
 int covo_disturb_table(covo_handle_t h, const covo_env_params *params, const float *state, int32_t batch,
@@ -334,6 +339,30 @@ int covo_softmax_update_cov(covo_handle_t h, const float *cost, const float *a, 
                                      a_mean_out, a_cov_out, (hipStream_t)stream);
 }
 
+int covo_softmax_reduce_cov(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
+                            const float *a_mean_old, float *record_out, void *stream)
+{
+    REQUIRE(h, "covo_softmax_reduce_cov: null handle");
+    CHECK_DEVICE(h, "covo_softmax_reduce_cov");
+    REQUIRE(cost && a && a_mean_old && record_out, "covo_softmax_reduce_cov: bad argument");
+    REQUIRE(N > 0 && N <= h->cfg.n_local, "covo_softmax_reduce_cov: N=%d outside (0, n_local=%d]", N, h->cfg.n_local);
+    return launch_softmax_reduce_cov(h, cost, a, N, groupmin, (N + 63) / 64, a_mean_old, record_out, (hipStream_t)stream);
+}
+
+int covo_merge_ranks_cov(covo_handle_t h, const float *records, int32_t G, const float *a_mean_old, float gamma_mean,
+                         const float *a_cov_old, float gamma_sigma, float *a_mean_out, float *a_cov_out, double *pos_stats_out,
+                         void *stream)
+{
+    REQUIRE(h, "covo_merge_ranks_cov: null handle");
+    CHECK_DEVICE(h, "covo_merge_ranks_cov");
+    REQUIRE(records && a_mean_old && a_cov_old && a_mean_out && a_cov_out && G > 0, "covo_merge_ranks_cov: bad argument");
+    int rc = launch_merge_cov(records, G, COVO_RANK_RECORD_COV_FLOATS, h->cfg.lam, a_mean_old, gamma_mean, a_cov_old, gamma_sigma,
+                              a_mean_out, a_cov_out, (hipStream_t)stream);
+    if (rc) return rc;
+    if (pos_stats_out != nullptr) rc = launch_rank_stats_sum(records, G, pos_stats_out, (hipStream_t)stream, true);
+    return rc;
+}
+
 int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a_mean_old, float gamma_mean,
                float *a_mean_out, void *stream)
 {
@@ -368,11 +397,31 @@ int covo_exchange_connect(covo_handle_t h, const void *handles)
     return exchange_connect(h, handles);
 }
 
+int covo_exchange_set_timeout(covo_handle_t h, double seconds)
+{
+    REQUIRE(h, "covo_exchange_set_timeout: null handle");
+    return exchange_set_timeout(h, seconds);
+}
+
+int covo_device_bus_id(int32_t device, char *out, int32_t len)
+{
+    REQUIRE(out && len >= 16, "covo_device_bus_id: out == NULL or len < 16");
+    COVO_CHECK_HIP(hipDeviceGetPCIBusId(out, len, device));
+    return 0;
+}
+
 int covo_exchange_records(covo_handle_t h, const float *record, float *gathered_out, void *stream)
 {
     REQUIRE(h && record && gathered_out, "covo_exchange_records: null argument");
     CHECK_DEVICE(h, "covo_exchange_records");
     return exchange_records(h, record, gathered_out, nullptr, (hipStream_t)stream);
+}
+
+int covo_exchange_records_cov(covo_handle_t h, const float *record, float *gathered_out, void *stream)
+{
+    REQUIRE(h && record && gathered_out, "covo_exchange_records_cov: null argument");
+    CHECK_DEVICE(h, "covo_exchange_records_cov");
+    return exchange_records(h, record, gathered_out, nullptr, (hipStream_t)stream, COVO_RANK_RECORD_COV_FLOATS);
 }
 
 int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, void *stream)
@@ -403,7 +452,7 @@ int covo_hessian(covo_handle_t h, const float *state, const float *pos_traj, con
         h->ws_hess_bytes = need;
     }
     return launch_hessian(state, pos_traj, vel_traj, T, *params, a_mean, batch, R_out, h->ws_hess, (hipStream_t)stream, nullptr, 0,
-                          nullptr, f_disturb_steps);
+                          nullptr, f_disturb_steps, nullptr, h->status_dev);
 }
 
 int covo_hessian_pairs(covo_handle_t h, const float *state, const float *pos_traj, const float *vel_traj, int32_t T,
@@ -444,12 +493,14 @@ int covo_debug_set_ns_tail(int n_squarings, int n_iters)
     }
     g_ns_tail_squarings = n_squarings;
     g_ns_tail_iters = n_iters;
+    ++g_dbg_epoch;  // captured step graphs hold the old launch set: every handle re-captures at its next step
     return 0;
 }
 
 int covo_debug_set_ns_deflate(int on)
 {
     g_ns_deflate = on ? 1 : 0;
+    ++g_dbg_epoch;  // ... and the old switch as a kernel argument of the Ritz launch
     return 0;
 }
 
@@ -534,10 +585,19 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
             // sample-sharded: every rank's record to every rank (peer writes, exchange.hip), then the same merge on all of them.
             // partial_out is this rank's RANK record: {m, s, v} there, its position sums (if any) at + COVO_PARTIAL_FLOATS
             const float *gathered = nullptr;
-            if ((rc = exchange_records(h, args->partial_out, nullptr, &gathered, s))) return rc;
-            if ((rc = launch_merge(gathered, exchange_world(h), h->cfg.lam, args->a_mean_shift, args->gamma_mean, args->a_mean, s,
-                                   nullptr, 1, COVO_RANK_RECORD_FLOATS)))
-                return rc;
+            if (args->mode == COVO_MODE_MPPI && args->gamma_sigma != 0.0f) {
+                // mppi.py:119-125 on sharded ranks: the record also carries the 320 second moments (COVO_RANK_RECORD_COV_FLOATS);
+                // a_cov was shifted in place by the begin launch and is adapted in place, identically on every rank
+                if ((rc = exchange_records(h, args->partial_out, nullptr, &gathered, s, COVO_RANK_RECORD_COV_FLOATS))) return rc;
+                if ((rc = launch_merge_cov(gathered, exchange_world(h), COVO_RANK_RECORD_COV_FLOATS, h->cfg.lam, args->a_mean_shift,
+                                           args->gamma_mean, args->a_cov, args->gamma_sigma, args->a_mean, args->a_cov, s)))
+                    return rc;
+            } else {
+                if ((rc = exchange_records(h, args->partial_out, nullptr, &gathered, s))) return rc;
+                if ((rc = launch_merge(gathered, exchange_world(h), h->cfg.lam, args->a_mean_shift, args->gamma_mean, args->a_mean, s,
+                                       nullptr, 1, COVO_RANK_RECORD_FLOATS)))
+                    return rc;
+            }
         }
         rc = launch_env_step(state_true, const_cast<float *>(args->state), args->pos_traj, args->vel_traj, acc_traj, args->T,
                              *params, args->a_mean, rng_step, noisy_on, obs_noise_scale, log, t, s);
@@ -619,8 +679,8 @@ int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_ste
     REQUIRE(args->mode != COVO_MODE_COVO_OFFLINE || (args->L_table && args->n_table > 0), "covo_mpc_step: offline needs L_table");
     REQUIRE(args->mode != COVO_MODE_MPPI || args->a_cov, "covo_mpc_step: mppi needs a_cov");
     CHECK_MODEL(params, "covo_mpc_step");
-    REQUIRE(args->gamma_sigma == 0.0f || (args->mode == COVO_MODE_MPPI && args->partial_out == nullptr),
-            "covo_mpc_step: gamma_sigma != 0 is MPPI's covariance adaptation (mppi.py:119-125), single shard only");
+    REQUIRE(args->gamma_sigma == 0.0f || args->mode == COVO_MODE_MPPI,
+            "covo_mpc_step: gamma_sigma != 0 is MPPI's covariance adaptation (mppi.py:119-125)");
     REQUIRE(!needs_table(params) || args->derive_keys == 1, "covo_mpc_step: disturb_kind=%d needs derive_keys = 1 (the per-step "
             "disturbance tables are derived from the raw controller key on the device)", params->disturb_kind);
     return covo_step_impl(h, params, args, key0, key1, f_disturb_shared, (hipStream_t)stream);

@@ -30,6 +30,7 @@ struct covo_ctx {
     int *status_host;         // host-mapped sticky status word (COVO_DEVSTAT_* bits written by kernels), see covo_device_status
     int *status_dev;          // its device address
     void *exchange;           // Exchange (exchange.hip): peer-write exchange of the rank records, or null
+    int dbg_epoch;            // g_dbg_epoch when this handle's step graphs were captured (a debug setter since then: re-capture)
 };
 
 void covo_set_error(const char *fmt, ...);
@@ -39,6 +40,7 @@ void covo_set_error(const char *fmt, ...);
 // Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
 extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_deflate;  // sigma_ns.hip
+extern int g_dbg_epoch;  // capi.hip: bumped by every debug setter whose value a captured step graph bakes in as a kernel argument
 
 #define COVO_CHECK_HIP(expr)                                                         \
     do {                                                                             \
@@ -102,15 +104,19 @@ struct CovDeferred {
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr, const float *state_for_time = nullptr,
                       int n_table = 0, int batch = 1,  // batch > 1 (in-kernel Philox only): dense per-instance L, mu, dyn, a
-                      bool eps_tiled = false, const CovDeferred *cov = nullptr);       // eps is the tile-ordered image of eps_tiles.hpp
+                      bool eps_tiled = false, const CovDeferred *cov = nullptr,        // eps is the tile-ordered image of eps_tiles.hpp
+                      bool propagate_nan = false);                                     // COVO_FLAG_PROPAGATE_NAN: jnp.clip's NaN semantics
 int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
-                           int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr);
+                           int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr,
+                           bool propagate_nan = false);
+static inline bool covo_propagate_nan(const covo_ctx *h) { return (h->cfg.flags & COVO_FLAG_PROPAGATE_NAN) != 0; }
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr,
                    float *records = nullptr, float lam = 0.0f,   // records: one online-softmax record per workgroup (rollout.hip)
                    const float *f_tab = nullptr,                 // [H][4] per-step disturbance table (disturb.hip), device
-                   int xcd_groups = 0);   // 64-sample groups per workgroup of the kernel that wrote `a` (0: the noise GEMM's for this N)
+                   int xcd_groups = 0,    // 64-sample groups per workgroup of the kernel that wrote `a` (0: the noise GEMM's for this N)
+                   bool propagate_nan = false);  // the re-clip of untrusted stripes keeps a NaN (COVO_FLAG_PROPAGATE_NAN)
 int launch_disturb_table(const covo_env_params &p, const float *state, int batch, const uint32_t *keys_dev, uint32_t key0,
                          uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s);
 int launch_disturb_tables_step(const covo_env_params &p, const float *state, const uint32_t *dyn, int rollout_deterministic,
@@ -136,17 +142,23 @@ int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N,
 int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
                  hipStream_t s, float *partial_out = nullptr, int batch = 1, int stride = COVO_PARTIAL_FLOATS);
 // exchange.hip: the rank records of a sample-sharded step and their peer-write exchange
-int launch_rank_stats_sum(const float *records, int G, double *out, hipStream_t s);
+int launch_rank_stats_sum(const float *records, int G, double *out, hipStream_t s, bool cov = false);
 int exchange_create(covo_ctx *h, int world, int rank, void *handle_out);
 int exchange_connect(covo_ctx *h, const void *handles);
+int exchange_set_timeout(covo_ctx *h, double seconds);
 void exchange_destroy(covo_ctx *h);
 bool exchange_ready(const covo_ctx *h);
 int exchange_world(const covo_ctx *h);
-int exchange_records(covo_ctx *h, const float *record, float *gathered_dst, const float **gathered_out, hipStream_t s);
+int exchange_records(covo_ctx *h, const float *record, float *gathered_dst, const float **gathered_out, hipStream_t s,
+                     int nfloats = COVO_RANK_RECORD_FLOATS);
 size_t softmax_cov_workspace_floats(int max_blocks);
 int launch_softmax_update_cov(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                               const float *a_mean_old, float gamma_mean, const float *a_cov_old, float gamma_sigma,
                               float *a_mean_out, float *a_cov_out, hipStream_t s);
+int launch_softmax_reduce_cov(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
+                              const float *a_mean_old, float *record_out, hipStream_t s);
+int launch_merge_cov(const float *records, int G, int stride, float lam, const float *a_mean_old, float gamma_mean,
+                     const float *a_cov_old, float gamma_sigma, float *a_mean_out, float *a_cov_out, hipStream_t s);
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
 size_t hessian_workspace_bytes(int batch);
 struct SymStatsOut;  // sym_stats.hpp
@@ -155,7 +167,8 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
                    size_t traj_stride = 0,
                    const SymStatsOut *stats = nullptr,   // batch 1: KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
                    const float *f_tab = nullptr,         // [batch][H][4] per-step disturbance table (disturb.hip), device
-                   const void *models_dev = nullptr);    // dm::Model[batch] next to consts_dev (drag / mixed with per-instance parameters)
+                   const void *models_dev = nullptr,     // dm::Model[batch] next to consts_dev (drag / mixed with per-instance parameters)
+                   int *status_dev = nullptr);           // the handle's sticky status word: COVO_DEVSTAT_ADJOINT on a costate time-out
 // true: launch_hessian leaves R's Sigma-chain statistics when asked to (the adjoint kernels do, for every disturbance model;
 // launch_hessian_pairs does not)
 inline bool hessian_leaves_stats(const covo_env_params &p)

@@ -54,6 +54,7 @@ struct AdjArgs {
     double drag_k;                   // c_drag * (-|disturb_scale| / 1.5^2)   (free.py:41-47)
     double drag_off[3];              // disturb_params[:3] / 2
     const dm::Model *models;         // per batch entry next to cs (device, nullable): overrides drag_k / drag_off
+    int *status;                     // the handle's sticky device status (nullable): COVO_DEVSTAT_ADJOINT when a costate wait times out
 };
 
 __host__ __device__ inline double adj_drag_coeff(const dm::Model &m)
@@ -83,7 +84,7 @@ size_t hessian_workspace_bytes(int batch) { return (size_t)batch * WS_COUNT_MAX 
 
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev,
-                   size_t traj_stride, const SymStatsOut *stats, const float *f_tab, const void *models_dev)
+                   size_t traj_stride, const SymStatsOut *stats, const float *f_tab, const void *models_dev, int *status_dev)
 {
     const bool fs = p.disturb_kind == COVO_DISTURB_DRAG || p.disturb_kind == COVO_DISTURB_MIXED;
     if (fs && (consts_dev != nullptr) != (models_dev != nullptr)) {
@@ -105,6 +106,7 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     for (int i = 0; i < 3; ++i) A.drag_off[i] = 0.5 * (double)m.dp[i];
     A.models = reinterpret_cast<const dm::Model *>(models_dev);
     A.reward = p.reward_kind;
+    A.status = status_dev;
     A.state = state;
     A.pos_traj = pos_traj;
     A.vel_traj = vel_traj;

@@ -296,7 +296,14 @@ __device__ __forceinline__ void adj_hd_pairs(const AdjArgs &A, int k, int b, int
     // (workgroup 8, dispatched before this one) has stored lam_{k+1}: row k + 1 of WS_LAM still holding KB's "unset" pattern means
     // not yet.  lam_31 is stored first and the chain runs down at ~0.16 us per step, the hyper-dual step above takes ~5 us: only
     // the first few steps wait at all, and none longer than the chain itself (round 3; the contraction used to be a launch of
-    // its own, 3 us, with these 14 numbers per pair going through memory).  The spin is bounded (0.2 s -> NaN).
+    // its own, 3 us, with these 14 numbers per pair going through memory).
+    // Forward progress rests on IN-ORDER workgroup dispatch: within batch entry b, workgroup (8, b) -- the costate chain -- is
+    // placed on a CU before the pollers (9..40, b) of the same entry are (x runs fastest in the dispatch order of a 2-D grid), so
+    // a poller never occupies the slot the chain is waiting for, also when the grid (41 x batch workgroups: covo-offline's 300,
+    // the env-batched step) is far from co-resident.  HIP does not promise that order; gfx950's dispatcher keeps it.  The spin is
+    // therefore bounded (0.5 s of the wall clock): on a time-out the pair contracts with the NaN pattern -- R, Sigma and L of that
+    // call are NaN -- AND the handle's sticky COVO_DEVSTAT_ADJOINT bit is raised, so the next call fails with COVO_E_DEVICE
+    // instead of planning on NaNs silently (like the Sigma chain's barriers and the exchange).
     double g = h[0];
     if (k <= HH - 2) {
         const double *__restrict__ Lk = ws + WS_LAM + 16 * (k + 1);
@@ -309,7 +316,11 @@ __device__ __forceinline__ void adj_hd_pairs(const AdjArgs &A, int k, int b, int
                 lam[i] = __hip_atomic_load(Lk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unset |= (unsigned long long)__double_as_longlong(lam[i]) == ADJ_LAM_UNSET;
             }
-            if (!unset || wall_clock64() - t0 > 20000000LL) break;
+            if (!unset) break;
+            if (wall_clock64() - t0 > 50000000LL) {
+                if (A.status != nullptr) __hip_atomic_fetch_or(A.status, COVO_DEVSTAT_ADJOINT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
             __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll

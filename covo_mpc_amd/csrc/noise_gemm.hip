@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
                                                               int64_t sample_offset, int N, int ntiles,
                                                               float4 *__restrict__ a_out, const uint32_t *__restrict__ dyn,
                                                               const float *__restrict__ state_for_time, int n_table,
-                                                              const CovDeferred cov)
+                                                              const CovDeferred cov, int nanp)
 {
     // dyn (nullable): {key0, key1} in device memory -- lets a captured graph see a fresh key every replay.
     // state_for_time (nullable): L is a table [n_table][128][128]; use row state.time (covo.py:107-108, clamped
@@ -345,10 +345,17 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
                     const int t = 8 * rt + 2 * g + kh;
                     const float4 m4 = *reinterpret_cast<const float4 *>(mus + 4 * t);
                     float4 v;
-                    v.x = qm::clip11_(m4.x + acc[rt][4 * g + 0]);
-                    v.y = qm::clip11_(m4.y + acc[rt][4 * g + 1]);
-                    v.z = qm::clip11_(m4.z + acc[rt][4 * g + 2]);
-                    v.w = qm::clip11_(m4.w + acc[rt][4 * g + 3]);
+                    if (nanp) {  // COVO_FLAG_PROPAGATE_NAN (wave-uniform): a NaN sample stays NaN, as under jnp.clip (covo.py:224)
+                        v.x = qm::clip11_nan_(m4.x + acc[rt][4 * g + 0]);
+                        v.y = qm::clip11_nan_(m4.y + acc[rt][4 * g + 1]);
+                        v.z = qm::clip11_nan_(m4.z + acc[rt][4 * g + 2]);
+                        v.w = qm::clip11_nan_(m4.w + acc[rt][4 * g + 3]);
+                    } else {
+                        v.x = qm::clip11_(m4.x + acc[rt][4 * g + 0]);
+                        v.y = qm::clip11_(m4.y + acc[rt][4 * g + 1]);
+                        v.z = qm::clip11_(m4.z + acc[rt][4 * g + 2]);
+                        v.w = qm::clip11_(m4.w + acc[rt][4 * g + 3]);
+                    }
                     // -DNG_STORE_WT / -DNG_STORE_NT (write-through / nontemporal stores, so that the 33.5 MB do not wait dirty in
                     // the L2s for the end-of-kernel write-back): 24.6 -> 21.3 us in the isolated replay of the in-kernel-Philox
                     // variant, but bench.py on every config moves by less than its run-to-run spread (4 791 / 4 824 / 4 786
@@ -411,7 +418,7 @@ template <bool PHILOX>
 __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__restrict__ Ls, const float *__restrict__ mu,
                                                               const float4 *__restrict__ eps, uint32_t k0, uint32_t k1,
                                                               int64_t sample_offset, int N, float4 *__restrict__ a_out,
-                                                              const uint32_t *__restrict__ dyn)
+                                                              const uint32_t *__restrict__ dyn, int nanp)
 {
     if (dyn != nullptr) { k0 = dyn[0]; k1 = dyn[1]; }
     int t;
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void noise_blockdiag_kernel(const float *__res
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = fmaf((k <= i) ? Lt[i * 4 + k] : 0.0f, ev[k], acc);
-        o[i] = qm::clip11_(mt[i] + acc);
+        o[i] = nanp ? qm::clip11_nan_(mt[i] + acc) : qm::clip11_(mt[i] + acc);  // mppi.py:66 (COVO_FLAG_PROPAGATE_NAN)
     }
     a_out[(size_t)t * N + n] = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -460,12 +467,13 @@ int noise_gemm_groups_per_workgroup(int N, int batch)
 
 int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_t k0, uint32_t k1, int64_t sample_offset,
                       int N, float *a, hipStream_t s, const uint32_t *dyn, const float *state_for_time, int n_table, int batch,
-                      bool eps_tiled, const CovDeferred *cov)
+                      bool eps_tiled, const CovDeferred *cov, bool propagate_nan)
 {
     CovDeferred cv;
     std::memset(&cv, 0, sizeof(cv));
     if (cov != nullptr) cv = *cov;
     const int ntiles = (N + 31) / 32;
+    const int nanp = propagate_nan ? 1 : 0;
     const int block = noise_gemm_block_threads(N, batch);
     const bool split = noise_gemm_split(N, batch);
     const int waves_per_block = block / 64;
@@ -486,15 +494,15 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
     do {                                                                                                                         \
         if (eps != nullptr && eps_tiled)                                                                                         \
             hipLaunchKernelGGL((noise_gemm_kernel<false, true, __VA_ARGS__>), dim3(grid), dim3(block), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, \
-                               N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv); \
+                               N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv, nanp); \
         else if (eps != nullptr)                                                                                                 \
             hipLaunchKernelGGL((noise_gemm_kernel<false, false, __VA_ARGS__>), dim3(grid), dim3(block), lds, s, L, mu, eps, 0u, 0u,          \
                                (int64_t)0, N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time,  \
-                               n_table, cv);                                                                                     \
+                               n_table, cv, nanp);                                                                               \
         else                                                                                                                     \
             hipLaunchKernelGGL((noise_gemm_kernel<true, false, __VA_ARGS__>), dim3(grid, batch), dim3(block), lds, s, L, mu,                 \
                                (const float *)nullptr, k0, k1, sample_offset, N, ntiles, reinterpret_cast<float4 *>(a), dyn,     \
-                               state_for_time, n_table, cv);                                                                     \
+                               state_for_time, n_table, cv, nanp);                                                               \
     } while (0)
     if (block == 512) NG_GO(512);
     else if (split) NG_GO(256, true);
@@ -505,17 +513,18 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
 }
 
 int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, uint32_t k0, uint32_t k1,
-                           int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn)
+                           int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn, bool propagate_nan)
 {
+    const int nanp = propagate_nan ? 1 : 0;
     const size_t total = (size_t)N * COVO_H;
     const int grid = (int)((total + 255) / 256);
     if (eps != nullptr)
         hipLaunchKernelGGL(noise_blockdiag_kernel<false>, dim3(grid), dim3(256), 0, s, Ls, mu,
                            reinterpret_cast<const float4 *>(eps), 0u, 0u, (int64_t)0, N, reinterpret_cast<float4 *>(a),
-                           (const uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, nanp);
     else
         hipLaunchKernelGGL(noise_blockdiag_kernel<true>, dim3((N + 255) / 256, COVO_H), dim3(256), 0, s, Ls, mu,
-                           (const float4 *)nullptr, k0, k1, sample_offset, N, reinterpret_cast<float4 *>(a), dyn);
+                           (const float4 *)nullptr, k0, k1, sample_offset, N, reinterpret_cast<float4 *>(a), dyn, nanp);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -24,6 +24,9 @@ __device__ __forceinline__ float log_(float x) { return __builtin_amdgcn_logf(x)
 __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ float sat01_(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 __device__ __forceinline__ float clip11_(float x) { return __builtin_amdgcn_fmed3f(x, -1.0f, 1.0f); }
+// jnp.clip's NaN semantics (minimum(maximum(x, lo), hi) PROPAGATES a NaN; v_med3 / v_max / v_min return the other operand):
+// COVO_FLAG_PROPAGATE_NAN -- v_cmp_u + v_cndmask on top of the v_med3
+__device__ __forceinline__ float clip11_nan_(float x) { return (x != x) ? x : __builtin_amdgcn_fmed3f(x, -1.0f, 1.0f); }
 __device__ __forceinline__ float value_(float x) { return x; }
 
 // |atan2(y, x)|: odd minimax polynomial of atan on [0,1] (max abs error 1.2e-7) + octant fix-up.

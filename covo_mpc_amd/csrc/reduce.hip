@@ -172,10 +172,16 @@ __device__ __forceinline__ int cov_pair(int i, int j)
 // MPPI with gamma_sigma != 0 (mppi.py:109-125): merge G stage-1 records that carry second moments, new mean as merge_kernel,
 // then a_cov'[t] = gamma_sigma sum_n w_n (a_n - mean')(a_n - mean')^T + (1 - gamma_sigma) a_cov[t] with the NEW mean (sic):
 // with d = a - mu, e = mean' - mu, m1 = sum w d:  sum w (d - e)(d - e)^T = S2 - m1 e^T - e m1^T + e e^T   (sum w = 1).
+// FINAL = false (a sample-sharded rank, round 4): the merged, UNNORMALISED record {m, s, v[128], pad[2], S2[320]} goes to
+// a_mean_out instead -- this rank's contribution to the exchange; the G rank records are then merged by the FINAL variant on
+// every rank (the second moments are about mu, the shifted OLD mean, which all ranks share).
+// stride: floats between consecutive records (RD_COV_RECORD_FLOATS, or COVO_RANK_RECORD_COV_FLOATS for all-gathered rank records).
+template <bool FINAL>
 __global__ __launch_bounds__(MG_THREADS) void merge_cov_kernel(const float *__restrict__ partials, int G, float inv_lam,
                                                                const float *__restrict__ a_mean_old, float gamma_mean,
                                                                const float *__restrict__ a_cov_old, float gamma_sigma,
-                                                               float *__restrict__ a_mean_out, float *__restrict__ a_cov_out)
+                                                               float *__restrict__ a_mean_out, float *__restrict__ a_cov_out,
+                                                               int stride)
 {
     __shared__ float scale[MG_MAXG];
     __shared__ float redm[MG_THREADS / 64];
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_cov_kernel(const float *__re
     __shared__ float sv2[MG_SLICES][RD_COV_FLOATS];
     __shared__ float smean[COVO_NA], sm1[COVO_NA], se[COVO_NA], s2[RD_COV_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int REC = RD_COV_RECORD_FLOATS;
+    const int REC = stride;
     float m = __builtin_inff();
     for (int g = tid; g < G; g += MG_THREADS) m = fminf(m, partials[(size_t)g * REC]);
     m = wave_min(m);
@@ -231,6 +237,26 @@ __global__ __launch_bounds__(MG_THREADS) void merge_cov_kernel(const float *__re
         if (third) sv2[slice][col + 2 * COVO_NA] = vc;
     }
     __syncthreads();
+    if (!FINAL) {  // the merged record, unnormalised (a_mean_out = record [RD_COV_RECORD_FLOATS])
+        float *__restrict__ rec = a_mean_out;
+        if (tid < COVO_NA) {
+            v = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MG_SLICES; ++i) v += sv[i][tid];
+            rec[2 + tid] = v;
+        }
+        for (int c2 = tid; c2 < RD_COV_FLOATS; c2 += MG_THREADS) {
+            float v2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MG_SLICES; ++i) v2 += sv2[i][c2];
+            rec[COVO_PARTIAL_FLOATS + c2] = v2;
+        }
+        if (tid == 0) {
+            rec[0] = m;
+            rec[1] = s;
+        }
+        return;
+    }
     const float inv_s = 1.0f / s;
     if (tid < COVO_NA) {
         v = 0.0f;
@@ -390,8 +416,31 @@ int launch_softmax_update_cov(covo_ctx *h, const float *cost, const float *a, in
     if (grid > h->max_red_blocks) grid = h->max_red_blocks;
     hipLaunchKernelGGL(softmax_partial_kernel<true>, dim3(grid, 1), dim3(RD_BLOCK), 0, s, cost, reinterpret_cast<const float4 *>(a), N,
                        blockmin, n_blockmin, inv_lam, h->ws_partials_cov, reinterpret_cast<const float4 *>(a_mean_old));
-    hipLaunchKernelGGL(merge_cov_kernel, dim3(1), dim3(MG_THREADS), 0, s, h->ws_partials_cov, grid, inv_lam, a_mean_old, gamma_mean,
-                       a_cov_old, gamma_sigma, a_mean_out, a_cov_out);
+    if (a_cov_out != nullptr)
+        hipLaunchKernelGGL(merge_cov_kernel<true>, dim3(1), dim3(MG_THREADS), 0, s, h->ws_partials_cov, grid, inv_lam, a_mean_old,
+                           gamma_mean, a_cov_old, gamma_sigma, a_mean_out, a_cov_out, RD_COV_RECORD_FLOATS);
+    else  // a sample-sharded rank: a_mean_out = this rank's record {m, s, v, pad, S2} (launch_softmax_reduce_cov)
+        hipLaunchKernelGGL(merge_cov_kernel<false>, dim3(1), dim3(MG_THREADS), 0, s, h->ws_partials_cov, grid, inv_lam, a_mean_old,
+                           1.0f, (const float *)nullptr, 0.0f, a_mean_out, (float *)nullptr, RD_COV_RECORD_FLOATS);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// stage 1 with second moments + local merge -> this rank's record {m, s, v[128], pad[2], S2[320]} (unnormalised): the first
+// COVO_PARTIAL_FLOATS + 320 floats of a COVO_RANK_RECORD_COV_FLOATS rank record
+int launch_softmax_reduce_cov(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
+                              const float *a_mean_old, float *record_out, hipStream_t s)
+{
+    return launch_softmax_update_cov(h, cost, a, N, blockmin, n_blockmin, a_mean_old, 1.0f, nullptr, 0.0f, record_out, nullptr, s);
+}
+
+// the G all-gathered rank records (stride floats apart) -> new mean and adapted covariances, identically on every rank
+int launch_merge_cov(const float *records, int G, int stride, float lam, const float *a_mean_old, float gamma_mean,
+                     const float *a_cov_old, float gamma_sigma, float *a_mean_out, float *a_cov_out, hipStream_t s)
+{
+    if (G > MG_MAXG) { covo_set_error("covo_merge_ranks_cov: G=%d > %d", G, MG_MAXG); return COVO_E_BADARG; }
+    hipLaunchKernelGGL(merge_cov_kernel<true>, dim3(1), dim3(MG_THREADS), 0, s, records, G, 1.0f / lam, a_mean_old, gamma_mean,
+                       a_cov_old, gamma_sigma, a_mean_out, a_cov_out, stride);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }

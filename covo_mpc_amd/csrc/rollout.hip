@@ -116,7 +116,7 @@ static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int 
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev,
-                   float *records, float lam, const float *f_tab, int xcd_groups)
+                   float *records, float lam, const float *f_tab, int xcd_groups, bool propagate_nan)
 {
     RolloutArgs A;
     fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev, f_tab,
@@ -129,7 +129,7 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
         covo_set_error("rollout: reward_kind=%d", p.reward_kind);
         return COVO_E_BADARG;
     }
-    A.clip = trust_clipped ? 0 : 1;
+    A.clip = trust_clipped ? 0 : (propagate_nan ? 2 : 1);
     A.records = records;
     A.inv_lam = records ? 1.0f / lam : 0.0f;
     return dispatch_rollout<false>(A, nullptr, 0, pos_stats, s);

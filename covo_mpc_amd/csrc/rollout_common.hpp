@@ -19,7 +19,8 @@ struct RolloutArgs {
     int xcd_remap;              // > 0: workgroup -> sample chunks follow the noise GEMM's XCD placement; = 64-sample groups per GEMM workgroup
     float *records;             // nullable: [workgroups][COVO_PARTIAL_FLOATS] online-softmax records (rollout_record below)
     float inv_lam;
-    int clip;      // 1: re-apply step_env's clip to the stripes (quadrotor.py:223,258); 0: the producer guarantees clipped stripes
+    int clip;      // 1: re-apply step_env's clip to the stripes (quadrotor.py:223,258); 2: the same with jnp.clip's NaN propagation
+                   // (COVO_FLAG_PROPAGATE_NAN); 0: the producer guarantees clipped stripes
     int rollover;  // 1: is_terminal's rollover test is on (quadrotor.py:486-490)
     int reward;    // COVO_REWARD_*: selects the REWARD template variant
     int fdist;     // FDIST template variant (rollout_pipe.hpp): 0 one vector for all steps >= 1, 1 per-step table, 2 per-sample force
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
 
         float4 av = ring[k % PF];
         if (PF < COVO_H && k + PF < COVO_H) ring[k % PF] = ap[(size_t)(k + PF) * stride];
-        if (CLIP) { av.x = qm::clip11_(av.x); av.y = qm::clip11_(av.y); av.z = qm::clip11_(av.z); av.w = qm::clip11_(av.w); }
+        if (CLIP) { av.x = qm::clip11_(av.x); av.y = qm::clip11_(av.y); av.z = qm::clip11_(av.z); av.w = qm::clip11_(av.w); }  // (lab baseline: no NaN variant)
         const float fx = (k == 0) ? f0x : fsx;
         const float fy = (k == 0) ? f0y : fsy;
         const float fz = (k == 0) ? f0z : fsz;

@@ -153,7 +153,10 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         for (int k = 0; k < COVO_H; ++k) {
             float4 a4 = ring[k % PF];
             if (k + PF < COVO_H - 1) ring[k % PF] = ap[(size_t)(k + PF) * stride];
-            if (A.clip) { a4.x = qm::clip11_(a4.x); a4.y = qm::clip11_(a4.y); a4.z = qm::clip11_(a4.z); a4.w = qm::clip11_(a4.w); }
+            if (A.clip == 1) { a4.x = qm::clip11_(a4.x); a4.y = qm::clip11_(a4.y); a4.z = qm::clip11_(a4.z); a4.w = qm::clip11_(a4.w); }
+            else if (A.clip == 2) {  // COVO_FLAG_PROPAGATE_NAN: jnp.clip's NaN semantics (quadrotor.py:223,258)
+                a4.x = qm::clip11_nan_(a4.x); a4.y = qm::clip11_nan_(a4.y); a4.z = qm::clip11_nan_(a4.z); a4.w = qm::clip11_nan_(a4.w);
+            }
             float tau = __builtin_fmaf(a4.x, ctau, ctau);  // quadrotor.py:259, free.py:82,98,103
             if (ROLL && k > 0) {  // quadrotor.py:486-490 on the stored state (step 0: wave T, from the state itself)
                 const bool roll = (w < RP_COS_PI_4) | (fmaxf(fmaxf(fabsf(gx), fabsf(gy)), fabsf(gz)) > groll);

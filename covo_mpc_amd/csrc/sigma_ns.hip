@@ -49,6 +49,7 @@
 // Agreement with the LAPACK-eigh oracle: ~1e-13 relative (fp64), tests/test_gpu_parity.py.
 // `batch` matrices per launch (grid.z / grid.y): covo-offline's 300-step table, env-batched configs.
 #include "covo_common.hpp"
+#include <cstdlib>
 #include <cstring>
 #include "wave_reduce.hpp"
 #include "chol_lds.hpp"
@@ -990,7 +991,9 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // iterations 6..11 are folded (same box, bench / closed loop steps/s: tail 3: 5 029 / 4 644, 5: 5 192 / 4 734, 6: 5 227 / 4 675,
 // 7: 5 238 / 4 697, 8: 5 180 / 4 645; without deflation, tail 3: 4 949 / 4 505).
 int g_ns_tail_iters = 6, g_ns_tail_squarings = 9;
-int g_ns_deflate = 1;  // COVO_NS_DEFLATE=0 / covo_debug_set_ns_deflate(0): the undeflated iteration (A/B measurements, tests)
+// COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
+// iteration (A/B measurements, tests)
+int g_ns_deflate = [] { const char *e = std::getenv("COVO_NS_DEFLATE"); return (e && e[0] == '0') ? 0 : 1; }();
 
 SymStatsOut sigma_ns_stats_out(void *workspace)
 {

@@ -203,6 +203,7 @@ void step_state_destroy(covo_ctx *h)
 }
 
 int g_dbg_hess_mask = 15, g_dbg_sigma_stages = 4;
+int g_dbg_epoch = 0;
 static const int g_dbg_eps_ahead = [] {  // COVO_EPS_AHEAD=0: the GEMM draws epsilon itself (A/B measurements)
     const char *v = std::getenv("COVO_EPS_AHEAD");
     return v ? std::atoi(v) : 1;
@@ -228,7 +229,8 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         const bool stats = (M & 2) && (M & 4) && (g_dbg_hess_mask & 15) == 15 && hessian_leaves_stats(p);
         const SymStatsOut so = sigma_ns_stats_out(h->ws_sigma);
         if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s, nullptr, 0,
-                                            stats ? &so : nullptr, tables ? st->f_tab_hess : nullptr))) return rc;  // :134-185
+                                            stats ? &so : nullptr, tables ? st->f_tab_hess : nullptr, nullptr, h->status_dev)))
+            return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
         // epsilon needs only the act key: it is drawn under the chain's single-workgroup finalize launch, the GEMM loads it
         const bool ahead = st->eps_tiled != nullptr && (M & 4) && g_dbg_sigma_stages >= 4 && g_dbg_eps_ahead;
@@ -245,18 +247,19 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
                                              (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, defer ? &cov : nullptr, stats))) return rc;
         if (ahead) {
             if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, reinterpret_cast<const float *>(st->eps_tiled), 0, 0,
-                                                   a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true, &cov)))
+                                                   a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true, &cov, covo_propagate_nan(h))))
                 return rc;
         } else if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, nullptr, 0,
-                                                      1, false, &cov)))
+                                                      1, false, &cov, covo_propagate_nan(h))))
             return rc;
     } else if (a.mode == COVO_MODE_COVO_OFFLINE) {
         if ((M & 8) && (rc = launch_noise_gemm(a.L_table, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, state,
-                                    a.n_table)))
+                                    a.n_table, 1, false, nullptr, covo_propagate_nan(h))))
             return rc;
     } else {  // MPPI: shift a_cov, factor the 4x4 blocks, per-step draws (mppi.py:43-66)
         // (a_cov was shifted and factored into st->Ls by the begin launch)
-        if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn))) return rc;
+        if ((rc = launch_noise_blockdiag(st->Ls, am_shift, nullptr, 0, 0, a.sample_offset, N, a.a, s, st->dyn, covo_propagate_nan(h))))
+            return rc;
     }
     const bool clipped = true;  // a comes straight from the noise kernels above
     // the rollout's workgroups leave the softmax update's stage-1 records themselves when they fit the merge (rollout.hip:
@@ -271,6 +274,8 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
                                          a.mode == COVO_MODE_MPPI ? 4 : 0)))  // MPPI's block-diagonal kernel: 256 samples per workgroup
         return rc;
     if (!(M & 32)) return 0;
+    if (cov_adapt && a.partial_out != nullptr)  // a sample-sharded rank: its record with the second moments (836-float kind)
+        return launch_softmax_reduce_cov(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, am_shift, a.partial_out, s);
     if (cov_adapt)  // mppi.py:109-125: new mean, then a_cov (already shifted by the begin launch) adapted in place
         return launch_softmax_update_cov(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, am_shift, a.gamma_mean, a.a_cov, a.gamma_sigma,
                                          a.a_mean, a.a_cov, s);
@@ -291,6 +296,10 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     if (!h->step) {
         int rc = step_state_init(h);
         if (rc) return rc;
+    }
+    if (h->dbg_epoch != g_dbg_epoch) {  // a debug setter changed what a captured graph baked in (launch set, deflation switch)
+        step_graphs_drop(h);
+        h->dbg_epoch = g_dbg_epoch;
     }
     StepState *st = reinterpret_cast<StepState *>(h->step);
     // per-step scalars: kernel arguments of the begin launch
@@ -525,12 +534,14 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
     // covo.py:231: CoVO's sampling rollouts run step_env(deterministic=True); get_hessian likewise (covo.py:152)
     if (b->tables && (rc = launch_disturb_tables_batched(b->models, a.states, b->dyn, E, 1, b->tab_rollout, b->tab_hess, s))) return rc;
     if ((rc = launch_hessian(a.states, a.pos_traj, a.vel_traj, a.T, b->params[0], b->a_mean_shift, E, b->R, h->ws_hess, s,
-                             b->consts, (size_t)a.T * 3, nullptr, b->tables ? b->tab_hess : nullptr, b->models)))
+                             b->consts, (size_t)a.T * 3, nullptr, b->tables ? b->tab_hess : nullptr, b->models, h->status_dev)))
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
     if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
                               (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0))) return rc;
-    if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E))) return rc;
+    if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E, false, nullptr,
+                                covo_propagate_nan(h))))
+        return rc;
     if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, s))) return rc;
     const int G = rollout_workgroups(N, false, E);
     if (G <= h->max_red_blocks)  // the rollout's workgroups have left the records (rollout_record): instance e's are [e][G]
@@ -543,6 +554,10 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
                            hipStream_t s)
 {
     const int E = args->n_envs;
+    if (h->dbg_epoch != g_dbg_epoch) {  // as in covo_step_impl
+        step_graphs_drop(h);
+        h->dbg_epoch = g_dbg_epoch;
+    }
     BatchState *b = reinterpret_cast<BatchState *>(h->batch);
     if (!b) {
         b = new BatchState();

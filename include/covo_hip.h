@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define COVO_ABI_VERSION 3
+#define COVO_ABI_VERSION 4
 
 #define COVO_H 32            /* horizon (compile-time in the fused kernels)          */
 #define COVO_DU 4            /* action dim, quadjax/envs/quadrotor.py:198            */
@@ -58,6 +58,13 @@ extern "C" {
                                         its workgroups being co-resident (the Sigma chain then runs every phase as its own
                                         launch instead of folding the often-idle ones into two persistent launches) */
 
+#define COVO_FLAG_PROPAGATE_NAN 8    /* covo_config.flags: the action clips (covo.py:224, mppi.py:66, quadrotor.py:223,258) keep a NaN
+                                        like jnp.clip = minimum(maximum(x, lo), hi) does.  Default (flag off): the kernels clip with
+                                        v_med3 / maxNum / minNum, where a NaN operand loses -- a NaN sample becomes -1.
+                                        The one place quadjax produces NaNs by itself on this path: covo-offline on `hovering`, whose
+                                        Sigma-table row 0 is NaN (norm'(0)); there quadjax's mean is NaN from the first step on, and
+                                        with this flag so is this library's; without it the episode carries on. */
+
 #define COVO_MODE_MPPI 0
 #define COVO_MODE_COVO_ONLINE 1
 #define COVO_MODE_COVO_OFFLINE 2
@@ -70,9 +77,19 @@ extern "C" {
 #define COVO_RANK_RECORD_FLOATS (COVO_PARTIAL_FLOATS + 2 * COVO_POS_STATS_DOUBLES) /* 516: the record one rank of a sample-sharded
                                         step contributes to the exchange: {m, s, v[128], pad[2]} + the 192 fp64 position sums of
                                         covo.py:281 (zeros when not requested): ONE message of 2 064 bytes per rank and step */
-#define COVO_EXCHANGE_HANDLE_BYTES 64 /* opaque inter-process handle of a rank's exchange buffer (covo_exchange_create) */
+#define COVO_COV_FLOATS (COVO_H * 10)  /* MPPI's covariance adaptation (mppi.py:119-125): the 10 second moments i <= j of the 4 action
+                                        components of every step, sum_n w_n d_i d_j about the shifted OLD mean */
+#define COVO_RANK_RECORD_COV_FLOATS (COVO_PARTIAL_FLOATS + COVO_COV_FLOATS + 2 * COVO_POS_STATS_DOUBLES) /* 836: the rank record of a
+                                        sample-sharded MPPI step with gamma_sigma != 0: {m, s, v[128], pad[2]} + 320 second moments +
+                                        the 192 fp64 position sums -- still ONE message (3 344 bytes) per rank and step */
+#define COVO_EXCHANGE_HANDLE_BYTES 128 /* opaque inter-process handle of a rank's exchange buffer (covo_exchange_create): the hipIpc
+                                        handle + whether the buffer is fine-grained + the PCI bus id of its device */
 
-#define COVO_DEVSTAT_EXCHANGE 2      /* covo_exchange_records: a peer's record did not arrive within 2 s; the gathered records are NaN */
+#define COVO_DEVSTAT_EXCHANGE 2      /* covo_exchange_records: a peer's record did not arrive within the exchange's time-out
+                                        (covo_exchange_set_timeout, default 60 s); the gathered records are NaN */
+#define COVO_DEVSTAT_ADJOINT 4       /* covo_hessian / covo_mpc_step: a hyper-dual workgroup of the adjoint Hessian's chain launch
+                                        gave up waiting for a costate row of the same launch (0.2 s: the costate workgroup was not
+                                        co-resident); that call's Hessian, Sigma and L are NaN */
 #define COVO_DEVSTAT_GRID_BARRIER 1  /* a grid barrier of the Sigma chain's persistent launches timed out (its workgroups were not
                                         co-resident within 0.2 s: GPU shared with other work); that call's Sigma / L are NaN */
 
@@ -242,6 +259,17 @@ int covo_softmax_update_cov(covo_handle_t h, const float *cost, const float *a, 
                             const float *a_mean_old, float gamma_mean, const float *a_cov_old, float gamma_sigma,
                             float *a_mean_out, float *a_cov_out, void *stream);
 
+/* The same on sample-sharded ranks (round 4): covo_softmax_reduce_cov leaves this rank's UNNORMALISED record
+ * {m, s, v[128], pad[2], S2[320]} (S2 = the weighted second moments about a_mean_old, which every rank shares) in the first
+ * COVO_PARTIAL_FLOATS + COVO_COV_FLOATS floats of record_out -- a COVO_RANK_RECORD_COV_FLOATS rank record whose last 192 doubles are
+ * the position sums (or zeros); after ONE exchange of the G records (all-gather, or covo_exchange_records_cov)
+ * covo_merge_ranks_cov forms the new mean and the adapted covariances identically on every rank and, if asked, adds the position sums. */
+int covo_softmax_reduce_cov(covo_handle_t h, const float *cost, const float *a, int32_t N, const float *groupmin,
+                            const float *a_mean_old, float *record_out, void *stream);
+int covo_merge_ranks_cov(covo_handle_t h, const float *records /* [G][COVO_RANK_RECORD_COV_FLOATS] */, int32_t G,
+                         const float *a_mean_old, float gamma_mean, const float *a_cov_old, float gamma_sigma, float *a_mean_out,
+                         float *a_cov_out, double *pos_stats_out, void *stream);
+
 /* Merge G shard records (this GPU's, or the all-gathered records of all ranks), normalise,
  * blend with the old mean (controllers/covo.py:270-275):
  *   a_mean_out = gamma_mean * (sum_g v_g e^{-(m_g-m)/lam}) / (sum_g s_g e^{-(m_g-m)/lam})
@@ -261,11 +289,23 @@ int covo_merge_ranks(covo_handle_t h, const float *records, int32_t G, const flo
  * all-gathered by the caller (any transport: they are 64 opaque bytes), every rank calls covo_exchange_connect with all G of
  * them (rank order).  Per step: covo_exchange_records enqueues, on `stream`, the push of this rank's record into every peer's
  * buffer and the wait for all G records, which land in gathered_out [float[G][COVO_RANK_RECORD_FLOATS], device]; no host
- * synchronisation.  A peer that does not deliver within 2 s raises COVO_DEVSTAT_EXCHANGE and leaves NaN records.  With a
- * connected exchange covo_run_episode also runs on sample-sharded handles (args->partial_out = this rank's record). */
+ * synchronisation.  A peer that does not deliver within the time-out (covo_exchange_set_timeout; default 60 s, or
+ * COVO_EXCHANGE_TIMEOUT_S at covo_exchange_create) raises COVO_DEVSTAT_EXCHANGE and leaves NaN records.  With a
+ * connected exchange covo_run_episode also runs on sample-sharded handles (args->partial_out = this rank's record).
+ * covo_exchange_connect returns COVO_E_UNSUPPORTED, before mapping anything, when two ranks sit on DIFFERENT devices and either
+ * buffer is coarse-grained (the fine-grained allocation failed): remote xGMI writes into it would not be guaranteed visible.
+ * NOT measured over xGMI (the build pool has single-GPU boxes): the host mirror keeps the collective unless asked. */
 int covo_exchange_create(covo_handle_t h, int32_t world, int32_t rank, void *handle_out /* [host COVO_EXCHANGE_HANDLE_BYTES] */);
 int covo_exchange_connect(covo_handle_t h, const void *handles /* [host world x COVO_EXCHANGE_HANDLE_BYTES] */);
+int covo_exchange_set_timeout(covo_handle_t h, double seconds);
 int covo_exchange_records(covo_handle_t h, const float *record, float *gathered_out, void *stream);
+/* the same for the COVO_RANK_RECORD_COV_FLOATS record kind (gathered_out: float[G][COVO_RANK_RECORD_COV_FLOATS]) */
+int covo_exchange_records_cov(covo_handle_t h, const float *record, float *gathered_out, void *stream);
+
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` of this process -> out (NUL-terminated, len >= 16): the PHYSICAL identity
+ * of a GPU.  Device indices are per-process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumber them: every isolated rank sees
+ * index 0), so ranks that must know whether they share a GPU compare this, not the index. */
+int covo_device_bus_id(int32_t device, char *out, int32_t len);
 
 /* a_mean <- [a_mean[1:], a_mean[-1]] (controllers/covo.py:201-203).  in != out. */
 int covo_shift_mean(covo_handle_t h, const float *a_mean_in, float *a_mean_out, void *stream);
@@ -354,7 +394,8 @@ typedef struct covo_step_args {
     float *cost;             /* work: float[n_samples] */
     float *groupmin;         /* work: float[ceil(n_samples/64)] */
     double *pos_stats;       /* nullable, as in covo_rollout_cost */
-    float *partial_out;      /* nullable: float[132] record instead of finishing locally */
+    float *partial_out;      /* nullable: this shard's record instead of finishing locally -- float[COVO_PARTIAL_FLOATS], or, MPPI with
+                              *    gamma_sigma != 0, float[COVO_PARTIAL_FLOATS + COVO_COV_FLOATS] (with the second moments) */
     int64_t sample_offset;   /* global id of this shard's first sample */
     float gamma_mean;
     float sample_sigma;

@@ -455,6 +455,32 @@ def merge_partials(ms, ss, vs, lam, gamma_mean, a_mean):
     return (v / s).reshape(a_mean.shape) * gamma_mean + a_mean * (1 - gamma_mean)
 
 
+def softmax_partial_cov(cost, a_sampled, lam, mu):
+    """The same with MPPI's second moments about `mu` (the shifted OLD mean every shard knows; SURVEY 5.8 + mppi.py:119-125):
+    S2[t] = sum_n w_n d_n[t] d_n[t]^T, d = a - mu.  a_sampled (n, H, du) -> (m, s, v (H*du,), S2 (H, du, du))."""
+    m = np.min(cost)
+    w = np.exp(-(cost - m) / cost.dtype.type(lam))
+    d = a_sampled - mu[None]
+    S2 = np.einsum("n,nti,ntj->tij", w, d, d)
+    return m, np.sum(w), w @ a_sampled.reshape(len(cost), -1), S2
+
+
+def merge_partials_cov(ms, ss, vs, S2s, lam, gamma_mean, a_mean, a_cov, gamma_sigma):
+    """Merge the shards' partials with second moments -> (new mean, adapted covariances); mathematically identical to
+    mppi.py:109-125 on the unsharded samples: sum_n w_n (a_n - mean')(a_n - mean')^T with the NEW mean expands, with d = a - mu,
+    e = mean' - mu, m1 = sum_n w_n d_n and sum_n w_n = 1, to  S2 - m1 e^T - e m1^T + e e^T."""
+    ms = np.asarray(ms); ss = np.asarray(ss); vs = np.asarray(vs); S2s = np.asarray(S2s)
+    m = np.min(ms)
+    scale = np.exp(-(ms - m) / ms.dtype.type(lam))
+    s = np.sum(ss * scale)
+    wmean = (np.sum(vs * scale[:, None], axis=0) / s).reshape(a_mean.shape)
+    S2 = np.sum(S2s * scale[:, None, None, None], axis=0) / s
+    mean_new = wmean * gamma_mean + a_mean * (1 - gamma_mean)
+    m1, e = wmean - a_mean, mean_new - a_mean
+    C = S2 - m1[:, :, None] * e[:, None, :] - e[:, :, None] * m1[:, None, :] + e[:, :, None] * e[:, None, :]
+    return mean_new, C * gamma_sigma + a_cov * (1 - gamma_sigma)
+
+
 def pos_stats(poses):
     """covo.py:281: mean / population std over samples of post-step positions."""
     return np.mean(poses, axis=1), np.std(poses, axis=1)

@@ -23,16 +23,15 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
 RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 N_LOCAL, H = 65536, 32
 CU, SIMD = 256, 1024
-KERNEL_SRCS = ["covo_mpc_amd/csrc/rollout_pipe.hpp", "covo_mpc_amd/csrc/rollout.hip", "covo_mpc_amd/csrc/quad_model.hpp",
-               "covo_mpc_amd/csrc/noise_gemm.hip", "covo_mpc_amd/csrc/eps_tiles.hpp"]
+sys.path.insert(0, root)
+from bench import KERNEL_SRCS, kernel_src_sha  # noqa: E402  (ONE list: bench.py decides staleness with the same hash)
 
-
-def kernel_src_sha():
-    h = hashlib.sha256()
-    for f in KERNEL_SRCS:
-        with open(os.path.join(root, f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+# cycles a SATURATED VALU pipe needs per wave-instruction, measured with the same counters on a known load
+# (scripts/probe/valu_calib.hip -> profiles/r04_valu_calib.json: 8 independent v_fma_f32 on 8 waves per SIMD)
+try:
+    SAT_CYCLES_PER_VALU_INST = json.load(open(os.path.join(root, "profiles", "r04_valu_calib.json")))["saturated_pipe_cycles_per_inst"]
+except Exception:
+    SAT_CYCLES_PER_VALU_INST = None
 
 
 def load(which):
@@ -131,13 +130,21 @@ for tag, e in per_kernel.items():
                                   "wait_any": e["SQ_WAIT_ANY"] / wc}
         d["cycles_per_wave"] = wc * 4 / e["SQ_WAVES"]
         d["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
-        d["cycles_per_valu_inst"] = e["SQ_ACTIVE_INST_VALU"] * 4 / e["SQ_INSTS_VALU"]
         if tag.startswith("rollout"):
             d["valu_wave_insts_per_64_samples_per_step"] = e["SQ_INSTS_VALU"] / (N_LOCAL / 64) / H
-        valu = e["SQ_ACTIVE_INST_VALU"] * 4 / SIMD   # cycles a SIMD's VALU pipe executed instructions
-        d["valu_pipe_cycles_per_simd"] = valu
-        if busy:
+        # VALU-pipe utilisation, CALIBRATED.  SQ_ACTIVE_INST_VALU is a per-WAVE quad-cycle count summed
+        # over co-resident waves: it reads exactly 4 "cycles" per instruction whatever the pipe does (profiles/r04_valu_calib.json:
+        # 4.00 at every load; r03's formula read 1.79 for a saturated pipe) and is not pipe time.  What is: instructions per SIMD x
+        # the measured cycles per instruction of a saturated pipe (2.24 on gfx950 at ~2.0 GHz; a transcendental holds it ~4.5x
+        # as long, so this is a LOWER bound of the pipe's busy share for a stream with v_rsq / v_sqrt / v_log / v_rcp in it).
+        insts_simd = e["SQ_INSTS_VALU"] / SIMD
+        d["valu_insts_per_simd"] = insts_simd
+        if busy and SAT_CYCLES_PER_VALU_INST:
+            valu = insts_simd * SAT_CYCLES_PER_VALU_INST
+            d["saturated_pipe_cycles_per_valu_inst"] = SAT_CYCLES_PER_VALU_INST
+            d["valu_pipe_cycles_per_simd"] = valu
             d["valu_pipe_util"] = valu / busy
+            d["cycles_per_valu_inst_achieved"] = busy / insts_simd
             if du:
                 d["valu_pipe_floor_us_at_that_clock"] = valu / (busy / du)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and busy and e["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:

@@ -3,11 +3,14 @@ sample-sharded controller (covo_mpc_step writing this shard's rank record -> ONE
 every rank checks the sharded result (new mean AND covo.py:281's pos_mean / pos_std, which ride in the same record) against an
 unsharded controller fed the same keys.  argv: controller name, exchange ("collective": all-gather over gloo, staged through
 the host; "peer": direct writes into hipIpc-mapped buffers, csrc/exchange.hip -- then also a whole sharded episode segment
-enqueued from C by covo_run_episode)."""
+enqueued from C by covo_run_episode).  Controller "mppi-cov": MPPI with gamma_sigma = 0.3 (mppi.py:119-125) -- the 836-float
+rank records with the weighted second moments; the adapted covariances are compared too."""
 import os
 import sys
 
-os.environ["COVO_SHARED_DEVICE"] = "1"  # two ranks share cuda:0: no launch may rely on co-resident workgroups (_core.py)
+NCCL = len(sys.argv) > 3 and sys.argv[3] == "nccl"  # one GPU per rank, RCCL (only on boxes with >= 2 GPUs)
+if not NCCL:
+    os.environ["COVO_SHARED_DEVICE"] = "1"  # two ranks share cuda:0: no launch may rely on co-resident workgroups (_core.py)
 
 import numpy as np
 import torch
@@ -17,27 +20,52 @@ import torch.distributed as dist
 def main():
     name, exchange = sys.argv[1], sys.argv[2]
     inject = exchange == "auto_fail"  # rank 1 cannot export its exchange buffer: every rank must fall back, nobody may hang
+    coarse = exchange == "auto_coarse"  # coarse-grained exchange buffers on (pretended) different devices: connect must refuse
     if inject:
         exchange = "auto"
         os.environ["COVO_DEBUG_FAIL_EXCHANGE_RANK"] = "1"
-    os.environ["COVO_EXCHANGE"] = exchange
-    dist.init_process_group("gloo")
+    if coarse:
+        exchange = "auto"
+        os.environ["COVO_DEBUG_EXCHANGE_COARSE"] = "1"
+        os.environ["COVO_DEBUG_EXCHANGE_BUS_ID"] = "fake:%s" % os.environ.get("RANK", "0")
+    if exchange == "collective":
+        os.environ.pop("COVO_EXCHANGE", None)  # the DEFAULT must be the collective (the peer path is opt-in)
+    else:
+        os.environ["COVO_EXCHANGE"] = exchange
+    DEV = "cuda:0"
+    if NCCL:
+        DEV = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(DEV)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(DEV))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import covo_mpc_amd as cm
     from covo_mpc_amd import random as cr
-    task = "hovering" if name == "mppi" else "tracking_zigzag"
+    task = "hovering" if name.startswith("mppi") else "tracking_zigzag"
     env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
-                         generate_noisy_state=True, device="cuda:0")
+                         generate_noisy_state=True, device=DEV)
     N = 4096
-    cs, cps = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0", process_group=dist.group.WORLD)
-    c1, cp1 = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device="cuda:0")
+    cov = name == "mppi-cov"
+    if cov:  # quadjax's factory fixes gamma_sigma = 0 (quadrotor.py:715): built directly, lam = 0.5 so that many samples carry weight
+        _, cp0 = cm.envs.get_controller(env, "mppi", f"N{N}_H32_lam0.5", device=DEV)
+        cp0 = cp0.replace(gamma_sigma=0.3)
+        cs = cm.controllers.MPPIController(env=env, control_params=cp0, N=N, H=32, lam=0.5, device=DEV, process_group=dist.group.WORLD)
+        c1 = cm.controllers.MPPIController(env=env, control_params=cp0, N=N, H=32, lam=0.5, device=DEV)
+        cps = cp1 = cp0
+        assert cs.core.cov_records and cs.core.rec_floats == 836 and not c1.core.cov_records
+    else:
+        cs, cps = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV, process_group=dist.group.WORLD)
+        c1, cp1 = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
     # "auto": the construction-time self-test picks the peer path when it works on every rank (here: two ranks, one GPU)
-    want_exchange = ("collective" if inject else "peer") if exchange == "auto" else exchange
+    want_exchange = ("collective" if (inject or coarse) else "peer") if exchange == "auto" else exchange
+    assert cs.core.shared_device == (not NCCL)  # physical identity (PCI bus id), not the per-process device index
     assert cs.core.n_local == N // world and cs.core.offset == rank * (N // world) and cs.core.exchange == want_exchange
     assert cs.core.device_status() == 0
     params = env.default_params
     obs, info, state = env.reset(cr.PRNGKey(4), params)
-    cps = cs.reset(state, params, cs.init_control_params, cr.PRNGKey(5))
+    cps = cs.reset(state, params, cs.init_control_params, cr.PRNGKey(5))  # (built with gamma_sigma = 0.3 for "mppi-cov")
     cp1 = c1.reset(state, params, c1.init_control_params, cr.PRNGKey(5))
     key = cr.PRNGKey(6)
     for step in range(5):  # eager, capture, replays
@@ -46,6 +74,9 @@ def main():
         u1, cp1, inf1 = c1(obs, state, params, k_act, cp1, info)
         err = (cps.a_mean - cp1.a_mean).abs().max().item()
         assert err < 2e-6, (name, rank, step, err)  # online-softmax merge: fp32 reassociation only
+        if cov:
+            ec = (cps.a_cov - cp1.a_cov).abs().max().item()
+            assert ec < 2e-6 and (cps.a_cov - 0.25 * torch.eye(4, device=DEV)).abs().max().item() > 1e-3, (rank, step, ec)
         for k in ("pos_mean", "pos_std"):  # the shards' position sums travelled in the rank records (no second collective)
             e = (infs[k] - inf1[k]).abs().max().item()
             assert e < 2e-6, (name, rank, step, k, e)
@@ -60,7 +91,7 @@ def main():
         logs = []
         for ctrl in (cs, c1):
             ctrl.alias_outputs = True
-            ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(41), params, (ctrl.core.lib, ctrl.core.h), "cuda:0")
+            ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(41), params, (ctrl.core.lib, ctrl.core.h), DEV)
             cp = ctrl.reset(ep.state0, params, ctrl.init_control_params, cr.PRNGKey(42))
             cp, rng = ctrl.run_episode(ep, params, cp, cr.PRNGKey(43), n)
             logs.append((ep.read_log().copy(), cp.a_mean.cpu().numpy().copy(), ep.true.cpu().numpy().copy()))

@@ -121,7 +121,12 @@ def test_jax_stream_with_table_models(name, kind):
     bitstream (host-built table, random_jax) -- the rollout costs equal the oracle's with exactly those draws, and differ from the
     run on the library's own stream."""
     import covo_mpc_amd as cm
-    from covo_mpc_amd import random_jax as rj
+    from oracle import jax_rng_np as J  # the checker's restatement of jax's stream (not the product's host twin)
+
+    class rj:
+        PRNGKey = staticmethod(J.prng_key)
+        split = staticmethod(J.split)
+        uniform = staticmethod(lambda key, shape, lo, hi: J.uniform(key, int(np.prod(shape)), lo, hi).reshape(shape))
     N = 512
     env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
                          generate_noisy_state=True, device=DEV)

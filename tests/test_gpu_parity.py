@@ -65,12 +65,18 @@ def test_randn_matches_philox_oracle_and_is_shard_invariant():
     assert np.abs(z2 - rng_np.randn(123, 456, 1 << 33, 64, 128)).max() < 2e-5
 
 
-def test_randn_jax_equals_the_numpy_twin_and_is_shard_invariant():
-    """covo_randn_jax (csrc/rng_jax.hip) against covo_mpc_amd/random_jax.py, which is pinned to jax's published outputs
-    (tests/test_host.py): the threefry integers are exact, the normals agree to the last ulp of log1p / sqrt."""
-    from covo_mpc_amd import random_jax as rj
+def test_randn_jax_equals_the_oracle_twin_and_is_shard_invariant():
+    """covo_randn_jax (csrc/rng_jax.hip) against oracle/jax_rng_np.py -- the checker, an independent restatement pinned to jax's
+    published outputs (tests/test_oracle.py), not the product's own host twin: the threefry integers are exact, the normals
+    agree to the last ulp of log1p / sqrt."""
+    from oracle import jax_rng_np as J
+
+    class rj:  # the oracle under the names the body below uses
+        controller_epsilon = staticmethod(lambda key, N, sample_offset=0, n_samples=None: J.controller_epsilon(
+            key, N, offset=sample_offset, count=n_samples))
+        controller_epsilon_mppi = staticmethod(lambda key, N, n_samples=None: J.controller_epsilon_mppi(key, N, count=n_samples))
     N = 1000
-    key = rj.split(rj.PRNGKey(1))[1]
+    key = J.split(J.prng_key(1))[1]
     core = SamplingCore(N, 32, 0.01, 1.0, device=DEV)
     z = core.randn_jax(key).cpu().numpy().copy()
     ref = rj.controller_epsilon(key, N)
@@ -102,6 +108,80 @@ def test_noise_gemm_bit_exact(N):
     ref = CO.noise_gemm(L, mu, eps)
     assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
     assert (np.abs(got) == 1.0).mean() > 0.001  # the clip is exercised
+
+
+def test_nan_propagation_flag_in_the_action_clips():
+    """COVO_FLAG_PROPAGATE_NAN (SamplingCore(propagate_nan=True)): the clips of covo.py:224 / mppi.py:66 / quadrotor.py:223,258 keep
+    a NaN like jnp.clip = minimum(maximum(x, lo), hi); without the flag (the kernels' maxNum / minNum clip) a NaN
+    sample becomes -1.  Everything that is not NaN is bit-identical under both settings."""
+    rng = np.random.default_rng(4)
+    N = 1000
+    A = rng.normal(size=(128, 128))
+    L = np.linalg.cholesky(A @ A.T / 128 + 0.05 * np.eye(128)).astype(np.float32)
+    mu = (0.3 * rng.normal(size=128)).astype(np.float32)
+    eps = rng.normal(size=(N, 128)).astype(np.float32)
+    eps[7, 40] = np.nan                                   # one NaN draw: rows >= 40 of sample 7 (L is lower triangular)
+    mun = mu.copy()
+    mun[13] = np.nan                                      # a NaN mean entry: action 13 of EVERY sample
+    out = {}
+    for flag in (False, True):
+        core = SamplingCore(N, 32, 0.01, 1.0, device=DEV, propagate_nan=flag)
+        assert core.propagate_nan == flag
+        Ld, ed = torch.from_numpy(L).to(DEV), torch.from_numpy(eps).to(DEV)
+        a1 = core.noise_gemm(Ld, torch.from_numpy(mu).to(DEV), ed).permute(1, 0, 2).reshape(N, 128).cpu().numpy().copy()
+        a2 = core.noise_gemm(Ld, torch.from_numpy(mun).to(DEV), ed).permute(1, 0, 2).reshape(N, 128).cpu().numpy().copy()
+        Ls = torch.eye(4, device=DEV).repeat(32, 1, 1) * 0.5
+        a3 = core.noise_blockdiag(Ls, torch.from_numpy(mun).to(DEV), ed).permute(1, 0, 2).reshape(N, 128).cpu().numpy().copy()
+        out[flag] = (a1, a2, a3)
+        # the rollout's own re-clip of stripes it cannot trust (covo_rollout_cost on a handle without COVO_FLAG_ACTIONS_CLIPPED)
+        s, p, _ = make_problem(seed=3, time=10)
+        acts = sample_actions(p, rng, N)
+        acts[5, 3, 2] = np.nan
+        cost = _run_rollout(core, s, p, acts, np.zeros(3))
+        assert np.isnan(cost[5]) == flag and np.isfinite(np.delete(cost, 5)).all()
+    a1f, a2f, a3f = out[False]
+    a1t, a2t, a3t = out[True]
+    assert np.isfinite(a1f).all() and np.all(a1f[7, 40:] == -1.0)           # default: NaN loses against the clip bounds
+    assert np.isnan(a1t[7, 40:]).all() and np.isfinite(a1t[7, :40]).all()   # flag: NaN stays
+    keep = np.ones_like(a1f, dtype=bool)
+    keep[7, 40:] = False
+    assert np.array_equal(a1f[keep], a1t[keep])
+    assert np.all(a2f[:, 13] == -1.0) and np.isnan(a2t[:, 13]).all() and np.all(a3f[:, 13] == -1.0) and np.isnan(a3t[:, 13]).all()
+
+
+def test_covo_offline_hovering_nan_row_follows_the_flag():
+    """The one place quadjax makes a NaN by itself on this path: covo-offline on `hovering` -- at reset position and
+    velocity sit exactly on their targets, JAX's JVP of the norm at 0 is NaN, row 0 of a_cov_offline is NaN (the Hessian
+    kernels mirror the convention) and under jnp.clip (covo.py:224) every sample of step 0, hence every later mean, is NaN.
+    With propagate_nan=True this library does the same; by default the NaN samples of that one step become -1 and the episode
+    carries on."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="hovering", enable_randomizer=False, disturb_type="none", disable_rollover_terminate=True,
+                         generate_noisy_state=False, device=DEV)
+    params = env.default_params
+    res = {}
+    for flag in (False, True):
+        _, cp0 = cm.envs.get_controller(env, "covo-offline", "N1024_H32_lam0.01", device=DEV)
+        c = cm.controllers.CoVOController(env=env, control_params=cp0, N=1024, H=32, lam=0.01, mode="offline", device=DEV,
+                                          compute_info=False, propagate_nan=flag)
+        obs, info, state = env.reset(cr.PRNGKey(2), params)
+        cp = c.reset(state, params, cp0, cr.PRNGKey(3))
+        assert torch.isnan(cp.a_cov_offline[0]).any() and torch.isfinite(cp.a_cov_offline[1:]).all()
+        key = cr.PRNGKey(4)
+        for _ in range(3):
+            key, k_act, k_step = cr.split(key, 3)
+            u, cp, _ = c(obs, state, params, k_act, cp, info)
+            obs, state, reward, done, info = env.step(k_step, state, np.nan_to_num(u.cpu().numpy()), params)
+        res[flag] = cp.a_mean.cpu().numpy()
+    assert np.isfinite(res[False]).all()
+    assert np.isnan(res[True]).all()
+
+
+def test_device_bus_id_is_a_physical_identity():
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    bus = core.device_bus_id()
+    assert len(bus) >= 7 and bus.count(":") >= 1 and bus == SamplingCore(256, 32, 0.01, 1.0, device=DEV).device_bus_id()
 
 
 def test_in_kernel_philox_equals_randn_then_gemm():
@@ -755,7 +835,8 @@ def test_closed_loop_on_device():
 
 
 @pytest.mark.parametrize("name,exchange", [("covo-online", "collective"), ("covo-online", "peer"), ("mppi", "collective"),
-                                           ("mppi", "peer"), ("covo-online", "auto"), ("mppi", "auto_fail")])
+                                           ("mppi", "peer"), ("covo-online", "auto"), ("mppi", "auto_fail"),
+                                           ("mppi-cov", "collective"), ("mppi-cov", "peer"), ("mppi", "auto_coarse")])
 def test_two_ranks_one_gpu(name, exchange):
     """SURVEY.md 8e through the PRODUCT path: two processes (gloo rendezvous, both on cuda:0) run the sample-sharded
     controller -- fused step writing this shard's rank record (softmax partial + position sums), ONE exchange (all-gather, or
@@ -769,6 +850,25 @@ def test_two_ranks_one_gpu(name, exchange):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", script, name, exchange],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DIST_GPU_OK" in r.stdout
+
+
+@pytest.mark.parametrize("name", ["covo-online", "mppi-cov"])
+def test_two_ranks_two_gpus_rccl(name):
+    """The nccl (= RCCL) branch of exchange_records and one GPU per rank: only where the box has two GPUs (the build pool's boxes
+    have one: skipped there, so the leg stays 'unexercised on this pool' rather than silently untested on a multi-GPU box)."""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "_dist_gpu_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", script, name, "collective", "nccl"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "DIST_GPU_OK" in r.stdout
@@ -792,6 +892,12 @@ def test_device_status_is_sticky_and_refuses_further_work():
     assert core.device_status(clear=True) == _lib.COVO_DEVSTAT_GRID_BARRIER and core.device_status() == 0
     S2, L2 = core.sigma(Rm, 0.5)
     assert torch.isfinite(S2).all() and torch.isfinite(L2).all()
+    # the adjoint Hessian's costate wait raises its own bit on a time-out (round 4): same contract
+    _lib.check(core.lib.covo_debug_raise_device_status(core.h, _lib.COVO_DEVSTAT_ADJOINT, core.stream()), "raise")
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.CovoError, match="adjoint"):
+        core.sigma(Rm, 0.5)
+    assert core.device_status(clear=True) == _lib.COVO_DEVSTAT_ADJOINT
 
 
 def test_shared_device_flag_runs_the_chain_phase_by_phase_with_identical_results():
@@ -845,7 +951,13 @@ def test_controller_step_on_the_jax_bitstream(name, task):
     (covo.py:212-220 / mppi.py:53-60); the step then equals the oracle's on that epsilon, and differs from the Philox run."""
     import covo_mpc_amd as cm
     from covo_mpc_amd import random as cr
-    from covo_mpc_amd import random_jax as rj
+    from oracle import jax_rng_np as J  # the checker of the jax stream: the oracle's restatement, not the product's twin
+
+    class rj:
+        PRNGKey = staticmethod(J.prng_key)
+        split = staticmethod(J.split)
+        controller_epsilon = staticmethod(J.controller_epsilon)
+        controller_epsilon_mppi = staticmethod(J.controller_epsilon_mppi)
     N = 512
     env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="none", disable_rollover_terminate=True,
                          generate_noisy_state=True, device=DEV)

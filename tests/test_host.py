@@ -89,16 +89,20 @@ def test_zigzag_generator_shape_and_speed():
     assert np.allclose(np.linalg.norm(vel[0]), seg_len / 41 / 0.02, rtol=1e-5)  # divides by point_per_seg + 1
 
 
-def test_world_size_2_gloo_exchange():
-    """Two CPU processes (gloo): each reduces its shard (oracle arithmetic) to one record, ONE all-gather
-    exchanges the records, both merge -> identical to the unsharded update."""
+@pytest.mark.parametrize("world,kind", [(2, "plain"), (8, "plain"), (8, "cov")])
+def test_world_size_N_gloo_exchange(world, kind):
+    """`world` CPU processes (gloo; 8 = the ranks of one MI355X node): each reduces its shard (oracle arithmetic) to ONE rank
+    record -- softmax partial + position sums, "cov": + MPPI's second moments (mppi.py:119-125) --, the product's
+    exchange_records makes all records known to all ranks, every rank merges device-free -> identical to the unsharded update
+    on every rank (tests/_dist_worker.py)."""
     script = os.path.join(ROOT, "tests", "_dist_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", script],
-                       env=env, capture_output=True, text=True, timeout=300)
+    port = str(29533 + world + (1 if kind == "cov" else 0))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", port, script, kind],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "DIST_OK" in r.stdout
+    assert f"DIST_OK {world} {kind}" in r.stdout
 
 
 def test_env_reward_and_disturbance_model_reach_the_c_params():

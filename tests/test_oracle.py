@@ -282,3 +282,38 @@ def test_force_table_semantics_equal_the_model_functions(kind):
     R1 = CO.hessian(s, p, a, H, kind=kind, draws=draws)
     R2 = CO.hessian(s, p, a, H, kind=kind, table=tab)
     assert np.abs(R1 - R2).max() < 1e-12 * max(1.0, np.abs(R1).max())
+
+
+def test_jax_bitstream_oracle_known_answers():
+    """oracle/jax_rng_np.py -- the independent checker of the product's jax-stream path (covo_randn_jax, noise_stream = "jax") --
+    against everything jax publishes about its default stream: the three Random123 threefry2x32-20 vectors jax's own tests use,
+    and the values its documentation prints for PRNGKey(0) (split: "JAX PRNG design"; uniform / normal: "Sharp bits"; the ten
+    normals of the quickstart) and normal(PRNGKey(42)).  The fp32 erfinv is bounded by scipy's double-precision one."""
+    from oracle import jax_rng_np as J
+    for key, ctr, exp in [((0, 0), (0, 0), (0x6B200159, 0x99BA4EFE)),
+                          ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+                          ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))]:
+        y0, y1 = J.threefry_block(key[0], key[1], [ctr[0]], [ctr[1]])
+        assert (int(y0[0]), int(y1[0])) == exp
+    k = J.prng_key(0)
+    assert k.tolist() == [0, 0]
+    assert J.split(k).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    assert abs(float(J.uniform(k, 1)[0]) - 0.41845703) < 1e-8
+    assert abs(float(J.normal(k, 1)[0]) - (-0.20584226)) < 2e-8
+    quick = [-0.3721109, 0.26423115, -0.18252768, -0.7368197, -0.44030377, -0.1521442, -0.67135346, -0.5908641, 0.73168886,
+             0.5673026]
+    assert np.abs(J.normal(k, 10) - np.array(quick, dtype=np.float32)).max() < 1e-7
+    assert abs(float(J.normal(J.prng_key(42), 1)[0]) - (-0.18471177)) < 2e-8
+    z, zx = J.normal(J.prng_key(9), 1 << 18), J.normal_exact(J.prng_key(9), 1 << 18)
+    d = np.abs(z - zx)
+    assert d.max() < 5e-5 and d[np.abs(zx) < 3].max() < 4e-6 and abs(z.std() - 1) < 5e-3
+    # layout: odd counts are padded with one zero counter and cut again; the controllers' row of a sharded draw
+    assert np.array_equal(J.bits(k, 3), J._stream(k, [0, 1, 2]))
+    e = J.controller_epsilon(J.prng_key(7), 6, offset=2, count=3)
+    assert e.shape == (3, 128) and np.array_equal(e[0], J.normal(J.split(J.prng_key(7), 6)[2], 128))
+    # and the product's host twin (covo_mpc_amd/random_jax.py: another expression of the same published algorithms) says the same
+    from covo_mpc_amd import random_jax as rj
+    assert np.array_equal(rj.split(rj.PRNGKey(3), 5), J.split(J.prng_key(3), 5))
+    assert np.array_equal(rj.controller_epsilon(rj.PRNGKey(7), 6, sample_offset=2, n_samples=3), e)
+    em = J.controller_epsilon_mppi(J.prng_key(5), 16, count=4)
+    assert np.array_equal(rj.controller_epsilon_mppi(rj.PRNGKey(5), 16, n_samples=4), em)
