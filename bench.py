@@ -173,13 +173,128 @@ def pmc_counters(args, n_local):
         return None, None
 
 
+def bench_envs(args, world, rank, device, backend):
+    """--config envs = BASELINE.json configs[4]: covo-online on the lissajous `tracking` task with domain randomisation
+    (quadjax/envs/quadrotor.py:132-171), E env instances x N = 4096 samples per GPU in ONE batched graph (covo_mpc_step_batched),
+    the 256 instances of the config env-sharded 32 per rank over 8 GPUs -- "replicas only": complete independent MPC problems,
+    NO collective on the data path (the process group only brackets the timed region).  weak scaling: per-GPU work is fixed.
+    A step = one batched control step = E_local controller __call__s; value = instances x steps / s over all ranks,
+    teacher-forced on the instances' noisy states after a short closed-loop warm-up (means carried), like the default config.
+    Extra: closed_loop (covo_run_episode_batched: control + env step of all instances, one host sync per episode), the step's
+    launch groups, and the batched rollout kernel against the HBM roofline."""
+    import torch
+    import torch.distributed as dist
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    H, E = 32, args.envs_per_gpu
+    N = args.N if args.N is not None else 4096
+    env = cm.envs.Quad3D(task="tracking", obs_type="quad_params", enable_randomizer=True, disturb_type="gaussian",
+                         disable_rollover_terminate=True, generate_noisy_state=True, device=device)
+    c0, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H{H}_lam{args.lam}", device=device, compute_info=False)
+    cp0 = c0.init_control_params
+    c0.core.close()
+    del c0
+    gids = [rank * E + e for e in range(E)]  # global instance ids of this rank
+    params = [env.sample_params(cr.PRNGKey(1000 + g)) for g in gids]
+    b = cm.controllers.BatchedCoVOController(env, E, N, H, args.lam, discount=cp0.discount, gamma_mean=cp0.gamma_mean,
+                                             sample_sigma=cp0.sample_sigma, a_mean_init=cp0.a_mean, device=device)
+    ep = cm.envs.BatchedDeviceEpisode(env, [cr.PRNGKey(2000 + g) for g in gids], params, (b.core.lib, b.core.h), device)
+    rngs = np.stack([np.asarray(cr.PRNGKey(3000 + g)) for g in gids])
+    rngs = b.run_episode(ep, rngs, 20)          # off the reset point, on the device
+    torch.cuda.synchronize()
+    keys = np.stack([np.asarray(cr.PRNGKey(4000 + g)) for g in gids]).astype(np.uint32)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        keys[:, 1] += 1
+        b(None, keys)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keys[:, 1] += 1
+        b(None, keys)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(b.a_mean).all(), "non-finite a_mean after the timed region"
+    # launch groups of the step (graph replays of 10 copies each, GPU time per copy)
+    phases = {}
+    try:
+        t_all = b.time_phases(2 | 4 | 8 | 16 | 32)
+        phases = {"hessian_us": b.time_phases(2), "sigma_us": b.time_phases(4), "noise_gemm_us": b.time_phases(8),
+                  "rollout_us": b.time_phases(16), "update_us": b.time_phases(32), "all_but_begin_us": t_all}
+    except Exception as e:  # noqa: BLE001
+        phases = {"error": str(e)}
+    # closed loop: one 300-step episode of all instances, controller and env on the device
+    closed = None
+    if not args.no_closed_loop:
+        ep2 = cm.envs.BatchedDeviceEpisode(env, [cr.PRNGKey(5000 + g) for g in gids], params, (b.core.lib, b.core.h), device)
+        b.a_mean.copy_(torch.as_tensor(cp0.a_mean, device=device).reshape(1, -1).expand(E, -1))
+        r2 = np.stack([np.asarray(cr.PRNGKey(6000 + g)) for g in gids])
+        r2 = b.run_episode(ep2, r2, 5)            # first-use costs (re-capture on the new buffers), untimed
+        T = params[0].max_steps_in_episode - 5
+        barrier()
+        t0 = time.perf_counter()
+        b.run_episode(ep2, r2, T)
+        log = ep2.read_log()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        closed = {"unit": "control-steps/s (env instances x steps, control + env step on the device)", "value": world * E * T / el,
+                  "steps_per_instance": int(T), "err_pos_mean_m": float(log[:, 5:, 1].mean()),
+                  "err_pos_max_instance_m": float(log[:, 5:, 1].mean(axis=1).max())}
+    if rank == 0:
+        alg_bytes = E * N * ROLLOUT_BYTES_PER_SAMPLE
+        ro_us = phases.get("rollout_us")
+        out = {
+            "metric": "mpc_control_steps_per_sec", "value": world * E * args.steps / elapsed,
+            "unit": "control-steps/s (env instances x steps)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"covo-online `tracking` with domain randomisation, {world * E} env instances x N={N} H={H} "
+                                   f"lam={args.lam} sigma=0.5: {E} instances per GPU in one batched graph (covo_mpc_step_batched), "
+                                   f"env-sharded over {world} rank(s), no collective (BASELINE.json configs[4]; teacher-forced noisy "
+                                   "states after a 20-step closed-loop warm-up)",
+                       "controller": "covo-online", "envs_total": world * E, "envs_per_gpu": E, "N_per_env": N, "H": H},
+            "phases_us_per_batched_step": phases,
+        }
+        if ro_us:
+            ach = alg_bytes / (ro_us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "rollout_pipe3_kernel<..., BATCHED = true, REC = true> (all instances, one launch)",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg_bytes, "launch_us": ro_us,
+                               "launch_us_statistic": "graph replay of 10 copies of the batched rollout launch on the step's buffers "
+                                                      "(covo_debug_time_batched), fastest of 3 replays"}
+        if closed is not None:
+            out["closed_loop"] = closed
+        print(json.dumps(out))
+    b.core.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="samples", choices=["samples", "envs"],
+                    help="samples: BASELINE configs[3] (default; the headline: N samples sharded over the GPUs); envs: configs[4] "
+                         "(domain-randomised env instances, env-sharded, no collective)")
+    ap.add_argument("--envs-per-gpu", type=int, default=32, help="--config envs: instances per GPU (256 / 8)")
     ap.add_argument("--controller", default="covo-online", choices=["covo-online", "covo-offline", "mppi"])
-    ap.add_argument("--N", type=int, default=65536, help="global number of samples")
+    ap.add_argument("--N", type=int, default=None, help="global number of samples (default 65536; --config envs: per instance, default 4096)")
     ap.add_argument("--lam", type=float, default=0.01)
     ap.add_argument("--info", action="store_true", help="also compute pos_mean/pos_std (covo.py:281); XLA drops "
                     "them as dead code in the reference's eval loop (quadrotor.py:523-538)")
@@ -212,6 +327,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(device))
         pg = dist.group.WORLD
+    if args.config == "envs":
+        return bench_envs(args, world, rank, device, backend)
+    if args.N is None:
+        args.N = 65536
 
     import covo_mpc_amd as cm
     from covo_mpc_amd import random as cr

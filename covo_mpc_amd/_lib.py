@@ -127,10 +127,15 @@ _SIGS = {
     "covo_run_episode": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), _P, _P, C.c_int32,
                                    C.c_float, _P, C.POINTER(C.c_uint32), C.c_int32, _P]),
     "covo_mpc_step_batched": (C.c_int, [_P, C.POINTER(BatchArgsC), C.POINTER(EnvParamsC), C.POINTER(C.c_uint32), _P]),
+    "covo_env_step_batched": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P,
+                                        C.POINTER(C.c_uint32), C.c_int32, C.c_float, _P, C.c_int32, C.c_int32, _P]),
+    "covo_run_episode_batched": (C.c_int, [_P, C.POINTER(BatchArgsC), C.POINTER(EnvParamsC), _P, _P, C.c_int32, C.c_float, _P,
+                                           C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, _P]),
     "covo_debug_set_ns_tail": (C.c_int, [C.c_int, C.c_int]),
     "covo_debug_set_ns_deflate": (C.c_int, [C.c_int]),
     "covo_debug_time_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.POINTER(C.c_float), _P]),
+    "covo_debug_time_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_sigma_jacobi": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "covo_sigma_profile": (C.c_int, [_P, _P, C.c_float, _P, _P, _P, _P]),
     "covo_mpc_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_uint32, C.c_uint32,

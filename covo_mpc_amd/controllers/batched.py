@@ -67,6 +67,8 @@ class BatchedCoVOController:
         a.a, a.cost, a.groupmin = self._a.data_ptr(), self._cost.data_ptr(), self._groupmin.data_ptr()
         a.gamma_mean, a.sample_sigma = self.gamma_mean, self.sample_sigma
         self._args = a
+        self._states_buf = self._states
+        self._episode = None
 
     def __call__(self, noisy_states, rng_acts):
         """One control step of every instance.  noisy_states: E env states (or a float32 [E, 32] device tensor of
@@ -74,13 +76,58 @@ class BatchedCoVOController:
         if self._args is None:
             raise RuntimeError("call set_instances(env_states, env_params) first")
         torch = self.core.torch
-        if torch.is_tensor(noisy_states):
-            self._states.copy_(noisy_states, non_blocking=True)
+        buf = self._states_buf  # the tensor args.states points at: the controller's own, or a bound episode's noisy states
+        if noisy_states is None or noisy_states is buf:
+            pass  # a bound BatchedDeviceEpisode: the env step kernel has already written them
+        elif torch.is_tensor(noisy_states):
+            buf.copy_(noisy_states, non_blocking=True)
         else:
             packed = [as_device_state(s, self.core.device).packed for s in noisy_states]
-            torch.stack(packed, out=self._states)
+            torch.stack(packed, out=buf)
         keys = np.ascontiguousarray(np.asarray(rng_acts, dtype=np.uint32).reshape(self.E, 2))
         check(self.core.lib.covo_mpc_step_batched(self.core.h, C.byref(self._args), self._params,
                                                   keys.ctypes.data_as(C.POINTER(C.c_uint32)), self.core.stream()),
               "covo_mpc_step_batched")
         return self.a_mean.view(self.E, COVO_H, 4)[:, 0]
+
+    def time_phases(self, step_mask: int, reps: int = 10) -> float:
+        """GPU microseconds of the selected launch groups of the LAST batched step (2 Hessian, 4 Sigma, 8 GEMM, 16 rollout,
+        32 update), replayed `reps` times from one graph (covo_debug_time_batched)."""
+        us = C.c_float(0.0)
+        self.core.torch.cuda.synchronize()
+        check(self.core.lib.covo_debug_time_batched(self.core.h, int(step_mask), int(reps), C.byref(us), self.core.stream()),
+              "covo_debug_time_batched")
+        return float(us.value)
+
+    def bind_episode(self, episode):
+        """Plan from a BatchedDeviceEpisode's buffers: its noisy states ARE the controller's input (rewritten by every env step on
+        the device), its trajectories and parameters the instances' (once per episode)."""
+        if episode.E != self.E:
+            raise ValueError(f"episode has {episode.E} instances, controller {self.E}")
+        self._traj = (episode.pos_traj, episode.vel_traj, episode.T)
+        self._params = episode.params_c
+        a = _lib.BatchArgsC()
+        a.n_envs, a.n_samples, a.T = self.E, self.N, episode.T
+        a.states, a.pos_traj, a.vel_traj = episode.noisy.data_ptr(), episode.pos_traj.data_ptr(), episode.vel_traj.data_ptr()
+        a.a_mean, a.a_cov = self.a_mean.data_ptr(), self.a_cov.data_ptr()
+        a.a, a.cost, a.groupmin = self._a.data_ptr(), self._cost.data_ptr(), self._groupmin.data_ptr()
+        a.gamma_mean, a.sample_sigma = self.gamma_mean, self.sample_sigma
+        self._args = a
+        self._states_buf = episode.noisy
+        self._episode = episode
+
+    def run_episode(self, episode, rngs, n_steps: int):
+        """covo_run_episode_batched: n_steps x { batched control step on the noisy states -> batched env step }, all enqueued by
+        ONE C call; every instance's key chain threaded like eval_env's run_one_step (quadrotor.py:520-538).  rngs: uint32
+        [E, 2] -> the chains' keys after the segment.  Asynchronous; episode.read_log() synchronises."""
+        if getattr(self, "_episode", None) is not episode:
+            self.bind_episode(episode)
+        env = self.env
+        keys = np.ascontiguousarray(np.asarray(rngs, dtype=np.uint32).reshape(self.E, 2)).copy()
+        check(self.core.lib.covo_run_episode_batched(
+            self.core.h, C.byref(self._args), self._params, _lib.ptr(episode.true), _lib.ptr(episode.acc_traj),
+            1 if env.generate_noisy_state else 0, float(env.default_params.obs_noise_scale), _lib.ptr(episode.log),
+            int(episode.log.shape[1]), int(episode.n_steps), keys.ctypes.data_as(C.POINTER(C.c_uint32)), int(n_steps),
+            self.core.stream()), "covo_run_episode_batched")
+        episode.n_steps += int(n_steps)
+        return keys

@@ -609,6 +609,88 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
     return 0;
 }
 
+static int check_batch_models(const covo_env_params *params, int E, const char *what)
+{
+    for (int e = 0; e < E; ++e) {
+        CHECK_MODEL(&params[e], what);
+        if (params[e].reward_kind != params[0].reward_kind || params[e].rollover_terminate != params[0].rollover_terminate ||
+            params[e].disturb_kind != params[0].disturb_kind || params[e].max_steps_in_episode != params[0].max_steps_in_episode) {
+            covo_set_error("%s: instance %d differs from instance 0 in reward_kind / rollover_terminate / disturb_kind / "
+                           "max_steps_in_episode (one kernel variant per launch)", what, e);
+            return COVO_E_BADARG;
+        }
+    }
+    return 0;
+}
+
+int covo_env_step_batched(covo_handle_t h, int32_t n_envs, float *states, float *noisy_states, const float *pos_traj,
+                          const float *vel_traj, const float *acc_traj, int32_t T, const covo_env_params *params,
+                          const float *a_mean, const uint32_t *step_keys, int32_t noisy_on, float obs_noise_scale, float *log,
+                          int32_t log_stride, int32_t log_index, void *stream)
+{
+    REQUIRE(h, "covo_env_step_batched: null handle");
+    CHECK_DEVICE(h, "covo_env_step_batched");
+    REQUIRE(n_envs > 0 && n_envs <= COVO_MAX_ENVS, "covo_env_step_batched: n_envs=%d outside (0, %d]", n_envs, COVO_MAX_ENVS);
+    REQUIRE(states && noisy_states && pos_traj && vel_traj && acc_traj && params && a_mean && step_keys && T > 0,
+            "covo_env_step_batched: bad argument");
+    REQUIRE(log == nullptr || (log_index >= 0 && log_index < log_stride), "covo_env_step_batched: log_index=%d outside [0, %d)",
+            log_index, log_stride);
+    int rc = check_batch_models(params, n_envs, "covo_env_step_batched");
+    if (rc) return rc;
+    const void *inst = nullptr;
+    if ((rc = batch_env_inst(h, params, n_envs, (hipStream_t)stream, &inst))) return rc;
+    return launch_env_step_batched(states, noisy_states, pos_traj, vel_traj, acc_traj, T, params[0], inst, n_envs, a_mean, step_keys,
+                                   noisy_on, obs_noise_scale, log, log_stride, log_index, (hipStream_t)stream);
+}
+
+int covo_run_episode_batched(covo_handle_t h, const covo_batch_args *args, const covo_env_params *params, float *states_true,
+                             const float *acc_traj, int32_t noisy_on, float obs_noise_scale, float *log, int32_t log_stride,
+                             int32_t log_index, uint32_t *rngs, int32_t n_steps, void *stream)
+{
+    REQUIRE(h, "covo_run_episode_batched: null handle");
+    CHECK_DEVICE(h, "covo_run_episode_batched");
+    REQUIRE(args && params && states_true && acc_traj && rngs && n_steps > 0, "covo_run_episode_batched: bad argument");
+    const int E = args->n_envs;
+    REQUIRE(E > 0 && E <= COVO_MAX_ENVS, "covo_run_episode_batched: n_envs=%d outside (0, %d]", E, COVO_MAX_ENVS);
+    REQUIRE(args->n_samples > 0 && args->n_samples <= h->cfg.n_local, "covo_run_episode_batched: n_samples=%d outside (0, %d]",
+            args->n_samples, h->cfg.n_local);
+    REQUIRE(args->states && args->pos_traj && args->vel_traj && args->a_mean && args->a && args->cost && args->groupmin && args->T > 0,
+            "covo_run_episode_batched: bad step arguments");
+    REQUIRE(log == nullptr || (log_index >= 0 && log_index + n_steps <= log_stride),
+            "covo_run_episode_batched: log rows [%d, %d) outside [0, %d)", log_index, log_index + n_steps, log_stride);
+    int rc = check_batch_models(params, E, "covo_run_episode_batched");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const void *inst = nullptr;
+    if ((rc = batch_env_inst(h, params, E, s, &inst))) return rc;
+    uint32_t act_keys[2 * COVO_MAX_ENVS], step_keys[2 * COVO_MAX_ENVS], next[2 * COVO_MAX_ENVS];
+    for (int t = 0; t < n_steps; ++t) {
+        // per instance, run_one_step (quadrotor.py:520-538): rng, rng_act, rng_step, rng_control = split(rng, 4); ...; rng, _ = split(rng)
+        for (int e = 0; e < E; ++e) {
+            const uint32_t key[2] = {rngs[2 * e], rngs[2 * e + 1]};
+            uint32_t nrng[2];
+            host_philox_split(key, 0u, nrng);
+            host_philox_split(key, 1u, &act_keys[2 * e]);
+            host_philox_split(key, 2u, &step_keys[2 * e]);
+            host_philox_split(nrng, 0u, &next[2 * e]);
+        }
+        if ((rc = covo_step_batched_impl(h, args, params, act_keys, s))) return rc;
+        if ((rc = launch_env_step_batched(states_true, const_cast<float *>(args->states), args->pos_traj, args->vel_traj, acc_traj,
+                                          args->T, params[0], inst, E, args->a_mean, step_keys, noisy_on, obs_noise_scale, log,
+                                          log_stride, log_index + t, s)))
+            return rc;
+        std::memcpy(rngs, next, (size_t)2 * E * sizeof(uint32_t));
+    }
+    return 0;
+}
+
+int covo_debug_time_batched(covo_handle_t h, int32_t step_mask, int32_t reps, float *us_out, void *stream)
+{
+    REQUIRE(h && us_out && reps > 0, "covo_debug_time_batched: bad argument");
+    CHECK_DEVICE(h, "covo_debug_time_batched");
+    return covo_debug_time_batched_impl(h, step_mask, reps, us_out, (hipStream_t)stream);
+}
+
 int covo_mpc_step_batched(covo_handle_t h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,
                           void *stream)
 {

@@ -199,11 +199,19 @@ SymStatsOut sigma_ns_stats_out(void *workspace);
 void step_state_destroy(covo_ctx *h);
 void step_graphs_drop(covo_ctx *h);  // before re-allocating h->ws_sigma / h->ws_hess: captured graphs hold their addresses
 void batch_state_destroy(covo_ctx *h);
+int covo_debug_time_batched_impl(covo_ctx *h, int step_mask, int reps, float *us_out, hipStream_t run);
 int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,
                            hipStream_t s);
 int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_args *args, uint32_t key0, uint32_t key1,
                    const float *f_shared, hipStream_t s);
 int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s);
+size_t env_step_inst_bytes(int n);
+void env_step_fill_inst(const covo_env_params *params, int n, void *out);  // host: EnvInst[n] (to be copied to the device)
+int launch_env_step_batched(float *states, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
+                            const covo_env_params &params0, const void *inst_dev, int E, const float *a_mean,
+                            const uint32_t *step_keys, int noisy_on, float obs_noise_scale, float *log, int log_stride,
+                            int log_index, hipStream_t s);
+int batch_env_inst(covo_ctx *h, const covo_env_params *params, int E, hipStream_t s, const void **inst_dev);  // step.hip
 int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
                     const covo_env_params &p, const float *action, const uint32_t *step_key, int noisy_on,
                     float obs_noise_scale, float *log, int log_index, hipStream_t s);

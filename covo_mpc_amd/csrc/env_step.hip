@@ -14,6 +14,7 @@
 // counter layout: block j = Philox4x32-10(counter (j,0,0,0xB175), key), words b[0..2n), u1 = b[i], u2 = b[n+i],
 // z = sqrt(-2 ln u1) cos(2 pi u2) in fp64, rounded to fp32.  Auto-reset on done (base.py:33-39) stays on the
 // host: the done flag is logged, an episode of max_steps_in_episode steps never raises it before its end.
+#include <cstring>
 #include "covo_common.hpp"
 #include "disturb_model.hpp"
 
@@ -53,7 +54,7 @@ __device__ __forceinline__ void host_split(const uint32_t (&key)[2], uint32_t i,
     child[1] = r[1];
 }
 
-__global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
+__device__ __forceinline__ void env_step_body(const EnvStepArgs &A)
 {
     __shared__ float z[16];
     __shared__ float sst[COVO_STATE_FLOATS];   // the state as loaded, then as stepped
@@ -194,6 +195,103 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A)
         asm volatile("" : "+v"(nz));  // keeps hipcc from contracting the product into the add below (__fadd_rn / __fmul_rn do not)
         A.noisy[lane] = noisy_field ? v + nz : v;
     }
+}
+
+__global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A) { env_step_body(A); }
+
+// ---- E env instances in one launch (BASELINE configs[4]; quadrotor.py:132-171 samples each instance's parameters, :506-591
+// drives it): workgroup e steps instance e -- its own true state, noisy copy, trajectories, action (the first four entries of
+// its mean), model constants and key.  Same body as the single-instance kernel, so instance e's step is bit-identical to
+// covo_env_step on that instance alone.
+struct EnvInst {            // what domain randomisation varies per instance (device array, built once per episode)
+    qm::Consts<float> c;
+    dm::Model dist;
+};
+struct EnvStepBatchKeys {
+    uint32_t k[COVO_MAX_ENVS][2];  // the key Quad3D.step receives, per instance
+};
+struct EnvStepBatchArgs {
+    float *states;         // [E][32] true states, updated in place
+    float *noisy;          // [E][32] the noisy copies (the batched controller's `states`)
+    const float *pos_traj, *vel_traj, *acc_traj;  // [E][T][3]
+    const float *a_mean;   // [E][128]: instance e's action = a_mean[e][0..3]
+    float *log;            // [E][log_stride][4] or null
+    const EnvInst *inst;   // [E]
+    int T, log_index, log_stride, noisy_on;
+    float obs_noise_scale;
+    int reward, max_steps, rollover;
+};
+__global__ __launch_bounds__(64) void env_step_batched_kernel(const EnvStepBatchArgs B, const EnvStepBatchKeys K)
+{
+    const int e = blockIdx.x;
+    EnvStepArgs A;
+    A.state = B.states + (size_t)e * COVO_STATE_FLOATS;
+    A.noisy = B.noisy + (size_t)e * COVO_STATE_FLOATS;
+    A.pos_traj = B.pos_traj + (size_t)e * B.T * 3;
+    A.vel_traj = B.vel_traj + (size_t)e * B.T * 3;
+    A.acc_traj = B.acc_traj + (size_t)e * B.T * 3;
+    A.action = B.a_mean + (size_t)e * COVO_NA;
+    A.log = B.log ? B.log + (size_t)e * B.log_stride * 4 : nullptr;
+    A.T = B.T;
+    A.log_index = B.log_index;
+    A.noisy_on = B.noisy_on;
+    A.obs_noise_scale = B.obs_noise_scale;
+    A.dist = B.inst[e].dist;
+    A.reward = B.reward;
+    A.step_key[0] = K.k[e][0];
+    A.step_key[1] = K.k[e][1];
+    A.c = B.inst[e].c;
+    A.max_steps = B.max_steps;
+    A.rollover = B.rollover;
+    env_step_body(A);
+}
+
+size_t env_step_inst_bytes(int n) { return (size_t)n * sizeof(EnvInst); }
+void env_step_fill_inst(const covo_env_params *params, int n, void *out)
+{
+    EnvInst *o = reinterpret_cast<EnvInst *>(out);
+    for (int i = 0; i < n; ++i) {
+        o[i].c = make_consts<float>(params[i]);
+        o[i].dist = dm::make_model(params[i]);
+    }
+}
+
+// params0: what all instances share (reward, max_steps, rollover switch); the per-instance constants come from `inst`
+int launch_env_step_batched(float *states, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
+                            const covo_env_params &params0, const void *inst_dev, int E, const float *a_mean,
+                            const uint32_t *step_keys /* host [E][2] */, int noisy_on, float obs_noise_scale, float *log,
+                            int log_stride, int log_index, hipStream_t s)
+{
+    if (E <= 0 || E > COVO_MAX_ENVS) {
+        covo_set_error("env_step_batched: n_envs=%d outside (0, %d]", E, COVO_MAX_ENVS);
+        return COVO_E_BADARG;
+    }
+    EnvStepBatchArgs B;
+    B.states = states;
+    B.noisy = noisy;
+    B.pos_traj = pos_traj;
+    B.vel_traj = vel_traj;
+    B.acc_traj = acc_traj;
+    B.a_mean = a_mean;
+    B.log = log;
+    B.inst = reinterpret_cast<const EnvInst *>(inst_dev);
+    B.T = T;
+    B.log_index = log_index;
+    B.log_stride = log_stride;
+    B.noisy_on = noisy_on;
+    B.obs_noise_scale = obs_noise_scale;
+    B.reward = params0.reward_kind;
+    B.max_steps = params0.max_steps_in_episode;
+    B.rollover = params0.rollover_terminate != 0;
+    EnvStepBatchKeys K;
+    std::memset(&K, 0, sizeof(K));
+    for (int e = 0; e < E; ++e) {
+        K.k[e][0] = step_keys[2 * e];
+        K.k[e][1] = step_keys[2 * e + 1];
+    }
+    hipLaunchKernelGGL(env_step_batched_kernel, dim3(E), dim3(64), 0, s, B, K);
+    COVO_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_env_step(float *state, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,

@@ -461,6 +461,9 @@ struct BatchState {
     void *models = nullptr;         // dm::Model[E]            (disturbance tables, drag / mixed Hessian)
     float *tab_rollout = nullptr, *tab_hess = nullptr;  // [E][H][4] the step's disturbance tables (periodic / sin / drag / mixed)
     bool tables = false;            // the instances' disturbance model needs them
+    void *env_inst = nullptr;       // EnvInst[env_inst_n] (env_step.hip): the per-instance constants of covo_env_step_batched
+    int env_inst_n = 0;
+    std::vector<covo_env_params> env_inst_params;
     std::vector<char> ro_args_host;
     std::vector<covo_env_params> params;
     covo_batch_args key;
@@ -513,11 +516,41 @@ void step_graphs_drop(covo_ctx *h)
     if (b) b->have_key = false;
 }
 
+// the device array of per-instance env constants for covo_env_step_batched, rebuilt only when the parameters change
+int batch_env_inst(covo_ctx *h, const covo_env_params *params, int E, hipStream_t s, const void **inst_dev)
+{
+    BatchState *b = reinterpret_cast<BatchState *>(h->batch);
+    if (!b) {
+        b = new BatchState();
+        h->batch = b;
+    }
+    const bool same = b->env_inst != nullptr && b->env_inst_n == E && (int)b->env_inst_params.size() == E &&
+                      std::memcmp(b->env_inst_params.data(), params, (size_t)E * sizeof(covo_env_params)) == 0;
+    if (!same) {
+        COVO_CHECK_HIP(hipStreamSynchronize(s));  // launches that read the old array are done
+        if (b->env_inst_n != E) {
+            (void)hipFree(b->env_inst);
+            b->env_inst = nullptr;
+            b->env_inst_n = 0;
+            COVO_CHECK_HIP(hipMalloc(&b->env_inst, env_step_inst_bytes(E)));
+            b->env_inst_n = E;
+        }
+        std::vector<char> tmp(env_step_inst_bytes(E));
+        env_step_fill_inst(params, E, tmp.data());
+        COVO_CHECK_HIP(hipMemcpy(b->env_inst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+        b->env_inst_params.assign(params, params + E);
+    }
+    *inst_dev = b->env_inst;
+    return 0;
+}
+
 void batch_state_destroy(covo_ctx *h)
 {
     BatchState *b = reinterpret_cast<BatchState *>(h->batch);
     if (!b) return;
     batch_state_free(b);
+    (void)hipFree(b->env_inst);  // (not in batch_state_free: the batched step re-allocates its scratch when the instance count
+                                 // changes, possibly between batch_env_inst and the env step launch that reads this array)
     delete b;
     h->batch = nullptr;
 }
@@ -529,25 +562,75 @@ void batch_state_destroy(covo_ctx *h)
 static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, hipStream_t s)
 {
     const int E = a.n_envs, N = a.n_samples;
+    const int M = g_dbg_step_mask;  // 63 outside covo_debug_time_batched (which replays selected launch groups)
     int rc;
-    hipLaunchKernelGGL(batch_begin_kernel, dim3(E), dim3(COVO_NA + 64), 0, s, a.a_mean, b->a_mean_shift, b->dyn);
+    if (M & 1) hipLaunchKernelGGL(batch_begin_kernel, dim3(E), dim3(COVO_NA + 64), 0, s, a.a_mean, b->a_mean_shift, b->dyn);
     // covo.py:231: CoVO's sampling rollouts run step_env(deterministic=True); get_hessian likewise (covo.py:152)
-    if (b->tables && (rc = launch_disturb_tables_batched(b->models, a.states, b->dyn, E, 1, b->tab_rollout, b->tab_hess, s))) return rc;
-    if ((rc = launch_hessian(a.states, a.pos_traj, a.vel_traj, a.T, b->params[0], b->a_mean_shift, E, b->R, h->ws_hess, s,
-                             b->consts, (size_t)a.T * 3, nullptr, b->tables ? b->tab_hess : nullptr, b->models, h->status_dev)))
+    if ((M & 1) && b->tables && (rc = launch_disturb_tables_batched(b->models, a.states, b->dyn, E, 1, b->tab_rollout, b->tab_hess, s)))
+        return rc;
+    if ((M & 2) && (rc = launch_hessian(a.states, a.pos_traj, a.vel_traj, a.T, b->params[0], b->a_mean_shift, E, b->R, h->ws_hess, s,
+                                        b->consts, (size_t)a.T * 3, nullptr, b->tables ? b->tab_hess : nullptr, b->models,
+                                        h->status_dev)))
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
-    if ((rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
-                              (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0))) return rc;
-    if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E, false, nullptr,
-                                covo_propagate_nan(h))))
+    if ((M & 4) && (rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
+                                         (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0))) return rc;
+    if ((M & 8) && (rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E, false, nullptr,
+                                           covo_propagate_nan(h))))
         return rc;
-    if ((rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, s))) return rc;
+    if ((M & 16) && (rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, s))) return rc;
+    if (!(M & 32)) return 0;
     const int G = rollout_workgroups(N, false, E);
     if (G <= h->max_red_blocks)  // the rollout's workgroups have left the records (rollout_record): instance e's are [e][G]
         return launch_merge(b->partials, G, h->cfg.lam, b->a_mean_shift, a.gamma_mean, a.a_mean, s, nullptr, E);
     return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, b->a_mean_shift, a.gamma_mean, a.a_mean, s,
                                  b->partials, E);
+}
+
+// profiling aid (bench.py --config envs): `reps` copies of the selected launch groups of the LAST covo_mpc_step_batched call in
+// one graph; GPU microseconds per copy.  step_mask as in covo_debug_time_step (1 begin, 2 Hessian, 4 Sigma, 8 GEMM, 16 rollout,
+// 32 update).  The copies re-read the same means and states (the begin launch is normally left out: it would re-split the keys).
+int covo_debug_time_batched_impl(covo_ctx *h, int step_mask, int reps, float *us_out, hipStream_t run)
+{
+    BatchState *b = reinterpret_cast<BatchState *>(h->batch);
+    if (!b || !b->have_key) {
+        covo_set_error("covo_debug_time_batched: call covo_mpc_step_batched first");
+        return COVO_E_BADARG;
+    }
+    hipStream_t cs = h->side_stream;
+    COVO_CHECK_HIP(hipStreamSynchronize(run));
+    g_dbg_step_mask = step_mask;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    int rc = 0;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        for (int r = 0; r < reps && !rc; ++r) rc = batch_enqueue(h, b, b->key, cs);
+        e = hipStreamEndCapture(cs, &g);
+    }
+    g_dbg_step_mask = 63;
+    if (rc) return rc;
+    COVO_CHECK_HIP(e);
+    COVO_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t e0, e1;
+    COVO_CHECK_HIP(hipEventCreate(&e0));
+    COVO_CHECK_HIP(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        COVO_CHECK_HIP(hipEventRecord(e0, run));
+        COVO_CHECK_HIP(hipGraphLaunch(ge, run));
+        COVO_CHECK_HIP(hipEventRecord(e1, run));
+        COVO_CHECK_HIP(hipStreamSynchronize(run));
+        float ms = 0.f;
+        COVO_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0 && ms < best) best = ms;
+    }
+    *us_out = best * 1e3f / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+    return 0;
 }
 
 int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_env_params *params, const uint32_t *keys,

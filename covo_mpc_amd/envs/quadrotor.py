@@ -325,6 +325,97 @@ class DeviceEpisode:
         return out
 
 
+class BatchedDeviceEpisode:
+    """E independent env instances on the device (BASELINE configs[4]): instance e has its own (domain-randomised,
+    quadrotor.py:132-171) parameters, reset key, true state, noisy copy, reference trajectory and log.  `step` launches
+    covo_env_step_batched -- every instance's Quad3D.step in ONE launch; BatchedCoVOController.run_episode enqueues whole
+    episodes (control step + env step for all instances) from one C call."""
+
+    def __init__(self, env: "Quad3D", keys, params_list, lib_handle, device):
+        import torch
+        from .. import _lib
+        from ..controllers.base import env_model_params_c
+        self.env, self.params, self.device = env, list(params_list), device
+        self.lib, self.h = lib_handle
+        self._lib = _lib
+        self.E = len(self.params)
+        if not 0 < self.E <= _lib.COVO_MAX_ENVS or len(keys) != self.E:
+            raise ValueError(f"{self.E} instances (1..{_lib.COVO_MAX_ENVS}), {len(keys)} keys")
+        states, noisy = [], []
+        for k, p in zip(keys, self.params):
+            obs, info, st = env.reset(k, p)
+            states.append(st)
+            noisy.append(info["noisy_state"] if info["noisy_state"] is not None else st)
+        self.states0 = states
+        T = int(states[0].pos_traj.shape[0])
+        if any(int(s.pos_traj.shape[0]) != T for s in states):
+            raise ValueError("all instances must share the trajectory length T")
+        if any(p.max_steps_in_episode != self.params[0].max_steps_in_episode for p in self.params):
+            raise ValueError("all instances must share max_steps_in_episode")
+        self.T = T
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        self.true = up(np.stack([s.pack() for s in states]))
+        self.noisy = up(np.stack([s.pack() for s in noisy]))
+        self.pos_traj = up(np.stack([s.pos_traj for s in states]))
+        self.vel_traj = up(np.stack([s.vel_traj for s in states]))
+        self.acc_traj = up(np.stack([s.acc_traj for s in states]))
+        self.log = torch.zeros((self.E, self.params[0].max_steps_in_episode + 1, 4), dtype=torch.float32, device=device)
+        self.params_c = (_lib.EnvParamsC * self.E)(*[env_model_params_c(env, p) for p in self.params])
+        self.n_steps = 0
+
+    def step(self, step_keys, a_mean, stream=None):
+        """step_keys: uint32 [E, 2] (the key Quad3D.step receives, per instance); a_mean: float32 [E, 128] device tensor whose first
+        four entries per instance are the action.  Asynchronous."""
+        import ctypes as C
+        import torch
+        keys = np.ascontiguousarray(np.asarray(step_keys, dtype=np.uint32).reshape(self.E, 2))
+        ptr = self._lib.ptr
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if stream is None else stream
+        self._lib.check(self.lib.covo_env_step_batched(
+            self.h, self.E, ptr(self.true), ptr(self.noisy), ptr(self.pos_traj), ptr(self.vel_traj), ptr(self.acc_traj), self.T,
+            self.params_c, ptr(a_mean), keys.ctypes.data_as(C.POINTER(C.c_uint32)), 1 if self.env.generate_noisy_state else 0,
+            float(self.env.default_params.obs_noise_scale), ptr(self.log), int(self.log.shape[1]), self.n_steps, st),
+            "covo_env_step_batched")
+        self._keep = (keys, a_mean)
+        self.n_steps += 1
+
+    def read_log(self):
+        """-> float32 [E, n_steps, 4] = reward, err_pos, err_vel, done (pre-step states); synchronises and checks the device status."""
+        out = self.log[:, :self.n_steps].cpu().numpy()
+        st = int(self.lib.covo_device_status(self.h, 0))
+        if st != 0:
+            raise self._lib.CovoError(f"device status 0x{st:x} after the batched episode segment (covo_device_status)")
+        return out
+
+
+def eval_env_batched(env: Quad3D, n_envs: int, controller_params: str = "N4096_H32_lam0.01", n_steps=None, seed: int = 1, device=None,
+                     verbose: bool = True):
+    """BASELINE configs[4] as a driver: `n_envs` domain-randomised instances of `env` (each with parameters from
+    env.sample_params, its own reset key and key chain, quadrotor.py:132-171 + 506-591 per instance) run one episode under
+    covo-online, controller and env on the device, ONE host sync.  -> mean position error per instance [n_envs]."""
+    from .. import controllers
+    rng = crandom.PRNGKey(seed)
+    ks = crandom.split(rng, 3 * n_envs + 1)
+    params = [env.sample_params(ks[e]) for e in range(n_envs)]
+    N, H, lam = (lambda p: (int(p[0][1:]), int(p[1][1:]), float(p[2][3:])))(controller_params.split("_"))
+    c0, cp0 = get_controller(env, "covo-online", controller_params, device=device, compute_info=False)
+    cp0 = c0.init_control_params
+    b = controllers.BatchedCoVOController(env, n_envs, N, H, lam, discount=cp0.discount, gamma_mean=cp0.gamma_mean,
+                                          sample_sigma=cp0.sample_sigma, a_mean_init=cp0.a_mean, device=c0.core.device)
+    del c0
+    ep = BatchedDeviceEpisode(env, ks[n_envs:2 * n_envs], params, (b.core.lib, b.core.h), b.core.device)
+    T = params[0].max_steps_in_episode if n_steps is None else int(n_steps)
+    t0 = time_module.time()
+    b.run_episode(ep, ks[2 * n_envs:3 * n_envs], T)
+    log = ep.read_log()
+    if verbose:
+        el = time_module.time() - t0
+        print(f"{n_envs} instances x {T} steps in {el:.2f}s = {n_envs * T / el:.0f} env-steps/s; "
+              f"err_pos mean over instances: {log[:, :, 1].mean():.3f} (min {log[:, :, 1].mean(axis=1).min():.3f}, "
+              f"max {log[:, :, 1].mean(axis=1).max():.3f})")
+    return log[:, :, 1].mean(axis=1)
+
+
 def eval_env_device(env: Quad3D, controller, total_steps=30000, num_trajs=4, seed=1, verbose=True):
     """eval_env (quadrotor.py:506-591) with the env step on the device: same key threading, same protocol (num_trajs
     reset keys x episodes x max_steps_in_episode steps, mean/std over episodes of the mean position error), one host

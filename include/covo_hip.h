@@ -486,12 +486,35 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
                      const float *acc_traj, int32_t noisy_on, float obs_noise_scale, float *log, uint32_t *rng,
                      int32_t n_steps, void *stream);
 
+/* BASELINE configs[4] end to end: the env step and the episode driver for n_envs INDEPENDENT, domain-randomised env instances
+ * (quadrotor.py:132-171 samples each instance's parameters; :506-591 is the per-instance eval loop, which the reference reaches
+ * through jax.vmap).  covo_env_step_batched = covo_env_step for every instance in ONE launch (workgroup e = instance e: its own
+ * true state states[e], noisy copy noisy[e], trajectories [e][T][3], action a_mean[e][0..3], parameters params[e], key
+ * step_keys[e]; log float[n_envs][log_stride][4], nullable); instance e's step is bit-identical to covo_env_step on it alone.
+ * All instances share reward_kind, rollover_terminate, max_steps_in_episode and disturb_kind (as in covo_mpc_step_batched).
+ * covo_run_episode_batched = n_steps x { covo_mpc_step_batched on the noisy states -> covo_env_step_batched }, every instance's
+ * key chain threaded like run_one_step (rngs: host uint32[n_envs][2], in/out); args->states = the noisy states (rewritten by
+ * every env step).  Asynchronous; one host sync per episode segment.  "Replicas only": instances shard over ranks with no
+ * collective (bench.py --config envs). */
+int covo_env_step_batched(covo_handle_t h, int32_t n_envs, float *states, float *noisy_states, const float *pos_traj,
+                          const float *vel_traj, const float *acc_traj, int32_t T, const covo_env_params *params /* [n_envs] */,
+                          const float *a_mean /* [n_envs][128] */, const uint32_t *step_keys /* host [n_envs][2] */,
+                          int32_t noisy_on, float obs_noise_scale, float *log, int32_t log_stride, int32_t log_index, void *stream);
+int covo_run_episode_batched(covo_handle_t h, const covo_batch_args *args, const covo_env_params *params /* [n_envs] */,
+                             float *states_true /* [n_envs][32] */, const float *acc_traj /* [n_envs][T][3] */, int32_t noisy_on,
+                             float obs_noise_scale, float *log /* [n_envs][log_stride][4], nullable */, int32_t log_stride,
+                             int32_t log_index, uint32_t *rngs /* host [n_envs][2], in/out */, int32_t n_steps, void *stream);
+
 /* Profiling aid: `reps` copies of the selected launches of one control step, captured into one hipGraph and
  * replayed; *us_out = GPU microseconds per copy.  step_mask bits: 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM,
  * 16 rollout, 32 softmax update; hess_mask bits: the four kernels of the adjoint Hessian; sigma_stages 1..4:
  * prep+squarings, +Ritz, +Newton-Schulz, +finalize.  Uses the buffers in `args` exactly like covo_mpc_step. */
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
                          int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream);
+
+/* The same for the LAST covo_mpc_step_batched call of the handle (all instances; the begin launch, bit 1, re-splits the keys and
+ * is normally left out). */
+int covo_debug_time_batched(covo_handle_t h, int32_t step_mask, int32_t reps, float *us_out, void *stream);
 
 /* Test hook: a one-thread kernel on `stream` ORs `bits` into the handle's status word the way a failing kernel would
  * (device store to host-mapped memory); covo_device_status / COVO_E_DEVICE can then be exercised without starving a barrier. */

@@ -636,3 +636,136 @@ def test_mppi_step_with_covariance_adaptation(graph, monkeypatch):
     cov = outs[0][1].astype(np.float64)
     assert np.abs(cov - np.transpose(cov, (0, 2, 1))).max() < 1e-7
     assert all(np.linalg.eigvalsh(c).min() > 0 for c in cov) and np.abs(cov - 0.25 * np.eye(4)).max() > 1e-3
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs[4] end to end (round 4)
+def _dr_env():
+    import covo_mpc_amd as cm
+    return cm.envs.Quad3D(task="tracking", obs_type="quad_params", enable_randomizer=True, disturb_type="gaussian",
+                          disable_rollover_terminate=True, generate_noisy_state=True, device=DEV)
+
+
+def _oracle_params(params):
+    """ref_np.Params of one domain-randomised instance (quadrotor.py:135-160 varies m, I, action_scale, alpha_bodyrate,
+    disturb_params; I does not enter the body-rate model)."""
+    return R.Params(m=float(params.m), action_scale=float(params.action_scale), alpha_bodyrate=float(params.alpha_bodyrate),
+                    disturb_params=tuple(float(x) for x in params.disturb_params)).fp32()
+
+
+def test_env_instances_32_batched_step_vs_fp64_oracle():
+    """BASELINE configs[4] at its per-GPU shape: E = 32 domain-randomised `tracking` instances x N = 4096 in
+    ONE covo_mpc_step_batched call; three sampled instances are checked against the fp64 oracle run with THEIR OWN parameters:
+    per-sample rollout costs (1e-5), the Sigma each sampled from (oracle hyper-dual Hessian -> eigh, 2e-5) and the new mean
+    (oracle softmax of the oracle costs)."""
+    import covo_mpc_amd as cm
+    N, E = 4096, 32
+    env = _dr_env()
+    params = [env.sample_params(cr.PRNGKey(500 + e)) for e in range(E)]
+    ep = None
+    c0, cp0 = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV, compute_info=False)
+    cp0 = c0.init_control_params
+    b = cm.controllers.BatchedCoVOController(env, E, N, 32, 0.01, discount=cp0.discount, gamma_mean=cp0.gamma_mean,
+                                             sample_sigma=cp0.sample_sigma, a_mean_init=cp0.a_mean, device=DEV)
+    ep = cm.envs.BatchedDeviceEpisode(env, [cr.PRNGKey(600 + e) for e in range(E)], params, (b.core.lib, b.core.h), DEV)
+    b.bind_episode(ep)
+    assert np.ptp([float(p.m) for p in params]) > 1e-3  # different plants
+    # a few closed-loop steps first (states off the reset point), all on the device
+    rngs = np.stack([np.asarray(cr.PRNGKey(700 + e)) for e in range(E)])
+    rngs = b.run_episode(ep, rngs, 4)
+    torch.cuda.synchronize()
+    noisy = ep.noisy.cpu().numpy().copy()
+    a_mean_before = b.a_mean.cpu().numpy().copy()
+    k_acts = np.stack([np.asarray(cr.split(cr.PRNGKey(800 + e))[1]) for e in range(E)])
+    b(None, k_acts)  # ONE batched control step on the episode's current noisy states
+    torch.cuda.synchronize()
+    for e in (0, 13, 31):
+        traj = (ep.states0[e].pos_traj, ep.states0[e].vel_traj, ep.states0[e].acc_traj)
+        so = _oracle_state(noisy[e], traj)
+        po = _oracle_params(params[e])
+        a_dev = b._a[e].permute(1, 0, 2).contiguous().cpu().numpy()
+        cost_ref = CO.rollout(so, po, a_dev.astype(np.float64), 1.0, np.zeros(3), dtype=np.float64)
+        assert rel_err(b._cost[e].cpu().numpy(), cost_ref).max() < 1e-5, e
+        am = R.shift_mean(a_mean_before[e].reshape(32, 4).astype(np.float64))
+        Sref = R.optimize_sigma(CO.hessian(so, po, am.reshape(-1), 32), 0.5, 32, 4)
+        S = b.a_cov[e].cpu().numpy()
+        assert np.linalg.norm(S - Sref) / np.linalg.norm(Sref) < 2e-5, e
+        a_ref, _ = R.softmax_update(cost_ref, a_dev.astype(np.float64), 0.01, 1.0, am)
+        top2 = np.sort(cost_ref)[:2]
+        err = np.abs(b.a_mean[e].view(32, 4).cpu().numpy() - a_ref).max()
+        assert err < 1e-4 or (top2[1] - top2[0]) < 1e-3, (e, err)
+    assert np.abs(b.a_mean[0].cpu().numpy() - b.a_mean[13].cpu().numpy()).max() > 1e-4  # different plans
+
+
+def test_batched_env_step_vs_oracle_and_single_instance_kernel():
+    """covo_env_step_batched (E = 32, one launch): every instance's step equals covo_env_step on that instance alone bit for bit,
+    and three sampled instances land where oracle/ref_np.py::step_env + noisy_state (fp64, THEIR parameters, the draws their
+    step keys give) put them."""
+    import covo_mpc_amd as cm
+    E = 32
+    env = _dr_env()
+    params = [env.sample_params(cr.PRNGKey(900 + e)) for e in range(E)]
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    keys0 = [cr.PRNGKey(1000 + e) for e in range(E)]
+    ep = cm.envs.BatchedDeviceEpisode(env, keys0, params, (core.lib, core.h), DEV)
+    singles = {e: cm.envs.DeviceEpisode(env, keys0[e], params[e], (core.lib, core.h), DEV) for e in (0, 13, 31)}
+    rng = np.random.default_rng(7)
+    key = cr.PRNGKey(77)
+    a_mean = torch.zeros((E, 128), dtype=torch.float32, device=DEV)
+    for t in range(12):
+        before = ep.true.cpu().numpy().copy()
+        key, sub = cr.split(key)
+        step_keys = np.asarray(cr.split(sub, E))
+        u = np.clip(np.array([-0.3378, 0, 0, 0]) + 0.3 * rng.normal(size=(E, 4)), -1.2, 1.2).astype(np.float32)
+        a_mean[:, :4] = torch.from_numpy(u).to(DEV)
+        ep.step(step_keys, a_mean)
+        t_dev, n_dev = ep.true.cpu().numpy(), ep.noisy.cpu().numpy()
+        for e, se in singles.items():
+            se.step(step_keys[e], torch.from_numpy(u[e]).to(DEV))
+            assert torch.equal(se.true, ep.true[e]) and torch.equal(se.noisy, ep.noisy[e]), (t, e)
+            kd, kp, kv, kq, ko = cm.envs.DeviceEpisode.leaf_keys(step_keys[e])
+            p = _oracle_params(params[e])
+            traj = (ep.states0[e].pos_traj, ep.states0[e].vel_traj, ep.states0[e].acc_traj)
+            s = _oracle_state(before[e], traj)
+            nxt, r, done = R.step_env(s, u[e].astype(np.float64), p, R.Disturb("gaussian", cr.normal(kd, (3,)).astype(np.float64)),
+                                      False, R.REWARD_FNS["penyaw"])
+            noisy = R.noisy_state(nxt, p, cr.normal(kp, (3,)).astype(np.float64), cr.normal(kv, (3,)).astype(np.float64),
+                                  cr.normal(kq, (4,)).astype(np.float64), cr.normal(ko, (3,)).astype(np.float64))
+            assert np.abs(t_dev[e, :25] - _pack_oracle(nxt)[:25]).max() < 2e-6, (t, e)
+            assert np.abs(n_dev[e, :25] - _pack_oracle(noisy)[:25]).max() < 2e-6, (t, e)
+    log = ep.read_log()
+    assert log.shape == (E, 12, 4)
+    for e, se in singles.items():
+        assert np.array_equal(se.read_log(), log[e])
+
+
+def test_run_episode_batched_equals_per_instance_episodes():
+    """covo_run_episode_batched (E instances: control step + env step, every key chain threaded on the host side of ONE C call)
+    against E separate covo_run_episode runs of plain covo-online controllers with the same keys: logs, means and final states
+    bit-identical per instance (the batched step is bit-identical to the single step, the batched env step to the single one)."""
+    import covo_mpc_amd as cm
+    N, E, n = 1024, 4, 20
+    env = _dr_env()
+    params = [env.sample_params(cr.PRNGKey(40 + e)) for e in range(E)]
+    c0, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV, compute_info=False)
+    cp0 = c0.init_control_params
+    b = cm.controllers.BatchedCoVOController(env, E, N, 32, 0.01, discount=cp0.discount, gamma_mean=cp0.gamma_mean,
+                                             sample_sigma=cp0.sample_sigma, a_mean_init=cp0.a_mean, device=DEV)
+    reset_keys = [cr.PRNGKey(50 + e) for e in range(E)]
+    ep = cm.envs.BatchedDeviceEpisode(env, reset_keys, params, (b.core.lib, b.core.h), DEV)
+    rngs0 = np.stack([np.asarray(cr.PRNGKey(60 + e)) for e in range(E)])
+    rngs = b.run_episode(ep, rngs0, n // 2)
+    rngs = b.run_episode(ep, rngs, n - n // 2)  # two segments: the chains and the log rows continue
+    log = ep.read_log()
+    assert log.shape == (E, n, 4) and np.all(log[:, 1:, 1] > 0)  # (row 0: the reset state sits on its target)
+    for e in range(E):
+        c, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV, compute_info=False)
+        c.alias_outputs = True
+        se = cm.envs.DeviceEpisode(env, reset_keys[e], params[e], (c.core.lib, c.core.h), DEV)
+        cp = c.reset(se.state0, params[e], c.init_control_params, cr.PRNGKey(2))
+        cp, rng = c.run_episode(se, params[e], cp, rngs0[e], n)
+        assert np.array_equal(se.read_log(), log[e]), e
+        assert torch.equal(cp.a_mean.reshape(-1), b.a_mean[e]) and torch.equal(se.true, ep.true[e]), e
+        assert np.array_equal(np.asarray(rng, dtype=np.uint32), rngs[e]), e
+    # the driver: parameters, reset keys and key chains drawn from one seed
+    err = cm.envs.eval_env_batched(env, 3, f"N{N}_H32_lam0.01", n_steps=30, seed=5, device=DEV, verbose=False)
+    assert err.shape == (3,) and np.all(np.isfinite(err)) and np.all(err < 0.5)

@@ -120,7 +120,7 @@ def test_nan_propagation_flag_in_the_action_clips():
     L = np.linalg.cholesky(A @ A.T / 128 + 0.05 * np.eye(128)).astype(np.float32)
     mu = (0.3 * rng.normal(size=128)).astype(np.float32)
     eps = rng.normal(size=(N, 128)).astype(np.float32)
-    eps[7, 40] = np.nan                                   # one NaN draw: rows >= 40 of sample 7 (L is lower triangular)
+    L[50, 20] = np.nan                                    # a NaN factor entry (a NaN Sigma row): action 50 of every sample
     mun = mu.copy()
     mun[13] = np.nan                                      # a NaN mean entry: action 13 of EVERY sample
     out = {}
@@ -141,11 +141,9 @@ def test_nan_propagation_flag_in_the_action_clips():
         assert np.isnan(cost[5]) == flag and np.isfinite(np.delete(cost, 5)).all()
     a1f, a2f, a3f = out[False]
     a1t, a2t, a3t = out[True]
-    assert np.isfinite(a1f).all() and np.all(a1f[7, 40:] == -1.0)           # default: NaN loses against the clip bounds
-    assert np.isnan(a1t[7, 40:]).all() and np.isfinite(a1t[7, :40]).all()   # flag: NaN stays
-    keep = np.ones_like(a1f, dtype=bool)
-    keep[7, 40:] = False
-    assert np.array_equal(a1f[keep], a1t[keep])
+    assert np.isfinite(a1f).all() and np.all(a1f[:, 50] == -1.0)            # default: NaN loses against the clip bounds
+    assert np.isnan(a1t[:, 50]).all() and np.isfinite(np.delete(a1t, 50, axis=1)).all()   # flag: NaN stays
+    assert np.array_equal(np.delete(a1f, 50, axis=1), np.delete(a1t, 50, axis=1))
     assert np.all(a2f[:, 13] == -1.0) and np.isnan(a2t[:, 13]).all() and np.all(a3f[:, 13] == -1.0) and np.isnan(a3t[:, 13]).all()
 
 
