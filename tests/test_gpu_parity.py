@@ -156,7 +156,7 @@ def test_covo_offline_hovering_nan_row_follows_the_flag():
     import covo_mpc_amd as cm
     from covo_mpc_amd import random as cr
     env = cm.envs.Quad3D(task="hovering", enable_randomizer=False, disturb_type="none", disable_rollover_terminate=True,
-                         generate_noisy_state=False, device=DEV)
+                         generate_noisy_state=True, device=DEV)
     params = env.default_params
     res = {}
     for flag in (False, True):
@@ -1054,3 +1054,33 @@ def test_sigma_deflation_on_real_hessians():
     for i, Rm in enumerate(mats):
         ref = R.optimize_sigma(Rm, 0.5, 32, 4)
         assert np.linalg.norm(Sb[i].cpu().numpy() - ref) / np.linalg.norm(ref) < 1e-6, i
+
+
+@pytest.mark.parametrize("config", ["samples", "envs"])
+def test_bench_multi_rank_path_rehearsal(config):
+    """bench.py's N > 1 path (rendezvous on 127.0.0.1, sharding, barrier + max-over-ranks timing, rank-0 JSON line) with two ranks
+    SHARING this box's one GPU over gloo (COVO_BENCH_BACKEND=gloo: functional rehearsal only -- the product backend is nccl = RCCL,
+    one rank per GPU, which this pool cannot run).  samples: N sharded, one exchange of the rank records per step ("strong");
+    envs: BASELINE configs[4], env instances sharded, no collective on the data path ("weak")."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = "29551" if config == "samples" else "29553"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PYTHONPATH=root, COVO_BENCH_BACKEND="gloo",
+               COVO_SHARED_DEVICE="1")
+    extra = ["--N", "2048"] if config == "samples" else ["--config", "envs", "--envs-per-gpu", "2", "--N", "1024"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+                        "--warmup", "2", "--no-closed-loop", "--no-cpu-baseline", "--no-info-leg"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["metric"] == "mpc_control_steps_per_sec"
+    if config == "samples":
+        assert d["scaling"] == "strong" and d["config"]["N_local"] == 1024 and "collective" in d["config"]["workload"]
+    else:
+        assert d["scaling"] == "weak" and d["config"]["envs_total"] == 4 and "no collective" in d["config"]["workload"]
