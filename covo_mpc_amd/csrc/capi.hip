@@ -87,6 +87,8 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     h->exchange = nullptr;
     const int nb = (cfg->n_local + 255) / 256, ng = (cfg->n_local + 63) / 64;
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&h->ws_ticket, COVO_U1_MAX_BATCH * sizeof(unsigned)));
+    COVO_CHECK_HIP(hipMemset(h->ws_ticket, 0, COVO_U1_MAX_BATCH * sizeof(unsigned)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials_cov, softmax_cov_workspace_floats(h->max_red_blocks) * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)(nb > 256 ? nb : 256) * COVO_H * 6 * sizeof(double)));  // one row per rollout workgroup
@@ -121,6 +123,7 @@ int covo_destroy(covo_handle_t h)
     } while (0)
     DESTROY(hipFree(h->ws_partials));
     DESTROY(hipFree(h->ws_partials_cov));
+    DESTROY(hipFree(h->ws_ticket));
     DESTROY(hipFree(h->ws_blockmin));
     DESTROY(hipFree(h->ws_stats));
     DESTROY(hipFree(h->ws_sigma));

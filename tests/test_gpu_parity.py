@@ -1084,3 +1084,44 @@ def test_bench_multi_rank_path_rehearsal(config):
         assert d["scaling"] == "strong" and d["config"]["N_local"] == 1024 and "collective" in d["config"]["workload"]
     else:
         assert d["scaling"] == "weak" and d["config"]["envs_total"] == 4 and "no collective" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("lam", [0.01, 0.5, 5.0])
+def test_one_launch_update_experiment_matches_the_default_path(lam):
+    """COVO_UPDATE=one_launch (softmax_update1_kernel: plain rollout + ONE update launch with a sparse and a dense mode; measured
+    slower than the default record epilogue + merge, kept as an opt-in experiment): same plans as the default path to fp32
+    reassociation, at lambdas where a handful (sparse mode), thousands and all samples (dense mode, ticket + records) carry weight.
+    The switch is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import numpy as np, torch, sys
+sys.path.insert(0, {root!r})
+import covo_mpc_amd as cm
+from covo_mpc_amd import random as cr
+env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                     generate_noisy_state=True, device="cuda:0")
+params = env.default_params
+out = []
+for name in ("mppi", "covo-online"):
+    c, cp = cm.envs.get_controller(env, name, "N4096_H32_lam{lam}", device="cuda:0", compute_info=False)
+    obs, info, state = env.reset(cr.PRNGKey(3), params)
+    cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
+    key = cr.PRNGKey(6)
+    for i in range(4):
+        key, k_act, k_step = cr.split(key, 3)
+        u, cp, _ = c(obs, state, params, k_act, cp, info)
+        obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+    out.append(cp.a_mean.cpu().numpy())
+np.save(sys.argv[1], np.stack(out))
+"""
+    res = []
+    for mode in ("records", "one_launch"):
+        path = f"/tmp/covo_update_{mode}_{lam}.npy"
+        env = dict(os.environ, COVO_UPDATE=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        res.append(np.load(path))
+    assert np.isfinite(res[0]).all() and np.abs(res[0] - res[1]).max() < 2e-5, np.abs(res[0] - res[1]).max()
