@@ -93,6 +93,18 @@ def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
                       f"softmax update, OpenMP on all host cores; {el:.1f} s of CPU work"}
 
 
+def sigma_chain_counts(core):
+    """(squarings, Newton-Schulz iterations) the Sigma chain of the LAST covo-online step ran (scalar slots of its workspace;
+    synchronises).  The launch count of a step is data dependent: these are what make two values comparable."""
+    import torch
+    from covo_mpc_amd import _lib
+    out = torch.zeros(24, dtype=torch.float64).pin_memory()
+    _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out), 11 * 128 * 128, 24, core.stream()), "sigma workspace")
+    torch.cuda.synchronize()
+    o = out.numpy()
+    return float(o[8]), float(o[6])  # SC_SQ, SC_ITERS (csrc/sigma_ns.hip)
+
+
 def closed_loop(env, controller, params, T):
     """the same controller in CLOSED loop for one episode (env step included): with the env step as a
     device kernel and the whole episode enqueued by one C call (covo_run_episode: one host sync per episode) and with the Python env on the host (one sync and
@@ -131,6 +143,19 @@ def closed_loop(env, controller, params, T):
     torch.cuda.synchronize()
     res["host_env"] = T / (time.perf_counter() - t0)
     res["host_env_err_pos_mean_m"] = float(np.mean(errs))
+    if getattr(controller, "mode", None) == "online":
+        # the Sigma chain's data-dependent iteration counts over a closed-loop episode (untimed pass, one read-back per step)
+        obs, info, state = env.reset(cr.PRNGKey(21), params)
+        cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(22))
+        key = cr.PRNGKey(23)
+        cnt = []
+        for _ in range(T):
+            key, k_act, k_step = cr.split(key, 3)
+            u, cp, _ = controller(obs, state, params, k_act, cp, info)
+            cnt.append(sigma_chain_counts(core))
+            obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+        res["sigma_chain_mean_squarings"] = float(np.mean([c[0] for c in cnt]))
+        res["sigma_chain_mean_newton_schulz_iterations"] = float(np.mean([c[1] for c in cnt]))
     return res
 
 
@@ -449,6 +474,34 @@ def main():
         except Exception:
             in_step_us = gemm_in_step_us = None
 
+    # ---- what the timed steps ran, for comparing values like for like: the Sigma chain's data-dependent
+    # squaring / Newton-Schulz counts on the timed states (an untimed replay, one read-back per step), and the step's launch
+    # groups split into what every rank of a sample-sharded run REPEATS (Hessian + Sigma chain) and what shrinks with 1 / G
+    # (noise GEMM, rollout, update): the expected strong scaling is on the line, not left to be discovered (item 5)
+    chain_counts = split = None
+    if args.controller == "covo-online" and rank == 0:
+        try:
+            cpx = cp
+            cnt = []
+            for i in range(min(args.steps, 100)):
+                _, cpx = step(args.warmup + i, key, cpx)
+                cnt.append(sigma_chain_counts(core))
+            chain_counts = {"mean_squarings": float(np.mean([c[0] for c in cnt])),
+                            "mean_newton_schulz_iterations": float(np.mean([c[1] for c in cnt])), "steps": len(cnt)}
+        except Exception as e:  # noqa: BLE001
+            chain_counts = {"error": str(e)}
+    if world == 1:
+        try:
+            rep = core.time_phases(2 | 4) if args.controller == "covo-online" else 0.0
+            sh = core.time_phases(8 | 16 | 32)
+            split = {"replicated_us": rep, "sharded_us": sh,
+                     "note": "graph replay of the launch groups of one step at N_local = N: Hessian + Sigma chain are repeated by every "
+                             "rank of a sample-sharded run (north_star: the eigendecomposition stays single-GPU), noise GEMM + "
+                             "rollout + update shrink with 1 / G and ONE ~10-20 us exchange of the 2 064-byte rank records is added: "
+                             f"expected speed-up at G = 8 about {(rep + sh) / (rep + sh / 8 + 15.0):.2f}x (unmeasured: no multi-GPU box)"}
+        except Exception as e:  # noqa: BLE001
+            split = {"error": str(e)}
+
     n_local, exchange_name = core.n_local, core.exchange
     closed = closed_loop(env, controller, params, n_states) if (world == 1 and rank == 0 and not args.no_closed_loop) else None
 
@@ -546,6 +599,10 @@ def main():
                                     "flop_per_sample": {"dense_equivalent": GEMM_FLOP_PER_SAMPLE_DENSE,
                                                         "issued": GEMM_FLOP_PER_SAMPLE_ISSUED},
                                     "counters": (kin.get("noise_gemm") or {}).get("derived")}
+        if chain_counts is not None:
+            out["sigma_chain"] = chain_counts
+        if split is not None:
+            out["sample_sharding_split"] = split
         if closed is not None:
             out["closed_loop"] = closed
         if world == 1 and not args.no_cpu_baseline:

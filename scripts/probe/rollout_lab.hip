@@ -14,6 +14,10 @@
 #include "../../covo_mpc_amd/csrc/rollout.hip"
 
 void covo_set_error(const char *fmt, ...) { (void)fmt; }
+// what rollout.hip expects from the rest of the library (not linked into the lab)
+int noise_gemm_groups_per_workgroup(int, int) { return 4; }
+void launch_rollout_variant_r0(const RolloutArgs &, const RolloutArgs *, int, bool, int, bool, hipStream_t) {}
+void launch_rollout_variant_r1(const RolloutArgs &, const RolloutArgs *, int, bool, int, bool, hipStream_t) {}
 
 static float time_launches(const std::function<void()> &fn, int reps)
 {
@@ -76,7 +80,7 @@ int main(int argc, char **argv)
         hipMalloc(&dg, (size_t)(N / 64 + 1) * 4);
         hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice);
         RolloutArgs A;
-        fill_rollout_args(A, dst, dpt, dvt, T, prm, fsh, da, N, 1.0f, dc, dg, nullptr, nullptr);
+        fill_rollout_args(A, dst, dpt, dvt, T, prm, fsh, da, N, 1.0f, dc, dg, nullptr, nullptr, nullptr);
         RolloutArgs A2 = A;
         A2.cost = dc2;
         A.clip = A2.clip = 0;
@@ -110,6 +114,12 @@ int main(int argc, char **argv)
         report("pipe3 CH=" #CH " GROUPS=" #G, [&] {                                                                               \
             hipLaunchKernelGGL((rollout_pipe3_kernel<true, false, CH, G>), dim3((N + 64 * G - 1) / (64 * G)), dim3(192 * G), 0, 0, A2, nullptr); }, true)
         PIPE3(1, 1); PIPE3(2, 1); PIPE3(1, 2); PIPE3(1, 4); PIPE3(2, 4);
+#define PIPE4(CH, G)                                                                                                             \
+        report("pipe4 CH=" #CH " GROUPS=" #G, [&] {                                                                               \
+            hipLaunchKernelGGL((rollout_pipe4_kernel<true, false, CH, G>), dim3((N + 64 * G - 1) / (64 * G)), dim3((2 + CH) * 64 * G), 0, 0, A2, nullptr); }, true)
+        PIPE4(2, 1); PIPE4(2, 2); PIPE4(2, 4); PIPE4(4, 1); PIPE4(4, 2); PIPE4(1, 4);
+        report("pipe4 CH=2 GROUPS=4 +rollover", [&] { hipLaunchKernelGGL((rollout_pipe4_kernel<true, true, 2, 4>), dim3((N + 255) / 256), dim3(1024), 0, 0, A2, nullptr); }, false);
+        report("pipe4 CH=2 GROUPS=4 discount", [&] { hipLaunchKernelGGL((rollout_pipe4_kernel<false, false, 2, 4>), dim3((N + 255) / 256), dim3(1024), 0, 0, A2, nullptr); }, true);
         report("pipe3 CH=1 GROUPS=4 +rollover", [&] { hipLaunchKernelGGL((rollout_pipe3_kernel<true, true, 1, 4>), dim3((N + 255) / 256), dim3(768), 0, 0, A2, nullptr); }, false);
         report("pipe3 CH=1 GROUPS=4 discount", [&] { hipLaunchKernelGGL((rollout_pipe3_kernel<false, false, 1, 4>), dim3((N + 255) / 256), dim3(768), 0, 0, A2, nullptr); }, true);
         report("pipe3 CH=2 no barriers (garbage)", [&] { hipLaunchKernelGGL((rollout_pipe3_kernel<true, false, 2, 1, false, -2>), dim3((N + 63) / 64), dim3(192), 0, 0, A2, nullptr); }, false);
