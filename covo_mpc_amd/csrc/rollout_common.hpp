@@ -67,12 +67,17 @@ template <int NWAVES, int NW>
 __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost, bool valid, int n, int wave, bool carrier, int lane,
                                                int wg, float *s_m, float *s_s, float (*s_v)[COVO_NA])
 {
-    const float wm = wave_min(valid ? cost : __builtin_inff());
-    if (carrier && lane == 0) s_m[wave] = wm;
+    // (round 4: the waves that carry no cost -- two of three per SIMD in the pipelined kernel -- only take part in the two
+    // barriers and the final stores; they used to run the whole epilogue on zero weights next to the one wave that matters)
+    if (carrier) {
+        const float wm = wave_min(valid ? cost : __builtin_inff());
+        if (lane == 0) s_m[wave] = wm;
+    }
     __syncthreads();
     float m = s_m[0];
 #pragma unroll
     for (int i = 1; i < NW; ++i) m = fminf(m, s_m[i]);
+    if (carrier) {
     const float w = valid ? expf((m - cost) * A.inv_lam) : 0.0f;
     const float sw = wave_sum(w);
     unsigned long long live = __ballot(w > 0.0f);
@@ -115,8 +120,9 @@ __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost,
     acc.y += __shfl_xor(acc.y, 32, COVO_WAVE);
     acc.z += __shfl_xor(acc.z, 32, COVO_WAVE);
     acc.w += __shfl_xor(acc.w, 32, COVO_WAVE);
-    if (carrier && half == 0) *reinterpret_cast<float4 *>(&s_v[wave][4 * t]) = acc;
-    if (carrier && lane == 0) s_s[wave] = sw;
+    if (half == 0) *reinterpret_cast<float4 *>(&s_v[wave][4 * t]) = acc;
+    if (lane == 0) s_s[wave] = sw;
+    }
     __syncthreads();
     float *rec = A.records + (size_t)wg * COVO_PARTIAL_FLOATS;
     const int tid = threadIdx.x;
