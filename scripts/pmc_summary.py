@@ -8,7 +8,7 @@ roofline_gemm.counters).
   sq_a / sq_b   : SQ counters (quad-cycles for *_CYCLES / WAIT_* / ACTIVE_INST_*; SQ_VALU_MFMA_BUSY_CYCLES in cycles) and
                   GRBM_GUI_ACTIVE (cycles) -- effective shader clock = GRBM_GUI_ACTIVE / dispatch duration
 
-usage: pmc_summary.py [gpurun_out dir] [round tag, default r03]"""
+usage: pmc_summary.py [gpurun_out dir] [round tag, default r04]"""
 import collections
 import csv
 import glob
@@ -20,7 +20,7 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
-RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
 N_LOCAL, H = 65536, 32
 CU, SIMD = 256, 1024
 sys.path.insert(0, root)
@@ -29,9 +29,13 @@ from bench import KERNEL_SRCS, kernel_src_sha  # noqa: E402  (ONE list: bench.py
 # cycles a SATURATED VALU pipe needs per wave-instruction, measured with the same counters on a known load
 # (scripts/probe/valu_calib.hip -> profiles/r04_valu_calib.json: 8 independent v_fma_f32 on 8 waves per SIMD)
 try:
-    SAT_CYCLES_PER_VALU_INST = json.load(open(os.path.join(root, "profiles", "r04_valu_calib.json")))["saturated_pipe_cycles_per_inst"]
+    _cal = json.load(open(os.path.join(root, "profiles", "r04_valu_calib.json")))
+    SAT_CYCLES_PER_VALU_INST = _cal["saturated_pipe_cycles_per_inst"]
+    # a transcendental in the rollout's mix (7 fma + 1 rsq, 8 waves per SIMD): 8 x (cycles per instruction of the mix) - 7 x saturated
+    _mix = [r for r in _cal["rows"] if r["stream"] == "7 fma + 1 rsq" and r["waves_per_simd"] == 8][0]
+    TRANS_CYCLES = 8.0 * _mix["pipe_cycles_per_inst_measured"] - 7.0 * SAT_CYCLES_PER_VALU_INST
 except Exception:
-    SAT_CYCLES_PER_VALU_INST = None
+    SAT_CYCLES_PER_VALU_INST = TRANS_CYCLES = None
 
 
 def load(which):
@@ -147,6 +151,18 @@ for tag, e in per_kernel.items():
             d["cycles_per_valu_inst_achieved"] = busy / insts_simd
             if du:
                 d["valu_pipe_floor_us_at_that_clock"] = valu / (busy / du)
+        if busy and SAT_CYCLES_PER_VALU_INST and "SQ_INSTS_VALU_TRANS_F32" in e:
+            # with the transcendentals at their measured pipe time (13 cycles each in a 7 + 1 mix, against 2.24)
+            tr = e["SQ_INSTS_VALU_TRANS_F32"] / SIMD
+            pipe = (insts_simd - tr) * SAT_CYCLES_PER_VALU_INST + tr * TRANS_CYCLES
+            d["trans_insts_per_simd"] = tr
+            d["trans_pipe_cycles_per_inst"] = TRANS_CYCLES
+            d["valu_and_trans_pipe_cycles_per_simd"] = pipe
+            d["valu_and_trans_pipe_util"] = pipe / busy
+            if du:
+                d["valu_and_trans_pipe_floor_us_at_that_clock"] = pipe / (busy / du)
+            if tag.startswith("rollout"):
+                d["trans_wave_insts_per_64_samples_per_step"] = e["SQ_INSTS_VALU_TRANS_F32"] / (N_LOCAL / 64) / H
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and busy and e["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
         mf = e["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMD   # cycles a SIMD's matrix pipe was busy
         d["mfma_pipe_cycles_per_simd"] = mf

@@ -2,9 +2,9 @@
 # Everything profiles/ holds for one round, in one GPU call: the unprofiled bench line, the rocprofv3 kernel stats of the
 # same command, the separate --pmc passes (FETCH_SIZE, WRITE_SIZE, two SQ passes; counters are never combined with
 # traces, every pass has the program itself right after `--`), the phase times and the stand-alone kernel table.
-# Run on the GPU box from the repo root; outputs land in gpurun_out/.   usage: scripts/profile_bench.sh [round tag, default r03]
+# Run on the GPU box from the repo root; outputs land in gpurun_out/.   usage: scripts/profile_bench.sh [round tag, default r04]
 R="$(cd "$(dirname "$0")/.." && pwd)"
-RND="${1:-r03}"
+RND="${1:-r04}"
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" > "$R/gpurun_out/bench_line.json" 2> "$R/gpurun_out/bench_line.err"
@@ -20,8 +20,13 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -o b
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE \
     --output-format csv -d "$R/gpurun_out/pmc_sq_a" -o bench -- python3 "$R/bench.py" $PMC_ARGS > /dev/null 2> "$R/gpurun_out/pmc_sq_a.err"
 # SQ pass B: matrix-pipe busy cycles (MFMA utilisation of the noise GEMM), LDS instruction counts / conflicts
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE \
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE \
     --output-format csv -d "$R/gpurun_out/pmc_sq_b" -o bench -- python3 "$R/bench.py" $PMC_ARGS > /dev/null 2> "$R/gpurun_out/pmc_sq_b.err"
+# BASELINE configs[4] (bench.py --config envs): its line and the kernel stats of the same command
+python3 "$R/bench.py" --config envs > "$R/gpurun_out/bench_envs_line.json" 2> /dev/null
+rm -rf "$R/gpurun_out/prof_envs"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_envs" -o envs -- python3 "$R/bench.py" --config envs --steps 50 --warmup 5 \
+    > /dev/null 2> "$R/gpurun_out/prof_envs.err"
 cd "$R"
 python3 scripts/phase_times.py > gpurun_out/phase_times.log 2>/dev/null
 python3 scripts/kbench.py > gpurun_out/kbench.log 2>/dev/null
@@ -31,7 +36,13 @@ python3 scripts/pmc_summary.py gpurun_out "$RND" > gpurun_out/pmc_summary.log 2>
 mkdir -p gpurun_out/profiles_out
 cp profiles/"$RND"_bench_pmc_* gpurun_out/profiles_out/
 cp gpurun_out/prof_stats/bench_kernel_stats.csv gpurun_out/profiles_out/"$RND"_bench_kernel_stats.csv
-rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b gpurun_out/prof_stats
+find gpurun_out/prof_envs -name "*kernel_stats.csv" -exec cp {} gpurun_out/profiles_out/"$RND"_bench_envs_kernel_stats.csv \;
+cp gpurun_out/bench_envs_line.json gpurun_out/profiles_out/"$RND"_bench_envs_line.json
+cp gpurun_out/bench_line.json gpurun_out/profiles_out/"$RND"_bench_line.json
+cp gpurun_out/bench_line_under_rocprof.json gpurun_out/profiles_out/"$RND"_bench_line_under_rocprof.json
+cp gpurun_out/phase_times.log gpurun_out/profiles_out/"$RND"_phase_times.log
+cp gpurun_out/kbench.log gpurun_out/profiles_out/"$RND"_kbench.log
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b gpurun_out/prof_stats gpurun_out/prof_envs
 ls gpurun_out/profiles_out
 tail -c 1500 gpurun_out/bench_line.json
 tail -5 gpurun_out/pmc_summary.log
