@@ -306,6 +306,10 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
     }
     int ti, tj;
     tri_tile(w, ti, tj);
+    // batched launches (gridDim.y > 1: the env-batched step, covo-offline's table): every squaring the cap allows is launched for
+    // every matrix, and most matrices are done long before the slowest -- a finished one must not pull its 32 KB of operands
+    // through the L2s again (round 4: the flag first there; batch 1 keeps the operand loads ahead of the flag, one round trip)
+    if (!FIRST && !COH && gridDim.y > 1 && s[SC_SQ_DONE] != 0.0) return false;
     TileOps ops;
     if (FIRST) tile_load<COH>(ops, X, X, ti, tj, lane, wv, LoadAffine{alpha, beta});
     else tile_load<COH>(ops, X, X, ti, tj, lane, wv, LoadPlain{});
@@ -683,6 +687,7 @@ __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztal
     double *s = scall + (size_t)b * SC_COUNT;
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
+    if (!COH && gridDim.y > 1 && s[SC_NS_DONE] != 0.0) return false;  // batched: the flag before the operands (see ns_square_body)
     TileOps ops;
     tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
     const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // written by ns_first_kernel's extra workgroup
@@ -710,6 +715,7 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Za
     const size_t off = (size_t)b * SN * SN;
     const int ti = w >> 3, tj = w & 7;
     // Y' = Y.T : left factor Y -> pass Y^T;   Z' = T.Z : left factor T -> pass T^T
+    if (!COH && gridDim.y > 1 && s[SC_NS_DONE] != 0.0) return false;  // batched: the flag before the operands (see ns_square_body)
     TileOps ops;
     tile_load<COH>(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
     if (ns_converged<COH>(s, iter, lane, false)) return false;  // part 1 of this iteration raised the flag
