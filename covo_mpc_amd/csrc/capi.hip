@@ -490,12 +490,18 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
 
 int covo_debug_set_ns_tail(int n_squarings, int n_iters)
 {
-    if (n_squarings < 0 || n_squarings > 64 || n_iters < 0 || n_iters > 64) {
+    if (n_squarings > 64 || n_iters > 64 || (n_squarings < 0) != (n_iters < 0)) {
         covo_set_error("covo_debug_set_ns_tail: (%d, %d) out of range", n_squarings, n_iters);
         return COVO_E_BADARG;
     }
-    g_ns_tail_squarings = n_squarings;
-    g_ns_tail_iters = n_iters;
+    if (n_squarings < 0) {  // back to the defaults (sigma_ns.hip)
+        g_ns_tail_squarings = g_ns_tail_squarings_batched = 15;
+        g_ns_tail_iters = 11;
+        g_ns_tail_iters_batched = 5;
+    } else {
+        g_ns_tail_squarings = g_ns_tail_squarings_batched = n_squarings;  // batch 1 and batched launches alike
+        g_ns_tail_iters = g_ns_tail_iters_batched = n_iters;
+    }
     ++g_dbg_epoch;  // captured step graphs hold the old launch set: every handle re-captures at its next step
     return 0;
 }

@@ -12,8 +12,9 @@
 // (v_mfma_f64_16x16x4_f64).  What one link of such a chain costs was measured first
 // (scripts/probe/chain_probe.hip, profiles/r01_chain_probe.log): an empty graph node 1.6 us; one wave per
 // 16x16 tile with K = 128: 4.2 us; one 256-thread workgroup per tile with K split over its 4 waves:
-// 2.6 us; the same phases inside ONE persistent launch separated by a counter barrier: 6.1 us (spread
-// over the XCDs) / 22.8 us (confined to one XCD) -- so: separate launches, K-split tiles.
+// 2.6 us; the same phases inside ONE persistent launch separated by a counter barrier and fences: 6.1 us (spread
+// over the XCDs) / 22.8 us (confined to one XCD) -- so: separate launches, K-split tiles (round 1).  Rounds 2-4 found the
+// persistent form that does pay (no fences: sc1 accesses; then one XCD, plain stores, flag words): see ns_flag_barrier.
 //   1. lambda_min:  a Chebyshev filter of degree 2^k built by repeated squaring.  Y0 = affine map of A that sends
 //      [cut, hi] to [-1, 1] and everything BELOW cut above 1 (hi >= lambda_max: min of the Gershgorin and Frobenius
 //      bounds; cut = min_i A_ii + 2^-10 (hi - min_i A_ii) > lambda_min, a Rayleigh quotient).  T_2(x) = 2x^2 - 1
@@ -58,6 +59,18 @@
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// -DNS_STAMPS: workgroup 0 of the iteration tail records wall_clock64() (10 ns) at the seams of every phase (scripts/ns_tail_cost.py)
+#ifdef NS_STAMPS
+__shared__ long long g_stamp[192];
+__shared__ int g_nstamp;
+#define NS_STAMP()                                                                    \
+    do {                                                                              \
+        if (threadIdx.x == 0 && g_nstamp < 192) g_stamp[g_nstamp++] = wall_clock64(); \
+    } while (0)
+#else
+#define NS_STAMP() do { } while (0)
+#endif
+
 constexpr int SN = COVO_NA;  // 128
 constexpr int NS_SQUARINGS = 16;   // cap: Chebyshev degree 2^16.  Real CoVO Hessians stop at 6..12; the cap matters for bottoms
                                    // that sit within 1e-5 of the spectrum's width of the next eigenvalues (round 3's fuzz sweep:
@@ -96,7 +109,9 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, 
        SC_RPART = SC_ERR + NS_ITERS * 64,          // sym_stats.hpp: per-row, per-column-block |.|-sums (128 x 8)
        SC_FPART = SC_RPART + 128 * 8,              // per-tile sums of squares (36)
        SC_U = SC_FPART + 64,                       // the bottom Ritz vector u (128)
-       SC_COUNT = SC_U + 128 };
+       SC_FLAGS = SC_U + 128,                      // barrier flag words of the two persistent launches: 2 x 64 unsigned (ns_flag_barrier)
+       SC_STAMPS = SC_FLAGS + 64,                  // -DNS_STAMPS: 192 time stamps of the iteration tail's workgroup 0
+       SC_COUNT = SC_STAMPS + 192 };
 constexpr double NS_DEFL_SAFETY = 0.7;   // the NS table assumes 1e-2 + 0.7 x (gap bound): the bound's linearisation is good to ~3 %
 constexpr double NS_DEFL_MIN_GAP = 2e-2; // below this the interval shrinks by < 3x: not worth a rank-1 correction
 constexpr double NS_DEFL_RESID = 1e-8;   // |A u - theta u| <= 1e-8 gap: eigenvector angle <= 1e-8, Sigma error <= 1e-7 relative
@@ -128,19 +143,24 @@ struct LoadScaledBDefl {  // (A + delta I)/s + gam u u^T  (deflated bottom eigen
     }
 };
 
-// COH: the access is an agent-scope relaxed atomic (sc1): coherent across the XCDs' L2s without cache-wide fences.  Used by
+// COH = 1: the access is an agent-scope relaxed atomic (sc1): coherent across the XCDs' L2s without cache-wide fences.  Used by
 // the persistent launches below, whose phases exchange tiles and slots across workgroups INSIDE one kernel; the same
-// bodies compiled with COH = false (plain cached accesses) serve the one-launch-per-phase kernels.  Same arithmetic.
-template <bool COH>
+// bodies compiled with COH = 0 (plain cached accesses) serve the one-launch-per-phase kernels.  Same arithmetic.
+// COH = 2 (round 4): the persistent launch has VERIFIED that all its workgroups sit on ONE XCD (ns_flag_barrier).  Stores are then
+// plain -- write-through the CU's L1 into the XCD's L2, which every reader shares -- and only the loads stay sc1 (they skip the
+// L1s; a line that is dirty in the local L2 is served from there).  A phase drops from 2.9-3.3 to ~1.9 us
+// (scripts/probe/xcd_chain_probe.hip: "sc1 loads, flag words polled sc1" against "sc1 loads + sc1 stores").
+constexpr int COH_NONE = 0, COH_AGENT = 1, COH_XCD = 2;
+template <int COH>
 __device__ __forceinline__ double gld(const double *p)
 {
-    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (COH != COH_NONE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ void gst(double *p, double v)
 {
-    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (COH == COH_AGENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
 
@@ -149,7 +169,7 @@ struct TileOps {
 };
 // issue the 16 operand loads of this wave's K-quarter (callers issue them BEFORE looking at any flag: every
 // launch of the chain then pays one memory latency, not one per dependent scalar)
-template <bool COH = false, class F>
+template <int COH = COH_NONE, class F>
 __device__ __forceinline__ void tile_load(TileOps &o, const double *A, const double *B, int ti, int tj, int lane, int kq, F f)
 {
     const int lo = lane & 15, hi = lane >> 4;
@@ -197,6 +217,24 @@ __device__ __forceinline__ double slot_sum(const double *__restrict__ p, int n, 
     return wr::wave64_allsum((lane < n) ? p[lane] : 0.0);
 }
 
+// (matrix, tile) of this workgroup.  Batch 1: grid (tiles).  Batched: grid (tiles, batch rounded up to 8); the linear workgroup id
+// round-robins over the 8 XCDs, so matrix b takes the ids = b (mod 8): ALL the tiles of one matrix run on one XCD and every
+// launch of the chain finds its operands (128 KB each, written by the launch before on the same XCD) behind ONE L2 -- with
+// (blockIdx.x, blockIdx.y) = (tile, matrix) every XCD pulled every matrix through the fabric.  Same tiles, same arithmetic.
+__device__ __forceinline__ bool ns_block(int batch, int &b, int &w)
+{
+    if (gridDim.y == 1) {
+        b = 0;
+        w = (int)blockIdx.x;
+        return true;
+    }
+    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x, slot = id >> 3;
+    b = (int)(slot / gridDim.x) * 8 + (int)(id & 7u);
+    w = (int)(slot % gridDim.x);
+    return b < batch;
+}
+static inline dim3 ns_grid(int tiles, int batch) { return dim3(tiles, batch == 1 ? 1 : (batch + 7) / 8 * 8); }
+
 // The squaring stage (a filter iteration: self-correcting) works on exactly symmetric matrices: only tiles
 // with ti >= tj are computed and every value is stored together with its mirror image (36 tiles).
 constexpr int NS_TILES = 36;
@@ -208,13 +246,13 @@ __device__ __forceinline__ void tri_tile(int w, int &ti, int &tj)
 }
 // (staging the transposed copy through LDS so that both orientations leave as 128-byte row segments was measured and
 // changes nothing, neither behind the write-back L2 nor with the write-through stores of the persistent launches)
-template <bool COH = false>
+template <int COH = COH_NONE>
 __device__ __forceinline__ void store_both(double *O, double *Ot, int row, int col, double v)
 {
     gst<COH>(O + (size_t)row * SN + col, v);
     gst<COH>(Ot + (size_t)col * SN + row, v);
 }
-template <bool COH = false>
+template <int COH = COH_NONE>
 __device__ __forceinline__ void store_sym(double *O, int row, int col, double v)
 {
     if (row >= col) {
@@ -235,15 +273,18 @@ __device__ __forceinline__ SymStatsOut ns_stats_out(double *s)
     return o;
 }
 __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ Aall,
-                                                      double *__restrict__ scall)
+                                                      double *__restrict__ scall, int batch)
 {
     __shared__ double tmp[16][17];
     __shared__ double part[4];
-    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *R = Rin + (size_t)b * SN * SN;
     double *A = Aall + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
     if (w == 0 && tid < SC_COEF) s[tid] = 0.0;  // scalars and the two "done" flags
+    if (w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
     int I, J;
     tri_tile(w, I, J);
     const int i = 16 * I + (lane >> 4) + 4 * wv, j = 16 * J + (lane & 15);
@@ -257,7 +298,7 @@ __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__
 // tiles); |Xout|_F^2 partials go to slot row step+1, t_out to slot 63 of that row.
 // FIRST: Xin is A and the operand is Y0 = alpha I - beta A (see the header), t_in = 1.
 // Returns false when the filter is found stationary (nothing was written).  Workgroup w of matrix b.
-template <bool FIRST, bool COH>
+template <bool FIRST, int COH>
 __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, double *scall, int step, int xbuf_out, int b, int w,
                                                double (*red)[4][64], double *part)
 {
@@ -270,6 +311,7 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
         // the input statistics from the per-tile partials (sym_stats.hpp), every workgroup for itself in the same fixed order;
         // workgroup 0 keeps the per-row sums for the Ritz launch and (fused step: there was no prep launch) clears the scalars
         if (w == 0 && tid < SC_COEF) s[tid] = 0.0;
+        if (w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
         double ra = 0.0, dgv = 0.0;
         if (tid < SN) {
 #pragma unroll
@@ -348,11 +390,13 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
 
 template <bool FIRST>
 __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict__ Xin, double *__restrict__ Xout,
-                                                        double *__restrict__ scall, int step, int xbuf_out)
+                                                        double *__restrict__ scall, int step, int xbuf_out, int batch)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    (void)ns_square_body<FIRST, false>(Xin, Xout, scall, step, xbuf_out, blockIdx.y, blockIdx.x, red, part);
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    (void)ns_square_body<FIRST, COH_NONE>(Xin, Xout, scall, step, xbuf_out, b, w, red, part);
 }
 
 // ---- Rayleigh-Ritz on the RITZ largest-diagonal columns of X: lambda_min(A), delta; then the scale s of
@@ -614,10 +658,13 @@ __device__ __forceinline__ void ns_coef(double l, double &a, double &bq)
 // ---- Newton-Schulz iteration 0 (Z0 = I, Y0 = B/s read from A on load):  Y1 = a0 Y0 + b0 Y0^2,  Z1 = a0 I + b0 Y0
 __global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict__ Aall, double *__restrict__ Yout,
                                                        double *__restrict__ Ytout, double *__restrict__ Zout,
-                                                       double *__restrict__ Ztout, double *__restrict__ scall, int zbuf_out)
+                                                       double *__restrict__ Ztout, double *__restrict__ scall, int zbuf_out,
+                                                       int batch)
 {
     __shared__ double red[4][4][64];
-    const int b = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t off = (size_t)b * SN * SN;
     const double *A = Aall + off;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -663,7 +710,7 @@ __global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict_
     store_both(Zout + off, Ztout + off, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
 }
 
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ bool ns_converged(double *s, int iter, int lane, bool writer)
 {
     // both loads are issued before either is looked at
@@ -679,7 +726,7 @@ __device__ __forceinline__ bool ns_converged(double *s, int iter, int lane, bool
 
 // ---- Newton-Schulz step k >= 1, part 1:  T = a_k I + b_k Z.Y  (64 tiles; T and T^T are stored).
 // Returns false when the iteration has converged (nothing was written).  Workgroup w of matrix b.
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztall, double *Tall, double *Ttall, double *scall,
                                           int iter, int b, int w, double (*red)[4][64], double *part)
 {
@@ -692,8 +739,10 @@ __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztal
     tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
     const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // written by ns_first_kernel's extra workgroup
     if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
+    if (COH) NS_STAMP();  // operands + slots have arrived
     const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
+    if (COH) NS_STAMP();  // products reduced
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
     store_both<COH>(Tall + off, Ttall + off, row, col, fma(bq, p, (row == col) ? a : 0.0));
     const double d = p - ((row == col) ? 1.0 : 0.0);
@@ -703,7 +752,7 @@ __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztal
 }
 
 // ---- part 2:  Y' = Y.T (tiles 0..63),  Z' = T.Z (tiles 64..127); each with its transpose.  Workgroup wx in 0..127.
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
                                            double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
                                            int zbuf_out, int b, int wx, double (*red)[4][64])
@@ -732,7 +781,7 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Za
 
 // both part-2 tiles of one workgroup (tile w of Y' and tile w of Z') with all 32 operand loads in flight together: the
 // persistent launch runs part 2 on 64 workgroups, and two dependent coherent-load round trips per phase would cost 1.5 us
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ bool ns_YZ2_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
                                             double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
                                             int zbuf_out, int w, double (*red)[4][64])
@@ -744,6 +793,7 @@ __device__ __forceinline__ bool ns_YZ2_body(const double *Ytall, const double *Z
     tile_load<COH>(oy, Ytall, Tall, ti, tj, lane, wv, LoadPlain{});  // Y' = Y.T
     tile_load<COH>(oz, Ttall, Zall, ti, tj, lane, wv, LoadPlain{});  // Z' = T.Z
     if (ns_converged<COH>(s, iter, lane, false)) return false;
+    NS_STAMP();  // operands + slots have arrived
     if (w == 0 && tid == 0) {
         gst<COH>(s + SC_ZBUF, (double)zbuf_out);
         gst<COH>(s + SC_ITERS, (double)(iter + 1));
@@ -755,96 +805,245 @@ __device__ __forceinline__ bool ns_YZ2_body(const double *Ytall, const double *Z
     const f64x4 az = tile_mma(oz);
     __syncthreads();  // red is reused
     const double vz = tile_reduce(az, red, wv, lane);
+    NS_STAMP();  // products reduced
+    store_both<COH>(Zout, Ztout, row, col, vz);
+    return true;
+}
+
+// the same two tiles one after the other (16 operand loads in flight instead of 32): the batched persistent launch wants all
+// its workgroups resident (<= 64 VGPRs: 8 workgroups per CU) and hides the second load latency behind the other matrices' phases
+template <int COH>
+__device__ __forceinline__ bool ns_YZ2_lean_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
+                                                 double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
+                                                 int zbuf_out, int w, double (*red)[4][64])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *s = scall;
+    const int ti = w >> 3, tj = w & 7;
+    TileOps o;
+    tile_load<COH>(o, Ytall, Tall, ti, tj, lane, wv, LoadPlain{});  // Y' = Y.T
+    if (ns_converged<COH>(s, iter, lane, false)) return false;
+    if (w == 0 && tid == 0) {
+        gst<COH>(s + SC_ZBUF, (double)zbuf_out);
+        gst<COH>(s + SC_ITERS, (double)(iter + 1));
+    }
+    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+    const f64x4 ay = tile_mma(o);
+    const double vy = tile_reduce(ay, red, wv, lane);
+    store_both<COH>(Yout, Ytout, row, col, vy);
+    __builtin_amdgcn_sched_barrier(0);  // the second tile's 16 loads reuse the first tile's registers
+    tile_load<COH>(o, Ttall, Zall, ti, tj, lane, wv, LoadPlain{});  // Z' = T.Z
+    const f64x4 az = tile_mma(o);
+    __syncthreads();  // red is reused
+    const double vz = tile_reduce(az, red, wv, lane);
     store_both<COH>(Zout, Ztout, row, col, vz);
     return true;
 }
 
 __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
                                                    double *__restrict__ Tall, double *__restrict__ Ttall,
-                                                   double *__restrict__ scall, int iter)
+                                                   double *__restrict__ scall, int iter, int batch)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    (void)ns_T_body<false>(Yall, Ztall, Tall, Ttall, scall, iter, blockIdx.y, blockIdx.x, red, part);
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    (void)ns_T_body<COH_NONE>(Yall, Ztall, Tall, Ttall, scall, iter, b, w, red, part);
 }
 
 __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
                                                     const double *__restrict__ Tall, const double *__restrict__ Ttall,
                                                     double *__restrict__ Yout, double *__restrict__ Ytout,
                                                     double *__restrict__ Zout, double *__restrict__ Ztout,
-                                                    double *__restrict__ scall, int iter, int zbuf_out)
+                                                    double *__restrict__ scall, int iter, int zbuf_out, int batch)
 {
     __shared__ double red[4][4][64];
-    (void)ns_YZ_body<false>(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, blockIdx.y, blockIdx.x, red);
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    (void)ns_YZ_body<COH_NONE>(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, b, w, red);
 }
 
 // ---- the chain's dependent phases inside ONE persistent launch (batch 1 only: the launch's workgroups must be
 // co-resident).  A captured graph cannot branch, so as separate launches every phase the caps allow costs 1.6 us even
 // after convergence, and a live one ~3.2-3.7 us, most of it launch floor.  Here every workgroup keeps its tile, the phases
-// are separated by a counter barrier across the grid, and all workgroups leave together at the first phase that finds
-// the iteration converged (they all read the same slots).  What makes that barrier affordable is measured in
-// scripts/probe/barrier_probe.hip: with cached accesses + agent-scope release/acquire fences (every fence writes back
-// / invalidates the XCD's whole L2) a phase costs 6-9 us -- 15 us with 128 workgroups polling -- and loses against a
-// launch; with every inter-phase access an agent-scope relaxed atomic (sc1, coherent across the XCDs' L2s; COH = true in
-// the bodies above) the barrier needs no fence, only s_waitcnt + the counter: 2.9 us per phase, GEMM included.
+// are separated by a barrier across the launch, and all workgroups leave together at the first phase that finds the
+// iteration converged (they all read the same slots).  What makes that barrier affordable was measured in
+// scripts/probe/barrier_probe.hip and xcd_chain_probe.hip:
+//  * cached accesses + agent-scope release/acquire fences (every fence writes back / invalidates the XCD's whole L2): 6-9 us per
+//    phase, 15 with 128 workgroups polling -- loses against a launch;
+//  * every inter-phase access an agent-scope relaxed atomic (sc1, coherent across the XCDs' L2s; COH_AGENT in the bodies above)
+//    and one counter: no fence, 2.9 us per phase, GEMM included (rounds 2-3);
+//  * round 4: the launch is CONFINED TO ONE XCD -- the grid is 8 x the workgroups needed and only the linear ids = 0 (mod 8) stay:
+//    the dispatcher deals ids round-robin over the XCDs.  Workgroups that share an L2 need no write-through: plain stores,
+//    sc1 loads (COH_XCD) and, instead of a counter every workgroup adds to, one flag word per workgroup that one wave polls with a
+//    single load: 1.85 us per phase.  Placement is a performance assumption, never a correctness one: every workgroup publishes
+//    its XCC id with its first (coherent) flag, everybody sees the same 36 / 64 ids after the first barrier, and only if they are
+//    all equal do the later phases switch to COH_XCD; otherwise the launch carries on as in round 3 (COH_AGENT throughout).
 // The spin is bounded (0.2 s): a barrier that cannot complete leaves the iteration unconverged instead of hanging the GPU.
-__device__ __forceinline__ bool ns_grid_barrier(unsigned *ctr, unsigned target, double *fail_flag)
+#ifndef NS_POLL_SLEEP
+#define NS_POLL_SLEEP 1
+#endif
+__device__ __forceinline__ unsigned ns_xcc_id()
 {
-    __shared__ int ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have been acknowledged
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7u;
+}
+// Returns 0: timed out (the fail flag is raised); 1: passed; 2: passed and every workgroup of the launch reported the XCC id
+// `xcc`.  flags[w] = (XCC id << 24) | phase; nw <= 64 workgroups.  COH as the phase before it stored.
+template <int COH>
+__device__ __forceinline__ int ns_flag_barrier(unsigned *flags, unsigned phase, int w, int nw, unsigned xcc, double *fail_flag)
+{
+    __shared__ int res;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been acknowledged (by the L2 / by memory)
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    NS_STAMP();  // stores acknowledged
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned word = (xcc << 24) | phase;
+        if (lane == 0) {
+            if (COH == COH_XCD) asm volatile("global_store_dword %0, %1, off" ::"v"(flags + w), "v"(word) : "memory");
+            else __hip_atomic_store(flags + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const long long t0 = wall_clock64();
         int good = 1;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(8);
+        unsigned v = word;
+        for (;;) {
+            if (lane < nw) v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_ballot_w64((v & 0xffffffu) < phase) == 0) break;
+            __builtin_amdgcn_s_sleep(NS_POLL_SLEEP);
             if (wall_clock64() - t0 > 20000000LL) {
                 good = 0;
-                gst<true>(fail_flag, 1.0);  // never silently: the finalize launch turns this into NaN outputs
+                if (lane == 0) gst<COH_AGENT>(fail_flag, 1.0);  // never silently: the finalize launch turns this into NaN outputs
                 break;
             }
         }
-        ok = good;
+        const bool one_xcd = __builtin_amdgcn_ballot_w64((v >> 24) != xcc) == 0;
+        if (lane == 0) res = good ? (one_xcd ? 2 : 1) : 0;
     }
     __syncthreads();
-    return ok != 0;
+    NS_STAMP();  // barrier passed
+    return res;
 }
 
-// squarings step_first .. step_last (step >= 1) of the Chebyshev filter: 36 workgroups, X0 <-> X1 by parity
-__global__ __launch_bounds__(256) void ns_square_tail_kernel(double *X0, double *X1, double *scall, int step_first, int step_last)
+// (matrix, workgroup-in-matrix) of a persistent launch: grid = 8 x nw x ceil(batch / 8); linear id -> XCD id & 7, slot id >> 3;
+// matrix b = 8 (slot / nw) + XCD takes workgroups w = slot % nw -- batch 1: only XCD 0's workgroups stay.  Batched (round 4): every
+// matrix runs its WHOLE tail at its own pace next to the others (4 per XCD at 32 matrices) instead of paying, launch by launch,
+// for the slowest matrix of the batch; when the grid exceeds what is resident, workgroups are dispatched in id order, so the
+// matrices ahead of a partially resident one are complete or running and always finish: no deadlock.
+__device__ __forceinline__ bool ns_tail_block(int nw, int batch, int &b, int &w)
+{
+    const unsigned slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    b = (int)(slot / (unsigned)nw) * 8 + (int)xcd;
+    w = (int)(slot % (unsigned)nw);
+    return b < batch;
+}
+static inline dim3 ns_tail_grid(int nw, int batch) { return dim3(8 * nw * ((batch + 7) / 8)); }
+
+// squarings step_first + 1 .. step_last in coherence mode COH (the launch's first squaring has been done, phase 1 passed)
+template <int COH>
+__device__ __forceinline__ void ns_square_tail_rest(double *X0, double *X1, double *scall, int step_first, int step_last, int w, int nw,
+                                                    unsigned xcc, double (*red)[4][64], double *part)
+{
+    unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS);
+    unsigned phase = 1;
+    for (int step = step_first + 1; step <= step_last; ++step) {
+        const bool odd = (step & 1) != 0;  // step i reads the buffer step i-1 wrote: X0 after the first squaring
+        if (!ns_square_body<false, COH>(odd ? X0 : X1, odd ? X1 : X0, scall, step, odd ? 1 : 0, 0, w, red, part)) return;
+        if (step < step_last && !ns_flag_barrier<COH>(flags, ++phase, w, nw, xcc, scall + SC_BARFAIL)) return;
+    }
+}
+// squarings step_first .. step_last (step >= 1) of the Chebyshev filter: 36 workgroups (grid 8 x 36), X0 <-> X1 by parity
+__global__ __launch_bounds__(256) void ns_square_tail_kernel(double *X0, double *X1, double *scall, int step_first, int step_last,
+                                                             int batch)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    unsigned *ctr = reinterpret_cast<unsigned *>(scall + SC_BAR);  // zeroed by ns_prep_kernel every run
-    unsigned phase = 0;
-    for (int step = step_first; step <= step_last; ++step) {
-        const bool odd = (step & 1) != 0;  // step i reads the buffer step i-1 wrote: X0 after the first squaring
-        if (!ns_square_body<false, true>(odd ? X0 : X1, odd ? X1 : X0, scall, step, odd ? 1 : 0, 0, blockIdx.x, red, part)) return;
-        if (step < step_last && !ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
-    }
+    constexpr int nw = NS_TILES;
+    int b, w;
+    if (!ns_tail_block(nw, batch, b, w)) return;
+    X0 += (size_t)b * SN * SN;
+    X1 += (size_t)b * SN * SN;
+    scall += (size_t)b * SC_COUNT;
+    const unsigned xcc = ns_xcc_id();
+    const bool odd = (step_first & 1) != 0;
+    if (!ns_square_body<false, COH_AGENT>(odd ? X0 : X1, odd ? X1 : X0, scall, step_first, odd ? 1 : 0, 0, w, red, part)) return;
+    if (step_first == step_last) return;
+    const int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, nw, xcc, scall + SC_BARFAIL);
+    if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 5] = (double)r;  // diagnostics: which mode the squaring tail ran in
+    if (r == 2) ns_square_tail_rest<COH_XCD>(X0, X1, scall, step_first, step_last, w, nw, xcc, red, part);
+    else if (r == 1) ns_square_tail_rest<COH_AGENT>(X0, X1, scall, step_first, step_last, w, nw, xcc, red, part);
 }
 
 struct NsBufs {
     double *Y[2], *Yt[2], *Z[2], *Zt[2], *T, *Tt;
 };
 
-// Newton-Schulz iterations iter_first .. iter_last (iter >= 1): 64 workgroups (the barrier's cost grows with the number of
-// pollers: 2.9 us per phase at 64, 5.6 at 128, barrier_probe); workgroup w forms tile w of T, then tile w of Y' and of Z'
+// the rest of the Newton-Schulz tail after part 1 of iteration iter_first and the first barrier (`off`: this matrix in the buffers)
+template <int COH, bool LEAN>
+__device__ __forceinline__ void ns_iter_tail_rest(const NsBufs &B, size_t off, double *scall, int iter_first, int iter_last, int w, int nw,
+                                                  unsigned xcc, double (*red)[4][64], double *part)
+{
+    unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64;
+    unsigned phase = 1;
+    for (int iter = iter_first; iter <= iter_last; ++iter) {
+        const bool odd = (iter & 1) != 0;  // in = iter & 1, out = in ^ 1 (selects instead of indexed loads of the argument block)
+        const double *Yi = (odd ? B.Y[1] : B.Y[0]) + off, *Yti = (odd ? B.Yt[1] : B.Yt[0]) + off;
+        const double *Zi = (odd ? B.Z[1] : B.Z[0]) + off, *Zti = (odd ? B.Zt[1] : B.Zt[0]) + off;
+        double *Yo = (odd ? B.Y[0] : B.Y[1]) + off, *Yto = (odd ? B.Yt[0] : B.Yt[1]) + off;
+        double *Zo = (odd ? B.Z[0] : B.Z[1]) + off, *Zto = (odd ? B.Zt[0] : B.Zt[1]) + off;
+        if (iter > iter_first) {
+            if (!ns_T_body<COH>(Yi, Zti, B.T + off, B.Tt + off, scall, iter, 0, w, red, part)) return;  // all leave together
+            if (!ns_flag_barrier<COH>(flags, ++phase, w, nw, xcc, scall + SC_BARFAIL)) return;
+        }
+        if (LEAN) (void)ns_YZ2_lean_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, red);
+        else (void)ns_YZ2_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, red);
+        if (iter < iter_last && !ns_flag_barrier<COH>(flags, ++phase, w, nw, xcc, scall + SC_BARFAIL)) return;
+    }
+}
+// Newton-Schulz iterations iter_first .. iter_last (iter >= 1): 64 workgroups per matrix (a barrier's cost grows with the
+// number of workgroups); workgroup w forms tile w of T, then tile w of Y' and of Z'.  LEAN: the batched launch (see above).
+template <bool LEAN>
+__device__ __forceinline__ void ns_iter_tail(const NsBufs &B, double *scall, int iter_first, int iter_last, int batch,
+                                             double (*red)[4][64], double *part)
+{
+    constexpr int nw = 64;
+    int b, w;
+    if (!ns_tail_block(nw, batch, b, w)) return;
+    const size_t off = (size_t)b * SN * SN;
+    scall += (size_t)b * SC_COUNT;
+    const unsigned xcc = ns_xcc_id();
+    const bool odd = (iter_first & 1) != 0;
+#ifdef NS_STAMPS
+    if (threadIdx.x == 0) g_nstamp = 0;
+    __syncthreads();
+    NS_STAMP();
+#endif
+    if (!ns_T_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall, iter_first, 0, w,
+                              red, part))
+        return;
+    const int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, nw, xcc, scall + SC_BARFAIL);
+    if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 6] = (double)r;  // diagnostics: which mode the iteration tail ran in
+    if (r == 2) ns_iter_tail_rest<COH_XCD, LEAN>(B, off, scall, iter_first, iter_last, w, nw, xcc, red, part);
+    else if (r == 1) ns_iter_tail_rest<COH_AGENT, LEAN>(B, off, scall, iter_first, iter_last, w, nw, xcc, red, part);
+#ifdef NS_STAMPS
+    if (w == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 192; ++i) scall[SC_STAMPS + i] = (i < g_nstamp) ? (double)(g_stamp[i] - g_stamp[0]) : -1.0;
+#endif
+}
 __global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, double *scall, int iter_first, int iter_last)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    const int wx = blockIdx.x;
-    unsigned *ctr = reinterpret_cast<unsigned *>(scall + SC_BAR + 1);
-    unsigned phase = 0;
-    for (int iter = iter_first; iter <= iter_last; ++iter) {
-        const int in = iter & 1, out = in ^ 1;
-        if (!ns_T_body<true>(B.Y[in], B.Zt[in], B.T, B.Tt, scall, iter, 0, wx, red, part)) return;  // all leave together
-        if (!ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
-        (void)ns_YZ2_body<true>(B.Yt[in], B.Z[in], B.T, B.Tt, B.Y[out], B.Yt[out], B.Z[out], B.Zt[out], scall, iter, out, wx, red);
-        if (iter < iter_last && !ns_grid_barrier(ctr, gridDim.x * ++phase, scall + SC_BARFAIL)) return;
-    }
+    ns_iter_tail<false>(B, scall, iter_first, iter_last, 1, red, part);
+}
+// (forcing 8 waves per SIMD -- 64 VGPRs, 240 B of spills -- so that all 4 matrices an XCD gets out of 32 are resident together was
+// measured: 267 us against 176 at the compiler's 122 VGPRs / 3 workgroups per CU)
+__global__ __launch_bounds__(256) void ns_iter_tail_batched_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int batch)
+{
+    __shared__ double red[4][4][64];
+    __shared__ double part[4];
+    ns_iter_tail<true>(B, scall, iter_first, iter_last, batch, red, part);
 }
 
 // ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  ONE Cholesky serves both needs:
@@ -987,16 +1186,25 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 }
 
 // how many of the chain's last squarings / Newton-Schulz iterations run inside the persistent launches; covo_debug_set_ns_tail.
-// A folded phase costs nothing once the chain has converged (a separate launch: 1.6 us) and, while live, +0.4 us per
-// squaring / +1.4 us per iteration over its separate launch(es) (scripts/ns_tail_cost.py: a phase is coherent loads from the
-// Infinity Cache + write-through stores + the barrier -- no cheaper than a launch).  So the phases that are often idle are
-// folded: squarings 8..13 (live on 98 .. 17 % of closed-loop Hessians, on almost none of the bench's teacher-forced ones)
-// and iterations 10..12 (68 / 4 / 0 %).  Measured (scripts/tail_bench.py, N = 65 536): bench 4 411 -> 4 615 steps/s,
-// closed loop unchanged (4 126 -> 4 120); folding everything: 4 550 / 4 078.
-// Round 3: with the bottom eigenpair deflated the iteration needs 3..6 (bench) / 4..9 (closed loop) steps instead of 6..10, so
-// iterations 6..11 are folded (same box, bench / closed loop steps/s: tail 3: 5 029 / 4 644, 5: 5 192 / 4 734, 6: 5 227 / 4 675,
-// 7: 5 238 / 4 697, 8: 5 180 / 4 645; without deflation, tail 3: 4 949 / 4 505).
-int g_ns_tail_iters = 6, g_ns_tail_squarings = 9;
+// Rounds 2-3 (persistent launches spread over the XCDs, every access sc1, one counter): a folded phase cost nothing once the
+// chain had converged (a separate launch: 1.6 us) but, while live, +0.4 us per squaring / +1.4 us per iteration over its
+// separate launch(es), so only the often-idle phases were folded (squarings 7.., iterations 6..).
+// Round 4 (one XCD, plain stores, flag words; see ns_flag_barrier): a live folded squaring is 0.85 us CHEAPER than its launch, a
+// live iteration 0.7 us (scripts/ns_tail_cost.py on a 14-squaring / 9-iteration matrix: covo_sigma 167.5 us with nothing folded,
+// 156.5 squarings folded, 161.8 iterations folded, 151.7 both), so batch 1 folds everything but the first squaring and
+// iteration 0.  Same box, scripts/tail_bench.py, bench / closed loop steps/s: rounds 2-3 code (9, 6) 5 277-5 305 / 4 685-4 692;
+// round 4 code (9, 6) 5 236 / 4 644, (12, 8) 5 280 / 4 738, (15, 8) 5 364-5 384 / 4 811-4 829, (15, 11) 5 370-5 375 / 4 813-4 815.
+// Where the rest of a phase goes (workgroup 0's seams, -DNS_STAMPS): part 1 of an iteration = 1.08 us until the operands are in
+// (each CU of the one XCD pulls 64 KB through its 64 B/clk port), 0.40 MFMA + reduce, 0.64 until the stores are acknowledged,
+// 0.64 flag -> poll; part 2 = 1.36 / 0.84 (2 048 fp64-MFMA cycles per SIMD: a quarter of the phase is now the ONE XCD's matrix
+// throughput) / 0.6 / 1.3-1.7 (the other workgroup of the CU finishes its MFMAs later).
+// Batched (the env-batched step, covo-offline's table): all squarings are folded -- every matrix runs them at its own pace, 4
+// matrices per XCD at 32 -- but only the last 5 iterations: early on every matrix is live and 4 matrices x 64 workgroups on an
+// XCD's 32 CUs contend (3 workgroups per CU at 122 VGPRs) where a launch spreads each phase over the chip.  bench.py --config
+// envs, control-steps/s / Sigma us per batched step: (0, 0) 71 186 / 288; (15, 0) 73 395 / 274; (15, 3) 74 851 / 266;
+// (15, 5) 75 943 / 255; (15, 7) 73 142 / 274; (15, 11) 72 163 / 282; (11, 5) 75 007 / 261; (8, 5) 74 636 / 262.
+int g_ns_tail_iters = NS_ITERS - 1, g_ns_tail_squarings = NS_SQUARINGS - 1;
+int g_ns_tail_iters_batched = 5, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
 // COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
 // iteration (A/B measurements, tests)
 int g_ns_deflate = [] { const char *e = std::getenv("COVO_NS_DEFLATE"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -1031,30 +1239,30 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         attr_set = true;
     }
     if (r_has_stats && batch == 1) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
-    else hipLaunchKernelGGL(ns_prep_kernel, dim3(NS_TILES, batch), dim3(256), 0, s, R, A, sc);
-    hipLaunchKernelGGL(ns_square_kernel<true>, dim3(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0);
-    // batch 1: the remaining squarings / iterations run inside persistent launches (co-residency: 36 / 128 workgroups)
-    int sq_tail = (batch == 1 && persistent_ok) ? g_ns_tail_squarings : 0;
+    else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
+    hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0, batch);
+    // the remaining squarings / iterations run inside persistent launches (36 / 64 workgroups per matrix, one XCD per matrix)
+    int sq_tail = persistent_ok ? (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) : 0;
     if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
     const int sq_sep = NS_SQUARINGS - sq_tail;
     double *xi = X0, *xo = X1;
     for (int i = 1; i < sq_sep; ++i) {
-        hipLaunchKernelGGL(ns_square_kernel<false>, dim3(NS_TILES, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0);
+        hipLaunchKernelGGL(ns_square_kernel<false>, ns_grid(NS_TILES, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0, batch);
         double *t = xi; xi = xo; xo = t;
     }
-    if (sq_tail > 0) hipLaunchKernelGGL(ns_square_tail_kernel, dim3(NS_TILES), dim3(256), 0, s, X0, X1, sc, sq_sep, NS_SQUARINGS - 1);
+    if (sq_tail > 0) hipLaunchKernelGGL(ns_square_tail_kernel, ns_tail_grid(NS_TILES, batch), dim3(256), 0, s, X0, X1, sc, sq_sep, NS_SQUARINGS - 1, batch);
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
     if (g_dbg_sigma_stages < 3) return 0;
-    hipLaunchKernelGGL(ns_first_kernel, dim3(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1);  // 64 tiles + the table
-    int n_tail = (batch == 1 && persistent_ok) ? g_ns_tail_iters : 0;
+    hipLaunchKernelGGL(ns_first_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);  // 64 tiles + the table
+    int n_tail = persistent_ok ? (batch == 1 ? g_ns_tail_iters : g_ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
     const int n_sep = NS_ITERS - n_tail;
     for (int i = 1; i < n_sep; ++i) {
         const int in = i & 1, out = in ^ 1;
-        hipLaunchKernelGGL(ns_T_kernel, dim3(64, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i);
-        hipLaunchKernelGGL(ns_YZ_kernel, dim3(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
-                           Zt[out], sc, i, out);
+        hipLaunchKernelGGL(ns_T_kernel, ns_grid(64, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i, batch);
+        hipLaunchKernelGGL(ns_YZ_kernel, ns_grid(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
+                           Zt[out], sc, i, out, batch);
     }
     if (n_tail > 0) {
         NsBufs B;
@@ -1066,7 +1274,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         }
         B.T = T;
         B.Tt = Tt;
-        hipLaunchKernelGGL(ns_iter_tail_kernel, dim3(64), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1);
+        if (batch == 1) hipLaunchKernelGGL(ns_iter_tail_kernel, ns_tail_grid(64, 1), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1);
+        else hipLaunchKernelGGL(ns_iter_tail_batched_kernel, ns_tail_grid(64, batch), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, batch);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     EpsGenArgs g;

@@ -354,9 +354,10 @@ int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sam
  * sigma_ns.hip: 12 matrices [batch][128][128], then 64 scalars per matrix) to `out` (device). */
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 /* Test hook (process-wide): how many of the eigh-free Sigma chain's last Chebyshev squarings / Newton-Schulz iterations
- * run inside the two persistent launches (phases separated by grid barriers) instead of as one / two launches each.
- * Default (9, 6): the last nine squarings (of a cap of sixteen) and six iterations; (64, 64) = all but the first of each; (0, 0) = every phase its own launch.  The result does not
- * depend on it bit for bit; graphs captured before the call keep their launch sequence; batch > 1 never uses them. */
+ * run inside the two persistent launches (phases separated by barriers inside the launch) instead of as one / two launches
+ * each.  Defaults: one matrix (15, 11) = all but the first of each; batched launches (15, 5).  The call sets both; (64, 64) = all
+ * but the first of each, (0, 0) = every phase its own launch, (-1, -1) = back to the defaults.  The result does not depend on it
+ * bit for bit; graphs captured before the call are re-captured at their next step. */
 int covo_debug_set_ns_tail(int n_squarings, int n_iters);
 /* Test hook (process-wide): 0 switches the deflation of the bottom eigenpair in the eigh-free Sigma chain off (sigma_ns.hip: the
  * Newton-Schulz iteration then runs on B itself, ~2 iterations more); default on.  Results agree to fp64 rounding either way

@@ -14,4 +14,6 @@ buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()
 d = json.loads(buf.getvalue().strip().splitlines()[-1])
-print(f"tail sq={sq} it={it} deflate={defl}: value {d['value']:.0f} steps/s ({1e3*d['ms_per_step']:.1f} us)  closed loop {d['closed_loop']['device_env']:.0f}")
+cl = d.get("closed_loop") or {}
+print(f"tail sq={sq} it={it} deflate={defl}: value {d['value']:.0f} {d['unit'].split()[0]} ({1e3*d['ms_per_step']:.1f} us)  closed loop {cl.get('device_env', cl.get('value', 0)):.0f}"
+      + (f"  sigma {d['phases_us_per_batched_step']['sigma_us']:.1f} us" if "phases_us_per_batched_step" in d else ""))
