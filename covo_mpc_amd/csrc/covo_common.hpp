@@ -174,7 +174,7 @@ struct SymStatsOut;  // sym_stats.hpp
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev = nullptr,
                    size_t traj_stride = 0,
-                   const SymStatsOut *stats = nullptr,   // batch 1: KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
+                   const SymStatsOut *stats = nullptr,   // KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
                    const float *f_tab = nullptr,         // [batch][H][4] per-step disturbance table (disturb.hip), device
                    const void *models_dev = nullptr,     // dm::Model[batch] next to consts_dev (drag / mixed with per-instance parameters)
                    int *status_dev = nullptr);           // the handle's sticky status word: COVO_DEVSTAT_ADJOINT on a costate time-out
@@ -198,13 +198,13 @@ struct EpsGenArgs;  // eps_tiles.hpp
 // gen != null (fused step): the finalize launch also draws the step's epsilon in tile order (eps_tiles.hpp)
 // status: the handle's sticky status word (a timed-out grid barrier raises COVO_DEVSTAT_GRID_BARRIER there, next to the NaN
 // outputs); persistent_ok = false (COVO_FLAG_SHARED_DEVICE): every phase its own launch
-// r_has_stats (fused step, batch 1): R is exactly symmetric and its statistics (sym_stats.hpp) are already in the workspace -- left
+// r_has_stats (fused steps): R is exactly symmetric and its statistics (sym_stats.hpp) are already in the workspace -- left
 // there by the Hessian's last launch through sigma_ns_stats_out -- so the chain starts without its prep launch
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
                     hipStream_t s, const EpsGenArgs *gen = nullptr, int *status = nullptr, bool persistent_ok = true,
                     CovDeferred *cov = nullptr, bool r_has_stats = false);
 struct SymStatsOut;  // sym_stats.hpp
-SymStatsOut sigma_ns_stats_out(void *workspace);
+SymStatsOut sigma_ns_stats_out(void *workspace, int batch = 1);
 void step_state_destroy(covo_ctx *h);
 void step_graphs_drop(covo_ctx *h);  // before re-allocating h->ws_sigma / h->ws_hess: captured graphs hold their addresses
 void batch_state_destroy(covo_ctx *h);

@@ -47,7 +47,7 @@ struct AdjArgs {
     qm::Consts<double> c;            // shared model constants ...
     const qm::Consts<double> *cs;    // ... or one per batch entry (device, nullable): env instances with their own parameters
     size_t traj_stride;              // floats between the trajectories of consecutive batch entries (0: shared)
-    SymStatsOut stats;               // batch 1, rpart != null: KD also leaves the Sigma chain's input statistics of R there
+    SymStatsOut stats;               // rpart != null: KD also leaves the Sigma chain's input statistics of R there (every instance)
     const float4 *f_tab;             // [batch][H] per-step disturbance table (disturb.hip; wave-uniform kinds only) or null: no force after step 0
     int reward;                      // COVO_REWARD_*
     // adj16 only (drag / mixed: the force is part of the differentiated state); f_tab rows are then {g_k[3], c_k}
@@ -120,7 +120,8 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.stats.rpart = nullptr;
     A.stats.fpart = nullptr;
     A.stats.diag = nullptr;
-    if (stats != nullptr && batch == 1) A.stats = *stats;
+    A.stats.stride = 0;
+    if (stats != nullptr) A.stats = *stats;
     // launch shapes: KB 32 waves; KC 9 chains + KM's 32 hyper-dual workgroups (which also contract with the costate); KD 36 tiles
 #define ADJ_LAUNCH(NS, JAC)                                                                                                      \
     do {                                                                                                                          \

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
             R[(size_t)j * NA + i] = -v;
         }
     }
-    if (A.stats.rpart != nullptr && b == 0) {
+    if (A.stats.rpart != nullptr) {
         // the Sigma chain's input statistics of R = -v, tile by tile (sym_stats.hpp): the chain then needs no prep launch.  In a
         // diagonal tile R holds the lower half and its mirror image, so the statistics take the mirrored values too
         __shared__ double st_tmp[16][17];
@@ -615,7 +615,11 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
             __syncthreads();
             if (wv < 4 && i < j) rv = st_diag[lo][hi + 4 * wv];
         }
-        sym_tile_stats(wv < 4, rv, I, J, (int)blockIdx.x, lane, wv & 3, A.stats, st_tmp, st_part);
+        SymStatsOut so = A.stats;  // this instance's block
+        so.rpart += (size_t)b * so.stride;
+        so.fpart += (size_t)b * so.stride;
+        so.diag += (size_t)b * so.stride;
+        sym_tile_stats(wv < 4, rv, I, J, (int)blockIdx.x, lane, wv & 3, so, st_tmp, st_part);
     }
 }
 #undef ADJ_FOR_STATE

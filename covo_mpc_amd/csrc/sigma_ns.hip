@@ -270,6 +270,7 @@ __device__ __forceinline__ SymStatsOut ns_stats_out(double *s)
     o.rpart = s + SC_RPART;
     o.fpart = s + SC_FPART;
     o.diag = s + SC_DIAG;
+    o.stride = 0;
     return o;
 }
 __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ Aall,
@@ -1209,14 +1210,15 @@ int g_ns_tail_iters_batched = 5, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
 // iteration (A/B measurements, tests)
 int g_ns_deflate = [] { const char *e = std::getenv("COVO_NS_DEFLATE"); return (e && e[0] == '0') ? 0 : 1; }();
 
-SymStatsOut sigma_ns_stats_out(void *workspace)
+SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
 {
     double *ws = reinterpret_cast<double *>(workspace);
-    double *sc = ws + (size_t)11 * SN * SN;
+    double *sc = ws + (size_t)11 * batch * SN * SN;
     SymStatsOut o;
     o.rpart = sc + SC_RPART;
     o.fpart = sc + SC_FPART;
     o.diag = sc + SC_DIAG;
+    o.stride = SC_COUNT;
     return o;
 }
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
@@ -1238,7 +1240,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (r_has_stats && batch == 1) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
+    if (r_has_stats) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
     else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
     hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0, batch);
     // the remaining squarings / iterations run inside persistent launches (36 / 64 workgroups per matrix, one XCD per matrix)

@@ -574,13 +574,16 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
     // covo.py:231: CoVO's sampling rollouts run step_env(deterministic=True); get_hessian likewise (covo.py:152)
     if ((M & 1) && b->tables && (rc = launch_disturb_tables_batched(b->models, a.states, b->dyn, E, 1, b->tab_rollout, b->tab_hess, s)))
         return rc;
+    // as in the single step: the Hessian's last launch leaves every instance's Sigma-chain input statistics, no prep launch
+    const bool stats = (M & 2) && (M & 4) && (g_dbg_hess_mask & 15) == 15 && hessian_leaves_stats(b->params[0]);
+    const SymStatsOut so = sigma_ns_stats_out(h->ws_sigma, E);
     if ((M & 2) && (rc = launch_hessian(a.states, a.pos_traj, a.vel_traj, a.T, b->params[0], b->a_mean_shift, E, b->R, h->ws_hess, s,
-                                        b->consts, (size_t)a.T * 3, nullptr, b->tables ? b->tab_hess : nullptr, b->models,
+                                        b->consts, (size_t)a.T * 3, stats ? &so : nullptr, b->tables ? b->tab_hess : nullptr, b->models,
                                         h->status_dev)))
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
     if ((M & 4) && (rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
-                                         (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0))) return rc;
+                                         (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, nullptr, stats))) return rc;
     if ((M & 8) && (rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E, false, nullptr,
                                            covo_propagate_nan(h))))
         return rc;

@@ -9,6 +9,7 @@ struct SymStatsOut {
     double *rpart;  // [128][8]  sum over the 16 columns of column block cb of |A[r][c]|
     double *fpart;  // [36]      sum of squares of a lower tile (off-diagonal tiles counted twice)
     double *diag;   // [128]
+    size_t stride;  // doubles between the blocks of consecutive matrices of a batch (all three pointers)
 };
 
 // 256 threads (4 waves) hold the lower tile (I >= J) of the symmetric matrix: thread (lane = 16 hi + lo, wave wv) holds
