@@ -564,7 +564,10 @@ void batch_state_destroy(covo_ctx *h)
 // Seven batched launch sets for all E instances: begin, Hessian (4 kernels), Sigma chain (~47), noise GEMM, rollout,
 // softmax partials, merge -- every kernel takes the instance as a grid dimension.  (Measured alternative, E = 32,
 // N = 4096: per-instance GEMM/rollout/softmax launches 1 452 us per call; the same spread over 2 / 4 / 8 forked
-// branches of the graph 1 103 / 1 140 / 1 153 us, while hipGraphLaunch's host cost grew from 47 to >300 us.)
+// branches of the graph 1 103 / 1 140 / 1 153 us, while hipGraphLaunch's host cost grew from 47 to >300 us.  Round 4: the Sigma
+// chain of the two halves of the instances on two forked branches, every phase its own launch: 72 700 control-steps/s against
+// 71 200 unforked with the same launches and 76 300 with the persistent tails -- which must not run side by side: two persistent
+// launches can starve each other of workgroup slots, the barriers then time out.)
 static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, hipStream_t s)
 {
     const int E = a.n_envs, N = a.n_samples;
@@ -583,7 +586,7 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
     if ((M & 4) && (rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
-                                         (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, nullptr, stats))) return rc;
+                                                (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, nullptr, stats))) return rc;
     if ((M & 8) && (rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E, false, nullptr,
                                            covo_propagate_nan(h))))
         return rc;
