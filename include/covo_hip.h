@@ -56,7 +56,11 @@ extern "C" {
 #define COVO_FLAG_NO_GRAPH 2         /* covo_config.flags: covo_mpc_step always launches eagerly (no hipGraph) */
 #define COVO_FLAG_SHARED_DEVICE 4    /* covo_config.flags: other processes / streams compete for this GPU: no launch may depend on
                                         its workgroups being co-resident (the Sigma chain then runs every phase as its own
-                                        launch instead of folding the often-idle ones into two persistent launches) */
+                                        launch instead of folding them into two persistent launches).  Set it as well when TWO
+                                        HANDLES of one process run covo-online / covo_sigma steps concurrently on different
+                                        streams: two persistent launches side by side can hold the workgroup slots each other's
+                                        missing workgroups need (their barriers then time out: COVO_DEVSTAT_GRID_BARRIER).  Steps on
+                                        one stream, and any number of handles used one after the other, need nothing. */
 
 #define COVO_FLAG_PROPAGATE_NAN 8    /* covo_config.flags: the action clips (covo.py:224, mppi.py:66, quadrotor.py:223,258) keep a NaN
                                         like jnp.clip = minimum(maximum(x, lo), hi) does.  Default (flag off): the kernels clip with
