@@ -864,6 +864,117 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
     (void)ns_YZ_body<COH_NONE>(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, b, w, red);
 }
 
+// ---- batched launches of the Newton-Schulz phases: one workgroup = a 2 x 2 block of 16 x 16 tiles (round 4).  With one tile per
+// workgroup a batched phase moves 32 KB of operands per tile through the CU's L1 port (Y.T and T.Z at 32 matrices: 4 096
+// workgroups, 134 MB = as many port cycles as the fp64 MFMAs take) -- a 2 x 2 block shares its operands (64 KB for four tiles) and
+// needs a quarter of the workgroups.  EVERY tile is computed exactly as the one-tile bodies compute it -- wave q takes the
+// K-quarter [32 q, 32 q + 32), 8 MFMAs on an accumulator of its own, the four partial tiles summed (0 + 1) + (2 + 3), the
+// per-tile slots filled by the same reductions -- so a matrix of a batch still equals the same matrix alone bit for bit.
+struct QuadOps {
+    double a[2][8], b[2][8];
+};
+template <class F>
+__device__ __forceinline__ void quad_load(QuadOps &o, const double *A, const double *B, int mi, int mj, int lane, int kq, F f)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 32 * kq + 4 * kk + hi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            o.a[h][kk] = f(A[(size_t)k * SN + 32 * mi + 16 * h + lo], k, 32 * mi + 16 * h + lo);
+            o.b[h][kk] = f(B[(size_t)k * SN + 32 * mj + 16 * h + lo], k, 32 * mj + 16 * h + lo);
+        }
+    }
+}
+// the four tiles (ia, ib): this wave's element (row (lane >> 4) + 4 wv, col lane & 15) of each, v[2 ia + ib]
+__device__ __forceinline__ void quad_mma_reduce(const QuadOps &o, double (*redq)[4][4][64], int wv, int lane, double v[4])
+{
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[ia][kk], o.b[ib][kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) redq[2 * ia + ib][wv][r][lane] = acc[r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        v[t] = (redq[t][0][wv][lane] + redq[t][1][wv][lane]) + (redq[t][2][wv][lane] + redq[t][3][wv][lane]);
+}
+
+// part 1 (ns_T_body): grid (16 blocks, batch)
+__global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
+                                                        double *__restrict__ Tall, double *__restrict__ Ttall,
+                                                        double *__restrict__ scall, int iter, int batch)
+{
+    __shared__ double redq[4][4][4][64];
+    __shared__ double partq[4][4];
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *s = scall + (size_t)b * SC_COUNT;
+    const size_t off = (size_t)b * SN * SN;
+    const int mi = w >> 2, mj = w & 3;
+    if (s[SC_NS_DONE] != 0.0) return;  // the flag before the operands (see ns_square_body)
+    QuadOps ops;
+    quad_load(ops, Ztall + off, Yall + off, mi, mj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
+    if (ns_converged<COH_NONE>(s, iter, lane, w == 0 && tid == 0)) return;
+    double p[4];
+    quad_mma_reduce(ops, redq, wv, lane, p);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ti = 2 * mi + (t >> 1), tj = 2 * mj + (t & 1);
+        const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        store_both(Tall + off, Ttall + off, row, col, fma(bq, p[t], (row == col) ? a : 0.0));
+        const double d = p[t] - ((row == col) ? 1.0 : 0.0);
+        const double ws = wr::wave64_allsum(d * d);
+        if (lane == 0) partq[t][wv] = ws;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int ti = 2 * mi + (tid >> 1), tj = 2 * mj + (tid & 1);
+        s[SC_ERR + iter * 64 + ti * 8 + tj] = (partq[tid][0] + partq[tid][1]) + (partq[tid][2] + partq[tid][3]);
+    }
+}
+
+// part 2 (ns_YZ_body): grid (32 blocks, batch): blocks 0..15 of Y' = Y.T, 16..31 of Z' = T.Z
+__global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
+                                                         const double *__restrict__ Tall, const double *__restrict__ Ttall,
+                                                         double *__restrict__ Yout, double *__restrict__ Ytout,
+                                                         double *__restrict__ Zout, double *__restrict__ Ztout,
+                                                         double *__restrict__ scall, int iter, int zbuf_out, int batch)
+{
+    __shared__ double redq[4][4][4][64];
+    int b, wx;
+    if (!ns_block(batch, b, wx)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *s = scall + (size_t)b * SC_COUNT;
+    const bool isZ = wx >= 16;
+    const int w = wx & 15, mi = w >> 2, mj = w & 3;
+    const size_t off = (size_t)b * SN * SN;
+    if (s[SC_NS_DONE] != 0.0) return;
+    QuadOps ops;
+    quad_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, mi, mj, lane, wv, LoadPlain{});
+    if (ns_converged<COH_NONE>(s, iter, lane, false)) return;  // part 1 of this iteration raised the flag
+    if (wx == 0 && tid == 0) {
+        s[SC_ZBUF] = (double)zbuf_out;
+        s[SC_ITERS] = (double)(iter + 1);
+    }
+    double v[4];
+    quad_mma_reduce(ops, redq, wv, lane, v);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ti = 2 * mi + (t >> 1), tj = 2 * mj + (t & 1);
+        const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        store_both((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v[t]);
+    }
+}
+
 // ---- the chain's dependent phases inside ONE persistent launch (batch 1 only: the launch's workgroups must be
 // co-resident).  A captured graph cannot branch, so as separate launches every phase the caps allow costs 1.6 us even
 // after convergence, and a live one ~3.2-3.7 us, most of it launch floor.  Here every workgroup keeps its tile, the phases
@@ -1262,6 +1373,12 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     const int n_sep = NS_ITERS - n_tail;
     for (int i = 1; i < n_sep; ++i) {
         const int in = i & 1, out = in ^ 1;
+        if (batch > 1) {  // 2 x 2 tile blocks per workgroup: same tiles, same bits, half the operand traffic
+            hipLaunchKernelGGL(ns_T_quad_kernel, ns_grid(16, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i, batch);
+            hipLaunchKernelGGL(ns_YZ_quad_kernel, ns_grid(32, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
+                               Zt[out], sc, i, out, batch);
+            continue;
+        }
         hipLaunchKernelGGL(ns_T_kernel, ns_grid(64, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i, batch);
         hipLaunchKernelGGL(ns_YZ_kernel, ns_grid(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
                            Zt[out], sc, i, out, batch);
