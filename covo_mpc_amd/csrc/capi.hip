@@ -497,7 +497,7 @@ int covo_debug_set_ns_tail(int n_squarings, int n_iters)
     if (n_squarings < 0) {  // back to the defaults (sigma_ns.hip)
         g_ns_tail_squarings = g_ns_tail_squarings_batched = 15;
         g_ns_tail_iters = 11;
-        g_ns_tail_iters_batched = 5;
+        g_ns_tail_iters_batched = 4;
     } else {
         g_ns_tail_squarings = g_ns_tail_squarings_batched = n_squarings;  // batch 1 and batched launches alike
         g_ns_tail_iters = g_ns_tail_iters_batched = n_iters;

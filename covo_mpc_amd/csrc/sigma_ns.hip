@@ -975,6 +975,67 @@ __global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restric
     }
 }
 
+// iteration 0 (ns_first_kernel) the same way: grid (16 blocks + the table's workgroup, batch)
+template <class LD>
+__device__ __forceinline__ void ns_first_quad_tiles(const LD &ld, const double *A, double *Yout, double *Ytout, double *Zout,
+                                                    double *Ztout, double a0, double b0, int mi, int mj, int lane, int wv,
+                                                    double (*redq)[4][4][64])
+{
+    QuadOps ops;
+    quad_load(ops, A, A, mi, mj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
+    double y2[4];
+    quad_mma_reduce(ops, redq, wv, lane, y2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ti = 2 * mi + (t >> 1), tj = 2 * mj + (t & 1);
+        const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        const double y0 = ld(A[(size_t)row * SN + col], row, col);
+        store_both(Yout, Ytout, row, col, fma(b0, y2[t], a0 * y0));
+        store_both(Zout, Ztout, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
+    }
+}
+__global__ __launch_bounds__(256) void ns_first_quad_kernel(const double *__restrict__ Aall, double *__restrict__ Yout,
+                                                            double *__restrict__ Ytout, double *__restrict__ Zout,
+                                                            double *__restrict__ Ztout, double *__restrict__ scall, int zbuf_out,
+                                                            int batch)
+{
+    __shared__ double redq[4][4][4][64];
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t off = (size_t)b * SN * SN;
+    const double *A = Aall + off;
+    double *s = scall + (size_t)b * SC_COUNT;
+    const double scale = s[SC_SCALE];
+    const double delta = s[SC_DELTA], inv = 1.0 / scale;
+    const double lo = s[SC_LO], gam = s[SC_GAM];
+    if (w == 16) {  // the coefficient table (see ns_first_kernel)
+        if (tid == 0) {
+            double l = sqrt(lo / scale);
+            for (int k = 0; k < NS_ITERS; ++k) {
+                double a, bq;
+                ns_coef(l, a, bq);
+                s[SC_COEF + 2 * k] = a;
+                s[SC_COEF + 2 * k + 1] = bq;
+                l = fmin(1.0, l * fma(bq * l, l, a));
+            }
+        }
+        return;
+    }
+    double a0, b0;
+    ns_coef(sqrt(lo / scale), a0, b0);
+    if (w == 0 && tid == 0) {
+        s[SC_ZBUF] = (double)zbuf_out;
+        s[SC_ITERS] = 1.0;
+    }
+    const int mi = w >> 2, mj = w & 3;
+    if (gam != 0.0)  // (uniform)
+        ns_first_quad_tiles(LoadScaledBDefl{delta, inv, gam, s + SC_U}, A, Yout + off, Ytout + off, Zout + off, Ztout + off, a0, b0, mi, mj,
+                            lane, wv, redq);
+    else
+        ns_first_quad_tiles(LoadScaledB{delta, inv}, A, Yout + off, Ytout + off, Zout + off, Ztout + off, a0, b0, mi, mj, lane, wv, redq);
+}
+
 // ---- the chain's dependent phases inside ONE persistent launch (batch 1 only: the launch's workgroups must be
 // co-resident).  A captured graph cannot branch, so as separate launches every phase the caps allow costs 1.6 us even
 // after convergence, and a live one ~3.2-3.7 us, most of it launch floor.  Here every workgroup keeps its tile, the phases
@@ -1311,12 +1372,14 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // 0.64 flag -> poll; part 2 = 1.36 / 0.84 (2 048 fp64-MFMA cycles per SIMD: a quarter of the phase is now the ONE XCD's matrix
 // throughput) / 0.6 / 1.3-1.7 (the other workgroup of the CU finishes its MFMAs later).
 // Batched (the env-batched step, covo-offline's table): all squarings are folded -- every matrix runs them at its own pace, 4
-// matrices per XCD at 32 -- but only the last 5 iterations: early on every matrix is live and 4 matrices x 64 workgroups on an
+// matrices per XCD at 32 -- but only the last 4 iterations: early on every matrix is live and 4 matrices x 64 workgroups on an
 // XCD's 32 CUs contend (3 workgroups per CU at 122 VGPRs) where a launch spreads each phase over the chip.  bench.py --config
 // envs, control-steps/s / Sigma us per batched step: (0, 0) 71 186 / 288; (15, 0) 73 395 / 274; (15, 3) 74 851 / 266;
-// (15, 5) 75 943 / 255; (15, 7) 73 142 / 274; (15, 11) 72 163 / 282; (11, 5) 75 007 / 261; (8, 5) 74 636 / 262.
+// (15, 5) 75 943 / 255; (15, 7) 73 142 / 274; (15, 11) 72 163 / 282; (11, 5) 75 007 / 261; (8, 5) 74 636 / 262.  With the 2 x 2 blocks of
+// the batched launches (ns_T_quad_kernel ...), bench / closed loop: (15, 2) 79 172 / 72 844; (15, 3) 79 049 / 72 829; (15, 4) 80 580 /
+// 73 096; (15, 5) 80 223 / 70 336; (15, 6) 78 611 / 69 693 -> the last 4.
 int g_ns_tail_iters = NS_ITERS - 1, g_ns_tail_squarings = NS_SQUARINGS - 1;
-int g_ns_tail_iters_batched = 5, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
+int g_ns_tail_iters_batched = 4, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
 // COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
 // iteration (A/B measurements, tests)
 int g_ns_deflate = [] { const char *e = std::getenv("COVO_NS_DEFLATE"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -1367,7 +1430,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
     if (g_dbg_sigma_stages < 3) return 0;
-    hipLaunchKernelGGL(ns_first_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);  // 64 tiles + the table
+    if (batch > 1) hipLaunchKernelGGL(ns_first_quad_kernel, ns_grid(17, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
+    else hipLaunchKernelGGL(ns_first_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);  // 64 tiles + the table
     int n_tail = persistent_ok ? (batch == 1 ? g_ns_tail_iters : g_ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
     const int n_sep = NS_ITERS - n_tail;

@@ -359,7 +359,7 @@ int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sam
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 /* Test hook (process-wide): how many of the eigh-free Sigma chain's last Chebyshev squarings / Newton-Schulz iterations
  * run inside the two persistent launches (phases separated by barriers inside the launch) instead of as one / two launches
- * each.  Defaults: one matrix (15, 11) = all but the first of each; batched launches (15, 5).  The call sets both; (64, 64) = all
+ * each.  Defaults: one matrix (15, 11) = all but the first of each; batched launches (15, 4).  The call sets both; (64, 64) = all
  * but the first of each, (0, 0) = every phase its own launch, (-1, -1) = back to the defaults.  The result does not depend on it
  * bit for bit; graphs captured before the call are re-captured at their next step. */
 int covo_debug_set_ns_tail(int n_squarings, int n_iters);
