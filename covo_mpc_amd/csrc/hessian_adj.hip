@@ -121,6 +121,7 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.stats.fpart = nullptr;
     A.stats.diag = nullptr;
     A.stats.stride = 0;
+    A.stats.flags = nullptr;
     if (stats != nullptr) A.stats = *stats;
     // launch shapes: KB 32 waves; KC 9 chains + KM's 32 hyper-dual workgroups (which also contract with the costate); KD 36 tiles
 #define ADJ_LAUNCH(NS, JAC)                                                                                                      \

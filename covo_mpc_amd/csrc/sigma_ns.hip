@@ -271,6 +271,7 @@ __device__ __forceinline__ SymStatsOut ns_stats_out(double *s)
     o.fpart = s + SC_FPART;
     o.diag = s + SC_DIAG;
     o.stride = 0;
+    o.flags = nullptr;
     return o;
 }
 __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ Aall,
@@ -311,8 +312,10 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
     if (FIRST) {
         // the input statistics from the per-tile partials (sym_stats.hpp), every workgroup for itself in the same fixed order;
         // workgroup 0 keeps the per-row sums for the Ritz launch and (fused step: there was no prep launch) clears the scalars
-        if (w == 0 && tid < SC_COEF) s[tid] = 0.0;
-        if (w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
+        // (inside the persistent launch the scalars are cleared coherently -- the "done" flags are polled by every workgroup from
+        // the second squaring on -- and the barrier flag words have been cleared a launch earlier: KD or ns_prep_kernel)
+        if (w == 0 && tid < SC_COEF) gst<COH>(s + tid, 0.0);
+        if (COH == COH_NONE && w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
         double ra = 0.0, dgv = 0.0;
         if (tid < SN) {
 #pragma unroll
@@ -1126,9 +1129,10 @@ __device__ __forceinline__ void ns_square_tail_rest(double *X0, double *X1, doub
         if (step < step_last && !ns_flag_barrier<COH>(flags, ++phase, w, nw, xcc, scall + SC_BARFAIL)) return;
     }
 }
-// squarings step_first .. step_last (step >= 1) of the Chebyshev filter: 36 workgroups (grid 8 x 36), X0 <-> X1 by parity
-__global__ __launch_bounds__(256) void ns_square_tail_kernel(double *X0, double *X1, double *scall, int step_first, int step_last,
-                                                             int batch)
+// squarings step_first .. step_last of the Chebyshev filter: 36 workgroups per matrix, X0 <-> X1 by parity; step 0 (the first
+// squaring: reads A, forms the affine map on load) is part of the launch when everything is folded
+__global__ __launch_bounds__(256) void ns_square_tail_kernel(const double *A, double *X0, double *X1, double *scall, int step_first,
+                                                             int step_last, int batch)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
@@ -1140,7 +1144,10 @@ __global__ __launch_bounds__(256) void ns_square_tail_kernel(double *X0, double 
     scall += (size_t)b * SC_COUNT;
     const unsigned xcc = ns_xcc_id();
     const bool odd = (step_first & 1) != 0;
-    if (!ns_square_body<false, COH_AGENT>(odd ? X0 : X1, odd ? X1 : X0, scall, step_first, odd ? 1 : 0, 0, w, red, part)) return;
+    if (step_first == 0) {
+        (void)ns_square_body<true, COH_AGENT>(A + (size_t)b * SN * SN, X0, scall, 0, 0, 0, w, red, part);
+    } else if (!ns_square_body<false, COH_AGENT>(odd ? X0 : X1, odd ? X1 : X0, scall, step_first, odd ? 1 : 0, 0, w, red, part))
+        return;
     if (step_first == step_last) return;
     const int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, nw, xcc, scall + SC_BARFAIL);
     if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 5] = (double)r;  // diagnostics: which mode the squaring tail ran in
@@ -1393,6 +1400,7 @@ SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
     o.fpart = sc + SC_FPART;
     o.diag = sc + SC_DIAG;
     o.stride = SC_COUNT;
+    o.flags = sc + SC_FLAGS;
     return o;
 }
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
@@ -1416,7 +1424,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     }
     if (r_has_stats) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
     else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
-    hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0, batch);
+    const bool fold_first = persistent_ok && (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) >= NS_SQUARINGS - 1;
+    if (!fold_first) hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0, batch);
     // the remaining squarings / iterations run inside persistent launches (36 / 64 workgroups per matrix, one XCD per matrix)
     int sq_tail = persistent_ok ? (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) : 0;
     if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
@@ -1426,7 +1435,9 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         hipLaunchKernelGGL(ns_square_kernel<false>, ns_grid(NS_TILES, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0, batch);
         double *t = xi; xi = xo; xo = t;
     }
-    if (sq_tail > 0) hipLaunchKernelGGL(ns_square_tail_kernel, ns_tail_grid(NS_TILES, batch), dim3(256), 0, s, X0, X1, sc, sq_sep, NS_SQUARINGS - 1, batch);
+    if (sq_tail > 0)
+        hipLaunchKernelGGL(ns_square_tail_kernel, ns_tail_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, X1, sc, fold_first ? 0 : sq_sep,
+                           NS_SQUARINGS - 1, batch);
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
     if (g_dbg_sigma_stages < 3) return 0;

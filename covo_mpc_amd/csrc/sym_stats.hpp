@@ -9,7 +9,8 @@ struct SymStatsOut {
     double *rpart;  // [128][8]  sum over the 16 columns of column block cb of |A[r][c]|
     double *fpart;  // [36]      sum of squares of a lower tile (off-diagonal tiles counted twice)
     double *diag;   // [128]
-    size_t stride;  // doubles between the blocks of consecutive matrices of a batch (all three pointers)
+    size_t stride;  // doubles between the blocks of consecutive matrices of a batch (all pointers)
+    double *flags;  // != null: 64 doubles the producer clears (the barrier flag words of the Sigma chain's persistent launches)
 };
 
 // 256 threads (4 waves) hold the lower tile (I >= J) of the symmetric matrix: thread (lane = 16 hi + lo, wave wv) holds
