@@ -34,6 +34,8 @@ __device__ __forceinline__ void tile(const double *__restrict__ A, double *__res
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lo = lane & 15, hi = lane >> 4;
     const int ti = t >> 3, tj = t & 7;
+    if (LD == 5) asm volatile("buffer_inv sc1" ::: "memory");  // the CU's L1 (and the L2's non-coherent lines) forget; the XCD's L2 serves
+    if (LD == 6) asm volatile("buffer_inv sc0" ::: "memory");
     double a[8], b[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -230,6 +232,8 @@ int main()
         run<1, 1, 0>("sc1 loads, agent counter, sleep 0", nw, dA, dB, ctl, h, ref, phases);
         run<1, 0, 0>("sc1 loads, asm RMW counter", nw, dA, dB, ctl, h, ref, phases);
         run<1, 3, 0>("sc1 loads, flag words polled sc1", nw, dA, dB, ctl, h, ref, phases);
+        run<5, 3, 0>("buffer_inv sc1 + plain loads, plain st, flags", nw, dA, dB, ctl, h, ref, phases);
+        run<6, 3, 0>("buffer_inv sc0 + plain loads, plain st, flags", nw, dA, dB, ctl, h, ref, phases);
         run<4, 3, 0>("sc1 loads + sc1 stores, flags sc1", nw, dA, dB, ctl, h, ref, phases);
         run<4, 3, 1>("sc1 loads + sc1 stores, flags sc1, sleep 1", nw, dA, dB, ctl, h, ref, phases);
         run<4, 1, 0>("sc1 loads + sc1 stores, agent counter", nw, dA, dB, ctl, h, ref, phases);
