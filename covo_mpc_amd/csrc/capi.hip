@@ -513,6 +513,13 @@ int covo_debug_set_ns_deflate(int on)
     return 0;
 }
 
+int covo_debug_set_ns_coherence(int force_agent)
+{
+    g_ns_force_agent = force_agent ? 1 : 0;
+    ++g_dbg_epoch;  // a kernel argument of the persistent launches
+    return 0;
+}
+
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)
 {
     REQUIRE(h && out, "covo_debug_sigma_workspace: bad argument");

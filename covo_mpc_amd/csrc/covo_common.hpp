@@ -40,7 +40,7 @@ void covo_set_error(const char *fmt, ...);
 // many stages of the Sigma pipeline (1 prep+squarings, 2 +Ritz, 3 +Newton-Schulz, 4 +finalize) are enqueued.
 // Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
-extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate;  // sigma_ns.hip
+extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate, g_ns_force_agent;  // sigma_ns.hip
 extern int g_dbg_epoch;  // capi.hip: bumped by every debug setter whose value a captured step graph bakes in as a kernel argument
 
 #define COVO_CHECK_HIP(expr)                                                         \

@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void ns_square_tail_rest(double *X0, double *X1, doub
 // squarings step_first .. step_last of the Chebyshev filter: 36 workgroups per matrix, X0 <-> X1 by parity; step 0 (the first
 // squaring: reads A, forms the affine map on load) is part of the launch when everything is folded
 __global__ __launch_bounds__(256) void ns_square_tail_kernel(const double *A, double *X0, double *X1, double *scall, int step_first,
-                                                             int step_last, int batch)
+                                                             int step_last, int batch, int force_agent)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
@@ -1149,7 +1149,8 @@ __global__ __launch_bounds__(256) void ns_square_tail_kernel(const double *A, do
     } else if (!ns_square_body<false, COH_AGENT>(odd ? X0 : X1, odd ? X1 : X0, scall, step_first, odd ? 1 : 0, 0, w, red, part))
         return;
     if (step_first == step_last) return;
-    const int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, nw, xcc, scall + SC_BARFAIL);
+    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, nw, xcc, scall + SC_BARFAIL);
+    if (r == 2 && force_agent) r = 1;
     if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 5] = (double)r;  // diagnostics: which mode the squaring tail ran in
     if (r == 2) ns_square_tail_rest<COH_XCD>(X0, X1, scall, step_first, step_last, w, nw, xcc, red, part);
     else if (r == 1) ns_square_tail_rest<COH_AGENT>(X0, X1, scall, step_first, step_last, w, nw, xcc, red, part);
@@ -1184,7 +1185,7 @@ __device__ __forceinline__ void ns_iter_tail_rest(const NsBufs &B, size_t off, d
 // Newton-Schulz iterations iter_first .. iter_last (iter >= 1): 64 workgroups per matrix (a barrier's cost grows with the
 // number of workgroups); workgroup w forms tile w of T, then tile w of Y' and of Z'.  LEAN: the batched launch (see above).
 template <bool LEAN>
-__device__ __forceinline__ void ns_iter_tail(const NsBufs &B, double *scall, int iter_first, int iter_last, int batch,
+__device__ __forceinline__ void ns_iter_tail(const NsBufs &B, double *scall, int iter_first, int iter_last, int batch, int force_agent,
                                              double (*red)[4][64], double *part)
 {
     constexpr int nw = 64;
@@ -1202,7 +1203,8 @@ __device__ __forceinline__ void ns_iter_tail(const NsBufs &B, double *scall, int
     if (!ns_T_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall, iter_first, 0, w,
                               red, part))
         return;
-    const int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, nw, xcc, scall + SC_BARFAIL);
+    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, nw, xcc, scall + SC_BARFAIL);
+    if (r == 2 && force_agent) r = 1;
     if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 6] = (double)r;  // diagnostics: which mode the iteration tail ran in
     if (r == 2) ns_iter_tail_rest<COH_XCD, LEAN>(B, off, scall, iter_first, iter_last, w, nw, xcc, red, part);
     else if (r == 1) ns_iter_tail_rest<COH_AGENT, LEAN>(B, off, scall, iter_first, iter_last, w, nw, xcc, red, part);
@@ -1211,19 +1213,20 @@ __device__ __forceinline__ void ns_iter_tail(const NsBufs &B, double *scall, int
         for (int i = 0; i < 192; ++i) scall[SC_STAMPS + i] = (i < g_nstamp) ? (double)(g_stamp[i] - g_stamp[0]) : -1.0;
 #endif
 }
-__global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, double *scall, int iter_first, int iter_last)
+__global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int force_agent)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    ns_iter_tail<false>(B, scall, iter_first, iter_last, 1, red, part);
+    ns_iter_tail<false>(B, scall, iter_first, iter_last, 1, force_agent, red, part);
 }
 // (forcing 8 waves per SIMD -- 64 VGPRs, 240 B of spills -- so that all 4 matrices an XCD gets out of 32 are resident together was
 // measured: 267 us against 176 at the compiler's 122 VGPRs / 3 workgroups per CU)
-__global__ __launch_bounds__(256) void ns_iter_tail_batched_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int batch)
+__global__ __launch_bounds__(256) void ns_iter_tail_batched_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int batch,
+                                                                   int force_agent)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
-    ns_iter_tail<true>(B, scall, iter_first, iter_last, batch, red, part);
+    ns_iter_tail<true>(B, scall, iter_first, iter_last, batch, force_agent, red, part);
 }
 
 // ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  ONE Cholesky serves both needs:
@@ -1389,6 +1392,7 @@ int g_ns_tail_iters = NS_ITERS - 1, g_ns_tail_squarings = NS_SQUARINGS - 1;
 int g_ns_tail_iters_batched = 4, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
 // COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
 // iteration (A/B measurements, tests)
+int g_ns_force_agent = 0;  // covo_debug_set_ns_coherence: take the COH_AGENT fallback although the placement check passed
 int g_ns_deflate = [] { const char *e = std::getenv("COVO_NS_DEFLATE"); return (e && e[0] == '0') ? 0 : 1; }();
 
 SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
@@ -1437,7 +1441,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     }
     if (sq_tail > 0)
         hipLaunchKernelGGL(ns_square_tail_kernel, ns_tail_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, X1, sc, fold_first ? 0 : sq_sep,
-                           NS_SQUARINGS - 1, batch);
+                           NS_SQUARINGS - 1, batch, g_ns_force_agent);
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
     if (g_dbg_sigma_stages < 3) return 0;
@@ -1468,8 +1472,9 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         }
         B.T = T;
         B.Tt = Tt;
-        if (batch == 1) hipLaunchKernelGGL(ns_iter_tail_kernel, ns_tail_grid(64, 1), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1);
-        else hipLaunchKernelGGL(ns_iter_tail_batched_kernel, ns_tail_grid(64, batch), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, batch);
+        if (batch == 1) hipLaunchKernelGGL(ns_iter_tail_kernel, ns_tail_grid(64, 1), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, g_ns_force_agent);
+        else hipLaunchKernelGGL(ns_iter_tail_batched_kernel, ns_tail_grid(64, batch), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, batch,
+                                g_ns_force_agent);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     EpsGenArgs g;

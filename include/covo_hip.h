@@ -367,6 +367,10 @@ int covo_debug_set_ns_tail(int n_squarings, int n_iters);
  * Newton-Schulz iteration then runs on B itself, ~2 iterations more); default on.  Results agree to fp64 rounding either way
  * (not bit for bit: another iteration sequence); graphs captured before the call keep their behaviour. */
 int covo_debug_set_ns_deflate(int on);
+/* Test hook (process-wide): 1 makes the Sigma chain's persistent launches behave as if their workgroups had NOT all landed on one
+ * XCD (sigma_ns.hip: every access stays an agent-scope atomic, COH_AGENT) -- the fallback of the placement check, which no
+ * MI355X box takes by itself; 0 (default): as detected.  Same Sigma and L bit for bit. */
+int covo_debug_set_ns_coherence(int force_agent);
 int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 
 /* Profiling aid: covo_sigma for ONE matrix that also stores shader-clock ticks (s_memtime) at the kernel's

@@ -662,6 +662,15 @@ def test_batched_step_equals_replicas():
     assert (batched.a_mean[0] - batched.a_mean[1]).abs().max() > 1e-4  # different plants, different plans
 
 
+def core_scalars(core, batch, count=24):
+    """the first `count` scalars of matrix 0 of the Sigma chain's workspace after a covo_sigma call on `batch` matrices"""
+    from covo_mpc_amd import _lib
+    out = torch.zeros(count, dtype=torch.float64, device=DEV)
+    _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out), 11 * batch * 128 * 128, count, core.stream()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
 def test_sigma_tail_launch_is_bit_identical():
     """The Sigma chain's squarings and Newton-Schulz iterations run inside two persistent launches whose phases are
     separated by barriers inside the launch (sigma_ns.hip: ns_square_tail_kernel, ns_iter_tail_kernel; all workgroups of a matrix
@@ -703,7 +712,19 @@ def test_sigma_tail_launch_is_bit_identical():
         for i in range(3):  # and a matrix of a batch equals the same matrix alone
             Sig1, L1 = core.sigma(R_b[i:i + 1].contiguous(), 0.5)
             assert torch.equal(Sig1[0], outs[0][0][i]) and torch.equal(L1[0], outs[0][1][i])
+        # the placement check's fallback (workgroups of a launch NOT on one XCD: every access stays an agent-scope atomic), which no
+        # MI355X box takes by itself: forced, one matrix and the batch
+        tail_modes = lambda b: core_scalars(core, b)[21:23]
+        Sig_x, L_x = core.sigma(R_b[:1].contiguous(), 0.5)
+        assert list(tail_modes(1)) == [2.0, 2.0], tail_modes(1)  # both persistent launches found themselves on one XCD
+        _lib.check(lib.covo_debug_set_ns_coherence(1))
+        Sig_a, L_a = core.sigma(R_b[:1].contiguous(), 0.5)
+        assert list(tail_modes(1)) == [1.0, 1.0], tail_modes(1)
+        assert torch.equal(Sig_a, Sig_x) and torch.equal(L_a, L_x)
+        Sig_a, L_a = core.sigma(R_b, 0.5, batch=11)
+        assert torch.equal(Sig_a, outs[0][0]) and torch.equal(L_a, outs[0][1])
     finally:
+        _lib.check(lib.covo_debug_set_ns_coherence(0))
         _lib.check(lib.covo_debug_set_ns_tail(-1, -1))
 
 
