@@ -944,6 +944,13 @@ def test_shared_device_flag_runs_the_chain_phase_by_phase_with_identical_results
     S0, L0 = c0.sigma(Rm, 0.5)
     S1, L1 = c1.sigma(Rm, 0.5)
     assert torch.equal(S0, S1) and torch.equal(L0, L1) and torch.isfinite(S0).all()
+    # a batch (the env-batched step, covo-offline's table): per-matrix persistent launches against one-tile squaring launches +
+    # the 2 x 2-block launches of the iterations -- and row 0 of the batch against the single matrix
+    Rb = torch.cat([Rm * (1.0 + 0.5 * i) + 0.3 * i * torch.eye(128, dtype=Rm.dtype, device=Rm.device) for i in range(13)]).contiguous()
+    Sb0, Lb0 = c0.sigma(Rb, 0.5, batch=13)
+    Sb1, Lb1 = c1.sigma(Rb, 0.5, batch=13)
+    assert torch.equal(Sb0, Sb1) and torch.equal(Lb0, Lb1) and torch.isfinite(Sb0).all()
+    assert torch.equal(Sb0[0], S0[0]) and torch.equal(Lb0[0], L0[0])
 
 
 def test_workspace_growth_drops_the_captured_step_graph(monkeypatch):
