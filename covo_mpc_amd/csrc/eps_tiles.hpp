@@ -17,18 +17,23 @@ struct EpsGenArgs {
     const uint32_t *dyn;    // {key0, key1} in device memory (step.hip: the act key derived by step_begin_kernel)
     int64_t sample_offset;  // global id of local sample 0
     int N;
+    // env-batched step: n_inst instances of N samples each; instance e has its key at dyn + e * dyn_stride and its tiles at
+    // eps_tiled + e * eps_stride (single step: 1, 0, 0)
+    int n_inst, dyn_stride;
+    size_t eps_stride;
 };
 
 __device__ __forceinline__ void eps_tiles_generate(const EpsGenArgs &G, int wave_global, int wave_stride, int lane)
 {
-    const uint32_t k0 = G.dyn[0], k1 = G.dyn[1];
     const int ntiles = (G.N + 31) / 32;
     const int j = lane & 31, kh = lane >> 5;
-    for (int t = wave_global; t < ntiles; t += wave_stride) {
+    for (int tt = wave_global; tt < ntiles * G.n_inst; tt += wave_stride) {
+        const int e = tt / ntiles, t = tt - e * ntiles;
+        const uint32_t k0 = G.dyn[(size_t)e * G.dyn_stride], k1 = G.dyn[(size_t)e * G.dyn_stride + 1];
         int row = t * 32 + j;
         row = row < G.N ? row : G.N - 1;
         const uint64_t id = (uint64_t)(G.sample_offset + row);
-        float4 *out = G.eps_tiled + (size_t)t * 16 * 64 + lane;
+        float4 *out = G.eps_tiled + (size_t)e * G.eps_stride + (size_t)t * 16 * 64 + lane;
 #pragma unroll 4
         for (int q = 0; q < 16; ++q) {
             const float4 v = rngd::normal4((uint32_t)(2 * q + kh), id, k0, k1);

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
         mu += y * COVO_NA;
         a_out += y * ((size_t)COVO_H * N);
         if (dyn != nullptr) dyn += y * 12;
+        if (TILED) eps += y * ((size_t)ntiles * 16 * 64 * 4);  // the instance's tiles (eps_tiles.hpp)
     }
     NG_STAMP(0);
     if (dyn != nullptr) { k0 = dyn[0]; k1 = dyn[1]; }
@@ -498,7 +499,7 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
 #define NG_GO(...)                                                                                                             \
     do {                                                                                                                         \
         if (eps != nullptr && eps_tiled)                                                                                         \
-            hipLaunchKernelGGL((noise_gemm_kernel<false, true, __VA_ARGS__>), dim3(grid), dim3(block), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, \
+            hipLaunchKernelGGL((noise_gemm_kernel<false, true, __VA_ARGS__>), dim3(grid, batch), dim3(block), lds, s, L, mu, eps, 0u, 0u, (int64_t)0, \
                                N, ntiles, reinterpret_cast<float4 *>(a), (const uint32_t *)nullptr, state_for_time, n_table, cv, nanp); \
         else if (eps != nullptr)                                                                                                 \
             hipLaunchKernelGGL((noise_gemm_kernel<false, false, __VA_ARGS__>), dim3(grid), dim3(block), lds, s, L, mu, eps, 0u, 0u,          \

@@ -1482,12 +1482,16 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     g.dyn = nullptr;
     g.sample_offset = 0;
     g.N = 0;
+    g.n_inst = 1;
+    g.dyn_stride = 0;
+    g.eps_stride = 0;
     int passengers = 0;
     if (gen != nullptr && gen->eps_tiled != nullptr) {
         g = *gen;
-        const int ntiles = (g.N + 31) / 32;
-        passengers = (ntiles + 7) / 8;         // 8 waves per workgroup, one tile per wave ...
-        if (passengers > 255) passengers = 255;  // ... at most one workgroup on every other CU, waves stride over tiles
+        const long long ntiles = (long long)((g.N + 31) / 32) * g.n_inst;
+        passengers = (int)((ntiles + 7) / 8);  // 8 waves per workgroup, one tile per wave ...
+        const int room = batch < 128 ? 256 - batch : 128;  // ... at most one workgroup on every other CU, waves stride over tiles
+        if (passengers > room) passengers = room;
     }
     if (cov != nullptr) {
         std::memset(cov, 0, sizeof(*cov));

@@ -239,6 +239,9 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         gen.dyn = st->dyn;
         gen.sample_offset = a.sample_offset;
         gen.N = N;
+        gen.n_inst = 1;
+        gen.dyn_stride = 0;
+        gen.eps_stride = 0;
         // a_cov is written by the GEMM's first workgroups, not by the chain's one-workgroup finalize launch (CovDeferred)
         CovDeferred cov;
         std::memset(&cov, 0, sizeof(cov));
@@ -477,6 +480,8 @@ struct BatchState {
     bool have_key = false, have_graph = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    float4 *eps_tiled = nullptr;  // [E][ceil(N/32)][16][64]: the step's epsilon of every instance, drawn under the Sigma chain's
+    size_t eps_cap = 0;           // finalize launch (eps_tiles.hpp), as in the single step
 };
 
 static void batch_state_free(BatchState *b)
@@ -555,6 +560,7 @@ void batch_state_destroy(covo_ctx *h)
     BatchState *b = reinterpret_cast<BatchState *>(h->batch);
     if (!b) return;
     batch_state_free(b);
+    (void)hipFree(b->eps_tiled);
     (void)hipFree(b->env_inst);  // (not in batch_state_free: the batched step re-allocates its scratch when the instance count
                                  // changes, possibly between batch_env_inst and the env step launch that reads this array)
     delete b;
@@ -585,10 +591,25 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
                                         h->status_dev)))
         return rc;
     float *Sig = a.a_cov ? a.a_cov : b->Sigma;
-    if ((M & 4) && (rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, nullptr, h->status_dev,
-                                                (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, nullptr, stats))) return rc;
-    if ((M & 8) && (rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E, false, nullptr,
-                                           covo_propagate_nan(h))))
+    // epsilon needs only the act keys: every instance's is drawn under the chain's finalize launch (32 of 256 CUs factor), the GEMM
+    // loads it -- the in-kernel Philox costs the batched GEMM ~9 us, its matrix pipe hides no vector work
+    const bool ahead = b->eps_tiled != nullptr && (M & 4) && (M & 8) && g_dbg_sigma_stages >= 4 && g_dbg_eps_ahead;
+    EpsGenArgs gen;
+    gen.eps_tiled = ahead ? b->eps_tiled : nullptr;
+    gen.dyn = b->dyn;
+    gen.sample_offset = 0;
+    gen.N = N;
+    gen.n_inst = E;
+    gen.dyn_stride = 12;
+    gen.eps_stride = (size_t)((N + 31) / 32) * 16 * 64;
+    if ((M & 4) && (rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, &gen, h->status_dev,
+                                         (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, nullptr, stats))) return rc;
+    if (ahead) {
+        if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, reinterpret_cast<const float *>(b->eps_tiled), 0, 0, 0, N, a.a, s, nullptr,
+                                    nullptr, 0, E, true, nullptr, covo_propagate_nan(h))))
+            return rc;
+    } else if ((M & 8) && (rc = launch_noise_gemm(b->L, b->a_mean_shift, nullptr, 0, 0, 0, N, a.a, s, b->dyn, nullptr, 0, E, false,
+                                                  nullptr, covo_propagate_nan(h))))
         return rc;
     if ((M & 16) && (rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, s))) return rc;
     if (!(M & 32)) return 0;
@@ -708,6 +729,16 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
                               brec ? b->partials + (size_t)e * bG * COVO_PARTIAL_FLOATS : nullptr, h->cfg.lam, true,
                               b->tables ? b->tab_rollout + (size_t)e * COVO_H * 4 : nullptr);
         COVO_CHECK_HIP(hipMemcpy(b->ro_args, b->ro_args_host.data(), b->ro_args_host.size(), hipMemcpyHostToDevice));
+        {
+            const size_t need_e = (size_t)E * ((N + 31) / 32) * 16 * 64;
+            if (need_e > b->eps_cap) {
+                (void)hipFree(b->eps_tiled);
+                b->eps_tiled = nullptr;
+                b->eps_cap = 0;
+                COVO_CHECK_HIP(hipMalloc(&b->eps_tiled, need_e * sizeof(float4)));
+                b->eps_cap = need_e;
+            }
+        }
         const size_t need_s = sigma_ns_workspace_bytes(E), need_h = hessian_workspace_bytes(E);
         if (need_s > h->ws_sigma_bytes || need_h > h->ws_hess_bytes) step_graphs_drop(h);  // captured launches point into them
         if (need_s > h->ws_sigma_bytes) {
