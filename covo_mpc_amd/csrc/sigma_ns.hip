@@ -743,10 +743,8 @@ __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztal
     tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
     const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // written by ns_first_kernel's extra workgroup
     if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
-    if (COH) NS_STAMP();  // operands + slots have arrived
     const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
-    if (COH) NS_STAMP();  // products reduced
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
     store_both<COH>(Tall + off, Ttall + off, row, col, fma(bq, p, (row == col) ? a : 0.0));
     const double d = p - ((row == col) ? 1.0 : 0.0);
@@ -780,67 +778,6 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Za
     const double v = tile_reduce(acc, red, wv, lane);
     const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
     store_both<COH>((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v);
-    return true;
-}
-
-// both part-2 tiles of one workgroup (tile w of Y' and tile w of Z') with all 32 operand loads in flight together: the
-// persistent launch runs part 2 on 64 workgroups, and two dependent coherent-load round trips per phase would cost 1.5 us
-template <int COH>
-__device__ __forceinline__ bool ns_YZ2_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
-                                            double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
-                                            int zbuf_out, int w, double (*red)[4][64])
-{
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double *s = scall;
-    const int ti = w >> 3, tj = w & 7;
-    TileOps oy, oz;
-    tile_load<COH>(oy, Ytall, Tall, ti, tj, lane, wv, LoadPlain{});  // Y' = Y.T
-    tile_load<COH>(oz, Ttall, Zall, ti, tj, lane, wv, LoadPlain{});  // Z' = T.Z
-    if (ns_converged<COH>(s, iter, lane, false)) return false;
-    NS_STAMP();  // operands + slots have arrived
-    if (w == 0 && tid == 0) {
-        gst<COH>(s + SC_ZBUF, (double)zbuf_out);
-        gst<COH>(s + SC_ITERS, (double)(iter + 1));
-    }
-    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-    const f64x4 ay = tile_mma(oy);
-    const double vy = tile_reduce(ay, red, wv, lane);
-    store_both<COH>(Yout, Ytout, row, col, vy);
-    const f64x4 az = tile_mma(oz);
-    __syncthreads();  // red is reused
-    const double vz = tile_reduce(az, red, wv, lane);
-    NS_STAMP();  // products reduced
-    store_both<COH>(Zout, Ztout, row, col, vz);
-    return true;
-}
-
-// the same two tiles one after the other (16 operand loads in flight instead of 32): the batched persistent launch wants all
-// its workgroups resident (<= 64 VGPRs: 8 workgroups per CU) and hides the second load latency behind the other matrices' phases
-template <int COH>
-__device__ __forceinline__ bool ns_YZ2_lean_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
-                                                 double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
-                                                 int zbuf_out, int w, double (*red)[4][64])
-{
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double *s = scall;
-    const int ti = w >> 3, tj = w & 7;
-    TileOps o;
-    tile_load<COH>(o, Ytall, Tall, ti, tj, lane, wv, LoadPlain{});  // Y' = Y.T
-    if (ns_converged<COH>(s, iter, lane, false)) return false;
-    if (w == 0 && tid == 0) {
-        gst<COH>(s + SC_ZBUF, (double)zbuf_out);
-        gst<COH>(s + SC_ITERS, (double)(iter + 1));
-    }
-    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-    const f64x4 ay = tile_mma(o);
-    const double vy = tile_reduce(ay, red, wv, lane);
-    store_both<COH>(Yout, Ytout, row, col, vy);
-    __builtin_amdgcn_sched_barrier(0);  // the second tile's 16 loads reuse the first tile's registers
-    tile_load<COH>(o, Ttall, Zall, ti, tj, lane, wv, LoadPlain{});  // Z' = T.Z
-    const f64x4 az = tile_mma(o);
-    __syncthreads();  // red is reused
-    const double vz = tile_reduce(az, red, wv, lane);
-    store_both<COH>(Zout, Ztout, row, col, vz);
     return true;
 }
 
@@ -1066,7 +1003,7 @@ __device__ __forceinline__ unsigned ns_xcc_id()
     return x & 7u;
 }
 // Returns 0: timed out (the fail flag is raised); 1: passed; 2: passed and every workgroup of the launch reported the XCC id
-// `xcc`.  flags[w] = (XCC id << 24) | phase; nw <= 64 workgroups.  COH as the phase before it stored.
+// `xcc`.  flags[w] = (XCC id << 24) | phase; nw <= 64 workgroups (36 squaring tiles / 32 iteration pairs).  COH as the phase before it stored.
 template <int COH>
 __device__ __forceinline__ int ns_flag_barrier(unsigned *flags, unsigned phase, int w, int nw, unsigned xcc, double *fail_flag)
 {
@@ -1160,37 +1097,132 @@ struct NsBufs {
     double *Y[2], *Yt[2], *Z[2], *Zt[2], *T, *Tt;
 };
 
-// the rest of the Newton-Schulz tail after part 1 of iteration iter_first and the first barrier (`off`: this matrix in the buffers)
-template <int COH, bool LEAN>
-__device__ __forceinline__ void ns_iter_tail_rest(const NsBufs &B, size_t off, double *scall, int iter_first, int iter_last, int w, int nw,
-                                                  unsigned xcc, double (*red)[4][64], double *part)
+// ---- the iteration tail on PAIRS of tiles (round 4): workgroup w of 32 forms the tiles (2 p, tj) and (2 p + 1, tj), p = w >> 3,
+// tj = w & 7, of T, then of Y' and of Z'.  The two tiles share their right operand: 48 KB instead of 64 per two tiles, and what a
+// phase of the confined launch waits for is ONE L2 (profiles/r04_sigma_batch_l2_counters.log: 2 MB of operands for part 1, 4 MB
+// for part 2, against 16 channels x 64 B/clk) -- the MFMA time does not move (32 workgroups x one wave per SIMD x 16 / 32 MFMAs =
+// 64 x two waves x 8 / 16), and the barrier has half the workgroups.  Per tile the arithmetic of ns_T_body / ns_YZ_body.
+struct PairOps {
+    double a[2][8], b[8];
+};
+template <int COH, class F>
+__device__ __forceinline__ void pair_load(PairOps &o, const double *A, const double *B, int p, int tj, int lane, int kq, F f)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 32 * kq + 4 * kk + hi;
+        o.a[0][kk] = f(gld<COH>(A + (size_t)k * SN + 32 * p + lo), k, 32 * p + lo);
+        o.a[1][kk] = f(gld<COH>(A + (size_t)k * SN + 32 * p + 16 + lo), k, 32 * p + 16 + lo);
+        o.b[kk] = f(gld<COH>(B + (size_t)k * SN + 16 * tj + lo), k, 16 * tj + lo);
+    }
+}
+__device__ __forceinline__ void pair_mma_reduce(const PairOps &o, double (*redp)[4][4][64], int wv, int lane, double v[2])
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[h][kk], o.b[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redp[h][wv][r][lane] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) v[h] = (redp[h][0][wv][lane] + redp[h][1][wv][lane]) + (redp[h][2][wv][lane] + redp[h][3][wv][lane]);
+}
+constexpr int NS_PAIR_WG = 32;
+template <int COH>
+__device__ __forceinline__ bool ns_T_pair_body(const double *Y, const double *Zt, double *T, double *Tt, double *s, int iter, int w,
+                                               double (*redp)[4][4][64], double (*partp)[4])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = w >> 3, tj = w & 7;
+    PairOps ops;
+    pair_load<COH>(ops, Zt, Y, p, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double a = gld<COH>(s + SC_COEF + 2 * iter), bq = gld<COH>(s + SC_COEF + 2 * iter + 1);
+    if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;
+    NS_STAMP();  // operands + slots have arrived
+    double pv[2];
+    pair_mma_reduce(ops, redp, wv, lane, pv);
+    NS_STAMP();  // products reduced
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ti = 2 * p + h;
+        const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        store_both<COH>(T, Tt, row, col, fma(bq, pv[h], (row == col) ? a : 0.0));
+        const double d = pv[h] - ((row == col) ? 1.0 : 0.0);
+        const double ws = wr::wave64_allsum(d * d);
+        if (lane == 0) partp[h][wv] = ws;
+    }
+    __syncthreads();
+    if (tid < 2) gst<COH>(s + SC_ERR + iter * 64 + (2 * p + tid) * 8 + tj, (partp[tid][0] + partp[tid][1]) + (partp[tid][2] + partp[tid][3]));
+    return true;
+}
+// (all 48 operand loads of part 2 in flight together -- 190 VGPRs -- instead of pair after pair: measured for one matrix, no
+// difference: 5 449 / 5 459 / 5 435 against 5 425 / 5 470 / 5 432 steps/s on one box -- the phase waits for the L2's bytes, not for a
+// second latency)
+template <int COH>
+__device__ __forceinline__ bool ns_YZ_pair_body(const double *Yt, const double *Z, const double *T, const double *Tt, double *Yo, double *Yto,
+                                                double *Zo, double *Zto, double *s, int iter, int zbuf_out, int w,
+                                                double (*redp)[4][4][64])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = w >> 3, tj = w & 7;
+    PairOps ops;
+    pair_load<COH>(ops, Yt, T, p, tj, lane, wv, LoadPlain{});  // Y' = Y.T
+    if (ns_converged<COH>(s, iter, lane, false)) return false;
+    if (w == 0 && tid == 0) {
+        gst<COH>(s + SC_ZBUF, (double)zbuf_out);
+        gst<COH>(s + SC_ITERS, (double)(iter + 1));
+    }
+    NS_STAMP();  // operands + slots have arrived
+    double v[2];
+    pair_mma_reduce(ops, redp, wv, lane, v);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 16 * (2 * p + h) + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        store_both<COH>(Yo, Yto, row, col, v[h]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pair_load<COH>(ops, Tt, Z, p, tj, lane, wv, LoadPlain{});  // Z' = T.Z
+    __syncthreads();  // redp is reused
+    pair_mma_reduce(ops, redp, wv, lane, v);
+    NS_STAMP();  // both products reduced
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 16 * (2 * p + h) + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        store_both<COH>(Zo, Zto, row, col, v[h]);
+    }
+    return true;
+}
+template <int COH>
+__device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t off, double *scall, int iter_first, int iter_last, int w,
+                                                       unsigned xcc, double (*redp)[4][4][64], double (*partp)[4])
 {
     unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64;
     unsigned phase = 1;
     for (int iter = iter_first; iter <= iter_last; ++iter) {
-        const bool odd = (iter & 1) != 0;  // in = iter & 1, out = in ^ 1 (selects instead of indexed loads of the argument block)
+        const bool odd = (iter & 1) != 0;
         const double *Yi = (odd ? B.Y[1] : B.Y[0]) + off, *Yti = (odd ? B.Yt[1] : B.Yt[0]) + off;
         const double *Zi = (odd ? B.Z[1] : B.Z[0]) + off, *Zti = (odd ? B.Zt[1] : B.Zt[0]) + off;
         double *Yo = (odd ? B.Y[0] : B.Y[1]) + off, *Yto = (odd ? B.Yt[0] : B.Yt[1]) + off;
         double *Zo = (odd ? B.Z[0] : B.Z[1]) + off, *Zto = (odd ? B.Zt[0] : B.Zt[1]) + off;
         if (iter > iter_first) {
-            if (!ns_T_body<COH>(Yi, Zti, B.T + off, B.Tt + off, scall, iter, 0, w, red, part)) return;  // all leave together
-            if (!ns_flag_barrier<COH>(flags, ++phase, w, nw, xcc, scall + SC_BARFAIL)) return;
+            if (!ns_T_pair_body<COH>(Yi, Zti, B.T + off, B.Tt + off, scall, iter, w, redp, partp)) return;
+            if (!ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
         }
-        if (LEAN) (void)ns_YZ2_lean_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, red);
-        else (void)ns_YZ2_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, red);
-        if (iter < iter_last && !ns_flag_barrier<COH>(flags, ++phase, w, nw, xcc, scall + SC_BARFAIL)) return;
+        (void)ns_YZ_pair_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, redp);
+        if (iter < iter_last && !ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
     }
 }
-// Newton-Schulz iterations iter_first .. iter_last (iter >= 1): 64 workgroups per matrix (a barrier's cost grows with the
-// number of workgroups); workgroup w forms tile w of T, then tile w of Y' and of Z'.  LEAN: the batched launch (see above).
-template <bool LEAN>
-__device__ __forceinline__ void ns_iter_tail(const NsBufs &B, double *scall, int iter_first, int iter_last, int batch, int force_agent,
-                                             double (*red)[4][64], double *part)
+__global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int batch,
+                                                                int force_agent)
 {
-    constexpr int nw = 64;
+    __shared__ double redp[2][4][4][64];
+    __shared__ double partp[2][4];
     int b, w;
-    if (!ns_tail_block(nw, batch, b, w)) return;
+    if (!ns_tail_block(NS_PAIR_WG, batch, b, w)) return;
     const size_t off = (size_t)b * SN * SN;
     scall += (size_t)b * SC_COUNT;
     const unsigned xcc = ns_xcc_id();
@@ -1200,33 +1232,18 @@ __device__ __forceinline__ void ns_iter_tail(const NsBufs &B, double *scall, int
     __syncthreads();
     NS_STAMP();
 #endif
-    if (!ns_T_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall, iter_first, 0, w,
-                              red, part))
+    if (!ns_T_pair_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall, iter_first,
+                                   w, redp, partp))
         return;
-    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, nw, xcc, scall + SC_BARFAIL);
+    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL);
     if (r == 2 && force_agent) r = 1;
-    if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 6] = (double)r;  // diagnostics: which mode the iteration tail ran in
-    if (r == 2) ns_iter_tail_rest<COH_XCD, LEAN>(B, off, scall, iter_first, iter_last, w, nw, xcc, red, part);
-    else if (r == 1) ns_iter_tail_rest<COH_AGENT, LEAN>(B, off, scall, iter_first, iter_last, w, nw, xcc, red, part);
+    if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 6] = (double)r;
+    if (r == 2) ns_iter_tail_pair_rest<COH_XCD>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp);
+    else if (r == 1) ns_iter_tail_pair_rest<COH_AGENT>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp);
 #ifdef NS_STAMPS
-    if (w == 0 && threadIdx.x == 0)
+    if (b == 0 && w == 0 && threadIdx.x == 0)
         for (int i = 0; i < 192; ++i) scall[SC_STAMPS + i] = (i < g_nstamp) ? (double)(g_stamp[i] - g_stamp[0]) : -1.0;
 #endif
-}
-__global__ __launch_bounds__(256) void ns_iter_tail_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int force_agent)
-{
-    __shared__ double red[4][4][64];
-    __shared__ double part[4];
-    ns_iter_tail<false>(B, scall, iter_first, iter_last, 1, force_agent, red, part);
-}
-// (forcing 8 waves per SIMD -- 64 VGPRs, 240 B of spills -- so that all 4 matrices an XCD gets out of 32 are resident together was
-// measured: 267 us against 176 at the compiler's 122 VGPRs / 3 workgroups per CU)
-__global__ __launch_bounds__(256) void ns_iter_tail_batched_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int batch,
-                                                                   int force_agent)
-{
-    __shared__ double red[4][4][64];
-    __shared__ double part[4];
-    ns_iter_tail<true>(B, scall, iter_first, iter_last, batch, force_agent, red, part);
 }
 
 // ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  ONE Cholesky serves both needs:
@@ -1382,12 +1399,13 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // 0.64 flag -> poll; part 2 = 1.36 / 0.84 (2 048 fp64-MFMA cycles per SIMD: a quarter of the phase is now the ONE XCD's matrix
 // throughput) / 0.6 / 1.3-1.7 (the other workgroup of the CU finishes its MFMAs later).
 // Batched (the env-batched step, covo-offline's table): all squarings are folded -- every matrix runs them at its own pace, 4
-// matrices per XCD at 32 -- but only the last 4 iterations: early on every matrix is live and 4 matrices x 64 workgroups on an
-// XCD's 32 CUs contend (3 workgroups per CU at 122 VGPRs) where a launch spreads each phase over the chip.  bench.py --config
-// envs, control-steps/s / Sigma us per batched step: (0, 0) 71 186 / 288; (15, 0) 73 395 / 274; (15, 3) 74 851 / 266;
-// (15, 5) 75 943 / 255; (15, 7) 73 142 / 274; (15, 11) 72 163 / 282; (11, 5) 75 007 / 261; (8, 5) 74 636 / 262.  With the 2 x 2 blocks of
-// the batched launches (ns_T_quad_kernel ...), bench / closed loop: (15, 2) 79 172 / 72 844; (15, 3) 79 049 / 72 829; (15, 4) 80 580 /
-// 73 096; (15, 5) 80 223 / 70 336; (15, 6) 78 611 / 69 693 -> the last 4.
+// matrices per XCD at 32 -- but only the last 4 iterations: early on every matrix is live, and four matrices' workgroups on an XCD's
+// 32 CUs keep its ONE L2 busy 65-80 % of the launch (profiles/r04_sigma_batch_l2_counters.log) where a launch spreads each phase
+// over the chip.  bench.py --config envs, control-steps/s / Sigma us per batched step, one tile per workgroup (64 per matrix):
+// (0, 0) 71 186 / 288; (15, 0) 73 395 / 274; (15, 3) 74 851 / 266; (15, 5) 75 943 / 255; (15, 7) 73 142 / 274; (15, 11) 72 163 / 282.
+// With the 2 x 2 blocks of the batched launches and the pairs of the persistent one (32 workgroups per matrix), bench / closed
+// loop: (15, 3) 81 815 / 75 187; (15, 4) 82 553 / 75 641; (15, 5) 82 865 / 74 674; (15, 6) 82 978 / 74 796; (15, 8) 81 889 / 74 194;
+// (15, 11) 80 713 / 73 431 -> the last 4.
 int g_ns_tail_iters = NS_ITERS - 1, g_ns_tail_squarings = NS_SQUARINGS - 1;
 int g_ns_tail_iters_batched = 4, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
 // COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
@@ -1430,7 +1448,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
     const bool fold_first = persistent_ok && (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) >= NS_SQUARINGS - 1;
     if (!fold_first) hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0, batch);
-    // the remaining squarings / iterations run inside persistent launches (36 / 64 workgroups per matrix, one XCD per matrix)
+    // the remaining squarings / iterations run inside persistent launches (36 / 32 workgroups per matrix, one XCD per matrix)
     int sq_tail = persistent_ok ? (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) : 0;
     if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
     const int sq_sep = NS_SQUARINGS - sq_tail;
@@ -1472,9 +1490,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         }
         B.T = T;
         B.Tt = Tt;
-        if (batch == 1) hipLaunchKernelGGL(ns_iter_tail_kernel, ns_tail_grid(64, 1), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, g_ns_force_agent);
-        else hipLaunchKernelGGL(ns_iter_tail_batched_kernel, ns_tail_grid(64, batch), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, batch,
-                                g_ns_force_agent);
+        hipLaunchKernelGGL(ns_iter_tail_pair_kernel, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, batch,
+                           g_ns_force_agent);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     EpsGenArgs g;

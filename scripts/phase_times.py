@@ -67,4 +67,4 @@ for i in [5, 20, 44, 100, 200, 290]:
     t = o[16:21]
     print(i, "  ".join(f"{n}={o[j]:.5g}" for j, n in enumerate(names)),
           " finalize ticks: load %d chol %d logdet %d outputs %d" % tuple(t[k + 1] - t[k] for k in range(4)),
-          " tail modes (2 = one XCD): squarings %d iterations %d, iteration tail after its first barrier %.2f us" % (o[21], o[22], o[23] / 100.0))
+          " tail modes (2 = one XCD): squarings %d iterations %d" % (o[21], o[22]))
