@@ -296,6 +296,52 @@ __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__
     sym_tile_stats(true, v, I, J, w, lane, wv, ns_stats_out(s), tmp, part);
 }
 
+// the first squaring's prologue: the input statistics from the per-tile partials (sym_stats.hpp), every workgroup for itself in the
+// same fixed order -> alpha, beta of the affine map Y0 = alpha I - beta A and |Y0|_F^2; workgroup 0 keeps the per-row sums for the
+// Ritz launch and clears the scalars (inside the persistent launch coherently -- the "done" flags are polled by every workgroup
+// from the second squaring on; the barrier flag words have been cleared a launch earlier: KD or ns_prep_kernel).
+// scr: >= 12 doubles of LDS; two barriers inside (scr is free again on return).
+template <int COH>
+__device__ __forceinline__ void ns_square_first_stats(double *s, int w, int tid, int lane, int wv, double *scr, double &alpha,
+                                                      double &beta, double &nrm)
+{
+    if (w == 0 && tid < SC_COEF) gst<COH>(s + tid, 0.0);
+    if (COH == COH_NONE && w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
+    double ra = 0.0, dgv = 0.0;
+    if (tid < SN) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) ra += s[SC_RPART + tid * 8 + cb];
+        dgv = s[SC_DIAG + tid];
+        if (w == 0) s[SC_ROWABS + tid] = ra;
+    }
+    const double fp = (lane < NS_TILES) ? s[SC_FPART + lane] : 0.0;
+    const double f2 = wr::wave64_allsum(fp);
+    const double gmw = wr::wave64_allmax(tid < SN ? ra : 0.0), mdw = -wr::wave64_allmax(tid < SN ? -dgv : -1e300);
+    const double trw = wr::wave64_allsum(tid < SN ? dgv : 0.0);
+    if (lane == 0) {
+        scr[wv] = gmw;
+        scr[4 + wv] = mdw;
+        scr[8 + wv] = trw;
+    }
+    __syncthreads();
+    const double gm = fmax(scr[0], scr[1]), md = fmin(scr[4], scr[5]), tr = scr[8] + scr[9];
+    __syncthreads();  // scr is reused by the caller
+    // any hi >= lambda_max(A) and any cut > lambda_min(A) work; the tighter they are the faster the filter separates
+    const double hi = fmin(gm, sqrt(f2)) * (1.0 + 1e-12) + 1e-3;
+    const double cut = fma(NS_CUT_MARGIN, hi - md, md);
+    const double inv = 1.0 / (hi - cut);
+    alpha = (hi + cut) * inv;
+    beta = 2.0 * inv;
+    nrm = fma((double)SN * alpha, alpha, fma(-2.0 * alpha * beta, tr, beta * beta * f2));  // |alpha I - beta A|_F^2
+    if (w == 0 && tid == 0) {
+        s[SC_SHIFT] = hi;
+        s[SC_FRO2] = f2;
+        s[SC_TRACE] = tr;
+        s[SC_GERSH] = gm;
+        s[SC_N0] = nrm;
+    }
+}
+
 // ---- one doubling of the Chebyshev degree: Xout = Xin^2 / |Xin|_F^2 - I / t_out, t_out = 2 t_in^2 |Xin|_F^2 (36 lower
 // tiles); |Xout|_F^2 partials go to slot row step+1, t_out to slot 63 of that row.
 // FIRST: Xin is A and the operand is Y0 = alpha I - beta A (see the header), t_in = 1.
@@ -309,47 +355,7 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
     double *O = Xout + (size_t)b * SN * SN;
     double *s = scall + (size_t)b * SC_COUNT;
     double nrm, t_in = 1.0, alpha = 0.0, beta = 0.0;
-    if (FIRST) {
-        // the input statistics from the per-tile partials (sym_stats.hpp), every workgroup for itself in the same fixed order;
-        // workgroup 0 keeps the per-row sums for the Ritz launch and (fused step: there was no prep launch) clears the scalars
-        // (inside the persistent launch the scalars are cleared coherently -- the "done" flags are polled by every workgroup from
-        // the second squaring on -- and the barrier flag words have been cleared a launch earlier: KD or ns_prep_kernel)
-        if (w == 0 && tid < SC_COEF) gst<COH>(s + tid, 0.0);
-        if (COH == COH_NONE && w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
-        double ra = 0.0, dgv = 0.0;
-        if (tid < SN) {
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) ra += s[SC_RPART + tid * 8 + cb];
-            dgv = s[SC_DIAG + tid];
-            if (w == 0) s[SC_ROWABS + tid] = ra;
-        }
-        const double fp = (lane < NS_TILES) ? s[SC_FPART + lane] : 0.0;
-        const double f2 = wr::wave64_allsum(fp);
-        const double gmw = wr::wave64_allmax(tid < SN ? ra : 0.0), mdw = -wr::wave64_allmax(tid < SN ? -dgv : -1e300);
-        const double trw = wr::wave64_allsum(tid < SN ? dgv : 0.0);
-        if (lane == 0) {
-            part[wv] = gmw;
-            red[0][0][wv] = mdw;
-            red[0][1][wv] = trw;
-        }
-        __syncthreads();
-        const double gm = fmax(part[0], part[1]), md = fmin(red[0][0][0], red[0][0][1]), tr = red[0][1][0] + red[0][1][1];
-        __syncthreads();  // part / red are reused below
-        // any hi >= lambda_max(A) and any cut > lambda_min(A) work; the tighter they are the faster the filter separates
-        const double hi = fmin(gm, sqrt(f2)) * (1.0 + 1e-12) + 1e-3;
-        const double cut = fma(NS_CUT_MARGIN, hi - md, md);
-        const double inv = 1.0 / (hi - cut);
-        alpha = (hi + cut) * inv;
-        beta = 2.0 * inv;
-        nrm = fma((double)SN * alpha, alpha, fma(-2.0 * alpha * beta, tr, beta * beta * f2));  // |alpha I - beta A|_F^2
-        if (w == 0 && tid == 0) {
-            s[SC_SHIFT] = hi;
-            s[SC_FRO2] = f2;
-            s[SC_TRACE] = tr;
-            s[SC_GERSH] = gm;
-            s[SC_N0] = nrm;
-        }
-    }
+    if (FIRST) ns_square_first_stats<COH>(s, w, tid, lane, wv, &red[0][0][0], alpha, beta, nrm);
     int ti, tj;
     tri_tile(w, ti, tj);
     // batched launches (gridDim.y > 1: the env-batched step, covo-offline's table): every squaring the cap allows is launched for
@@ -1003,7 +1009,7 @@ __device__ __forceinline__ unsigned ns_xcc_id()
     return x & 7u;
 }
 // Returns 0: timed out (the fail flag is raised); 1: passed; 2: passed and every workgroup of the launch reported the XCC id
-// `xcc`.  flags[w] = (XCC id << 24) | phase; nw <= 64 workgroups (36 squaring tiles / 32 iteration pairs).  COH as the phase before it stored.
+// `xcc`.  flags[w] = (XCC id << 24) | phase; nw <= 64 workgroups (20 for the squarings, 32 for the iterations).  COH as the phase before it stored.
 template <int COH>
 __device__ __forceinline__ int ns_flag_barrier(unsigned *flags, unsigned phase, int w, int nw, unsigned xcc, double *fail_flag)
 {
@@ -1053,46 +1059,6 @@ __device__ __forceinline__ bool ns_tail_block(int nw, int batch, int &b, int &w)
 }
 static inline dim3 ns_tail_grid(int nw, int batch) { return dim3(8 * nw * ((batch + 7) / 8)); }
 
-// squarings step_first + 1 .. step_last in coherence mode COH (the launch's first squaring has been done, phase 1 passed)
-template <int COH>
-__device__ __forceinline__ void ns_square_tail_rest(double *X0, double *X1, double *scall, int step_first, int step_last, int w, int nw,
-                                                    unsigned xcc, double (*red)[4][64], double *part)
-{
-    unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS);
-    unsigned phase = 1;
-    for (int step = step_first + 1; step <= step_last; ++step) {
-        const bool odd = (step & 1) != 0;  // step i reads the buffer step i-1 wrote: X0 after the first squaring
-        if (!ns_square_body<false, COH>(odd ? X0 : X1, odd ? X1 : X0, scall, step, odd ? 1 : 0, 0, w, red, part)) return;
-        if (step < step_last && !ns_flag_barrier<COH>(flags, ++phase, w, nw, xcc, scall + SC_BARFAIL)) return;
-    }
-}
-// squarings step_first .. step_last of the Chebyshev filter: 36 workgroups per matrix, X0 <-> X1 by parity; step 0 (the first
-// squaring: reads A, forms the affine map on load) is part of the launch when everything is folded
-__global__ __launch_bounds__(256) void ns_square_tail_kernel(const double *A, double *X0, double *X1, double *scall, int step_first,
-                                                             int step_last, int batch, int force_agent)
-{
-    __shared__ double red[4][4][64];
-    __shared__ double part[4];
-    constexpr int nw = NS_TILES;
-    int b, w;
-    if (!ns_tail_block(nw, batch, b, w)) return;
-    X0 += (size_t)b * SN * SN;
-    X1 += (size_t)b * SN * SN;
-    scall += (size_t)b * SC_COUNT;
-    const unsigned xcc = ns_xcc_id();
-    const bool odd = (step_first & 1) != 0;
-    if (step_first == 0) {
-        (void)ns_square_body<true, COH_AGENT>(A + (size_t)b * SN * SN, X0, scall, 0, 0, 0, w, red, part);
-    } else if (!ns_square_body<false, COH_AGENT>(odd ? X0 : X1, odd ? X1 : X0, scall, step_first, odd ? 1 : 0, 0, w, red, part))
-        return;
-    if (step_first == step_last) return;
-    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, nw, xcc, scall + SC_BARFAIL);
-    if (r == 2 && force_agent) r = 1;
-    if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 5] = (double)r;  // diagnostics: which mode the squaring tail ran in
-    if (r == 2) ns_square_tail_rest<COH_XCD>(X0, X1, scall, step_first, step_last, w, nw, xcc, red, part);
-    else if (r == 1) ns_square_tail_rest<COH_AGENT>(X0, X1, scall, step_first, step_last, w, nw, xcc, red, part);
-}
-
 struct NsBufs {
     double *Y[2], *Yt[2], *Z[2], *Zt[2], *T, *Tt;
 };
@@ -1117,10 +1083,13 @@ __device__ __forceinline__ void pair_load(PairOps &o, const double *A, const dou
         o.b[kk] = f(gld<COH>(B + (size_t)k * SN + 16 * tj + lo), k, 16 * tj + lo);
     }
 }
-__device__ __forceinline__ void pair_mma_reduce(const PairOps &o, double (*redp)[4][4][64], int wv, int lane, double v[2])
+// (skip0: tile 0 of the pair is not wanted; v[0] is then meaningless)
+__device__ __forceinline__ void pair_mma_reduce(const PairOps &o, double (*redp)[4][4][64], int wv, int lane, double v[2],
+                                                bool skip0 = false)
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        if (h == 0 && skip0) continue;  // (uniform)
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[h][kk], o.b[kk], acc, 0, 0, 0);
@@ -1131,6 +1100,103 @@ __device__ __forceinline__ void pair_mma_reduce(const PairOps &o, double (*redp)
 #pragma unroll
     for (int h = 0; h < 2; ++h) v[h] = (redp[h][0][wv][lane] + redp[h][1][wv][lane]) + (redp[h][2][wv][lane] + redp[h][3][wv][lane]);
 }
+// ---- the squaring launch on pairs (round 4): the lower triangle's 36 tiles as 20 workgroups -- for m = 0..3 the pairs
+// {(2m, tj), (2m + 1, tj)}, tj = 0..2m, which share their right operand X(:, tj), and the diagonal tile (2m + 1, 2m + 1) alone
+// (it runs the pair's code with tile 0 -- an upper tile -- left out).  0.77 MB of operands per squaring instead of 1.15, 20
+// workgroups at the barrier instead of 36.  Per tile the arithmetic of ns_square_body.
+constexpr int NS_SQ_PAIR_WG = 20;
+template <bool FIRST, int COH>
+__device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, double *s, int step, int xbuf_out, int w,
+                                                    double (*redp)[4][4][64], double (*partp)[4])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double nrm, t_in = 1.0, alpha = 0.0, beta = 0.0;
+    if (FIRST) ns_square_first_stats<COH>(s, w, tid, lane, wv, &redp[0][0][0][0], alpha, beta, nrm);
+    // w -> (m, local): group m holds 2m + 2 workgroups (offsets 0, 2, 6, 12)
+    const int m = (w >= 12) ? 3 : (w >= 6) ? 2 : (w >= 2) ? 1 : 0;
+    const int local = w - m * (m + 1);
+    const bool single = local == 2 * m + 1;
+    const int tj = single ? 2 * m + 1 : local;
+    PairOps ops;
+    if (FIRST) pair_load<COH>(ops, X, X, m, tj, lane, wv, LoadAffine{alpha, beta});
+    else pair_load<COH>(ops, X, X, m, tj, lane, wv, LoadPlain{});
+    if (!FIRST) {
+        const double done = gld<COH>(s + SC_SQ_DONE);
+        const double p1 = (lane < NS_TILES) ? gld<COH>(s + SC_SQN + step * 64 + lane) : 0.0;
+        const double p0 = (lane < NS_TILES && step >= 2) ? gld<COH>(s + SC_SQN + (step - 1) * 64 + lane) : 0.0;
+        t_in = gld<COH>(s + SC_SQN + step * 64 + 63);
+        if (done != 0.0) return false;
+        nrm = wr::wave64_allsum(p1);
+        if (step >= 2 && t_in > NS_SQ_TGUARD) {
+            const double prev = wr::wave64_allsum(p0);
+            if (fabs(nrm - prev) <= NS_SQ_TOL * nrm) {
+                if (w == 0 && tid == 0) gst<COH>(s + SC_SQ_DONE, 1.0);
+                return false;
+            }
+        }
+    }
+    const double t_out = 2.0 * t_in * t_in * nrm;  // overflows to +inf once the filter has separated: 1 / t_out = 0
+    const double inv_t = 1.0 / t_out;
+    if (w == 0 && tid == 0) {
+        gst<COH>(s + SC_XBUF, (double)xbuf_out);
+        gst<COH>(s + SC_SQ, (double)(step + 1));
+        gst<COH>(s + SC_SQN + (step + 1) * 64 + 63, t_out);
+    }
+    double pv[2];
+    pair_mma_reduce(ops, redp, wv, lane, pv, single);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 0 && single) continue;  // (uniform)
+        const int ti = 2 * m + h;
+        const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        const double v = pv[h] * (1.0 / nrm) - ((row == col) ? inv_t : 0.0);
+        store_sym<COH>(O, row, col, v);
+        const double ws = wr::wave64_allsum((row > col) ? 2.0 * v * v : ((row == col) ? v * v : 0.0));
+        if (lane == 0) partp[h][wv] = ws;
+    }
+    __syncthreads();
+    if (tid < 2 && !(tid == 0 && single)) {
+        const int ti = 2 * m + tid;
+        gst<COH>(s + SC_SQN + (step + 1) * 64 + ti * (ti + 1) / 2 + tj, (partp[tid][0] + partp[tid][1]) + (partp[tid][2] + partp[tid][3]));
+    }
+    return true;
+}
+template <int COH>
+__device__ __forceinline__ void ns_square_tail_pair_rest(double *X0, double *X1, double *scall, int step_first, int step_last, int w,
+                                                         unsigned xcc, double (*redp)[4][4][64], double (*partp)[4])
+{
+    unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS);
+    unsigned phase = 1;
+    for (int step = step_first + 1; step <= step_last; ++step) {
+        const bool odd = (step & 1) != 0;  // step i reads the buffer step i-1 wrote: X0 after the first squaring
+        if (!ns_square_pair_body<false, COH>(odd ? X0 : X1, odd ? X1 : X0, scall, step, odd ? 1 : 0, w, redp, partp)) return;
+        if (step < step_last && !ns_flag_barrier<COH>(flags, ++phase, w, NS_SQ_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
+    }
+}
+__global__ __launch_bounds__(256) void ns_square_tail_pair_kernel(const double *A, double *X0, double *X1, double *scall, int step_first,
+                                                                  int step_last, int batch, int force_agent)
+{
+    __shared__ double redp[2][4][4][64];
+    __shared__ double partp[2][4];
+    int b, w;
+    if (!ns_tail_block(NS_SQ_PAIR_WG, batch, b, w)) return;
+    X0 += (size_t)b * SN * SN;
+    X1 += (size_t)b * SN * SN;
+    scall += (size_t)b * SC_COUNT;
+    const unsigned xcc = ns_xcc_id();
+    const bool odd = (step_first & 1) != 0;
+    if (step_first == 0) {
+        (void)ns_square_pair_body<true, COH_AGENT>(A + (size_t)b * SN * SN, X0, scall, 0, 0, w, redp, partp);
+    } else if (!ns_square_pair_body<false, COH_AGENT>(odd ? X0 : X1, odd ? X1 : X0, scall, step_first, odd ? 1 : 0, w, redp, partp))
+        return;
+    if (step_first == step_last) return;
+    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, NS_SQ_PAIR_WG, xcc, scall + SC_BARFAIL);
+    if (r == 2 && force_agent) r = 1;
+    if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 5] = (double)r;  // diagnostics: which mode the squaring launch ran in
+    if (r == 2) ns_square_tail_pair_rest<COH_XCD>(X0, X1, scall, step_first, step_last, w, xcc, redp, partp);
+    else if (r == 1) ns_square_tail_pair_rest<COH_AGENT>(X0, X1, scall, step_first, step_last, w, xcc, redp, partp);
+}
+
 constexpr int NS_PAIR_WG = 32;
 template <int COH>
 __device__ __forceinline__ bool ns_T_pair_body(const double *Y, const double *Zt, double *T, double *Tt, double *s, int iter, int w,
@@ -1405,7 +1471,8 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // (0, 0) 71 186 / 288; (15, 0) 73 395 / 274; (15, 3) 74 851 / 266; (15, 5) 75 943 / 255; (15, 7) 73 142 / 274; (15, 11) 72 163 / 282.
 // With the 2 x 2 blocks of the batched launches and the pairs of the persistent one (32 workgroups per matrix), bench / closed
 // loop: (15, 3) 81 815 / 75 187; (15, 4) 82 553 / 75 641; (15, 5) 82 865 / 74 674; (15, 6) 82 978 / 74 796; (15, 8) 81 889 / 74 194;
-// (15, 11) 80 713 / 73 431 -> the last 4.
+// (15, 11) 80 713 / 73 431 -> the last 4.  The squaring launch on pairs too (20 workgroups per matrix instead of 36, a third fewer
+// operand bytes): one matrix 5 464-5 470 / 4 874-4 886 against 5 428-5 457 / 4 844-4 854, batched 83 663 / 76 231 against 82 535 / 75 461.
 int g_ns_tail_iters = NS_ITERS - 1, g_ns_tail_squarings = NS_SQUARINGS - 1;
 int g_ns_tail_iters_batched = 4, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
 // COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
@@ -1448,7 +1515,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
     const bool fold_first = persistent_ok && (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) >= NS_SQUARINGS - 1;
     if (!fold_first) hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0, batch);
-    // the remaining squarings / iterations run inside persistent launches (36 / 32 workgroups per matrix, one XCD per matrix)
+    // the remaining squarings / iterations run inside persistent launches (20 / 32 workgroups per matrix, one XCD per matrix)
     int sq_tail = persistent_ok ? (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) : 0;
     if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
     const int sq_sep = NS_SQUARINGS - sq_tail;
@@ -1458,8 +1525,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         double *t = xi; xi = xo; xo = t;
     }
     if (sq_tail > 0)
-        hipLaunchKernelGGL(ns_square_tail_kernel, ns_tail_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, X1, sc, fold_first ? 0 : sq_sep,
-                           NS_SQUARINGS - 1, batch, g_ns_force_agent);
+        hipLaunchKernelGGL(ns_square_tail_pair_kernel, ns_tail_grid(NS_SQ_PAIR_WG, batch), dim3(256), 0, s, A, X0, X1, sc,
+                           fold_first ? 0 : sq_sep, NS_SQUARINGS - 1, batch, g_ns_force_agent);
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
     if (g_dbg_sigma_stages < 3) return 0;

@@ -673,7 +673,7 @@ def core_scalars(core, batch, count=24):
 
 def test_sigma_tail_launch_is_bit_identical():
     """The Sigma chain's squarings and Newton-Schulz iterations run inside two persistent launches whose phases are
-    separated by barriers inside the launch (sigma_ns.hip: ns_square_tail_kernel, ns_iter_tail_kernel; all workgroups of a matrix
+    separated by barriers inside the launch (sigma_ns.hip: ns_square_tail_pair_kernel, ns_iter_tail_pair_kernel; all workgroups of a matrix
     on one XCD, sc1 loads, plain stores once the placement is verified).  Every phase its own launch, only some of them folded,
     or all of them (the default for one matrix) must give the same Sigma and L bit for bit -- for one matrix and for a batch
     (every matrix of a batched launch runs its tail at its own pace; 11 matrices: XCDs with one and with two of them)."""
