@@ -269,8 +269,6 @@ __global__ __launch_bounds__(NG_BLOCK, 512 / NG_BLOCK) void noise_gemm_kernel(co
     // write (a rolled load -> write loop pays one L2 round trip per trip: 3.8 us of a 17 us launch, scripts/probe/
     // gemm_probe.hip); chunks right of the diagonal block are never read by the MFMA loop (row tile rt stops at
     // k < 32 (rt + 1)) and are neither loaded nor written, chunks right of the diagonal inside it are written as zeros.
-    // (These writes are the launch's SQ_LDS_BANK_CONFLICT cycles, 768 per workgroup: a lane stride of 4 floats puts lanes l, l + 8,
-    // l + 16, l + 24 of a row on one bank.  ~0.3 us; a rotation of the components costs as many v_cndmask: DESIGN.md 4.2.)
     {
         constexpr int TRIPS = COVO_NA * COVO_NA / 4 / NG_BLOCK;  // 16
         const int k4 = (tid & 31) * 4, i0 = tid >> 5;            // trip `it` handles row i0 + 8 it, columns k4 .. k4 + 3
