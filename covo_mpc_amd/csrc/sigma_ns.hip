@@ -1264,8 +1264,9 @@ __device__ __forceinline__ bool ns_YZ_pair_body(const double *Yt, const double *
 }
 template <int COH>
 __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t off, double *scall, int iter_first, int iter_last, int w,
-                                                       unsigned xcc, double (*redp)[4][4][64], double (*partp)[4])
+                                                       unsigned xcc, double (*redp)[4][4][64], double (*partp)[4], bool t_first)
 {
+    // t_first: part 1 of iteration iter_first is still to do (the launch began with iteration 0); else the launch's first phase was it
     unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64;
     unsigned phase = 1;
     for (int iter = iter_first; iter <= iter_last; ++iter) {
@@ -1274,7 +1275,7 @@ __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t o
         const double *Zi = (odd ? B.Z[1] : B.Z[0]) + off, *Zti = (odd ? B.Zt[1] : B.Zt[0]) + off;
         double *Yo = (odd ? B.Y[0] : B.Y[1]) + off, *Yto = (odd ? B.Yt[0] : B.Yt[1]) + off;
         double *Zo = (odd ? B.Z[0] : B.Z[1]) + off, *Zto = (odd ? B.Zt[0] : B.Zt[1]) + off;
-        if (iter > iter_first) {
+        if (iter > iter_first || t_first) {
             if (!ns_T_pair_body<COH>(Yi, Zti, B.T + off, B.Tt + off, scall, iter, w, redp, partp)) return;
             if (!ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
         }
@@ -1282,11 +1283,50 @@ __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t o
         if (iter < iter_last && !ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
     }
 }
-__global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const NsBufs B, double *scall, int iter_first, int iter_last, int batch,
-                                                                int force_agent)
+// iteration 0 (ns_first_kernel's tiles) on a pair, coherent stores: phase 0 of the launch when every iteration is folded
+template <class LD>
+__device__ __forceinline__ void ns_first_pair_tiles(const LD &ld, const double *A, double *Yo, double *Yto, double *Zo, double *Zto, double a0,
+                                                    double b0, int w, double (*redp)[4][4][64])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = w >> 3, tj = w & 7;
+    PairOps ops;
+    pair_load<COH_AGENT>(ops, A, A, p, tj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
+    double y2[2];
+    pair_mma_reduce(ops, redp, wv, lane, y2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 16 * (2 * p + h) + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        const double y0 = ld(A[(size_t)row * SN + col], row, col);
+        store_both<COH_AGENT>(Yo, Yto, row, col, fma(b0, y2[h], a0 * y0));
+        store_both<COH_AGENT>(Zo, Zto, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
+    }
+}
+// iter_first = 0 (one matrix, every iteration folded): the launch begins with iteration 0 (A: the chain's input), and the
+// coefficient table of the iterations to come -- a serial recurrence, ~1.5 us on one lane -- is the work of one of the workgroups
+// the launch would send away anyway (linear id 1: another XCD, so it publishes coherently and raises SC_BAR)
+__global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
+                                                                int batch, int force_agent)
 {
     __shared__ double redp[2][4][4][64];
     __shared__ double partp[2][4];
+    if (iter_first == 0 && blockIdx.x == 1) {
+        if (threadIdx.x == 0) {
+            double *s = scall;
+            const double scale = s[SC_SCALE], lo = s[SC_LO];
+            double l = sqrt(lo / scale);
+            for (int k = 0; k < NS_ITERS; ++k) {
+                double a, bq;
+                ns_coef(l, a, bq);
+                gst<COH_AGENT>(s + SC_COEF + 2 * k, a);
+                gst<COH_AGENT>(s + SC_COEF + 2 * k + 1, bq);
+                l = fmin(1.0, l * fma(bq * l, l, a));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            gst<COH_AGENT>(s + SC_BAR, 1.0);
+        }
+        return;
+    }
     int b, w;
     if (!ns_tail_block(NS_PAIR_WG, batch, b, w)) return;
     const size_t off = (size_t)b * SN * SN;
@@ -1298,14 +1338,48 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const NsBufs B, 
     __syncthreads();
     NS_STAMP();
 #endif
-    if (!ns_T_pair_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall, iter_first,
-                                   w, redp, partp))
+    if (iter_first == 0) {
+        double *s = scall;
+        const double scale = s[SC_SCALE], delta = s[SC_DELTA], inv = 1.0 / scale, lo = s[SC_LO], gam = s[SC_GAM];
+        double a0, b0;
+        ns_coef(sqrt(lo / scale), a0, b0);
+        if (w == 0 && threadIdx.x == 0) {
+            gst<COH_AGENT>(s + SC_ZBUF, 1.0);
+            gst<COH_AGENT>(s + SC_ITERS, 1.0);
+        }
+        if (gam != 0.0)  // (uniform)
+            ns_first_pair_tiles(LoadScaledBDefl{delta, inv, gam, s + SC_U}, A + off, B.Y[1] + off, B.Yt[1] + off, B.Z[1] + off, B.Zt[1] + off, a0,
+                                b0, w, redp);
+        else
+            ns_first_pair_tiles(LoadScaledB{delta, inv}, A + off, B.Y[1] + off, B.Yt[1] + off, B.Z[1] + off, B.Zt[1] + off, a0, b0, w, redp);
+    } else if (!ns_T_pair_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall,
+                                          iter_first, w, redp, partp))
         return;
     int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL);
     if (r == 2 && force_agent) r = 1;
     if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 6] = (double)r;
-    if (r == 2) ns_iter_tail_pair_rest<COH_XCD>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp);
-    else if (r == 1) ns_iter_tail_pair_rest<COH_AGENT>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp);
+    if (iter_first == 0) {
+        // the coefficient table must be there before part 1 of iteration 1 reads it (it normally is: ~2 us against this launch's ~4)
+        __shared__ int tab_ok;
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            int good = 1;
+            while (gld<COH_AGENT>(scall + SC_BAR) == 0.0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 20000000LL) {
+                    good = 0;
+                    gst<COH_AGENT>(scall + SC_BARFAIL, 1.0);
+                    break;
+                }
+            }
+            tab_ok = good;
+        }
+        __syncthreads();
+        if (!tab_ok) return;
+    }
+    const int it0 = iter_first == 0 ? 1 : iter_first;
+    if (r == 2) ns_iter_tail_pair_rest<COH_XCD>(B, off, scall, it0, iter_last, w, xcc, redp, partp, iter_first == 0);
+    else if (r == 1) ns_iter_tail_pair_rest<COH_AGENT>(B, off, scall, it0, iter_last, w, xcc, redp, partp, iter_first == 0);
 #ifdef NS_STAMPS
     if (b == 0 && w == 0 && threadIdx.x == 0)
         for (int i = 0; i < 192; ++i) scall[SC_STAMPS + i] = (i < g_nstamp) ? (double)(g_stamp[i] - g_stamp[0]) : -1.0;
@@ -1530,7 +1604,11 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (g_dbg_sigma_stages < 2) return 0;
     hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
     if (g_dbg_sigma_stages < 3) return 0;
-    if (batch > 1) hipLaunchKernelGGL(ns_first_quad_kernel, ns_grid(17, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
+    // one matrix with every iteration folded: iteration 0 is phase 0 of the persistent launch (ns_iter_tail_pair_kernel)
+    // (same box, three runs each: 5 464-5 467 / 4 888-4 900 steps/s bench / closed loop against 5 442-5 445 / 4 859-4 870 with its own launch)
+    const bool fold_iter0 = batch == 1 && persistent_ok && g_ns_tail_iters >= NS_ITERS - 1;
+    if (fold_iter0) {
+    } else if (batch > 1) hipLaunchKernelGGL(ns_first_quad_kernel, ns_grid(17, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
     else hipLaunchKernelGGL(ns_first_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);  // 64 tiles + the table
     int n_tail = persistent_ok ? (batch == 1 ? g_ns_tail_iters : g_ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
@@ -1557,8 +1635,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         }
         B.T = T;
         B.Tt = Tt;
-        hipLaunchKernelGGL(ns_iter_tail_pair_kernel, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 0, s, B, sc, n_sep, NS_ITERS - 1, batch,
-                           g_ns_force_agent);
+        hipLaunchKernelGGL(ns_iter_tail_pair_kernel, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 0, s, A, B, sc, fold_iter0 ? 0 : n_sep,
+                           NS_ITERS - 1, batch, g_ns_force_agent);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     EpsGenArgs g;
