@@ -30,6 +30,7 @@
 // PRE-step velocity and the current force; round 3 -- these two models used to take the 80 us per-pair kernel).
 #include "covo_common.hpp"
 #include "wave_reduce.hpp"
+#include <cstdlib>
 #include "sym_stats.hpp"
 #include "disturb_model.hpp"
 
@@ -124,10 +125,16 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.stats.flags = nullptr;
     if (stats != nullptr) A.stats = *stats;
     // launch shapes: KB 32 waves; KC 9 chains + KM's 32 hyper-dual workgroups (which also contract with the costate); KD 36 tiles
+    // batched: chains and hyper-dual workgroups as two launches (hessian_adj_body.hpp: adj_hd_kernel) -- 66.5 -> 62.5 us at 32 instances;
+    // one instance keeps them in one launch (the hyper-dual workgroups start under the chains: 27.9 -> 25.7 us in round 3)
+    const bool split_hd = batch >= 8;
 #define ADJ_LAUNCH(NS, JAC)                                                                                                      \
     do {                                                                                                                          \
         if (g_dbg_hess_mask & 1) hipLaunchKernelGGL(JAC, dim3(NS::HH, batch), dim3(64), 0, s, A);                                 \
-        if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(NS::adj_chain_kernel, dim3(9 + NS::HH, batch), dim3(256), 0, s, A);           \
+        if ((g_dbg_hess_mask & 2) && split_hd) {                                                                                  \
+            hipLaunchKernelGGL(NS::adj_chain_kernel, dim3(9, batch), dim3(256), 0, s, A);                                         \
+            hipLaunchKernelGGL(NS::adj_hd_kernel, dim3(NS::HH, batch), dim3(256), 0, s, A);                                       \
+        } else if (g_dbg_hess_mask & 2) hipLaunchKernelGGL(NS::adj_chain_kernel, dim3(9 + NS::HH, batch), dim3(256), 0, s, A);    \
         if (g_dbg_hess_mask & 8) hipLaunchKernelGGL(NS::adj_gemm_kernel, dim3(36, batch), dim3(512), 0, s, A);                    \
     } while (0)
     if (fs) ADJ_LAUNCH(adj16, adj16::adj_jac_kernel<true>);

@@ -357,6 +357,14 @@ __device__ __forceinline__ void adj_hd_padding(const AdjArgs &A, int k, int b, i
 // the same product with A^T and the vector in column 0 of a tile (wave 8).  ~330 cycles per step (four
 // dependent MFMAs + the MFMA -> operand hazard), 31 steps.  (One lane per column with the vector in
 // registers: 2000 cycles per step; 16-lane rows with ds_swizzle broadcasts: 1000.)
+// batched launches (round 4): the hyper-dual workgroups as a launch of their own -- inside adj_chain_kernel every workgroup reserves the
+// chains' 59 KB of LDS (two per CU), which the 32 hyper-dual workgroups of an instance never touch; 32 instances are 1 312 workgroups
+__global__ __launch_bounds__(256) void adj_hd_kernel(const AdjArgs A)
+{
+    adj_hd_padding(A, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, 256);
+    adj_hd_pairs(A, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x);
+}
+
 __global__ __launch_bounds__(256) void adj_chain_kernel(const AdjArgs A)
 {
     __shared__ double sjf[(HH - 1) * NX * NZ + 1];  // + one zero: what the lanes outside the 13 x 13 block read
