@@ -5,9 +5,17 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is one controller __call__ (quadjax/controllers/covo.py:187-283) on one synthetic noisy
-state of a tracking_zigzag episode, teacher-forced (states resident in HBM before the timed region,
-a_mean carried from step to step).  Workload (BASELINE.json north_star / configs[3]):
+`--gpus N` without a torchrun environment launches its own N ranks: the parent, before any GPU call, starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, relays its output (rank 0's JSON
+line) and exits with its code.
+
+A "step" is one controller __call__ (quadjax/controllers/covo.py:187-283), teacher-forced on the inputs of ONE closed-loop
+episode of the SAME controller ("averaged over a 300-step tracking_zigzag episode",
+quadjax/envs/quadrotor.py:506-579): an untimed recording pass runs the controller in closed loop (Python env on the
+host) and keeps, per step, the noisy state, the control_params.a_mean that went in and the controller key; the timed
+steps replay those inputs (resident in HBM) at indices spread evenly over all 300 steps, so K timed steps cover the
+whole episode and every one of them runs exactly the launches (the Sigma chain's data-dependent iteration counts
+included) that step of the closed loop ran.  Workload (BASELINE.json north_star / configs[3]):
 covo-online, tracking_zigzag, N = 65536 samples x H = 32, lambda = 0.01, sigma = 0.5; with G > 1 ranks
 the sample axis is sharded (N/G per GPU, "strong" scaling: total work fixed) and ONE exchange of the
 516-float rank records (online-softmax partial + position sums) crosses xGMI per step (RCCL all-gather; COVO_EXCHANGE=peer:
@@ -40,22 +48,43 @@ GEMM_FLOP_PER_SAMPLE_DENSE = 2 * 128 * 128  # dense-equivalent 2 n
 GEMM_FLOP_PER_SAMPLE_ISSUED = 20480         # lower-triangular k-skip in 32-wide groups: (1 + 2 + 3 + 4)/16 of the dense MFMAs
 
 
-def make_states(env, params, n_states, seed):
-    """Synthetic teacher-forced inputs: noisy states of a PID-tracked tracking_zigzag episode
-    (host plumbing, outside the timed region)."""
-    import covo_mpc_amd as cm
+def record_episode(env, controller, params, T, with_counts):
+    """The recording pass (untimed): one closed-loop episode of `controller` itself -- quadjax's eval_env loop
+    (quadrotor.py:506-579: rng -> rng_act, rng_step; controller; env.step) with the Python env on the host, seeds as in
+    closed_loop()'s host leg.  Per step it keeps what the controller __call__ was given: the noisy state (packed + host
+    object), control_params.a_mean and rng_act; for covo-online also the Sigma chain's (squarings, Newton-Schulz iterations).
+    -> dict(packed [T,32], states [T], a_means [T,128] device tensor, keys [T], counts [T,2] or None, s_reset, cp_reset)"""
+    import torch
     from covo_mpc_amd import random as cr
-    obs, info, state = env.reset(cr.PRNGKey(seed), params)
-    pid = cm.controllers.PIDController(env, cm.controllers.PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0))
-    cp, key = pid.init_control_params, cr.PRNGKey(seed + 1)
-    packed, states = [], []
-    for _ in range(n_states):
+    obs, info, state = env.reset(cr.PRNGKey(21), params)
+    s_reset = state
+    cp = cp_reset = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(22))
+    key = cr.PRNGKey(23)
+    packed, states, a_means, keys, counts, errs = [], [], [], [], [], []
+    alias = controller.alias_outputs
+    controller.alias_outputs = False  # the recorded means must not alias the controller's buffer
+    for _ in range(T):
+        key, k_act, k_step = cr.split(key, 3)
         packed.append(info["noisy_state"].pack())
         states.append(info["noisy_state"])
-        a, cp, _ = pid(obs, state, params, key, cp)
-        key, k = cr.split(key)
-        obs, state, reward, done, info = env.step_env(k, state, a, params)
-    return state, np.stack(packed), states
+        a_means.append(cp.a_mean.reshape(-1).clone())
+        keys.append(k_act)
+        u, cp, _ = controller(obs, state, params, k_act, cp, info)
+        if with_counts:
+            counts.append(sigma_chain_counts(controller.core))
+        obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+        errs.append(info["err_pos"])
+    controller.alias_outputs = alias
+    return {"packed": np.stack(packed), "states": states, "a_means": torch.stack(a_means), "keys": keys,
+            "counts": np.asarray(counts) if with_counts else None, "s_reset": s_reset, "cp_reset": cp_reset,
+            "err_pos_mean_m": float(np.mean(errs))}
+
+
+def spread_indices(K, T):
+    """K indices spread evenly over [0, T): the centres of K equal strata (K <= T), or the episode repeated (K > T)."""
+    if K <= T:
+        return [min(T - 1, (2 * i + 1) * T // (2 * K)) for i in range(K)]
+    return [i % T for i in range(K)]
 
 
 def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
@@ -105,7 +134,7 @@ def sigma_chain_counts(core):
     return float(o[8]), float(o[6])  # SC_SQ, SC_ITERS (csrc/sigma_ns.hip)
 
 
-def closed_loop(env, controller, params, T):
+def closed_loop(env, controller, params, T, rec=None):
     """the same controller in CLOSED loop for one episode (env step included): with the env step as a
     device kernel and the whole episode enqueued by one C call (covo_run_episode: one host sync per episode) and with the Python env on the host (one sync and
     one 128-B upload per step) -- reported next to the teacher-forced `value`, never in place of it."""
@@ -143,19 +172,10 @@ def closed_loop(env, controller, params, T):
     torch.cuda.synchronize()
     res["host_env"] = T / (time.perf_counter() - t0)
     res["host_env_err_pos_mean_m"] = float(np.mean(errs))
-    if getattr(controller, "mode", None) == "online":
-        # the Sigma chain's data-dependent iteration counts over a closed-loop episode (untimed pass, one read-back per step)
-        obs, info, state = env.reset(cr.PRNGKey(21), params)
-        cp = controller.reset(state, params, controller.init_control_params, cr.PRNGKey(22))
-        key = cr.PRNGKey(23)
-        cnt = []
-        for _ in range(T):
-            key, k_act, k_step = cr.split(key, 3)
-            u, cp, _ = controller(obs, state, params, k_act, cp, info)
-            cnt.append(sigma_chain_counts(core))
-            obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
-        res["sigma_chain_mean_squarings"] = float(np.mean([c[0] for c in cnt]))
-        res["sigma_chain_mean_newton_schulz_iterations"] = float(np.mean([c[1] for c in cnt]))
+    if rec is not None and rec["counts"] is not None:
+        # the Sigma chain's data-dependent iteration counts over the recorded closed-loop episode (same seeds as the host leg)
+        res["sigma_chain_mean_squarings"] = float(rec["counts"][:, 0].mean())
+        res["sigma_chain_mean_newton_schulz_iterations"] = float(rec["counts"][:, 1].mean())
     return res
 
 
@@ -309,6 +329,44 @@ def bench_envs(args, world, rank, device, backend):
         dist.destroy_process_group()
 
 
+def self_launch(n, argv):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free>
+    bench.py <argv>` as a child process (the driver's own N > 1 command line) and wait for it -> its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / peer mappings between the ranks
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(args, world, rank):
+    """--rendezvous-only: everything of the N-rank bench except the GPU work -- process group (gloo), the barrier bracket, the
+    max-over-ranks reduction, ONE line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "mpc_control_steps_per_sec", "value": None, "unit": "control-steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "rendezvous_only": True, "barrier_bracket_s": float(t.item()),
+                          "scaling": "weak" if args.config == "envs" else "strong"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,15 +385,27 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop episodes (profiler counter passes)")
     ap.add_argument("--no-info-leg", action="store_true", help="skip the second timed loop with pos_mean/pos_std on")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--task", default="tracking_zigzag", help="--config samples: the env task (BASELINE configs[0] is `hovering`)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch the ranks, form the process group, bracket an empty timed region and print the line's launch "
+                         "fields (n_gpus, ...) with value null: the N > 1 launcher on a box without GPUs (tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver's 1-GPU command is spelled: this process becomes the launcher.  It has made NO
+        # GPU call (torch is not even imported) and makes none: the ranks are CHILD processes of torch.distributed.run, whose
+        # output (rank 0's one JSON line) passes through and whose exit code is returned.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     # COVO_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
     # the 528-byte records are staged through the host); the product backend is nccl = RCCL over xGMI, one rank per GPU
@@ -362,44 +432,46 @@ def main():
     from covo_mpc_amd.dynamics.dataclass import DeviceState
 
     H = 32
-    env = cm.envs.Quad3D(task="tracking_zigzag", obs_type="quad", enable_randomizer=False, disturb_type="gaussian",
+    env = cm.envs.Quad3D(task=args.task, obs_type="quad", enable_randomizer=False, disturb_type="gaussian",
                          disable_rollover_terminate=True, generate_noisy_state=True, device=device)
     params = env.default_params
     controller, cp = cm.envs.get_controller(env, args.controller, f"N{args.N}_H{H}_lam{args.lam}", device=device,
                                             process_group=pg, compute_info=args.info)
     n_states = params.max_steps_in_episode
-    state0, packed, host_states = make_states(env, params, n_states, seed=1)
-    obs0, info0, s_reset = env.reset(cr.PRNGKey(1), params)
-    cp = controller.reset(s_reset, params, controller.init_control_params, cr.PRNGKey(7))  # offline: Sigma table
-    packed_d = torch.from_numpy(packed).to(device)
+    online = args.controller == "covo-online"
+    # ---- untimed recording pass: the controller's OWN closed-loop episode (every rank runs the same replicated env)
+    rec = record_episode(env, controller, params, n_states, with_counts=online)
+    host_states, s_reset = rec["states"], rec["s_reset"]
+    cp = rec["cp_reset"]  # offline: the Sigma table of this episode's reset state
+    packed_d = torch.from_numpy(rec["packed"]).to(device)
+    a_means_d = rec["a_means"].contiguous()  # [T, 128] on the device: control_params.a_mean of every recorded call
     dref = s_reset.to_device(device)
     dstates = [DeviceState(packed=packed_d[i], pos_traj=dref.pos_traj, vel_traj=dref.vel_traj, time=int(host_states[i].time))
                for i in range(n_states)]
     controller.alias_outputs = True  # returned tensors alias the controller's buffers: no per-step clones
     core = controller.core
+    # the timed steps' inputs: indices spread evenly over the whole episode (warm-up: its own spread)
+    idx_warm, idx_timed = spread_indices(args.warmup, n_states), spread_indices(args.steps, n_states)
+    a_mean_rows = [a_means_d[i].view(H, 4) for i in range(n_states)]
 
-    # the controller keys of all steps are inputs like the states: the chain rng, rng_act = split(rng) of eval_env's
-    # run_one_step (quadrotor.py:520-524, PRNGKey(1) from :517) is unrolled before the timed region
-    key = cr.PRNGKey(1)
-    act_keys = []
-    for i in range(args.warmup + args.steps):
-        key, k_act = cr.split(key)
-        act_keys.append(k_act)
+    def step(i, cp_prev):
+        """One teacher-forced controller __call__ on the recorded inputs of closed-loop step i: noisy state, a_mean, key.
+        (Everything else of control_params is what the previous call returned: covo-online's a_cov is an output only, covo-offline's
+        table is per episode, MPPI's a_cov -- gamma_sigma = 0: H identical blocks, invariant under the shift -- equals the recorded.)"""
+        u, cp_out, _ = controller(None, None, params, rec["keys"][i], cp_prev.replace(a_mean=a_mean_rows[i]),
+                                  {"noisy_state": dstates[i]})
+        return cp_out
 
-    def step(i, key, cp):
-        u, cp, _ = controller(None, None, params, act_keys[i], cp, {"noisy_state": dstates[i % n_states]})
-        return key, cp
-
-    for i in range(args.warmup):
-        key, cp = step(i, key, cp)
+    for i in idx_warm:
+        cp = step(i, cp)
     torch.cuda.synchronize()
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        key, cp = step(args.warmup + i, key, cp)
+    for i in idx_timed:
+        cp = step(i, cp)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -409,6 +481,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(cp.a_mean).all(), "non-finite a_mean after the timed region"
+    kstate = dstates[idx_timed[len(idx_timed) // 2]]  # the state the stand-alone kernel timings below run on
 
     # The rollout kernel of the timed steps runs inside the fused step and cannot be bracketed individually from the host.
     # `launch_us` = MEAN duration of back-to-back launches of the SAME kernel variant the step runs (with the softmax
@@ -424,17 +497,17 @@ def main():
         reps = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
-            core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), True)
+            core.rollout(kstate, pc, (0.0, 0.0, 0.0), True)
         e0.record()
         for _ in range(reps):
-            core.rollout(dstates[40], pc, (0.0, 0.0, 0.0), True)
+            core.rollout(kstate, pc, (0.0, 0.0, 0.0), True)
         e1.record()
         torch.cuda.synchronize()
         launch_us = launch_us_min = 1e3 * e0.elapsed_time(e1) / reps
         kernel_name = "rollout_pipe3_kernel<STATS> + pos_stats_finalize_kernel"
     else:
-        launch_us, launch_us_min = core.time_rollout(dstates[40], pc, reps=100, with_records=True)
-        standalone = core.time_rollout(dstates[40], pc, reps=100, with_records=False)
+        launch_us, launch_us_min = core.time_rollout(kstate, pc, reps=100, with_records=True)
+        standalone = core.time_rollout(kstate, pc, reps=100, with_records=False)
         kernel_name = "rollout_pipe3_kernel<..., REC = true>"
     in_step_us = gemm_in_step_us = in_step_rounds = gemm_in_step_rounds = in_step_rejected = None
     if world == 1:
@@ -479,15 +552,18 @@ def main():
     # groups split into what every rank of a sample-sharded run REPEATS (Hessian + Sigma chain) and what shrinks with 1 / G
     # (noise GEMM, rollout, update): the expected strong scaling is on the line, not left to be discovered (item 5)
     chain_counts = split = None
-    if args.controller == "covo-online" and rank == 0:
+    if online and rank == 0:
         try:
-            cpx = cp
             cnt = []
-            for i in range(min(args.steps, 100)):
-                _, cpx = step(args.warmup + i, key, cpx)
+            for i in idx_timed[:100]:
+                cp = step(i, cp)
                 cnt.append(sigma_chain_counts(core))
             chain_counts = {"mean_squarings": float(np.mean([c[0] for c in cnt])),
-                            "mean_newton_schulz_iterations": float(np.mean([c[1] for c in cnt])), "steps": len(cnt)}
+                            "mean_newton_schulz_iterations": float(np.mean([c[1] for c in cnt])), "steps": len(cnt),
+                            "episode_mean_squarings": float(rec["counts"][:, 0].mean()),
+                            "episode_mean_newton_schulz_iterations": float(rec["counts"][:, 1].mean()),
+                            "note": "untimed replay of the timed steps with one read-back each; episode_* = all 300 steps of the "
+                                    "recorded closed-loop episode the timed inputs were taken from"}
         except Exception as e:  # noqa: BLE001
             chain_counts = {"error": str(e)}
     if world == 1:
@@ -503,7 +579,7 @@ def main():
             split = {"error": str(e)}
 
     n_local, exchange_name = core.n_local, core.exchange
-    closed = closed_loop(env, controller, params, n_states) if (world == 1 and rank == 0 and not args.no_closed_loop) else None
+    closed = closed_loop(env, controller, params, n_states, rec) if (world == 1 and rank == 0 and not args.no_closed_loop) else None
 
     # ---- the same steps with covo.py:281's pos_mean / pos_std (a22) computed: a second controller, same inputs, same keys,
     # same barrier + sync bracket; reported NEXT to `value` (the reference's jitted eval loop drops the info as dead code,
@@ -520,22 +596,22 @@ def main():
         del controller, core, cp
         ctrl2, cp2 = cm.envs.get_controller(env, args.controller, f"N{args.N}_H{H}_lam{args.lam}", device=device,
                                             process_group=pg, compute_info=not args.info)
-        cp2 = ctrl2.reset(s_reset, params, ctrl2.init_control_params, cr.PRNGKey(7))
+        cp2 = ctrl2.reset(s_reset, params, ctrl2.init_control_params, cr.PRNGKey(22))
         ctrl2.alias_outputs = True
 
-        def step2(i, cp2):
-            u, cp2, _ = ctrl2(None, None, params, act_keys[i], cp2, {"noisy_state": dstates[i % n_states]})
-            return cp2
+        def step2(i, cp_prev):
+            u, cp_out, _ = ctrl2(None, None, params, rec["keys"][i], cp_prev.replace(a_mean=a_mean_rows[i]), {"noisy_state": dstates[i]})
+            return cp_out
 
-        for i in range(args.warmup):
+        for i in idx_warm:
             cp2 = step2(i, cp2)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            cp2 = step2(args.warmup + i, cp2)
+        for i in idx_timed:
+            cp2 = step2(i, cp2)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -561,10 +637,13 @@ def main():
             "metric": "mpc_control_steps_per_sec", "value": value, "unit": "control-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.controller} tracking_zigzag N={args.N} H={H} lam={args.lam} sigma=0.5 "
-                                   f"(teacher-forced noisy states of one 300-step episode; samples sharded {world}x"
-                                   f"{n_local}, one exchange of the 516-float rank records per step: {exchange_name})",
-                       "controller": args.controller, "N_global": args.N, "N_local": n_local, "H": H,
+            "config": {"workload": f"{args.controller} {args.task} N={args.N} H={H} lam={args.lam} sigma=0.5 "
+                                   f"(teacher-forced on the recorded inputs -- noisy state, a_mean, key -- of this controller's own "
+                                   f"{n_states}-step closed-loop episode, timed steps spread evenly over the episode; samples sharded "
+                                   f"{world}x{n_local}, one exchange of the 516-float rank records per step: {exchange_name})",
+                       "controller": args.controller, "task": args.task, "N_global": args.N, "N_local": n_local, "H": H,
+                       "timed_episode_steps": idx_timed if len(idx_timed) <= 64 else f"{len(idx_timed)} indices, stride "
+                                                                                    f"{n_states / len(idx_timed):.2f}",
                        "pos_stats_info": bool(args.info)},
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

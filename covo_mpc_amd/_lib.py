@@ -22,7 +22,7 @@ COVO_RANK_RECORD_FLOATS = COVO_PARTIAL_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 51
 COVO_COV_FLOATS = COVO_H * 10
 COVO_RANK_RECORD_COV_FLOATS = COVO_PARTIAL_FLOATS + COVO_COV_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 836: with MPPI's second moments
 COVO_EXCHANGE_HANDLE_BYTES = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 COVO_FLAG_ACTIONS_CLIPPED = 1
 
 
@@ -58,7 +58,7 @@ class StepArgsC(C.Structure):
                 ("L_table", _P), ("a", _P), ("cost", _P), ("groupmin", _P), ("pos_stats", _P), ("partial_out", _P),
                 ("sample_offset", C.c_int64), ("gamma_mean", C.c_float), ("sample_sigma", C.c_float),
                 ("derive_keys", C.c_int32), ("rollout_deterministic", C.c_int32), ("gamma_sigma", C.c_float),
-                ("pad_", C.c_int32)]
+                ("pad_", C.c_int32), ("a_mean_in", _P)]
 
 
 class BatchArgsC(C.Structure):
@@ -106,6 +106,7 @@ _SIGS = {
     "covo_softmax_update_cov": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_float, _P, C.c_float, _P, _P, _P]),
     "covo_merge": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P]),
     "covo_merge_ranks": (C.c_int, [_P, _P, C.c_int32, _P, C.c_float, _P, _P, _P]),
+    "covo_merge_ranks_wide": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_float, _P, _P, _P]),
     "covo_exchange_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "covo_exchange_connect": (C.c_int, [_P, _P]),
     "covo_exchange_set_timeout": (C.c_int, [_P, C.c_double]),

@@ -256,8 +256,11 @@ class SamplingCore:
         return self.gathered
 
     def merge_rank_records(self, a_mean_shifted, gamma_mean, out):
-        check(self.lib.covo_merge_ranks(self.h, ptr(self.gathered), self.world, ptr(a_mean_shifted), float(gamma_mean), ptr(out),
-                                        ptr(self.stats_total) if self.compute_info else None, self.stream()), "covo_merge_ranks")
+        # the stride / position-sum offset of the records THIS core exchanges: a core built with cov_records that runs a
+        # gamma_sigma == 0 step still exchanges the 836-float kind ({m, s, v} in front, the sums at its end)
+        check(self.lib.covo_merge_ranks_wide(self.h, ptr(self.gathered), self.world, int(self.rec_floats), ptr(a_mean_shifted),
+                                             float(gamma_mean), ptr(out), ptr(self.stats_total) if self.compute_info else None,
+                                             self.stream()), "covo_merge_ranks_wide")
         return out
 
     def merge_rank_records_cov(self, a_mean_shifted, gamma_mean, a_cov_shifted, gamma_sigma, out_mean, out_cov):
@@ -389,7 +392,7 @@ class SamplingCore:
         return t
 
     def _prepare_step(self, mode, dstate, a_mean, *, a_cov=None, L_table=None, gamma_mean=1.0, sample_sigma=0.5,
-                      want_stats=False, derive_keys=False, rollout_deterministic=True, gamma_sigma=0.0):
+                      want_stats=False, derive_keys=False, rollout_deterministic=True, gamma_sigma=0.0, carry_only=False):
         """Fixed-address buffers + struct covo_step_args of the fused step -> (args, a_mean buffer, shifted-mean
         buffer, a_cov buffer or None)."""
         torch = self.torch
@@ -398,8 +401,14 @@ class SamplingCore:
         packed = dstate.packed
         self._state_ref = packed
         am = self._persistent("a_mean", (COVO_NA,))
+        # control_params.a_mean is an INPUT of the call (covo.py:201): when it is not the handle's own buffer (a returned view of
+        # it) the step's first launch reads it where it lies (args.a_mean_in) -- no copy launch on the per-step path
+        a_mean_in = None
         if a_mean.data_ptr() != am.data_ptr():
-            am.copy_(a_mean.reshape(-1), non_blocking=True)
+            if not carry_only and a_mean.is_cuda and a_mean.dtype == torch.float32 and a_mean.is_contiguous() and a_mean.numel() == COVO_NA:
+                a_mean_in = a_mean
+            else:
+                am.copy_(a_mean.reshape(-1), non_blocking=True)
         am_shift = self._persistent("a_mean_shift", (COVO_NA,))
         cov_out = None
         if mode == _lib.MODE_COVO_ONLINE:
@@ -434,6 +443,8 @@ class SamplingCore:
             args.gamma_sigma = float(gamma_sigma)
             self._args_cache = (sig, args, (dstate.pos_traj, dstate.vel_traj, L_table))  # keep the tensors alive
         args.state = packed.data_ptr()
+        args.a_mean_in = a_mean_in.data_ptr() if a_mean_in is not None else None
+        self._a_mean_in_ref = a_mean_in  # alive until the step has run
         return args, am, am_shift, cov_out
 
     def step(self, mode, dstate, params_c, a_mean, key, *, f_shared=None, gamma_mean=1.0, **kw):
@@ -464,7 +475,7 @@ class SamplingCore:
                                       "COVO_EXCHANGE=peer): a torch.distributed collective cannot be enqueued from C")
         if self.world > 1 and mode == _lib.MODE_MPPI and float(kw.get("gamma_sigma", 0.0)) != 0.0:
             self._need_cov_records()
-        args, am, _, cov_out = self._prepare_step(mode, episode.noisy_state, a_mean, derive_keys=True, **kw)
+        args, am, _, cov_out = self._prepare_step(mode, episode.noisy_state, a_mean, derive_keys=True, carry_only=True, **kw)
         key = (C.c_uint32 * 2)(int(rng[0]), int(rng[1]))
         env = episode.env
         check(self.lib.covo_run_episode(self.h, C.byref(params_c), C.byref(args), ptr(episode.true), ptr(episode.acc_traj),

@@ -87,8 +87,6 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     h->exchange = nullptr;
     const int nb = (cfg->n_local + 255) / 256, ng = (cfg->n_local + 63) / 64;
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials, (size_t)h->max_red_blocks * COVO_PARTIAL_FLOATS * sizeof(float)));
-    COVO_CHECK_HIP(hipMalloc(&h->ws_ticket, COVO_U1_MAX_BATCH * sizeof(unsigned)));
-    COVO_CHECK_HIP(hipMemset(h->ws_ticket, 0, COVO_U1_MAX_BATCH * sizeof(unsigned)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_partials_cov, softmax_cov_workspace_floats(h->max_red_blocks) * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_blockmin, (size_t)ng * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&h->ws_stats, (size_t)(nb > 256 ? nb : 256) * COVO_H * 6 * sizeof(double)));  // one row per rollout workgroup
@@ -123,7 +121,6 @@ int covo_destroy(covo_handle_t h)
     } while (0)
     DESTROY(hipFree(h->ws_partials));
     DESTROY(hipFree(h->ws_partials_cov));
-    DESTROY(hipFree(h->ws_ticket));
     DESTROY(hipFree(h->ws_blockmin));
     DESTROY(hipFree(h->ws_stats));
     DESTROY(hipFree(h->ws_sigma));
@@ -388,6 +385,21 @@ int covo_merge_ranks(covo_handle_t h, const float *records, int32_t G, const flo
     return rc;
 }
 
+int covo_merge_ranks_wide(covo_handle_t h, const float *records, int32_t G, int32_t record_floats, const float *a_mean_old,
+                          float gamma_mean, float *a_mean_out, double *pos_stats_out, void *stream)
+{
+    REQUIRE(h, "covo_merge_ranks_wide: null handle");
+    CHECK_DEVICE(h, "covo_merge_ranks_wide");
+    REQUIRE(records && a_mean_old && a_mean_out && G > 0, "covo_merge_ranks_wide: bad argument");
+    REQUIRE(record_floats == COVO_RANK_RECORD_FLOATS || record_floats == COVO_RANK_RECORD_COV_FLOATS,
+            "covo_merge_ranks_wide: record_floats=%d is neither COVO_RANK_RECORD_FLOATS nor COVO_RANK_RECORD_COV_FLOATS", record_floats);
+    int rc = launch_merge(records, G, h->cfg.lam, a_mean_old, gamma_mean, a_mean_out, (hipStream_t)stream, nullptr, 1, record_floats);
+    if (rc) return rc;
+    if (pos_stats_out != nullptr)
+        rc = launch_rank_stats_sum(records, G, pos_stats_out, (hipStream_t)stream, record_floats == COVO_RANK_RECORD_COV_FLOATS);
+    return rc;
+}
+
 int covo_exchange_create(covo_handle_t h, int32_t world, int32_t rank, void *handle_out)
 {
     REQUIRE(h && handle_out, "covo_exchange_create: null argument");
@@ -494,10 +506,8 @@ int covo_debug_set_ns_tail(int n_squarings, int n_iters)
         covo_set_error("covo_debug_set_ns_tail: (%d, %d) out of range", n_squarings, n_iters);
         return COVO_E_BADARG;
     }
-    if (n_squarings < 0) {  // back to the defaults (sigma_ns.hip)
-        g_ns_tail_squarings = g_ns_tail_squarings_batched = 15;
-        g_ns_tail_iters = 11;
-        g_ns_tail_iters_batched = 4;
+    if (n_squarings < 0) {  // back to the defaults, defined in ONE place (sigma_ns.hip)
+        sigma_ns_tail_defaults();
     } else {
         g_ns_tail_squarings = g_ns_tail_squarings_batched = n_squarings;  // batch 1 and batched launches alike
         g_ns_tail_iters = g_ns_tail_iters_batched = n_iters;
@@ -580,6 +590,7 @@ int covo_run_episode(covo_handle_t h, const covo_env_params *params, const covo_
     CHECK_DEVICE(h, "covo_run_episode");
     REQUIRE(params && args && state_true && acc_traj && rng && n_steps > 0, "covo_run_episode: bad argument");
     REQUIRE(args->derive_keys == 1, "covo_run_episode: args->derive_keys must be 1 (the controller key is the raw rng_act)");
+    REQUIRE(args->a_mean_in == nullptr, "covo_run_episode: args->a_mean_in must be NULL (the episode carries the mean in args->a_mean)");
     CHECK_MODEL(params, "covo_run_episode");
     REQUIRE(args->partial_out == nullptr || (exchange_ready(h) && args->a_mean_shift != nullptr),
             "covo_run_episode: a sample-sharded step (partial_out != NULL) needs the peer-write exchange (covo_exchange_create / "

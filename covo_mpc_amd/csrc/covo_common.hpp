@@ -16,7 +16,6 @@ struct covo_ctx {
     // workspace (device)
     float *ws_partials;   // [max_blocks][COVO_PARTIAL_FLOATS] stage-1 records of the softmax reduce
     float *ws_partials_cov;  // [max_blocks][452] stage-1 records with second moments (MPPI covariance adaptation, reduce.hip)
-    unsigned *ws_ticket;  // arrival counter of softmax_update1_kernel (reduce.hip); zero between launches
     float *ws_blockmin;   // [ceil(n_local/64)] per-wave cost minima when the caller passes none
     double *ws_stats;     // [ceil(n_local/256)][H*6] per-block position statistics
     void *ws_sigma;       // scratch of the eigh-free Sigma pipeline (grown on demand, outside graph capture)
@@ -41,6 +40,7 @@ void covo_set_error(const char *fmt, ...);
 // Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
 extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate, g_ns_force_agent;  // sigma_ns.hip
+void sigma_ns_tail_defaults();  // sigma_ns.hip: the four tail lengths back to their defaults
 extern int g_dbg_epoch;  // capi.hip: bumped by every debug setter whose value a captured step graph bakes in as a kernel argument
 
 #define COVO_CHECK_HIP(expr)                                                         \
@@ -139,14 +139,6 @@ int launch_rollout_batched(const void *args_host, const void *args_dev, int nbat
 int launch_softmax_reduce(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out,
                           hipStream_t s, float *partials_ws = nullptr, int batch = 1);  // batch > 1: dense per-instance slices, own partials_ws
-// the same in ONE launch (stage 1 + last-arriver stage 2, reduce.hip); blockmin must be given (the rollout's per-group minima)
-// COVO_UPDATE=one_launch (round 4 experiment, measured slower -- reduce.hip): the fused steps run the whole update as ONE launch
-// behind the PLAIN rollout (softmax_update1_kernel) instead of the record epilogue inside the rollout + the merge launch
-bool covo_update1_enabled();
-constexpr int COVO_U1_MAX_BATCH = 64;  // tickets (one per instance of the env-batched step; = COVO_MAX_ENVS)
-int launch_softmax_update1(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
-                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out, hipStream_t s,
-                           int batch = 1, float *partials_ws = nullptr);  // batch > 1: partials_ws [batch][64][COVO_PARTIAL_FLOATS]
 // a_mean_out == null: the merged record goes to partial_out (sample-sharded step); batch > 1: dense per-instance slices
 int launch_merge(const float *partials, int G, float lam, const float *a_mean_old, float gamma_mean, float *a_mean_out,
                  hipStream_t s, float *partial_out = nullptr, int batch = 1, int stride = COVO_PARTIAL_FLOATS);

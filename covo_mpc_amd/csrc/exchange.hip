@@ -81,9 +81,13 @@ __global__ __launch_bounds__(512) void exchange_wait_kernel(float *__restrict__ 
 {
     __shared__ int ok;
     const int tid = threadIdx.x;
-    if (tid == 0) ok = 1;
+    // fail fast: once an exchange of this handle has timed out (sticky COVO_DEVSTAT_EXCHANGE, cleared by the host) every wait
+    // still queued behind it -- covo_run_episode enqueues whole episode segments -- leaves its NaN records without spinning its own
+    // full time-out in stream order (300 queued steps x 60 s otherwise)
+    if (tid == 0)
+        ok = (status != nullptr && (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & COVO_DEVSTAT_EXCHANGE)) ? 0 : 1;
     __syncthreads();
-    if (tid < world) {
+    if (ok != 0 && tid < world) {
         const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(local + ex_slot_floats(world)) +
                                          (size_t)parity * world + tid;
         const long long t0 = wall_clock64();

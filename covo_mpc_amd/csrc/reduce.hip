@@ -369,243 +369,6 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
     }
 }
 
-// ---- The whole update in ONE launch (round 4): covo.py:266-278 from the costs and the per-group minima the rollout leaves.
-// Every workgroup forms the exact global minimum m from the per-group minima (4 KiB at N = 65 536, L2) and counts the LIVE
-// groups -- those whose own minimum still has a weight exp((m - c)/lam) > 0; all other groups contribute exact zeros.  All
-// workgroups see the same numbers, so they take the same decision without talking to each other:
-//   * sparse (<= U1_LMAX live groups; at lam = 0.01 some tens of 1 024): workgroup 0 alone finishes the update -- its 16 waves
-//     take the live groups round robin: their costs (one round trip, all in flight), the stripes of their live samples (eight
-//     samples per trip), fixed-order sums, new mean; the other workgroups exit.  No records, no ticket.
-//   * dense: stage 1 as softmax_partial_kernel (grid-stride over all groups, one record {s, v[128]} per workgroup, all with the
-//     SAME m, published with agent-scope write-through stores), then the workgroup that takes the last ticket sums the records
-//     in workgroup order (all loads of that sum in flight together).
-// Fixed summation orders in both modes: bit-reproducible, and independent of which workgroup arrives last.
-// Replaces {record epilogue inside the rollout kernel (+1.7 .. 2.1 us on it) + merge_kernel (5.3 us)} of rounds 1-3 in the fused
-// single-instance step: 4.x us at lam = 0.01; the rollout then runs in its plain variant (cost + per-group minimum only).
-// Measured (round 4, one MI355X, bench.py, steps/s with this kernel vs with the records + merge path): covo-online N = 65 536
-// 5 367 vs 5 406, covo-offline 21 660 vs 23 230, MPPI 29 120 vs 31 260, MPPI N = 1 024 50 680 vs 55 320 -- the rollout loses its
-// 1.5 us epilogue (10.3 vs 11.8 us in the step) but this launch takes 6.3 us against merge_kernel's 5.3 (9.4 with 256-thread
-// workgroups and a 32-group sparse limit; 21 with a ticket for every one of 256 workgroups and the last arriver's loads
-// serialised): a negative result.  The records path stays the default; COVO_UPDATE=one_launch selects this one (tested).
-bool covo_update1_enabled()
-{
-    static const bool on = [] { const char *e = std::getenv("COVO_UPDATE"); return e && std::strcmp(e, "one_launch") == 0; }();
-    return on;
-}
-constexpr int U1_BLOCK = 1024;
-constexpr int U1_WAVES = U1_BLOCK / 64;
-constexpr int U1_GRID = 32;    // workgroups (dense mode: records, one ticket each)
-constexpr int U1_LMAX = 256;   // live groups the sparse mode takes: 16 per wave, their cost loads all in flight
-constexpr int U1_SLICES = U1_BLOCK / COVO_NA;  // 8
-
-// w-weighted stripe sum of the live lanes of one 64-sample group: lanes t < 32 own action stripe t, the two half-waves take
-// alternate live samples, up to 8 samples (4 per half) per trip with their loads issued together
-__device__ __forceinline__ void u1_accumulate(const float4 *__restrict__ a, int N, int g, float w, int lane, float4 &acc)
-{
-    const int t = lane & 31, half = lane >> 5;
-    unsigned long long live = __ballot(w > 0.0f);
-    while (live != 0ull) {
-        float wv[4];
-        float4 av[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int l0 = 0, l1 = 0;
-            bool one = false, two = false;
-            if (live != 0ull) {
-                l0 = (int)__builtin_ctzll(live);
-                live &= live - 1ull;
-                one = true;
-            }
-            if (live != 0ull) {
-                l1 = (int)__builtin_ctzll(live);
-                live &= live - 1ull;
-                two = true;
-            }
-            const int l = half ? l1 : l0;
-            wv[q] = __shfl(w, l, 64);
-            if (half ? !two : !one) wv[q] = 0.0f;
-            av[q] = a[(size_t)t * N + (g * 64 + l)];  // (a slot without a sample re-reads sample 0 of the group with weight 0)
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc.x = fmaf(wv[q], av[q].x, acc.x);
-            acc.y = fmaf(wv[q], av[q].y, acc.y);
-            acc.z = fmaf(wv[q], av[q].z, acc.z);
-            acc.w = fmaf(wv[q], av[q].w, acc.w);
-        }
-    }
-}
-
-template <bool FINAL>
-__global__ __launch_bounds__(U1_BLOCK) void softmax_update1_kernel(const float *__restrict__ cost, const float4 *__restrict__ a, int N,
-                                                                   const float *__restrict__ blockmin, int nbm, float inv_lam,
-                                                                   float *__restrict__ partials, unsigned *__restrict__ ticket,
-                                                                   const float *__restrict__ a_mean_old, float gamma_mean,
-                                                                   float *__restrict__ out)
-{
-    __shared__ float red[U1_WAVES], ss[U1_WAVES];
-    __shared__ int cnt[U1_WAVES];
-    __shared__ __attribute__((aligned(16))) float sv[U1_WAVES][COVO_NA];
-    __shared__ float hs[U1_GRID];
-    __shared__ int lst[U1_LMAX];
-    __shared__ int s_last;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {   // blockIdx.y (env-batched step): instance y's dense slices, its own records and ticket; its mean follows instance y - 1's
-        const size_t y = blockIdx.y;
-        cost += y * N;
-        a += y * ((size_t)COVO_H * N);
-        blockmin += y * nbm;
-        partials += y * U1_GRID * COVO_PARTIAL_FLOATS;
-        ticket += y;
-        if (FINAL) a_mean_old += y * COVO_NA;
-        out += y * (FINAL ? COVO_NA : COVO_PARTIAL_FLOATS);
-    }
-    const int ngroups = (N + 63) / 64;
-    // ---- exact global minimum of cost from the per-group minima (covo.py:266: cost - jnp.min(cost))
-    float m = __builtin_inff();
-    for (int i = tid; i < nbm; i += U1_BLOCK) m = fminf(m, blockmin[i]);
-    m = wave_min(m);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = red[0];
-#pragma unroll
-    for (int w = 1; w < U1_WAVES; ++w) m = fminf(m, red[w]);
-    // ---- the live groups, in ascending order (the first U1_LMAX of them listed)
-    int L = 0;
-    for (int base = 0; base < nbm; base += U1_BLOCK) {
-        const int g = base + tid;
-        const bool lv = g < nbm && expf((m - blockmin[g]) * inv_lam) > 0.0f;
-        const unsigned long long mask = __ballot(lv);
-        if (lane == 0) cnt[wave] = __builtin_popcountll(mask);
-        __syncthreads();
-        int off = L;
-        for (int w = 0; w < wave; ++w) off += cnt[w];
-        if (lv) {
-            const int pos = off + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (pos < U1_LMAX) lst[pos] = g;
-        }
-#pragma unroll
-        for (int w = 0; w < U1_WAVES; ++w) L += cnt[w];
-        __syncthreads();
-    }
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float s_lane = 0.0f;
-    const bool sparse = L <= U1_LMAX;
-    if (sparse) {
-        if (blockIdx.x != 0) return;
-        // wave w: live groups w, w + 4, ... of the list; their costs first (all in flight), then weights and stripes
-        float c[U1_LMAX / U1_WAVES];
-#pragma unroll
-        for (int q = 0; q < U1_LMAX / U1_WAVES; ++q) {
-            const int li = wave + U1_WAVES * q;
-            const int n = (li < L ? lst[li] : 0) * 64 + lane;
-            c[q] = (li < L && n < N) ? cost[n] : __builtin_inff();
-        }
-#pragma unroll
-        for (int q = 0; q < U1_LMAX / U1_WAVES; ++q) {
-            const int li = wave + U1_WAVES * q;
-            if (li < L) {  // wave-uniform
-                const float w = expf((m - c[q]) * inv_lam);  // covo.py:266 (exp(-inf) = 0 for the lanes past N)
-                s_lane += w;
-                u1_accumulate(a, N, lst[li], w, lane, acc);
-            }
-        }
-    } else {
-        const int gstride = gridDim.x * U1_WAVES;
-        for (int g = blockIdx.x * U1_WAVES + wave; g < ngroups; g += gstride) {
-            const int n = g * 64 + lane;
-            const float w = expf((m - ((n < N) ? cost[n] : __builtin_inff())) * inv_lam);
-            s_lane += w;
-            u1_accumulate(a, N, g, w, lane, acc);
-        }
-    }
-    acc.x += __shfl_xor(acc.x, 32, 64);
-    acc.y += __shfl_xor(acc.y, 32, 64);
-    acc.z += __shfl_xor(acc.z, 32, 64);
-    acc.w += __shfl_xor(acc.w, 32, 64);
-    const float s_wave = wave_sum(s_lane);
-    if (lane < 32) *reinterpret_cast<float4 *>(&sv[wave][4 * lane]) = acc;
-    if (lane == 0) ss[wave] = s_wave;
-    __syncthreads();
-    float s = 0.0f, v = 0.0f;
-#pragma unroll
-    for (int w = 0; w < U1_WAVES; ++w) {  // wave order: fixed
-        s += ss[w];
-        if (tid < COVO_NA) v += sv[w][tid];
-    }
-    if (!sparse) {
-        // ---- publish this workgroup's record, take a ticket; the last one sums all records in workgroup order
-        float *rec = partials + (size_t)blockIdx.x * COVO_PARTIAL_FLOATS;
-        if (tid < COVO_NA) __hip_atomic_store(rec + 2 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) __hip_atomic_store(rec + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have been acknowledged
-        __syncthreads();
-        if (tid == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
-        __syncthreads();
-        if (!s_last) return;
-        const int G = gridDim.x;  // <= U1_GRID
-        if (tid < U1_GRID)
-            hs[tid] = (tid < G) ? __hip_atomic_load(partials + (size_t)tid * COVO_PARTIAL_FLOATS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-        const int col = tid & (COVO_NA - 1), slice = tid >> 7;  // eight record slices x 128 columns: records slice, slice + 8, ...
-        float x[U1_GRID / U1_SLICES];
-#pragma unroll
-        for (int q = 0; q < U1_GRID / U1_SLICES; ++q) {
-            const int g = slice + U1_SLICES * q;
-            x[q] = (g < G) ? __hip_atomic_load(partials + (size_t)g * COVO_PARTIAL_FLOATS + 2 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-        }
-        v = 0.0f;
-#pragma unroll
-        for (int q = 0; q < U1_GRID / U1_SLICES; ++q) v += x[q];
-        __syncthreads();
-        sv[slice][col] = v;
-        __syncthreads();
-        s = 0.0f;
-        for (int g = 0; g < G; ++g) s += hs[g];  // record order: fixed
-        v = 0.0f;
-        if (tid < COVO_NA) {
-#pragma unroll
-            for (int q = 0; q < U1_SLICES; ++q) v += sv[q][tid];
-        }
-        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
-    }
-    if (tid < COVO_NA) {
-        if (FINAL) {
-            out[tid] = (v / s) * gamma_mean + a_mean_old[tid] * (1.0f - gamma_mean);  // covo.py:270-275
-        } else {
-            out[2 + tid] = v;
-            if (tid == 0) {
-                out[0] = m;
-                out[1] = s;
-            }
-        }
-    }
-}
-
-// a_mean_out != null: the new mean(s); else the merged record {m, s, v} to partial_out (sample-sharded rank).  batch > 1: the
-// env-batched step's dense per-instance slices (cost [batch][N], a [batch][H][N][4], blockmin [batch][n_blockmin], means [batch][128])
-int launch_softmax_update1(covo_ctx *h, const float *cost, const float *a, int N, const float *blockmin, int n_blockmin,
-                           float *partial_out, const float *a_mean_old, float gamma_mean, float *a_mean_out, hipStream_t s,
-                           int batch, float *partials_ws)
-{
-    const float inv_lam = 1.0f / h->cfg.lam;
-    const int ngroups = (N + 63) / 64;
-    int grid = (ngroups + U1_WAVES - 1) / U1_WAVES;
-    if (grid > U1_GRID) grid = U1_GRID;
-    if (batch > COVO_U1_MAX_BATCH) {
-        covo_set_error("softmax_update1: batch=%d > %d", batch, COVO_U1_MAX_BATCH);
-        return COVO_E_BADARG;
-    }
-    if (partials_ws == nullptr) partials_ws = h->ws_partials;  // (max_red_blocks = 256 >= U1_GRID records)
-    if (a_mean_out != nullptr)
-        hipLaunchKernelGGL(softmax_update1_kernel<true>, dim3(grid, batch), dim3(U1_BLOCK), 0, s, cost, reinterpret_cast<const float4 *>(a), N,
-                           blockmin, n_blockmin, inv_lam, partials_ws, h->ws_ticket, a_mean_old, gamma_mean, a_mean_out);
-    else
-        hipLaunchKernelGGL(softmax_update1_kernel<false>, dim3(grid, batch), dim3(U1_BLOCK), 0, s, cost, reinterpret_cast<const float4 *>(a), N,
-                           blockmin, n_blockmin, inv_lam, partials_ws, h->ws_ticket, (const float *)nullptr, 1.0f, partial_out);
-    COVO_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 __global__ void shift_mean_kernel(const float *__restrict__ in, float *__restrict__ out)
 {
     const int i = threadIdx.x;  // 128 threads; covo.py:201-203

@@ -285,4 +285,3 @@ __global__ __launch_bounds__(RO_BLOCK) void rollout_kernel(const RolloutArgs A_,
 #endif  // ROLLOUT_LAB_BASELINE
 
 #include "rollout_pipe.hpp"
-#include "rollout_pipe4.hpp"

@@ -16,27 +16,12 @@ static void launch_pipe3_groups(const RolloutArgs &A, const RolloutArgs *batch, 
 {
     const int ng = (A.N + COVO_WAVE - 1) / COVO_WAVE;
     const dim3 grid((ng + groups - 1) / groups, nb);
-#ifdef COVO_ROLLOUT_PIPE4
-    // round 4 experiment (rollout_pipe4.hpp): four waves per group (attitude | translation chain | two evaluation waves), no wave
-    // longer than 31 instructions per step.  Parity-green on every variant; NOT faster: 9.97 against 9.63 us stand-alone, 18.3
-    // against 16.6 us in the step on the same box (N = 65 536) -- the launch is bound by the SIMD's total issue (VALU +
-    // transcendentals + LDS), which the extra hand-off raises, not by its longest wave.  Built only with -DCOVO_ROLLOUT_PIPE4
-    // (make VARIANT=pipe4 ROLLOUT_FLAGS="-ffp-contract=off -DCOVO_ROLLOUT_PIPE4"; scripts/probe/rollout_lab.hip times both).
-    constexpr int CH = 2, W = 2 + CH;
-    if (groups == 4)
-        hipLaunchKernelGGL((rollout_pipe4_kernel<DISC1, ROLL, CH, 4, BATCHED, STATS, REC, REWARD, FDIST>), grid, dim3(W * 4 * COVO_WAVE), 0, s, A, batch);
-    else if (groups == 2)
-        hipLaunchKernelGGL((rollout_pipe4_kernel<DISC1, ROLL, CH, 2, BATCHED, STATS, REC, REWARD, FDIST>), grid, dim3(W * 2 * COVO_WAVE), 0, s, A, batch);
-    else
-        hipLaunchKernelGGL((rollout_pipe4_kernel<DISC1, ROLL, CH, 1, BATCHED, STATS, REC, REWARD, FDIST>), grid, dim3(W * COVO_WAVE), 0, s, A, batch);
-#else
     if (groups == 4)
         hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 4, BATCHED, -1, 3, STATS, REC, REWARD, FDIST>), grid, dim3(3 * 4 * COVO_WAVE), 0, s, A, batch);
     else if (groups == 2)
         hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 2, BATCHED, -1, 3, STATS, REC, REWARD, FDIST>), grid, dim3(3 * 2 * COVO_WAVE), 0, s, A, batch);
     else
         hipLaunchKernelGGL((rollout_pipe3_kernel<DISC1, ROLL, 2, 1, BATCHED, -1, 3, STATS, REC, REWARD, FDIST>), grid, dim3(3 * COVO_WAVE), 0, s, A, batch);
-#endif
 }
 
 // the run-time switches of one (DISC1, BATCHED, REWARD, FDIST) family: rollover termination, position statistics (never

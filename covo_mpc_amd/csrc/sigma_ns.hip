@@ -1547,8 +1547,15 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
 // loop: (15, 3) 81 815 / 75 187; (15, 4) 82 553 / 75 641; (15, 5) 82 865 / 74 674; (15, 6) 82 978 / 74 796; (15, 8) 81 889 / 74 194;
 // (15, 11) 80 713 / 73 431 -> the last 4.  The squaring launch on pairs too (20 workgroups per matrix instead of 36, a third fewer
 // operand bytes): one matrix 5 464-5 470 / 4 874-4 886 against 5 428-5 457 / 4 844-4 854, batched 83 663 / 76 231 against 82 535 / 75 461.
-int g_ns_tail_iters = NS_ITERS - 1, g_ns_tail_squarings = NS_SQUARINGS - 1;
-int g_ns_tail_iters_batched = 4, g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
+int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched;
+// THE defaults of the four tail lengths (also what covo_debug_set_ns_tail(-1, -1) restores)
+void sigma_ns_tail_defaults()
+{
+    g_ns_tail_iters = NS_ITERS - 1;
+    g_ns_tail_squarings = g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
+    g_ns_tail_iters_batched = 4;
+}
+static const int g_ns_tail_init = (sigma_ns_tail_defaults(), 0);
 // COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
 // iteration (A/B measurements, tests)
 int g_ns_force_agent = 0;  // covo_debug_set_ns_coherence: take the COH_AGENT fallback although the placement check passed

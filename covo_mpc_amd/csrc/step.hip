@@ -270,10 +270,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     const int G = rollout_workgroups(N, a.pos_stats != nullptr);
     // MPPI's covariance adaptation needs second moments the in-rollout records do not carry: its own stage 1 (reduce.hip)
     const bool cov_adapt = a.mode == COVO_MODE_MPPI && a.gamma_sigma != 0.0f;
-    // COVO_UPDATE=one_launch: the whole update as ONE launch behind the PLAIN rollout (softmax_update1_kernel, reduce.hip: measured
-    // slower than the record epilogue + merge; opt-in)
-    const bool update1 = covo_update1_enabled();
-    const bool records = G <= h->max_red_blocks && !cov_adapt && !update1;
+    const bool records = G <= h->max_red_blocks && !cov_adapt;
     if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
                                          records ? nullptr : a.groupmin, a.pos_stats, h->ws_stats, s, fdev,
                                          records ? h->ws_partials : nullptr, h->cfg.lam, tables ? st->f_tab_rollout : nullptr,
@@ -289,9 +286,6 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         if (a.partial_out != nullptr) return launch_merge(h->ws_partials, G, h->cfg.lam, nullptr, 1.0f, nullptr, s, a.partial_out);
         return launch_merge(h->ws_partials, G, h->cfg.lam, am_shift, a.gamma_mean, a.a_mean, s);
     }
-    if (update1)  // covo.py:266-278 in one launch; on a sample-sharded rank: this shard's record for the exchange
-        return launch_softmax_update1(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, a.partial_out,
-                                      a.partial_out ? nullptr : am_shift, a.gamma_mean, a.partial_out ? nullptr : a.a_mean, s);
     // weights + update: finish locally, or leave this shard's record for the all-gather (covo.py:266-275)
     if (a.partial_out != nullptr)
         return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, a.partial_out, nullptr, 1.0f, nullptr, s);
@@ -325,7 +319,9 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     // step_env(deterministic=True) (quadrotor.py:234-235)
     const float shared_noise_scale =
         (params->disturb_kind == COVO_DISTURB_GAUSSIAN && !args->rollout_deterministic) ? params->dyn_noise_scale : 0.0f;
-    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s, args->a_mean,
+    // control_params.a_mean of this call: the handle's own buffer (a carried mean) or the caller's input (args->a_mean_in)
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s,
+                       args->a_mean_in ? args->a_mean_in : args->a_mean,
                        args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
                        shared_noise_scale, blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls);
 
@@ -333,6 +329,7 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     std::memset(&k, 0, sizeof(k));
     k.args = *args;
     k.args.state = nullptr;  // read through the dyn block: a new state address does not invalidate the graph
+    k.args.a_mean_in = nullptr;  // read by the (eager) begin launch only
     k.params = *params;
     k.stream = s;
     const bool same = st->have_key && std::memcmp(&k, &st->key, sizeof(k)) == 0;
@@ -614,9 +611,6 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
     if ((M & 16) && (rc = launch_rollout_batched(b->ro_args_host.data(), b->ro_args, E, s))) return rc;
     if (!(M & 32)) return 0;
     const int G = rollout_workgroups(N, false, E);
-    if (covo_update1_enabled())  // one launch for all instances: grid.y = instance (reduce.hip)
-        return launch_softmax_update1(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, b->a_mean_shift, a.gamma_mean, a.a_mean, s, E,
-                                      b->partials);
     if (G <= h->max_red_blocks)  // the rollout's workgroups have left the records (rollout_record): instance e's are [e][G]
         return launch_merge(b->partials, G, h->cfg.lam, b->a_mean_shift, a.gamma_mean, a.a_mean, s, nullptr, E);
     return launch_softmax_reduce(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, nullptr, b->a_mean_shift, a.gamma_mean, a.a_mean, s,
@@ -720,7 +714,7 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
         b->ro_args_host.assign(rollout_args_bytes(E), 0);
         const int N = args->n_samples, ng = (N + 63) / 64;
         const int bG = rollout_workgroups(N, false, E);
-        const bool brec = bG <= h->max_red_blocks && !covo_update1_enabled();
+        const bool brec = bG <= h->max_red_blocks;
         for (int e = 0; e < E; ++e)
             rollout_fill_args(b->ro_args_host.data(), e, args->states + (size_t)e * COVO_STATE_FLOATS,
                               args->pos_traj + (size_t)e * args->T * 3, args->vel_traj + (size_t)e * args->T * 3, args->T,

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define COVO_ABI_VERSION 4
+#define COVO_ABI_VERSION 5
 
 #define COVO_H 32            /* horizon (compile-time in the fused kernels)          */
 #define COVO_DU 4            /* action dim, quadjax/envs/quadrotor.py:198            */
@@ -288,6 +288,13 @@ int covo_merge(covo_handle_t h, const float *partials, int32_t G, const float *a
 int covo_merge_ranks(covo_handle_t h, const float *records, int32_t G, const float *a_mean_old, float gamma_mean,
                      float *a_mean_out, double *pos_stats_out, void *stream);
 
+/* covo_merge_ranks over all-gathered records of `record_floats` floats each: COVO_RANK_RECORD_FLOATS, or
+ * COVO_RANK_RECORD_COV_FLOATS -- the records of a core built for MPPI's covariance adaptation that runs a step with
+ * gamma_sigma == 0: {m, s, v[128], pad[2]} in front, the 320 second-moment slots unused, the position sums at the END of the
+ * wider record.  Any other record_floats is refused. */
+int covo_merge_ranks_wide(covo_handle_t h, const float *records, int32_t G, int32_t record_floats, const float *a_mean_old,
+                          float gamma_mean, float *a_mean_out, double *pos_stats_out, void *stream);
+
 /* The exchange of the rank records as direct peer writes instead of a collective (exchange.hip).  Setup, once:
  * every rank calls covo_exchange_create (allocates its buffer, returns its inter-process handle), the G handles are
  * all-gathered by the caller (any transport: they are 64 opaque bytes), every rank calls covo_exchange_connect with all G of
@@ -420,6 +427,11 @@ typedef struct covo_step_args {
     float gamma_sigma;       /* MPPI: != 0 adapts a_cov in place after the mean update (mppi.py:119-125, covo_softmax_update_cov);
                               *    single shard */
     int32_t pad_;
+    const float *a_mean_in;  /* nullable: the control_params.a_mean INPUT of this call when it does not live in `a_mean` (float[128],
+                              *    read by the step's first launch only; covo.py:201 reads control_params.a_mean, :275 returns a new
+                              *    one).  NULL: `a_mean` is read and then overwritten (a controller that carries its own mean).  Like
+                              *    `state` it may change from call to call without invalidating the captured graph.  Must be NULL
+                              *    for covo_run_episode (the episode carries the mean). */
 } covo_step_args;
 
 int covo_mpc_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, uint32_t key0,

@@ -12,6 +12,7 @@
 #include <vector>
 #define ROLLOUT_LAB_BASELINE
 #include "../../covo_mpc_amd/csrc/rollout.hip"
+#include "rollout_pipe4.hpp"  // the round-4 four-stage experiment (not faster; lives with the probes)
 
 void covo_set_error(const char *fmt, ...) { (void)fmt; }
 // what rollout.hip expects from the rest of the library (not linked into the lab)

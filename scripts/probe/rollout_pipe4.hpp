@@ -1,4 +1,4 @@
-// rollout_pipe4.hpp -- the N-sample x H-step rollout as a wave pipeline of 2 + CH stages (gfx950).  Included by rollout_common.hpp.
+// rollout_pipe4.hpp -- the N-sample x H-step rollout as a wave pipeline of 2 + CH stages (gfx950).  Round-4 experiment, NOT part of the library: included by scripts/probe/rollout_lab.hip only.
 //
 // Round 4.  What the machine does, calibrated with the counters on a known load (scripts/probe/valu_calib.hip, profiles/r04_valu_calib.json):
 // a SIMD's VALU pipe takes one wave-instruction per 2.24 cycles when saturated, which needs >= 4 waves of dependent chains (8.6 /

@@ -4,7 +4,8 @@ every rank checks the sharded result (new mean AND covo.py:281's pos_mean / pos_
 unsharded controller fed the same keys.  argv: controller name, exchange ("collective": all-gather over gloo, staged through
 the host; "peer": direct writes into hipIpc-mapped buffers, csrc/exchange.hip -- then also a whole sharded episode segment
 enqueued from C by covo_run_episode).  Controller "mppi-cov": MPPI with gamma_sigma = 0.3 (mppi.py:119-125) -- the 836-float
-rank records with the weighted second moments; the adapted covariances are compared too."""
+rank records with the weighted second moments; the adapted covariances are compared too.  "mppi-cov0": the same core (836-float
+records) stepping with gamma_sigma = 0 -- covo_merge_ranks_wide must read the records at THEIR stride."""
 import os
 import sys
 
@@ -48,13 +49,16 @@ def main():
                          generate_noisy_state=True, device=DEV)
     N = 4096
     cov = name == "mppi-cov"
-    if cov:  # quadjax's factory fixes gamma_sigma = 0 (quadrotor.py:715): built directly, lam = 0.5 so that many samples carry weight
+    cov0 = name == "mppi-cov0"  # a core BUILT for the covariance records (836 floats) whose steps run with gamma_sigma == 0
+    if cov or cov0:  # quadjax's factory fixes gamma_sigma = 0 (quadrotor.py:715): built directly, lam = 0.5 so that many samples carry weight
         _, cp0 = cm.envs.get_controller(env, "mppi", f"N{N}_H32_lam0.5", device=DEV)
         cp0 = cp0.replace(gamma_sigma=0.3)
         cs = cm.controllers.MPPIController(env=env, control_params=cp0, N=N, H=32, lam=0.5, device=DEV, process_group=dist.group.WORLD)
         c1 = cm.controllers.MPPIController(env=env, control_params=cp0, N=N, H=32, lam=0.5, device=DEV)
         cps = cp1 = cp0
         assert cs.core.cov_records and cs.core.rec_floats == 836
+        if cov0:
+            cs.init_control_params = c1.init_control_params = cp0.replace(gamma_sigma=0.0)
     else:
         cs, cps = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV, process_group=dist.group.WORLD)
         c1, cp1 = cm.envs.get_controller(env, name, f"N{N}_H32_lam0.01", device=DEV)
@@ -75,7 +79,9 @@ def main():
         err = (cps.a_mean - cp1.a_mean).abs().max().item()
         # online-softmax merge: fp32 reassociation only; "mppi-cov" (lam = 0.5: thousands of samples carry weight, and the adapted
         # covariances feed the next step's draws) accumulates it over the steps
-        assert err < (1e-5 if cov else 2e-6), (name, rank, step, err)
+        assert err < (1e-5 if (cov or cov0) else 2e-6), (name, rank, step, err)  # (cov0: lam = 0.5 as well)
+        if cov0:  # the merge read {m, s, v} and the position sums at the 836-float stride; a_cov only shifts
+            assert float(cps.gamma_sigma) == 0.0 and (cps.a_cov - cp1.a_cov).abs().max().item() == 0.0
         if cov:
             ec = (cps.a_cov - cp1.a_cov).abs().max().item()
             assert ec < 1e-5 and (cps.a_cov - 0.25 * torch.eye(4, device=DEV)).abs().max().item() > 1e-3, (rank, step, ec)

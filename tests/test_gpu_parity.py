@@ -870,7 +870,8 @@ def test_closed_loop_on_device():
 
 @pytest.mark.parametrize("name,exchange", [("covo-online", "collective"), ("covo-online", "peer"), ("mppi", "collective"),
                                            ("mppi", "peer"), ("covo-online", "auto"), ("mppi", "auto_fail"),
-                                           ("mppi-cov", "collective"), ("mppi-cov", "peer"), ("mppi", "auto_coarse")])
+                                           ("mppi-cov", "collective"), ("mppi-cov", "peer"), ("mppi", "auto_coarse"),
+                                           ("mppi-cov0", "collective")])
 def test_two_ranks_one_gpu(name, exchange):
     """SURVEY.md 8e through the PRODUCT path: two processes (gloo rendezvous, both on cuda:0) run the sample-sharded
     controller -- fused step writing this shard's rank record (softmax partial + position sums), ONE exchange (all-gather, or
@@ -1129,44 +1130,23 @@ def test_bench_multi_rank_path_rehearsal(config):
         assert d["scaling"] == "weak" and d["config"]["envs_total"] == 4 and "no collective" in d["config"]["workload"]
 
 
-@pytest.mark.parametrize("lam", [0.01, 0.5, 5.0])
-def test_one_launch_update_experiment_matches_the_default_path(lam):
-    """COVO_UPDATE=one_launch (softmax_update1_kernel: plain rollout + ONE update launch with a sparse and a dense mode; measured
-    slower than the default record epilogue + merge, kept as an opt-in experiment): same plans as the default path to fp32
-    reassociation, at lambdas where a handful (sparse mode), thousands and all samples (dense mode, ticket + records) carry weight.
-    The switch is read once per process, hence the subprocess."""
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (the driver's 1-GPU command shape): the parent launches the two
+    ranks itself and relays ONE line with n_gpus = 2 (here the ranks share this box's GPU over gloo: functional only)."""
+    import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = f"""
-import numpy as np, torch, sys
-sys.path.insert(0, {root!r})
-import covo_mpc_amd as cm
-from covo_mpc_amd import random as cr
-env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
-                     generate_noisy_state=True, device="cuda:0")
-params = env.default_params
-out = []
-for name in ("mppi", "covo-online"):
-    c, cp = cm.envs.get_controller(env, name, "N4096_H32_lam{lam}", device="cuda:0", compute_info=False)
-    obs, info, state = env.reset(cr.PRNGKey(3), params)
-    cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
-    key = cr.PRNGKey(6)
-    for i in range(4):
-        key, k_act, k_step = cr.split(key, 3)
-        u, cp, _ = c(obs, state, params, k_act, cp, info)
-        obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
-    out.append(cp.a_mean.cpu().numpy())
-np.save(sys.argv[1], np.stack(out))
-"""
-    res = []
-    for mode in ("records", "one_launch"):
-        path = f"/tmp/covo_update_{mode}_{lam}.npy"
-        env = dict(os.environ, COVO_UPDATE=mode, PYTHONPATH=root)
-        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-        res.append(np.load(path))
-    # four closed-loop steps: the covo-online plan feeds its own Hessian, which amplifies the update's fp32 reassociation (1e-6
-    # per step) to 3.7e-5 at lambda = 0.5; plans are O(1)
-    assert np.isfinite(res[0]).all() and np.abs(res[0] - res[1]).max() < 1e-4, np.abs(res[0] - res[1]).max()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=root, COVO_BENCH_BACKEND="gloo", COVO_SHARED_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--N", "2048",
+                        "--no-closed-loop", "--no-cpu-baseline", "--no-info-leg"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["N_local"] == 1024 and d["value"] > 0
+    assert d["config"]["timed_episode_steps"] == [37, 112, 187, 262]  # spread over the controller's own 300-step episode

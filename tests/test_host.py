@@ -166,3 +166,41 @@ def test_jax_bitstream_known_answers():
     assert np.array_equal(rj.random_bits(k, 3), rj._threefry_counts(k, [0, 1, 2]))
     e = rj.controller_epsilon(rj.PRNGKey(7), 6, n=128, sample_offset=2, n_samples=3)
     assert e.shape == (3, 128) and np.array_equal(e[0], rj.normal(rj.split(rj.PRNGKey(7), 6)[2], (128,)))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment must run two ranks (the parent starts
+    torch.distributed.run as a child before any GPU call and relays rank 0's line).  No GPU here: --rendezvous-only runs
+    everything of the N-rank bench except the device work (process group, barrier bracket, max over ranks, one line)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["COVO_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["rendezvous_only"] is True
+    # a failing rank's exit code comes back through the launcher
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)  # no GPU here: the ranks' assert fires
+    assert r.returncode != 0
+
+
+def test_bench_spread_indices_cover_the_episode():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.spread_indices(20, 300) == [7 + 15 * i for i in range(20)]
+    assert b.spread_indices(300, 300) == list(range(300)) and b.spread_indices(5, 300) == [30, 90, 150, 210, 270]
+    idx = b.spread_indices(200, 300)
+    assert len(idx) == 200 and idx[0] == 0 and idx[-1] == 299 and all(b2 - a2 in (1, 2) for a2, b2 in zip(idx, idx[1:]))
+    assert b.spread_indices(650, 300)[:301] == list(range(300)) + [0] and b.spread_indices(0, 300) == []
