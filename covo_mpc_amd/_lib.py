@@ -134,6 +134,8 @@ _SIGS = {
                                            C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, _P]),
     "covo_debug_set_ns_tail": (C.c_int, [C.c_int, C.c_int]),
     "covo_debug_set_ns_deflate": (C.c_int, [C.c_int]),
+    "covo_debug_set_fuse_small": (C.c_int, [C.c_int]),
+    "covo_debug_set_merge_in_rollout": (C.c_int, [C.c_int]),
     "covo_debug_set_ns_coherence": (C.c_int, [C.c_int]),
     "covo_debug_time_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.POINTER(C.c_float), _P]),

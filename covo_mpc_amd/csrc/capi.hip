@@ -516,6 +516,20 @@ int covo_debug_set_ns_tail(int n_squarings, int n_iters)
     return 0;
 }
 
+int covo_debug_set_merge_in_rollout(int on)
+{
+    g_merge_in_rollout = on ? 1 : 0;
+    ++g_dbg_epoch;
+    return 0;
+}
+
+int covo_debug_set_fuse_small(int on)
+{
+    g_fuse_small = on ? 1 : 0;
+    ++g_dbg_epoch;  // a captured step graph holds one launch set or the other
+    return 0;
+}
+
 int covo_debug_set_ns_deflate(int on)
 {
     g_ns_deflate = on ? 1 : 0;

@@ -41,6 +41,8 @@ void covo_set_error(const char *fmt, ...);
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
 extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate, g_ns_force_agent;  // sigma_ns.hip
 void sigma_ns_tail_defaults();  // sigma_ns.hip: the four tail lengths back to their defaults
+extern int g_merge_in_rollout;  // step.hip: fused single-instance steps finish the softmax update inside the rollout launch
+extern int g_fuse_small;  // step.hip: the fused small step (step_small.hip) is taken where eligible
 extern int g_dbg_epoch;  // capi.hip: bumped by every debug setter whose value a captured step graph bakes in as a kernel argument
 
 #define COVO_CHECK_HIP(expr)                                                         \
@@ -111,13 +113,23 @@ int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, u
                            int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr,
                            bool propagate_nan = false);
 static inline bool covo_propagate_nan(const covo_ctx *h) { return (h->cfg.flags & COVO_FLAG_PROPAGATE_NAN) != 0; }
+// the softmax update's merge inside the record-leaving rollout launch (rollout_common.hpp: rollout_merge_last): the arrival counter
+// (0 between launches), where the result goes -- final: the new mean [128] blended with mean_old; else the merged record [130]
+struct RolloutMerge {
+    unsigned *ticket;
+    float *out;
+    const float *mean_old;
+    float gamma;
+    int final;
+};
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr,
                    float *records = nullptr, float lam = 0.0f,   // records: one online-softmax record per workgroup (rollout.hip)
                    const float *f_tab = nullptr,                 // [H][4] per-step disturbance table (disturb.hip), device
                    int xcd_groups = 0,    // 64-sample groups per workgroup of the kernel that wrote `a` (0: the noise GEMM's for this N)
-                   bool propagate_nan = false);  // the re-clip of untrusted stripes keeps a NaN (COVO_FLAG_PROPAGATE_NAN)
+                   bool propagate_nan = false,   // the re-clip of untrusted stripes keeps a NaN (COVO_FLAG_PROPAGATE_NAN)
+                   const RolloutMerge *merge = nullptr);  // with records: the launch's last workgroup merges them (no merge launch)
 int launch_disturb_table(const covo_env_params &p, const float *state, int batch, const uint32_t *keys_dev, uint32_t key0,
                          uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s);
 int launch_disturb_tables_step(const covo_env_params &p, const float *state, const uint32_t *dyn, int rollout_deterministic,

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "covo_common.hpp"
+#include "softmax_merge.hpp"
 
 constexpr int RD_BLOCK = 256;
 constexpr int RD_WAVES = RD_BLOCK / 64;
@@ -160,9 +161,6 @@ __global__ __launch_bounds__(RD_BLOCK) void softmax_partial_kernel(const float *
     }
 }
 
-constexpr int MG_THREADS = 1024;
-constexpr int MG_SLICES = MG_THREADS / COVO_NA;  // 8
-constexpr int MG_MAXG = 1024;
 
 // index of the pair (i, j), i <= j, in a record's 10 second moments per step
 __device__ __forceinline__ int cov_pair(int i, int j)
@@ -286,7 +284,8 @@ __global__ __launch_bounds__(MG_THREADS) void merge_cov_kernel(const float *__re
     }
 }
 
-// Merges G records {m, s, v[128]} with 1024 threads = 8 record-slices x 128 columns.
+// Merges G records {m, s, v[128]} with 1024 threads = 8 record-slices x 128 columns (softmax_merge.hpp: the body is shared
+// with the launches that finish their own update).
 // FINAL: a_mean_out = gamma * v/s + (1-gamma) * a_mean_old (covo.py:270-275); otherwise writes the
 // merged record to out.  Fixed summation order -> bit-reproducible.
 // stride: floats between consecutive records (COVO_PARTIAL_FLOATS, or COVO_RANK_RECORD_FLOATS for the all-gathered rank records
@@ -296,77 +295,14 @@ __global__ __launch_bounds__(MG_THREADS) void merge_kernel(const float *__restri
                                                            const float *__restrict__ a_mean_old, float gamma_mean,
                                                            float *__restrict__ out, int stride)
 {
-    __shared__ float scale[MG_MAXG];
-    __shared__ float redm[MG_THREADS / 64];
-    __shared__ float reds[MG_THREADS / 64];
-    __shared__ float sv[MG_SLICES][COVO_NA];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ MergeLds lds;
     {   // blockIdx.x (env-batched step): instance x merges its own G records into its own mean
         const size_t x = blockIdx.x;
         partials += x * G * stride;
         if (FINAL) a_mean_old += x * COVO_NA;
         out += x * (FINAL ? COVO_NA : COVO_PARTIAL_FLOATS);
     }
-    // phase 3's operands first (the first 256 records: every launch of the product's steps): they depend on nothing, so their
-    // memory round trip overlaps those of phases 1 and 2 (three dependent round trips to records other XCDs have just written
-    // were most of this launch)
-    const int col = tid & (COVO_NA - 1), slice = tid >> 7;
-    constexpr int MG_PRE = 32;
-    float vals[MG_PRE];
-#pragma unroll
-    for (int i = 0; i < MG_PRE; ++i) {
-        const int g = slice + MG_SLICES * i;
-        vals[i] = (g < G) ? partials[(size_t)g * stride + 2 + col] : 0.0f;
-    }
-    // phase 1: m = min_g m_g; a thread's record header {m_g, s_g} (G <= 1 024 = one record per thread) stays in registers for
-    // phase 2 -- with the operands above, every load of this launch is in flight before the first is used
-    const bool mine = tid < G;
-    const float my_m = mine ? partials[(size_t)tid * stride] : __builtin_inff();
-    const float my_s = mine ? partials[(size_t)tid * stride + 1] : 0.0f;
-    float m = wave_min(my_m);
-    if (lane == 0) redm[wave] = m;
-    __syncthreads();
-    m = redm[0];
-#pragma unroll
-    for (int i = 1; i < MG_THREADS / 64; ++i) m = fminf(m, redm[i]);
-    // phase 2: per-record scale and s = sum_g s_g scale_g
-    float s = 0.0f;
-    if (mine) {
-        const float sc = (my_s > 0.0f) ? expf((m - my_m) * inv_lam) : 0.0f;  // empty shard -> 0
-        scale[tid] = sc;
-        s = my_s * sc;
-    }
-    s = wave_sum(s);
-    if (lane == 0) reds[wave] = s;
-    __syncthreads();
-    s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < MG_THREADS / 64; ++i) s += reds[i];
-    // phase 3: v[col] = sum_g v_g[col] scale_g, record slices in parallel (ascending g within a slice, as before)
-    float v = 0.0f;
-#pragma unroll
-    for (int i = 0; i < MG_PRE; ++i) {
-        const int g = slice + MG_SLICES * i;
-        if (g < G) v = fmaf(vals[i], scale[g], v);
-    }
-#pragma unroll 4
-    for (int g = slice + MG_SLICES * MG_PRE; g < G; g += MG_SLICES) v = fmaf(partials[(size_t)g * stride + 2 + col], scale[g], v);
-    sv[slice][col] = v;
-    __syncthreads();
-    if (tid < COVO_NA) {
-        v = 0.0f;
-#pragma unroll
-        for (int i = 0; i < MG_SLICES; ++i) v += sv[i][tid];
-        if (FINAL) {
-            out[tid] = (v / s) * gamma_mean + a_mean_old[tid] * (1.0f - gamma_mean);
-        } else {
-            out[2 + tid] = v;
-            if (tid == 0) {
-                out[0] = m;
-                out[1] = s;
-            }
-        }
-    }
+    merge_body<MG_THREADS, FINAL, false>(partials, G, inv_lam, a_mean_old, gamma_mean, out, stride, lds);
 }
 
 __global__ void shift_mean_kernel(const float *__restrict__ in, float *__restrict__ out)

@@ -46,10 +46,10 @@ static void launch_rollout_pf(const RolloutArgs &A, const RolloutArgs *batch, in
 }
 #endif
 
-static void fill_rollout_args(RolloutArgs &A, const float *state, const float *pos_traj, const float *vel_traj, int T,
-                              const covo_env_params &p, const float *f_shared, const float *a, int N, float discount,
-                              float *cost, float *groupmin, double *stats_ws, const float *f_shared_dev, const float *f_tab,
-                              int xcd_groups = 0, int nbatch = 1)
+void fill_rollout_args(RolloutArgs &A, const float *state, const float *pos_traj, const float *vel_traj, int T,
+                       const covo_env_params &p, const float *f_shared, const float *a, int N, float discount,
+                       float *cost, float *groupmin, double *stats_ws, const float *f_shared_dev, const float *f_tab,
+                       int xcd_groups, int nbatch)
 {
     if (xcd_groups <= 0) xcd_groups = noise_gemm_groups_per_workgroup(N, nbatch);  // the producer is the noise GEMM unless told otherwise
     A.state = state;
@@ -71,6 +71,11 @@ static void fill_rollout_args(RolloutArgs &A, const float *state, const float *p
     A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? xcd_groups : 0;
     A.records = nullptr;
     A.inv_lam = 0.0f;
+    A.merge_ticket = nullptr;
+    A.merge_out = nullptr;
+    A.merge_mean_old = nullptr;
+    A.merge_gamma = 1.0f;
+    A.merge_final = 0;
     A.clip = 1;
     A.rollover = p.rollover_terminate != 0;
     A.reward = p.reward_kind;
@@ -116,7 +121,7 @@ static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int 
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev,
-                   float *records, float lam, const float *f_tab, int xcd_groups, bool propagate_nan)
+                   float *records, float lam, const float *f_tab, int xcd_groups, bool propagate_nan, const RolloutMerge *merge)
 {
     RolloutArgs A;
     fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev, f_tab,
@@ -132,6 +137,13 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     A.clip = trust_clipped ? 0 : (propagate_nan ? 2 : 1);
     A.records = records;
     A.inv_lam = records ? 1.0f / lam : 0.0f;
+    if (records != nullptr && merge != nullptr) {  // the launch finishes the softmax update itself (rollout_merge_last)
+        A.merge_ticket = merge->ticket;
+        A.merge_out = merge->out;
+        A.merge_mean_old = merge->mean_old;
+        A.merge_gamma = merge->gamma;
+        A.merge_final = merge->final;
+    }
     return dispatch_rollout<false>(A, nullptr, 0, pos_stats, s);
 }
 

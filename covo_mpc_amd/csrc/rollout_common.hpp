@@ -3,6 +3,7 @@
 // reward and disturbance variants -- split only to compile them in parallel).
 #pragma once
 #include "covo_common.hpp"
+#include "softmax_merge.hpp"
 
 struct RolloutArgs {
     const float *state;
@@ -28,7 +29,23 @@ struct RolloutArgs {
     float drag_k;         // fdist 2: c_drag * (-|disturb_scale| / 1.5^2)  (free.py:41-47)
     float drag_off[3];    // fdist 2: disturb_params[:3] / 2
     qm::Consts<float> c;
+    // nullable (fused single-instance steps): the workgroup that takes the last ticket also merges all records (softmax_merge.hpp:
+    // merge_kernel's arithmetic) -- the softmax update finishes inside this launch, no merge launch follows.  The records are then
+    // published with coherent stores.  merge_final: merge_out[128] = the new mean blended with merge_mean_old (covo.py:270-275);
+    // else merge_out[130] = the merged record (a sample-sharded rank)
+    unsigned *merge_ticket;
+    float *merge_out;
+    const float *merge_mean_old;
+    float merge_gamma;
+    int merge_final;
 };
+
+// rollout.hip: the argument block of one rollout over N samples (the producer of the stripes is the noise GEMM unless
+// xcd_groups says otherwise); records / clip are set by the caller
+void fill_rollout_args(RolloutArgs &A, const float *state, const float *pos_traj, const float *vel_traj, int T,
+                       const covo_env_params &p, const float *f_shared, const float *a, int N, float discount, float *cost,
+                       float *groupmin, double *stats_ws, const float *f_shared_dev, const float *f_tab, int xcd_groups = 0,
+                       int nbatch = 1);
 
 
 // scripts/probe/rollout_probe.hip compiles this file with ROLLOUT_PROBE: every workgroup leaves {XCC, HW_ID, start, end}
@@ -63,9 +80,13 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // v_readlane_b3
 // stripes of the few samples with a non-zero weight (at lam = 0.01 a weight underflows once c - m > 1.04) are re-read
 // from the L2 that has just served them.  Called by every wave of the workgroup: NWAVES waves in all, NW of them carry
 // costs (`carrier`, slot `wave` < NW); the others pass valid = false and only take part in the barriers and the final sums.
-template <int NWAVES, int NW>
+// A_LDS (the fused small step): the workgroup's ONE 64-sample group has its stripes in LDS (a_lds [H][64] float4; lane l owns
+// sample l); coh (wave-uniform): the record is read by another workgroup of the SAME launch (the last arriver merges): agent-scope
+// relaxed atomic stores (write-through, coherent across the XCDs' L2s), as the Sigma chain's persistent launches publish their tiles.
+template <int NWAVES, int NW, bool A_LDS = false>
 __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost, bool valid, int n, int wave, bool carrier, int lane,
-                                               int wg, float *s_m, float *s_s, float (*s_v)[COVO_NA])
+                                               int wg, float *s_m, float *s_s, float (*s_v)[COVO_NA],
+                                               const float4 *__restrict__ a_lds = nullptr, const bool coh = false)
 {
     // (round 4: the waves that carry no cost -- two of three per SIMD in the pipelined kernel -- only take part in the two
     // barriers and the final stores; they used to run the whole epilogue on zero weights next to the one wave that matters)
@@ -106,7 +127,7 @@ __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost,
             wv[q] = __shfl(w, l, COVO_WAVE);
             const int nl = __shfl(n, l, COVO_WAVE);
             if (half ? !two : !one) wv[q] = 0.0f;
-            av[q] = A.a[(size_t)t * A.N + nl];
+            av[q] = A_LDS ? a_lds[t * COVO_WAVE + l] : A.a[(size_t)t * A.N + nl];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -130,15 +151,36 @@ __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost,
         float v = s_v[0][tid];
 #pragma unroll
         for (int i = 1; i < NW; ++i) v += s_v[i][tid];
-        rec[2 + tid] = v;
+        if (coh) __hip_atomic_store(rec + 2 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else rec[2 + tid] = v;
     }
     if (tid == 0) {
         float ss = s_s[0];
 #pragma unroll
         for (int i = 1; i < NW; ++i) ss += s_s[i];
-        rec[0] = m;
-        rec[1] = ss;
+        if (coh) {
+            __hip_atomic_store(rec + 0, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + 1, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            rec[0] = m;
+            rec[1] = ss;
+        }
     }
+}
+
+// The update's second stage inside the launch that left the records: every workgroup takes a ticket once its (coherently stored)
+// record is acknowledged; the one that takes the last merges all gridDim.x records.  atomicInc wraps to 0 at the last arrival:
+// the counter re-arms itself for the next launch.  Called by every thread of every workgroup (barriers); THREADS = blockDim.x.
+template <int THREADS>
+__device__ __forceinline__ void rollout_merge_last(const RolloutArgs &A, MergeLds &M, int &last_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last_flag = (atomicInc(A.merge_ticket, gridDim.x - 1) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_flag) return;
+    if (A.merge_final) merge_body<THREADS, true, true>(A.records, (int)gridDim.x, A.inv_lam, A.merge_mean_old, A.merge_gamma, A.merge_out, COVO_PARTIAL_FLOATS, M);
+    else merge_body<THREADS, false, true>(A.records, (int)gridDim.x, A.inv_lam, nullptr, 1.0f, A.merge_out, COVO_PARTIAL_FLOATS, M);
 }
 
 #ifdef ROLLOUT_LAB_BASELINE  // the one-lane-per-sample kernel of round 1: only scripts/probe/rollout_lab.hip still compiles it

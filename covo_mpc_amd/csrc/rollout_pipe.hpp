@@ -102,42 +102,37 @@ __device__ __forceinline__ float rp3_atan2abs(float y, float x)
 //   free.py:41-56; rows {g_k, c_k} of A.f_tab, disturb.hip).
 // REC: every workgroup also leaves its online-softmax record (rollout_record; A.records != null) -- the variant the fused
 //   step runs; a template argument so that the profiler lists it under its own name.
-template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3, bool STATS = false,
-          bool REC = false, int REWARD = 0, int FDIST = 0>
-__global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) void rollout_pipe3_kernel(
-    const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
+// The three stages as a device function: the caller (rollout_pipe3_kernel below; step_small.hip's fused launch) owns the LDS and
+// decides which wave plays which role for which 64-sample group.  A_LDS: stage A takes the action stripes from `a_lds`
+// ([H][64] float4 of THIS group, left there by the launch's own noise draw) instead of A.a in HBM.  Returns this lane's cost
+// (role 2), its sample index n and whether the sample exists.  KEEP_ALL: the A and T waves come back too (the caller has an
+// epilogue for every wave: softmax records, position statistics); otherwise they leave the launch when their stage is done.
+template <bool DISC1, bool ROLL, int CH, int ONLY, bool STATS, bool KEEP_ALL, int REWARD, int FDIST, bool A_LDS, class StatsLds>
+__device__ __forceinline__ void rp3_stages(const RolloutArgs &A, Rp3Lds<CH> &lds, StatsLds &lds_st, const int role, const int gsub,
+                                           const int group, const int lane, const float4 *__restrict__ a_lds, float &cost, bool &valid_out,
+                                           int &n_out)
 {
     static_assert(COVO_H % CH == 0, "CH must divide the horizon");
-    const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
-    __shared__ Rp3Lds<CH> lds_all[ONLY >= 0 ? ONLY_WAVES : GROUPS];
-    __shared__ float lds_st[STATS ? GROUPS : 1][STATS ? COVO_H : 1][9];  // STATS: per group and step {sum d, sum d^2, shift} (d: see stage T)
     RP3_DECL();
-    const int lane = threadIdx.x & (COVO_WAVE - 1);
-    const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = ONLY >= 0 ? ONLY : wave_ / GROUPS;  // role-major: the GROUPS waves of one stage are neighbours
-    const int gsub = ONLY >= 0 ? 0 : wave_ % GROUPS;
-    Rp3Lds<CH> &lds = lds_all[ONLY >= 0 ? wave_ : gsub];
     const float *__restrict__ st = A.state;
-
-    int group = blockIdx.x * GROUPS + gsub;  // XCD affinity as in the two-stage kernel (speed only)
-    if (A.xcd_remap) {  // q = 64-sample groups per GEMM workgroup: group = q * (GEMM workgroup on this XCD) + (its m % q-th group)
-        const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + gsub, q = A.xcd_remap;
-        group = q * (x + 8 * (m / q)) + (m % q);
-    }
     const int n_raw = group * COVO_WAVE + lane;
     const bool valid = n_raw < A.N;
     const int n = valid ? n_raw : A.N - 1;
+    valid_out = valid;
+    n_out = n;
     const qm::Consts<float> c = A.c;
 
     if (role == 0) {
         // ============================================================ A: attitude (the serial chain: runs at high priority)
         const float4 *__restrict__ ap = A.a + n;
         const size_t stride = (size_t)A.N;
-        constexpr int PF = 12 < COVO_H ? 12 : COVO_H;  // stripes in flight
+        constexpr int PF = A_LDS ? 1 : (12 < COVO_H ? 12 : COVO_H);  // stripes in flight
         float4 ring[PF];
         RP3_STAMP(0);
+        if (!A_LDS) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) ring[i] = ap[(size_t)(i < COVO_H - 1 ? i : 0) * stride];
+            for (int i = 0; i < PF; ++i) ring[i] = ap[(size_t)(i < COVO_H - 1 ? i : 0) * stride];
+        }
         const float ctau = c.thrust_half * c.inv_m * c.dt;                     // tau = (a0 + 1) ctau = thrust dt / m
         const float kg0 = c.komega[0] * c.one_m_alpha * c.half_dt, kg1 = c.komega[1] * c.one_m_alpha * c.half_dt,
                     kg2 = c.komega[2] * c.one_m_alpha * c.half_dt;            // g' = alpha g + a kg,  g = dt/2 omega
@@ -151,8 +146,13 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         const float groll = 100.0f * c.half_dt;
 #pragma unroll
         for (int k = 0; k < COVO_H; ++k) {
-            float4 a4 = ring[k % PF];
-            if (k + PF < COVO_H - 1) ring[k % PF] = ap[(size_t)(k + PF) * stride];
+            float4 a4;
+            if (A_LDS) {
+                a4 = a_lds[k * COVO_WAVE + lane];
+            } else {
+                a4 = ring[k % PF];
+                if (k + PF < COVO_H - 1) ring[k % PF] = ap[(size_t)(k + PF) * stride];
+            }
             if (A.clip == 1) { a4.x = qm::clip11_(a4.x); a4.y = qm::clip11_(a4.y); a4.z = qm::clip11_(a4.z); a4.w = qm::clip11_(a4.w); }
             else if (A.clip == 2) {  // COVO_FLAG_PROPAGATE_NAN: jnp.clip's NaN semantics (quadrotor.py:223,258)
                 a4.x = qm::clip11_nan_(a4.x); a4.y = qm::clip11_nan_(a4.y); a4.z = qm::clip11_nan_(a4.z); a4.w = qm::clip11_nan_(a4.w);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         RP3_FLUSH(0);
         rp3_barrier<ONLY>();
         rp3_barrier<ONLY>();
-        if (!REC && !STATS) return;
+        if (!KEEP_ALL) return;
     }
 
     if (role == 1) {
@@ -360,10 +360,10 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         }
         RP3_FLUSH(1);
         rp3_barrier<ONLY>();
-        if (!REC && !STATS) return;
+        if (!KEEP_ALL) return;
     }
 
-    float cost = 0.0f;
+    cost = 0.0f;
     if (role == 2) {
     // ================================================================ R: reward
     constexpr float LN2 = 0.69314718056f;
@@ -413,11 +413,52 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
         if (lane == 0 && group * COVO_WAVE < A.N) A.groupmin[group] = wm;
     }
     }
+}
+
+// the s_barrier count of one stage wave (COVO_H / CH + 2): what a wave of the workgroup that plays no stage executes next to them
+template <int CH>
+__device__ __forceinline__ void rp3_idle_barriers()
+{
+#pragma unroll 1
+    for (int i = 0; i < COVO_H / CH + 2; ++i) rp3_barrier<-1>();
+}
+
+template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int ONLY = -1, int ONLY_WAVES = 3, bool STATS = false,
+          bool REC = false, int REWARD = 0, int FDIST = 0>
+__global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) void rollout_pipe3_kernel(
+    const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
+{
+    const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
+    __shared__ Rp3Lds<CH> lds_all[ONLY >= 0 ? ONLY_WAVES : GROUPS];
+    __shared__ float lds_st[STATS ? GROUPS : 1][STATS ? COVO_H : 1][9];  // STATS: per group and step {sum d, sum d^2, shift} (d: see stage T)
+    const int lane = threadIdx.x & (COVO_WAVE - 1);
+    const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = ONLY >= 0 ? ONLY : wave_ / GROUPS;  // role-major: the GROUPS waves of one stage are neighbours
+    const int gsub = ONLY >= 0 ? 0 : wave_ % GROUPS;
+    Rp3Lds<CH> &lds = lds_all[ONLY >= 0 ? wave_ : gsub];
+    const float *__restrict__ st = A.state;
+
+    int group = blockIdx.x * GROUPS + gsub;  // XCD affinity as in the two-stage kernel (speed only)
+    if (A.xcd_remap) {  // q = 64-sample groups per GEMM workgroup: group = q * (GEMM workgroup on this XCD) + (its m % q-th group)
+        const int x = blockIdx.x & 7, m = (int)(blockIdx.x >> 3) * GROUPS + gsub, q = A.xcd_remap;
+        group = q * (x + 8 * (m / q)) + (m % q);
+    }
+    float cost = 0.0f;
+    bool valid = false;
+    int n = 0;
+    rp3_stages<DISC1, ROLL, CH, ONLY, STATS, REC || STATS, REWARD, FDIST, false>(A, lds, lds_st, role, gsub, group, lane, nullptr, cost,
+                                                                                  valid, n);
     if (ONLY == -1 && REC) {  // every wave of the workgroup (the A and T waves carry no cost)
         __shared__ float rec_m[GROUPS], rec_s[GROUPS];
         __shared__ __attribute__((aligned(16))) float rec_v[GROUPS][COVO_NA];
+        const bool merge_here = !BATCHED && A.merge_ticket != nullptr;  // (wave-uniform kernel argument)
         rollout_record<3 * GROUPS, GROUPS>(A, cost, valid && role == 2, n, role == 2 ? gsub : 0, role == 2, lane, blockIdx.x, rec_m,
-                                           rec_s, rec_v);
+                                           rec_s, rec_v, nullptr, merge_here);
+        if (!BATCHED) {
+            __shared__ MergeLds merge_lds;
+            __shared__ int merge_last;
+            if (merge_here) rollout_merge_last<3 * GROUPS * COVO_WAVE>(A, merge_lds, merge_last);
+        }
     }
     if (STATS) {
         // this workgroup's {sum (p - p0), sum (p - p0)^2} per step and axis, in fp64, with each T wave's shift put back:

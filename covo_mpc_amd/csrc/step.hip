@@ -14,64 +14,8 @@
 #include "eps_tiles.hpp"
 #include "sym_stats.hpp"
 #include "rng_device.hpp"
-
-// MPPI's three tiny launches in one (mppi.py:43-49,59-61): shift the H covariance blocks in place (drop the first, repeat
-// the last) and factor each 4x4 block -- thread t owns block t; same arithmetic as covo_cholesky (sigma.hip:
-// symmetrise, fp64 right-looking Cholesky with sqrt and one division per column, fp32 out)
-// (called by every thread of the launch: it contains a barrier)
-__device__ __forceinline__ void mppi_prep(float *__restrict__ a_cov, float *__restrict__ Ls)
-{
-    const int t = threadIdx.x;  // >= 32 threads, H = 32 active
-    float blk[16];
-    if (t < COVO_H) {
-        const float *src = a_cov + 16 * ((t < COVO_H - 1) ? t + 1 : t);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) blk[i] = src[i];
-    }
-    __syncthreads();  // every block is read before any is overwritten
-    if (t >= COVO_H) return;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a_cov[16 * t + i] = blk[i];
-    double A[4][4];  // lower triangle, A[c][r] for r >= c (column-major like the LDS version)
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = c; r < 4; ++r) A[c][r] = 0.5 * ((double)blk[4 * r + c] + (double)blk[4 * c + r]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double djj = sqrt(A[j][j]);
-        const double inv = 1.0 / djj;
-        A[j][j] = djj;
-#pragma unroll
-        for (int i = j + 1; i < 4; ++i) A[j][i] = A[j][i] * inv;
-#pragma unroll
-        for (int c = j + 1; c < 4; ++c)
-#pragma unroll
-            for (int i = c; i < 4; ++i) A[c][i] -= A[j][i] * A[j][c];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Ls[16 * t + 4 * r + c] = (c <= r) ? (float)A[c][r] : 0.0f;
-}
-
-// child i of split(key, 2) / element i of normal(key, (3,)) exactly as covo_mpc_amd/random.py forms them
-__device__ __forceinline__ void host_split(const uint32_t (&key)[2], uint32_t i, uint32_t (&child)[2])
-{
-    uint32_t r[4];
-    rngd::philox4x32_10(i, 0u, 0u, 0x5EEDu, key[0], key[1], r);
-    child[0] = r[0];
-    child[1] = r[1];
-}
-__device__ __forceinline__ float host_normal3(const uint32_t (&key)[2], int i)
-{
-    uint32_t b1[4], b2[4];
-    rngd::philox4x32_10(0u, 0u, 0u, 0xB175u, key[0], key[1], b1);
-    rngd::philox4x32_10((uint32_t)((3 + i) >> 2), 0u, 0u, 0xB175u, key[0], key[1], b2);
-    const double u1 = ((double)(b1[i] >> 8) + 0.5) / 16777216.0;
-    const double u2 = ((double)(b2[(3 + i) & 3] >> 8) + 0.5) / 16777216.0;
-    return (float)(sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2));
-}
+#include "step_begin.hpp"
+#include "step_small.hpp"
 
 // the ONE eager launch of every step, ahead of the replayed graph.  What changes per step travels in its kernel
 // arguments (48 bytes; an async H2D copy of the same block runs as a ~5 us copy kernel on this stack): the controller's
@@ -80,9 +24,6 @@ __device__ __forceinline__ float host_normal3(const uint32_t (&key)[2], int i)
 // launches take their per-step scalars from -- with derive_keys, what the host would have computed from rng_act:
 //   rng, act_key = split(rng_act); rng, step_key = split(rng)                (covo.py:212,225 / mppi.py:53,69)
 //   MPPI: f_shared = scale * normal(split(split(split(step_key)[1])[0])[0], (3,))   (quadrotor.py:262, free.py:136,144)
-struct DynBlock {
-    uint32_t w[12];  // {key0, key1, f_shared[3] as float bits, pad[3], state pointer (8 bytes), raw rng_act (device block only)}
-};
 __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
                                   uint32_t *__restrict__ dyn, float *__restrict__ state_buf, int derive_keys,
                                   float shared_noise_scale, const DynBlock blk, float *__restrict__ mppi_cov,
@@ -92,7 +33,6 @@ __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__res
     // that is host bound at small N)
     if (mppi_cov != nullptr) mppi_prep(mppi_cov, mppi_Ls);
     const int i = threadIdx.x;  // 128 + 32 + 4 threads
-    const uint32_t raw[2] = {blk.w[0], blk.w[1]};
     if (i < COVO_NA) {
         a_mean_shift[i] = (i < COVO_NA - COVO_DU) ? a_mean[i + COVO_DU] : a_mean[i];
     } else if (i < COVO_NA + COVO_STATE_FLOATS) {
@@ -100,37 +40,7 @@ __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__res
         __builtin_memcpy(&src, &blk.w[8], sizeof(src));
         state_buf[i - COVO_NA] = src[i - COVO_NA];
     } else {
-        const int q = i - (COVO_NA + COVO_STATE_FLOATS);  // 0: act_key, 1..3: f_shared
-        if (q == 0) {  // the raw controller key, for what else is derived from it in the graph (disturb.hip: the step's tables)
-            dyn[10] = raw[0];
-            dyn[11] = raw[1];
-        }
-        if (!derive_keys) {
-            if (q == 0) {
-                dyn[0] = raw[0];
-                dyn[1] = raw[1];
-            } else {
-                dyn[2 + (q - 1)] = blk.w[2 + (q - 1)];
-            }
-            return;
-        }
-        uint32_t rng1[2], k[2], t[2];
-        host_split(raw, 0u, rng1);
-        if (q == 0) {
-            host_split(raw, 1u, k);
-            dyn[0] = k[0];
-            dyn[1] = k[1];
-        } else {
-            float f = 0.0f;
-            if (shared_noise_scale != 0.0f) {
-                host_split(rng1, 1u, k);  // step_key
-                host_split(k, 1u, t);     // raw_step: key, step_key = split(key)
-                host_split(t, 0u, k);     // step_fn:  key, key_dyn = split(key)
-                host_split(k, 0u, t);     // disturb_key, key = split(key)
-                f = shared_noise_scale * host_normal3(t, q - 1);
-            }
-            dyn[2 + (q - 1)] = __float_as_uint(f);
-        }
+        step_begin_derive(i - (COVO_NA + COVO_STATE_FLOATS), blk, derive_keys, shared_noise_scale, dyn);
     }
 }
 
@@ -150,6 +60,7 @@ struct StepState {
     float *Ls;            // [H][4][4] MPPI's block factors
     float4 *eps_tiled;    // covo-online: this step's epsilon in tile order, drawn under the Sigma chain (eps_tiles.hpp); or null
     float *f_tab_rollout, *f_tab_hess;  // [H][4] per-step disturbance tables of the sampling rollouts / the Hessian (disturb.hip)
+    unsigned *ticket;     // arrival counter of the fused small step (step_small.hip); 0 between launches
     // graph cache
     bool have_key, have_graph;
     StepKey key;
@@ -174,6 +85,8 @@ static int step_state_init(covo_ctx *h)
     COVO_CHECK_HIP(hipMalloc(&st->Ls, COVO_H * 16 * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->f_tab_rollout, COVO_H * 4 * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->f_tab_hess, COVO_H * 4 * sizeof(float)));
+    COVO_CHECK_HIP(hipMalloc(&st->ticket, sizeof(unsigned)));
+    COVO_CHECK_HIP(hipMemset(st->ticket, 0, sizeof(unsigned)));
     if (h->cfg.n_local <= EPS_AHEAD_MAX_N)
         COVO_CHECK_HIP(hipMalloc(&st->eps_tiled, (size_t)((h->cfg.n_local + 31) / 32) * 16 * 64 * sizeof(float4)));
     h->step = st;
@@ -198,6 +111,7 @@ void step_state_destroy(covo_ctx *h)
     (void)hipFree(st->eps_tiled);
     (void)hipFree(st->f_tab_rollout);
     (void)hipFree(st->f_tab_hess);
+    (void)hipFree(st->ticket);
     delete st;
     h->step = nullptr;
 }
@@ -207,6 +121,23 @@ int g_dbg_epoch = 0;
 static const int g_dbg_eps_ahead = [] {  // COVO_EPS_AHEAD=0: the GEMM draws epsilon itself (A/B measurements)
     const char *v = std::getenv("COVO_EPS_AHEAD");
     return v ? std::atoi(v) : 1;
+}();
+// COVO_FUSE_SMALL=0 / covo_debug_set_fuse_small(0): covo-offline and MPPI steps of <= 256 sample groups run their staged launches
+// (begin | noise | rollout + records | merge) instead of the one fused launch of step_small.hip (A/B measurements, parity tests)
+int g_fuse_small = [] {
+    const char *v = std::getenv("COVO_FUSE_SMALL");
+    return v ? std::atoi(v) : 1;
+}();
+// COVO_MERGE_IN_ROLLOUT=1 / covo_debug_set_merge_in_rollout(1): the records' merge by the rollout launch's last workgroup
+// (rollout_merge_last) instead of as a launch of its own (merge_kernel).  Same arithmetic, same bits -- and measured SLOWER at every
+// size (round 5, one MI355X: covo-online N = 65 536 5 005 against 5 070 steps/s, the sharded launch group 44.3 against 41.2 us;
+// covo-offline N = 8 192 staged 32.2k against 38.6k): every workgroup's tail gains a write-through acknowledgement and an
+// agent-scope atomic (two fabric round trips), the last one then pulls the records through sc1 loads -- more than the 2 us launch
+// boundary + 2.4-4.3 us merge_kernel it replaces.  Opt-in; the one-launch small step (step_small.hip) keeps it: there it also
+// removes a launch from a host-bound path.
+int g_merge_in_rollout = [] {
+    const char *v = std::getenv("COVO_MERGE_IN_ROLLOUT");
+    return v ? std::atoi(v) : 0;
 }();
 static int g_dbg_step_mask = 63;  // (1: unused, the begin launch is not part of the graph) 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
 
@@ -219,6 +150,10 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
     int rc;
     const float *state = st->state_buf;
+    // covo-offline / MPPI at small N: noise -> rollout -> records -> merge as ONE launch (the begin launch has left the step's
+    // scalars in st->dyn and the state in st->state_buf; MPPI: it has NOT touched a_cov, the fused launch shifts and factors)
+    if (M == 63 && g_fuse_small && step_small_eligible(h, p, a))
+        return launch_step_small(h, p, a, state, am_shift, nullptr, st->dyn, 0.0f, st->ticket, s);
     // periodic / sin / drag / mixed (free.py:10-58): the wave-uniform part of every rollout step's force, for the sampling
     // rollouts (shared step key) and for the Hessian's deterministic rollout (per-step keys), resolved once per control step
     const bool tables = p.disturb_kind >= COVO_DISTURB_PERIODIC && p.disturb_kind <= COVO_DISTURB_MIXED;
@@ -271,12 +206,21 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     // MPPI's covariance adaptation needs second moments the in-rollout records do not carry: its own stage 1 (reduce.hip)
     const bool cov_adapt = a.mode == COVO_MODE_MPPI && a.gamma_sigma != 0.0f;
     const bool records = G <= h->max_red_blocks && !cov_adapt;
+    // the update's merge inside the rollout launch (its last workgroup; rollout_merge_last) -- when the step runs both anyway
+    const bool merge_in = records && g_merge_in_rollout && (M & 16) && (M & 32);
+    RolloutMerge mg;
+    mg.ticket = st->ticket;
+    mg.final = a.partial_out == nullptr;
+    mg.out = a.partial_out ? a.partial_out : a.a_mean;
+    mg.mean_old = am_shift;
+    mg.gamma = a.gamma_mean;
     if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
                                          records ? nullptr : a.groupmin, a.pos_stats, h->ws_stats, s, fdev,
                                          records ? h->ws_partials : nullptr, h->cfg.lam, tables ? st->f_tab_rollout : nullptr,
-                                         a.mode == COVO_MODE_MPPI ? 4 : 0)))  // MPPI's block-diagonal kernel: 256 samples per workgroup
+                                         a.mode == COVO_MODE_MPPI ? 4 : 0, false,  // MPPI's block-diagonal kernel: 256 samples per workgroup
+                                         merge_in ? &mg : nullptr)))
         return rc;
-    if (!(M & 32)) return 0;
+    if (!(M & 32) || merge_in) return 0;
     if (cov_adapt && a.partial_out != nullptr)  // a sample-sharded rank: its record with the second moments (836-float kind)
         return launch_softmax_reduce_cov(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, am_shift, a.partial_out, s);
     if (cov_adapt)  // mppi.py:109-125: new mean, then a_cov (already shifted by the begin launch) adapted in place
@@ -320,10 +264,17 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     const float shared_noise_scale =
         (params->disturb_kind == COVO_DISTURB_GAUSSIAN && !args->rollout_deterministic) ? params->dyn_noise_scale : 0.0f;
     // control_params.a_mean of this call: the handle's own buffer (a carried mean) or the caller's input (args->a_mean_in)
+    const bool small = g_fuse_small && step_small_eligible(h, *params, *args);
+    if (small && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0) {
+        // an eager handle: the WHOLE step is one launch, the begin launch's work included (per workgroup, step_small.hip)
+        st->have_key = false;  // (st->dyn / st->state_buf are not refreshed: a later graph capture starts from an eager call)
+        return launch_step_small(h, *params, *args, args->state, args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, &blk,
+                                 nullptr, shared_noise_scale, st->ticket, s);
+    }
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s,
                        args->a_mean_in ? args->a_mean_in : args->a_mean,
                        args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
-                       shared_noise_scale, blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls);
+                       shared_noise_scale, blk, (args->mode == COVO_MODE_MPPI && !small) ? args->a_cov : (float *)nullptr, st->Ls);
 
     StepKey k;
     std::memset(&k, 0, sizeof(k));
@@ -382,6 +333,18 @@ int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const 
     }
     StepState *st = reinterpret_cast<StepState *>(h->step);
     hipStream_t cs = h->side_stream;
+    if (g_fuse_small && step_small_eligible(h, *params, *args) && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 && args->state != nullptr) {
+        // the last step ran as ONE fused launch and never filled the scratch the staged launches read (state copy, shifted
+        // mean, keys; MPPI: shifted covariance + block factors): one begin launch does, with the key the step would derive from (0, 0)
+        DynBlock blk;
+        std::memset(&blk, 0, sizeof(blk));
+        std::memcpy(&blk.w[8], &args->state, sizeof(const float *));
+        hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, run,
+                           args->a_mean_in ? args->a_mean_in : args->a_mean,
+                           args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys, 0.0f,
+                           blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls);
+        COVO_CHECK_HIP(hipStreamSynchronize(run));
+    }
     g_dbg_step_mask = step_mask;
     g_dbg_hess_mask = hess_mask;
     g_dbg_sigma_stages = sigma_stages;

@@ -361,6 +361,17 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
 int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out,
                       float *L_out, void *stream);
 
+/* 0: covo-offline / MPPI steps of <= 256 sample groups run their staged launches (begin | noise | rollout + records | merge)
+ * instead of the ONE fused launch of csrc/step_small.hip (the default where eligible; also COVO_FUSE_SMALL=0 in the environment).
+ * Both give the same bits; the switch exists for A/B measurements and the parity test.  Drops captured step graphs. */
+int covo_debug_set_fuse_small(int on);
+
+/* 1: the fused single-instance steps merge their softmax records inside the rollout launch, by the workgroup that takes the last
+ * ticket, instead of with a launch of their own (merge_kernel; the default: the in-launch merge measured slower at every size,
+ * csrc/step.hip).  Also COVO_MERGE_IN_ROLLOUT=1 in the environment.  Same arithmetic, same bits (csrc/softmax_merge.hpp).  Drops
+ * captured step graphs. */
+int covo_debug_set_merge_in_rollout(int on);
+
 /* Debug aid: copy `count` doubles from offset `offset_doubles` of the Sigma pipeline's scratch (layout in
  * sigma_ns.hip: 12 matrices [batch][128][128], then 64 scalars per matrix) to `out` (device). */
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);

@@ -1150,3 +1150,124 @@ def test_bench_gpus_2_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["N_local"] == 1024 and d["value"] > 0
     assert d["config"]["timed_episode_steps"] == [37, 112, 187, 262]  # spread over the controller's own 300-step episode
+
+
+@pytest.mark.parametrize("name,N,lam", [("covo-offline", 8192, "0.01"), ("covo-offline", 1000, "0.5"), ("covo-offline", 16384, "0.01"),
+                                        ("mppi", 1024, "0.01"), ("mppi", 100, "5.0"), ("covo-offline", 40, "0.01")])
+@pytest.mark.parametrize("graph", ["graph", "eager"])
+def test_small_fused_step_equals_staged(name, N, lam, graph, monkeypatch):
+    """SURVEY 8f-2 at the small configs (csrc/step_small.hip): begin + noise draw + rollout + softmax records + merge as ONE
+    launch against the staged launches of the same step (covo_debug_set_fuse_small(0)) -- same device functions, same record
+    order, same merge: new mean, actions, costs (and MPPI's shifted covariances) bit for bit, eager and as a captured graph, at
+    a full config, ragged sizes, a single partial group and temperatures where every sample carries weight; gamma_mean != 1."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    task = "hovering" if name == "mppi" else "tracking_zigzag"
+    env = cm.envs.Quad3D(task=task, enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=(N != 1000),
+                         generate_noisy_state=True, device=DEV)
+    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
+    lib = _lib.load_library()
+    params = env.default_params
+    res = []
+    try:
+        for fuse in (1, 0):
+            _lib.check(lib.covo_debug_set_fuse_small(fuse), "fuse_small")
+            c, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=False)
+            obs, info, state = env.reset(cr.PRNGKey(14), params)
+            cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
+            if N == 1000:
+                cp = cp.replace(gamma_mean=0.7)
+            key = cr.PRNGKey(16)
+            out = []
+            for step in range(5):  # graph: eager, capture, replays
+                key, k_act, k_step = cr.split(key, 3)
+                u, cp, _ = c(obs, state, params, k_act, cp, info)
+                out.append((cp.a_mean.clone(), c.core.a.clone(), c.core.cost.clone(), cp.a_cov.clone()))
+                obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+            assert c.core.device_status() == 0
+            res.append(out)
+            c.core.close()
+    finally:
+        _lib.check(lib.covo_debug_set_fuse_small(1), "fuse_small")
+    for step, (f, s) in enumerate(zip(*res)):
+        for what, x, y in zip(("a_mean", "a", "cost", "a_cov"), f, s):
+            assert torch.equal(x, y), (name, N, graph, step, what, (x - y).abs().max().item())
+    assert torch.isfinite(res[0][-1][0]).all() and (res[0][-1][0] - res[0][0][0]).abs().max() > 0
+
+
+def test_small_fused_step_on_a_sharded_rank_leaves_the_merged_record():
+    """The fused small step with partial_out set (a sample-sharded rank, N_local <= 16 384: the 8 192-sample shards of BASELINE
+    configs[3] under covo-offline / MPPI): the launch's last workgroup writes the rank's merged record {m, s, v} instead of the
+    mean -- bit-equal to the staged launches' record."""
+    core = SamplingCore(4096, 32, 0.01, 1.0, device=DEV, use_graph=False)
+    lib = core.lib
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    params = env.default_params
+    obs, info, state = env.reset(cr.PRNGKey(3), params)
+    from covo_mpc_amd.dynamics.dataclass import as_device_state
+    dstate = as_device_state(info["noisy_state"], DEV)
+    pc = params.to_c()
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(3, 128, 128, generator=g, dtype=torch.float64)
+    L = torch.linalg.cholesky(0.05 * A @ A.transpose(1, 2) + 0.2 * torch.eye(128, dtype=torch.float64)).float().to(DEV).contiguous()
+    a_mean = (0.1 * torch.randn(128, generator=g)).to(DEV)
+    recs = []
+    try:
+        for fuse in (1, 0):
+            _lib.check(lib.covo_debug_set_fuse_small(fuse), "fuse_small")
+            args, am, am_shift, _ = core._prepare_step(_lib.MODE_COVO_OFFLINE, dstate, a_mean, L_table=L, derive_keys=True)
+            rec = torch.zeros(_lib.COVO_PARTIAL_FLOATS, device=DEV)
+            args.partial_out = rec.data_ptr()
+            args.a_mean_shift = am_shift.data_ptr()
+            import ctypes as C
+            _lib.check(lib.covo_mpc_step(core.h, C.byref(pc), C.byref(args), 7, 9, None, core.stream()), "covo_mpc_step")
+            torch.cuda.synchronize()
+            recs.append((rec.clone(), am_shift.clone(), core.cost.clone()))
+            core._args_cache = None
+    finally:
+        _lib.check(lib.covo_debug_set_fuse_small(1), "fuse_small")
+    assert all(torch.equal(x, y) for x, y in zip(*recs)) and recs[0][0][1] > 0 and torch.isfinite(recs[0][0]).all()
+    core.close()
+
+
+@pytest.mark.parametrize("name,N,lam", [("covo-online", 65536, "0.01"), ("covo-online", 4096, "1.0"), ("mppi", 65536, "0.01"),
+                                        ("covo-offline", 32768, "0.01"), ("covo-online", 1000, "0.01")])
+@pytest.mark.parametrize("graph", ["graph", "eager"])
+def test_merge_inside_the_rollout_launch_equals_the_merge_launch(name, N, lam, graph, monkeypatch):
+    """VERDICT r04 item 4 (built, bit-identical, measured slower, opt-in): the fused steps' softmax update finishing INSIDE the
+    rollout launch -- the workgroup that takes the last ticket merges the records (rollout_merge_last: merge_kernel's arithmetic
+    over virtual lanes, csrc/softmax_merge.hpp; covo_debug_set_merge_in_rollout(1)) -- against the merge as a launch of its own
+    (the default): the same means bit for bit, with 256 records from
+    768-thread workgroups, 64 from 192-thread ones, a ragged count, with and without position statistics."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
+    lib = _lib.load_library()
+    params = env.default_params
+    res = []
+    try:
+        for on in (1, 0):
+            _lib.check(lib.covo_debug_set_merge_in_rollout(on), "merge_in_rollout")
+            c, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=(N == 4096))
+            obs, info, state = env.reset(cr.PRNGKey(24), params)
+            cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
+            key = cr.PRNGKey(26)
+            out = []
+            for step in range(4):
+                key, k_act, k_step = cr.split(key, 3)
+                u, cp, _ = c(obs, state, params, k_act, cp, info)
+                out.append((cp.a_mean.clone(), c.core.cost.clone()))
+                obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+            assert c.core.device_status() == 0
+            res.append(out)
+            c.core.close()
+    finally:
+        _lib.check(lib.covo_debug_set_merge_in_rollout(0), "merge_in_rollout")
+    for step, (f, s) in enumerate(zip(*res)):
+        assert torch.equal(f[0], s[0]) and torch.equal(f[1], s[1]), (name, N, graph, step, (f[0] - s[0]).abs().max().item())
+    assert torch.isfinite(res[0][-1][0]).all()
