@@ -111,10 +111,10 @@ __device__ __forceinline__ double rsqrt_f64_nr1(double x)
 //   U  wave w takes tile (p + w, p) of the panel (w = 0: the diagonal block) and applies ALL previous panels to it:
 //      tile -= L(i, q) L(p, q)^T for q < p, 4 p MFMAs on an accumulator that stays in registers (a right-looking
 //      version re-reads and re-writes every trailing tile once per panel through LDS: 19k of its 64k cycles);
-//   F  wave 0 factors the diagonal block column by column (rank-1 MFMA updates, see above) and carries the SAME
-//      operations on an identity tile, which ends up as W = L_pp^-1 -- two MFMAs per column on one SIMD's pipe
-//      (factoring the block redundantly in every wave next to its own tile made the pipe the bottleneck: 285
-//      cycles per column);
+//   F  wave 0 factors the diagonal block four columns at a time (a closed-form 4x4 factor on every lane + rank-4 MFMA
+//      updates, see there) and carries the SAME operations on an identity tile, which ends up as W = L_pp^-1
+//      (rounds 2-4: column by column with rank-1 MFMA updates, 362 cycles per column; factoring the block
+//      redundantly in every wave next to its own tile made the pipe the bottleneck: 285 cycles per column);
 //   T  the other waves finish their tiles with one 16x16x16 product  L(i, p)^T = W . tile^T  (4 MFMAs).
 // Column-major with stride ld (element (r, c) at A[c*ld + r]); the input must be the FULL symmetric matrix (the
 // diagonal blocks are read as stored); on return the lower triangle holds L.
@@ -132,14 +132,15 @@ __device__ __forceinline__ void chol_tile_update(const double *A, chol_f64x4 &Tt
     for (int kk = 0; kk < 4; ++kk) Tt = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], Tt, 0, 0, 0);
 }
 
-template <int ld>  // compile-time stride: every LDS address is base + immediate
+// NWAVES: 8 (one wave per tile row of a panel: the finalize launch's 512-thread workgroup) or 4 (a 256-thread workgroup: wave 0
+// factors, waves 1-3 take up to three tiles each -- the log-det factorisation riding in the Newton-Schulz launch, sigma_ns.hip);
+// the same tile arithmetic either way.
+template <int ld, int NWAVES = 8>  // compile-time stride: every LDS address is base + immediate
 __device__ void chol128_lds_mfma(double *A, int tid)
 {
+    constexpr int NW1 = NWAVES - 1, U = (7 + NW1 - 1) / NW1;  // worker waves, tiles per worker wave and panel
     __shared__ double Wsm[16 * 16];
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lo = lane & 15, hi = lane >> 4;
-    double maskg[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) maskg[g] = (hi == g) ? 1.0 : 0.0;
     __syncthreads();
 #ifdef CHOL_PROBE
     if (tid == 0) for (int q = 0; q < 32; ++q) chol_prof[q] = 0;
@@ -147,39 +148,93 @@ __device__ void chol128_lds_mfma(double *A, int tid)
     for (int p = 0; p < 8; ++p) {
         const long long c0 = CHOL_CLOCK();
         const int j0 = 16 * p;
-        const int ti = p + wave;  // this wave's tile row in the panel
-        const bool has = ti < 8;
         // ---- U: tile^T (k = panel column, r = row in tile) in C/D layout: register g, lane (lo = r, hi) = column 4g + hi
-        chol_f64x4 Tt = {0.0, 0.0, 0.0, 0.0};
-        if (has) {
+        // wave 0: the diagonal tile; worker wave w, slot u: tile row p + 1 + (w - 1) + NW1 u
+        chol_f64x4 TtU[U];
+        bool hasU[U];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Tt[r] = A[(j0 + hi + 4 * r) * ld + 16 * ti + lo];
-            if (p > 0) chol_tile_update<ld>(A, Tt, p - 1, p, ti, lo, hi);  // panels q < p-1 were applied during F(p-1)
+        for (int u = 0; u < U; ++u) {
+            const int ti = (wave == 0) ? p : p + wave + NW1 * u;
+            hasU[u] = ti < 8 && (wave != 0 || u == 0);
+            TtU[u] = chol_f64x4{0.0, 0.0, 0.0, 0.0};
+            if (hasU[u]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) TtU[u][r] = A[(j0 + hi + 4 * r) * ld + 16 * ti + lo];
+                if (p > 0) chol_tile_update<ld>(A, TtU[u], p - 1, p, ti, lo, hi);  // panels q < p-1 were applied during F(p-1)
+            }
         }
+        chol_f64x4 &Tt = TtU[0];
         CHOL_USE(Tt[0]);
         const long long c1 = CHOL_CLOCK();
         if (wave == 0) {
-            // ---- F: D = Tt (the symmetric diagonal block), W = identity; per column j: pivot -> rsqrt -> scaled row
+            // ---- F: D = Tt (the symmetric diagonal block), W = identity, four columns at a time (round 5).
+            // Rounds 2-4 factored column by column: pivot -> rsqrt -> scaled row -> two rank-1 MFMAs (D and W), 362 cycles per
+            // column, of which the two 64-cycle fp64 MFMAs and ~20 dependent fp64 VALU instructions add up on the one SIMD.  A
+            // 16x16x4 MFMA is a rank-FOUR update, and the layout already keeps column j in the lanes with hi = j & 3: the four
+            // columns 4 mm .. 4 mm + 3 ARE register mm.  So per micro-panel mm:
+            //   1. the 4x4 diagonal micro-block T (10 distinct entries of register mm) travels to all lanes by v_readlane;
+            //   2. every lane factors it, T = Lt Lt^T, and inverts the factor, M = Lt^-1 (closed form: 4 rsqrt chains);
+            //   3. ONE MFMA forms the micro-panel's final columns for all 16 rows: Lpan^T = M . Spanel^T -- A operand M (lanes
+            //      lo < 4), B operand register mm as it stands; the result row m = hi lands in C/D register 0 at lane (lo, hi)
+            //      = l[lo][4 mm + hi]: exactly the operand layout of the rank-4 update.  The same product on W's register mm
+            //      gives the four final rows of L_pp^-1;
+            //   4. ONE MFMA each applies the rank-4 update to D and to W (A operand masked to the rows below each column).
+            // 4 MFMAs per 4 columns instead of 8, and the serial chain per column is a quarter of {readlane, 4x4 factor, 2 MFMAs}.
             chol_f64x4 D = Tt, W, LD_ = {0.0, 0.0, 0.0, 0.0}, LW = LD_;
+            const chol_f64x4 Zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < 4; ++r) W[r] = (hi + 4 * r == lo) ? 1.0 : 0.0;
+            const int mcode = (lo < 4 && hi <= lo) ? 4 * lo + hi : -1;  // which entry of M this lane feeds into the A operand
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int hj = j & 3, rj = j >> 2;
-                const double piv = wr::bcast_lane(D[rj], 16 * hj + j);
-                const double y = __builtin_amdgcn_rsq(piv);
-                const double ym = y * maskg[hj], yhm = 0.5 * ym;
-                const double e = fma(-(piv * y), y, 1.0);
-                const double inv_m = fma(yhm, e, ym);                          // 1/sqrt(piv) in group hj, 0 elsewhere
-                const double lrow = D[rj] * inv_m;                             // L[j0+lo][j0+j] in group hj
-                const double a_op = D[rj] * (inv_m * ((lo > j) ? -1.0 : 0.0));  // rows > j only
-                const double wrow = W[rj] * inv_m;                             // row j of L_pp^-1 (final)
-                LD_[rj] += lrow;
-                LW[rj] += wrow;
-                // both rank-1 updates go out back to back: the wait for the D result then also covers W
+            for (int mm = 0; mm < 4; ++mm) {
+                // T[a][b] = S[4 mm + a][4 mm + b] sits in register mm at lane (lo = 4 mm + a, hi = b)
+                const double t00 = wr::bcast_lane(D[mm], 16 * 0 + 4 * mm + 0);
+                const double t10 = wr::bcast_lane(D[mm], 16 * 0 + 4 * mm + 1);
+                const double t20 = wr::bcast_lane(D[mm], 16 * 0 + 4 * mm + 2);
+                const double t30 = wr::bcast_lane(D[mm], 16 * 0 + 4 * mm + 3);
+                const double t11 = wr::bcast_lane(D[mm], 16 * 1 + 4 * mm + 1);
+                const double t21 = wr::bcast_lane(D[mm], 16 * 1 + 4 * mm + 2);
+                const double t31 = wr::bcast_lane(D[mm], 16 * 1 + 4 * mm + 3);
+                const double t22 = wr::bcast_lane(D[mm], 16 * 2 + 4 * mm + 2);
+                const double t32 = wr::bcast_lane(D[mm], 16 * 2 + 4 * mm + 3);
+                const double t33 = wr::bcast_lane(D[mm], 16 * 3 + 4 * mm + 3);
+                // Lt (below the diagonal) and the reciprocals of its diagonal
+                const double i0 = rsqrt_f64_nr1(t00);
+                const double l10 = t10 * i0, l20 = t20 * i0, l30 = t30 * i0;
+                const double i1 = rsqrt_f64_nr1(fma(-l10, l10, t11));
+                const double l21 = fma(-l20, l10, t21) * i1, l31 = fma(-l30, l10, t31) * i1;
+                const double i2 = rsqrt_f64_nr1(fma(-l21, l21, fma(-l20, l20, t22)));
+                const double l32 = fma(-l31, l21, fma(-l30, l20, t32)) * i2;
+                const double i3 = rsqrt_f64_nr1(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, t33))));
+                // M = Lt^-1 (lower)
+                const double m10 = -(l10 * i0) * i1;
+                const double m21 = -(l21 * i1) * i2;
+                const double m20 = -fma(l21, m10, l20 * i0) * i2;
+                const double m32 = -(l32 * i2) * i3;
+                const double m31 = -fma(l32, m21, l31 * i1) * i3;
+                const double m30 = -fma(l32, m20, fma(l31, m10, l30 * i0)) * i3;
+                double aop = 0.0;
+                aop = (mcode == 0) ? i0 : aop;
+                aop = (mcode == 4) ? m10 : aop;
+                aop = (mcode == 5) ? i1 : aop;
+                aop = (mcode == 8) ? m20 : aop;
+                aop = (mcode == 9) ? m21 : aop;
+                aop = (mcode == 10) ? i2 : aop;
+                aop = (mcode == 12) ? m30 : aop;
+                aop = (mcode == 13) ? m31 : aop;
+                aop = (mcode == 14) ? m32 : aop;
+                aop = (mcode == 15) ? i3 : aop;
                 __builtin_amdgcn_sched_barrier(0);
-                D = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, lrow, D, 0, 0, 0);
-                W = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, wrow, W, 0, 0, 0);
+                const chol_f64x4 P = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, D[mm], Zero, 0, 0, 0);  // P[0](lo, hi) = L[j0 + lo][j0 + 4 mm + hi]
+                const chol_f64x4 Q = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, W[mm], Zero, 0, 0, 0);  // Q[0](lo, hi) = L_pp^-1[4 mm + hi][lo]
+                const double lpan = P[0], wpan = Q[0];
+                const double a_op = (lo - hi > 4 * mm) ? -lpan : 0.0;  // column 4 mm + hi acts on the rows below it only
+                LD_[mm] = lpan;
+                LW[mm] = wpan;
+                if (mm < 3) {  // (the last micro-panel leaves nothing to update)
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, lpan, D, 0, 0, 0);
+                    W = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, wpan, W, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -187,29 +242,40 @@ __device__ void chol128_lds_mfma(double *A, int tid)
                 A[(j0 + hi + 4 * r) * ld + j0 + lo] = LD_[r];   // row j = hi + 4r of L^T; the upper triangle gets don't-cares
                 Wsm[(hi + 4 * r) * 16 + lo] = LW[r];            // W[k][c]
             }
-        } else if (p + wave < 8 && p > 0) {
-            // ---- look-ahead (the waves that wait for W): apply the panels q < p, already final, to tile (p + wave, p + 1)
+        } else if (p > 0) {
+            // ---- look-ahead (the waves that wait for W): apply the panels q < p, already final, to the tiles (tn, p + 1)
             // of the NEXT panel in place, so that its U phase only has panel p left (4 MFMAs instead of 4 (p + 1))
-            const int tn = p + wave;
-            chol_f64x4 Nt;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Nt[r] = A[(j0 + 16 + hi + 4 * r) * ld + 16 * tn + lo];
-            for (int q = 0; q < p; ++q) chol_tile_update<ld>(A, Nt, q, p + 1, tn, lo, hi);
+            for (int u = 0; u < U; ++u) {
+                const int tn = p + wave + NW1 * u;
+                if (tn < 8) {
+                    chol_f64x4 Nt;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A[(j0 + 16 + hi + 4 * r) * ld + 16 * tn + lo] = Nt[r];
+                    for (int r = 0; r < 4; ++r) Nt[r] = A[(j0 + 16 + hi + 4 * r) * ld + 16 * tn + lo];
+                    for (int q = 0; q < p; ++q) chol_tile_update<ld>(A, Nt, q, p + 1, tn, lo, hi);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A[(j0 + 16 + hi + 4 * r) * ld + 16 * tn + lo] = Nt[r];
+                }
+            }
         }
         __syncthreads();
         const long long c2 = CHOL_CLOCK();
         // ---- T: L(ti, p)^T = W . tile^T
-        if (has && wave > 0) {
-            chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            double wv[4];
+        if (wave > 0) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wv[kk] = Wsm[lo * 16 + 4 * kk + hi];  // A-operand [m = k = lo][c = hi]
+            for (int u = 0; u < U; ++u) {
+                if (hasU[u]) {
+                    const int ti = p + wave + NW1 * u;
+                    chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                    double wv[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[kk], Tt[kk], acc, 0, 0, 0);
+                    for (int kk = 0; kk < 4; ++kk) wv[kk] = Wsm[lo * 16 + 4 * kk + hi];  // A-operand [m = k = lo][c = hi]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A[(j0 + hi + 4 * r) * ld + 16 * ti + lo] = acc[r];
+                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[kk], TtU[u][kk], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A[(j0 + hi + 4 * r) * ld + 16 * ti + lo] = acc[r];
+                }
+            }
         }
         __syncthreads();
         const long long c3 = CHOL_CLOCK();

@@ -89,9 +89,11 @@ constexpr int RITZ = 4;            // Rayleigh-Ritz block: exact lambda_min for 
 
 // per-matrix scratch (doubles): scalars, the Newton-Schulz coefficient table, per-row data of A, and the
 // per-workgroup reduction slots (no atomics anywhere: fixed summation order, bit-reproducible)
-enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_LOGDET, SC_ZBUF, SC_ITERS, SC_XBUF, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
+enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_SUMLOGB, SC_ZBUF, SC_ITERS, SC_XBUF, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
        SC_FRO2, SC_TRACE, SC_GERSH, SC_N0,
-       SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug)
+       // (SC_SUMLOGB = 4: sum_i log diag(chol(B)), B = A + delta I: log det B = 2 SC_SUMLOGB -- ns_logdetB_workgroup)
+       SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug; 16-20), the persistent launches' modes (21, 22)
+       SC_LDFLAG = 23,         // != 0: SC_SUMLOGB is there (zeroed with the scalars at the head of the chain)
        SC_BAR = 24,            // grid-barrier counters of the two persistent launches (unsigned in slots 24, 25; zeroed with the scalars)
        SC_BARFAIL = 26,        // != 0: a grid barrier timed out -> the finalize launch poisons Sigma and L with NaN
        SC_CZ = 27,             // Sigma = cz sym(Z): read by the noise GEMM when it writes a_cov for the finalize launch (CovDeferred)
@@ -1302,14 +1304,23 @@ __device__ __forceinline__ void ns_first_pair_tiles(const LD &ld, const double *
         store_both<COH_AGENT>(Zo, Zto, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
     }
 }
+template <int NWAVES>
+__device__ void ns_logdetB_workgroup(const double *__restrict__ A, double *__restrict__ s, double *__restrict__ sm, double *__restrict__ red);
 // iter_first = 0 (one matrix, every iteration folded): the launch begins with iteration 0 (A: the chain's input), and the
 // coefficient table of the iterations to come -- a serial recurrence, ~1.5 us on one lane -- is the work of one of the workgroups
 // the launch would send away anyway (linear id 1: another XCD, so it publishes coherently and raises SC_BAR)
+// early_logdet (one matrix): linear id 2 factors B = A + delta I for its log det (ns_logdetB_workgroup; the launch then carries
+// 129 KiB of dynamic LDS: one workgroup per CU, which is how the XCD's 32 CUs host the 32 workgroups of the iterations anyway)
 __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
-                                                                int batch, int force_agent)
+                                                                int batch, int force_agent, int early_logdet)
 {
     __shared__ double redp[2][4][4][64];
     __shared__ double partp[2][4];
+    if (early_logdet && blockIdx.x == 2) {  // (another of the linear ids the launch sends away: XCD 2)
+        extern __shared__ __attribute__((aligned(16))) double ld_sm[];
+        ns_logdetB_workgroup<4>(A, scall, ld_sm, &partp[0][0]);
+        return;
+    }
     if (iter_first == 0 && blockIdx.x == 1) {
         if (threadIdx.x == 0) {
             double *s = scall;
@@ -1386,6 +1397,49 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
 #endif
 }
 
+// ---- log det B on its own (round 5).  Sigma = c B^(-1/2) needs log c = 2 log(sigma) + log det B / (2 n) (covo.py:124-128).  Rounds
+// 1-4 took log det B from the pivots of chol(Z) -- the LAST thing the chain computes, so nothing scaled by c (the factor of Sigma
+// the noise GEMM multiplies with) could leave before the whole factorisation was over.  B = A + delta I is known as soon as the Ritz
+// launch has delta, ~60 us earlier: one workgroup factors B itself (chol128_lds_mfma: cond(B) <= 1e6, fp64) next to the
+// Newton-Schulz iterations and leaves sum_i log diag(chol B) = log det B / 2 with a flag.  Every path of the chain takes cz from it
+// (one definition: a matrix of a batch still equals the same matrix alone bit for bit): the persistent iteration launch of a single
+// matrix hosts the workgroup (256 threads: NWAVES = 4; ns_iter_tail_pair_kernel), every other path runs it as a sibling of the
+// factoring workgroup inside the finalize launch (512 threads).  sm: [128][129] doubles of LDS; red: >= 4 doubles of LDS.
+template <int NWAVES>
+__device__ void ns_logdetB_workgroup(const double *__restrict__ A, double *__restrict__ s, double *__restrict__ sm, double *__restrict__ red)
+{
+    constexpr int THREADS = 64 * NWAVES, LD = SN + 1;
+    const int tid = threadIdx.x;
+    const double delta = s[SC_DELTA];  // (written by the Ritz launch, a kernel boundary ago)
+    const double2 *A2 = reinterpret_cast<const double2 *>(A);
+#pragma unroll 4
+    for (int e = tid; e < SN * SN / 2; e += THREADS) {  // A is stored exactly symmetric: the full matrix, both triangles
+        const int r = e / (SN / 2), c = 2 * (e % (SN / 2));
+        const double2 v = A2[e];
+        sm[c * LD + r] = v.x + ((r == c) ? delta : 0.0);
+        sm[(c + 1) * LD + r] = v.y + ((r == c + 1) ? delta : 0.0);
+    }
+    __syncthreads();
+    chol128_lds_mfma<LD, NWAVES>(sm, tid);
+    // sum log diag with ONE libm log: mantissas multiplied (64 factors in [1/2, 1) per wave), exponents added
+    if (tid < SN) {
+        const double d = sm[tid * LD + tid];
+        const double pm = wr::wave64_allprod(__builtin_amdgcn_frexp_mant(d));
+        const double pe = wr::wave64_allsum((double)__builtin_amdgcn_frexp_exp(d));
+        if ((tid & 63) == 0) {
+            red[2 * (tid >> 6)] = pm;
+            red[2 * (tid >> 6) + 1] = pe;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double sumlog = fma(red[1] + red[3], 0.6931471805599453, log(red[0] * red[2]));
+        gst<COH_AGENT>(s + SC_SUMLOGB, sumlog);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gst<COH_AGENT>(s + SC_LDFLAG, 1.0);
+    }
+}
+
 // ---- one workgroup per matrix: Z ~ sqrt(s) B^(-1/2), symmetrised.  ONE Cholesky serves both needs:
 //   Lz = chol(Z)  ->  log det B = n log s - 2 log det Z = n log s - 4 sum log diag(Lz);
 //   Sigma = cz Z (cz = c / sqrt(s))  ->  chol(Sigma) = sqrt(cz) Lz.
@@ -1398,18 +1452,29 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
                                                           const double *__restrict__ Zt0all, const double *__restrict__ Zt1all,
                                                           double *__restrict__ scall, float sample_sigma,
                                                           float *__restrict__ Sigma_out, float *__restrict__ L_out, int batch,
-                                                          const EpsGenArgs gen, int *status)
+                                                          const EpsGenArgs gen, int *status, const double *__restrict__ Aall,
+                                                          int logdet_here)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[512];
-    if ((int)blockIdx.x >= batch) {
+    // logdet_here: workgroups 2 b factor B_b = A_b + delta_b I for log det B_b next to the workgroups 2 b + 1 that factor Z_b
+    // (ns_logdetB_workgroup); otherwise the Newton-Schulz launch has done it long ago
+    // (ids 2 b / 2 b + 1: B_b's workgroup is dispatched BEFORE the one that waits for it -- with a batch beyond what is resident, e.g.
+    // covo-offline's 300-row table, workgroups that wait for siblings further down the grid would never let them in)
+    if (logdet_here && (int)blockIdx.x < 2 * batch && ((int)blockIdx.x & 1) == 0) {
+        const int b = (int)blockIdx.x >> 1;
+        ns_logdetB_workgroup<8>(Aall + (size_t)b * SN * SN, scall + (size_t)b * SC_COUNT, sm, red);
+        return;
+    }
+    const int first_passenger = logdet_here ? 2 * batch : batch;
+    if ((int)blockIdx.x >= first_passenger) {
         // passenger workgroups (fused step only, eps_tiles.hpp): draw the step's epsilon while workgroups 0..batch-1
         // factor; the dynamic LDS of this launch keeps them at one workgroup (8 waves) per CU
-        eps_tiles_generate(gen, ((int)blockIdx.x - batch) * 8 + (int)(threadIdx.x >> 6), ((int)gridDim.x - batch) * 8,
+        eps_tiles_generate(gen, ((int)blockIdx.x - first_passenger) * 8 + (int)(threadIdx.x >> 6), ((int)gridDim.x - first_passenger) * 8,
                            (int)(threadIdx.x & 63));
         return;
     }
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = logdet_here ? (int)blockIdx.x >> 1 : (int)blockIdx.x, tid = threadIdx.x;
     double *s = scall + (size_t)b * SC_COUNT;
     // the deflation vector goes to LDS with the launch's FIRST round trip (beside the two scalars the Z loads depend on): read
     // from global memory where it is used, behind `zc != 0`, it was a third dependent round trip of this one-workgroup launch
@@ -1465,26 +1530,31 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     tk[1] = clock64();
     chol128_lds_mfma<LD>(sm, tid);
     tk[2] = clock64();
-    // log det Z = 2 sum log diag(chol Z) with ONE libm log: mantissas multiplied (64 factors in [1/2, 1) per wave), exponents added
-    if (tid < SN) {
-        const double d = sm[tid * LD + tid];
-        const double pm = wr::wave64_allprod(__builtin_amdgcn_frexp_mant(d));
-        const double pe = wr::wave64_allsum((double)__builtin_amdgcn_frexp_exp(d));
-        if ((tid & 63) == 0) {
-            red[2 * (tid >> 6)] = pm;
-            red[2 * (tid >> 6) + 1] = pe;
+    // covo.py:124-128: log_s = 0.5 log_const - 0.5 log_o, log_const = (2 n 2 log(sigma) + sum log o)/n, i.e. Sigma = c B^(-1/2) with
+    // log c = 2 log(sigma) + log det B / (2n); Z = sqrt(scale) B^(-1/2), so Sigma = cz Z with cz = c / sqrt(scale)
+    // = sigma^2 exp(sumlogB / n) / sqrt(scale), sumlogB = sum_i log diag(chol B) = log det B / 2 (ns_logdetB_workgroup: a sibling
+    // workgroup of this launch, or -- one matrix -- a passenger of the Newton-Schulz launch, long done)
+    if (tid == 0) {
+        const long long t0 = wall_clock64();
+        int good = 1;
+        while (gld<COH_AGENT>(s + SC_LDFLAG) == 0.0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 20000000LL) {  // 0.2 s: the sibling never ran (a starved launch): fail in NaNs, loudly
+                good = 0;
+                break;
+            }
         }
+        red[0] = gld<COH_AGENT>(s + SC_SUMLOGB);
+        red[1] = good ? 0.0 : 1.0;
     }
     __syncthreads();
-    const double sumlog = fma(red[1] + red[3], 0.6931471805599453, log(red[0] * red[2]));  // sum_i log diag_i
-    // covo.py:124-128: log_s = 0.5 log_const - 0.5 log_o, log_const = (2 n 2 log(sigma) + sum log o)/n, i.e. Sigma = c B^(-1/2) with
-    // log c = 2 log(sigma) + log det B / (2n); log det B = n log(scale) - 4 sumlog and Z = sqrt(scale) B^(-1/2), so the scale
-    // cancels in cz = c / sqrt(scale) = sigma^2 exp(-2 sumlog / n)
+    const double sumlogB = red[0];
+    const bool ld_failed = red[1] != 0.0;
     // a timed-out grid barrier (ns_grid_barrier) left Z unconverged: fail like the reference's numerical failures do, in NaNs
-    const double poison = (s[SC_BARFAIL] != 0.0) ? __builtin_nan("") : 1.0;
-    if (tid == 0 && s[SC_BARFAIL] != 0.0 && status != nullptr)  // ... and loudly: the next C call on this handle fails (capi.hip)
+    const double poison = (s[SC_BARFAIL] != 0.0 || ld_failed) ? __builtin_nan("") : 1.0;
+    if (tid == 0 && (s[SC_BARFAIL] != 0.0 || ld_failed) && status != nullptr)  // ... and loudly: the next C call on this handle fails (capi.hip)
         __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const double cz = poison * ((double)sample_sigma * (double)sample_sigma) * exp(-2.0 * sumlog / n);
+    const double cz = poison * ((double)sample_sigma * (double)sample_sigma) * exp(sumlogB / n) * qm::rsq64_(s[SC_SCALE]);
     const double sq = cz * qm::rsq64_(cz);
     if (tid == 0) s[SC_CZ] = cz;
     tk[3] = clock64();
@@ -1520,7 +1590,6 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     }
     tk[4] = clock64();
     if (tid == 0) {
-        s[SC_LOGDET] = fma(n, log(s[SC_SCALE]), -4.0 * sumlog);  // log det B (diagnostics)
         for (int i = 0; i < 5; ++i) s[SC_PROF + i] = (double)(tk[i] - tk[0]);
     }
 }
@@ -1590,6 +1659,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (!attr_set) {
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_finalize_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_iter_tail_pair_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if (r_has_stats) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
@@ -1617,6 +1688,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (fold_iter0) {
     } else if (batch > 1) hipLaunchKernelGGL(ns_first_quad_kernel, ns_grid(17, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
     else hipLaunchKernelGGL(ns_first_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);  // 64 tiles + the table
+    bool early_logdet = false;
     int n_tail = persistent_ok ? (batch == 1 ? g_ns_tail_iters : g_ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
     const int n_sep = NS_ITERS - n_tail;
@@ -1642,8 +1714,10 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         }
         B.T = T;
         B.Tt = Tt;
-        hipLaunchKernelGGL(ns_iter_tail_pair_kernel, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 0, s, A, B, sc, fold_iter0 ? 0 : n_sep,
-                           NS_ITERS - 1, batch, g_ns_force_agent);
+        // one matrix: log det B rides in this launch (ns_logdetB_workgroup), ~50 us before the finalize launch wants it
+        early_logdet = batch == 1;
+        hipLaunchKernelGGL(ns_iter_tail_pair_kernel, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), early_logdet ? lds : 0, s, A, B, sc,
+                           fold_iter0 ? 0 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent, early_logdet ? 1 : 0);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     EpsGenArgs g;
@@ -1659,7 +1733,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         g = *gen;
         const long long ntiles = (long long)((g.N + 31) / 32) * g.n_inst;
         passengers = (int)((ntiles + 7) / 8);  // 8 waves per workgroup, one tile per wave ...
-        const int room = batch < 128 ? 256 - batch : 128;  // ... at most one workgroup on every other CU, waves stride over tiles
+        const int nfac = early_logdet ? batch : 2 * batch;  // factoring workgroups (Z, and B where its log det is not there yet)
+        const int room = nfac < 128 ? 256 - nfac : 128;  // ... at most one workgroup on every other CU, waves stride over tiles
         if (passengers > room) passengers = room;
     }
     if (cov != nullptr) {
@@ -1677,8 +1752,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
             Sigma = nullptr;
         }
     }
-    hipLaunchKernelGGL(ns_finalize_kernel, dim3(batch + passengers), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma,
-                       Sigma, L, batch, g, status);
+    hipLaunchKernelGGL(ns_finalize_kernel, dim3((early_logdet ? batch : 2 * batch) + passengers), dim3(512), lds, s, Z[0], Z[1], Zt[0],
+                       Zt[1], sc, sample_sigma, Sigma, L, batch, g, status, A, early_logdet ? 0 : 1);
     COVO_CHECK_HIP(hipGetLastError());
     return 0;
 }
