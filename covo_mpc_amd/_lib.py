@@ -136,6 +136,7 @@ _SIGS = {
     "covo_debug_set_ns_deflate": (C.c_int, [C.c_int]),
     "covo_debug_set_fuse_small": (C.c_int, [C.c_int]),
     "covo_debug_set_merge_in_rollout": (C.c_int, [C.c_int]),
+    "covo_debug_set_stream_gemm": (C.c_int, [C.c_int]),
     "covo_debug_set_ns_coherence": (C.c_int, [C.c_int]),
     "covo_debug_time_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.POINTER(C.c_float), _P]),

@@ -516,6 +516,13 @@ int covo_debug_set_ns_tail(int n_squarings, int n_iters)
     return 0;
 }
 
+int covo_debug_set_stream_gemm(int on)
+{
+    g_stream_gemm = on ? 1 : 0;
+    ++g_dbg_epoch;
+    return 0;
+}
+
 int covo_debug_set_merge_in_rollout(int on)
 {
     g_merge_in_rollout = on ? 1 : 0;

@@ -135,8 +135,16 @@ __device__ __forceinline__ void chol_tile_update(const double *A, chol_f64x4 &Tt
 // NWAVES: 8 (one wave per tile row of a panel: the finalize launch's 512-thread workgroup) or 4 (a 256-thread workgroup: wave 0
 // factors, waves 1-3 take up to three tiles each -- the log-det factorisation riding in the Newton-Schulz launch, sigma_ns.hip);
 // the same tile arithmetic either way.
-template <int ld, int NWAVES = 8>  // compile-time stride: every LDS address is base + immediate
-__device__ void chol128_lds_mfma(double *A, int tid)
+struct CholNoHook {
+    __device__ __forceinline__ void panel_done(int) const {}
+    __device__ __forceinline__ void before_barrier(int) const {}
+};
+// hook.panel_done(p): called by every thread once panel p (columns 16 p .. 16 p + 15 of L, all rows) is final in LDS and will not
+// be written again -- the finalize launch's streamed variant sends it on from there while the next panel is factored;
+// hook.before_barrier(p): called by every thread of panel p's iteration right before the barrier that ends its F / look-ahead
+// phase (the place to wait for what panel_done(p - 1) started without holding anybody up).
+template <int ld, int NWAVES = 8, class Hook = CholNoHook>  // compile-time stride: every LDS address is base + immediate
+__device__ void chol128_lds_mfma(double *A, int tid, Hook hook = Hook())
 {
     constexpr int NW1 = NWAVES - 1, U = (7 + NW1 - 1) / NW1;  // worker waves, tiles per worker wave and panel
     __shared__ double Wsm[16 * 16];
@@ -258,6 +266,7 @@ __device__ void chol128_lds_mfma(double *A, int tid)
                 }
             }
         }
+        hook.before_barrier(p);
         __syncthreads();
         const long long c2 = CHOL_CLOCK();
         // ---- T: L(ti, p)^T = W . tile^T
@@ -285,5 +294,6 @@ __device__ void chol128_lds_mfma(double *A, int tid)
         CHOL_STAMP(3, 0);
         CHOL_STAMP(8 + p, c1 - c0);
         CHOL_STAMP(16 + p, c2 - c1);
+        hook.panel_done(p);
     }
 }

@@ -41,6 +41,7 @@ void covo_set_error(const char *fmt, ...);
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
 extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate, g_ns_force_agent;  // sigma_ns.hip
 void sigma_ns_tail_defaults();  // sigma_ns.hip: the four tail lengths back to their defaults
+extern int g_stream_gemm;  // step.hip: covo-online's noise GEMM streamed inside the Sigma chain's finalize launch
 extern int g_merge_in_rollout;  // step.hip: fused single-instance steps finish the softmax update inside the rollout launch
 extern int g_fuse_small;  // step.hip: the fused small step (step_small.hip) is taken where eligible
 extern int g_dbg_epoch;  // capi.hip: bumped by every debug setter whose value a captured step graph bakes in as a kernel argument
@@ -204,9 +205,26 @@ struct EpsGenArgs;  // eps_tiles.hpp
 // outputs); persistent_ok = false (COVO_FLAG_SHARED_DEVICE): every phase its own launch
 // r_has_stats (fused steps): R is exactly symmetric and its statistics (sym_stats.hpp) are already in the workspace -- left
 // there by the Hessian's last launch through sigma_ns_stats_out -- so the chain starts without its prep launch
+// stream != null (fused covo-online step, one matrix, persistent launches allowed): the noise GEMM of the step is carried out INSIDE
+// the finalize launch, streamed under the factorisation (sigma_ns.hip: ns_finalize_stream_kernel); *streamed says whether it was
+// (else the caller launches the GEMM).  gen / cov / Sigma / L are then unused: a_cov goes to stream->a_cov_out, the factor to
+// stream->L_stream.
+struct StreamGemmArgs {
+    const float *mu;        // the shifted mean [128]
+    const uint32_t *dyn;    // {key0, key1}: the step's sampling key in device memory
+    int64_t sample_offset;  // global id of local sample 0
+    int N;                  // samples of this shard
+    float *a_out;           // [H][N][4] action stripes
+    float *L_stream;        // [128][128] fp32: chol(Sigma), written panel by panel (write-through) while the workers read it
+    unsigned *sync;         // [16]: [0] the step's sequence number (bumped by the begin launch), [1 + p]: panel p (16 columns) of
+                            // L_stream is complete for the sequence number it holds
+    float *a_cov_out;       // nullable: a_cov [128][128]
+    int nanp;               // COVO_FLAG_PROPAGATE_NAN
+};
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
                     hipStream_t s, const EpsGenArgs *gen = nullptr, int *status = nullptr, bool persistent_ok = true,
-                    CovDeferred *cov = nullptr, bool r_has_stats = false);
+                    CovDeferred *cov = nullptr, bool r_has_stats = false, const StreamGemmArgs *stream = nullptr,
+                    bool *streamed = nullptr);
 struct SymStatsOut;  // sym_stats.hpp
 SymStatsOut sigma_ns_stats_out(void *workspace, int batch = 1);
 void step_state_destroy(covo_ctx *h);

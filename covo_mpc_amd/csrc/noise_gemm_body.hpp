@@ -123,6 +123,33 @@ __device__ __forceinline__ void mfma_group(const float *__restrict__ La, BGroup 
     }
 }
 
+// Half of mfma_group<G, MASK>: the chunks {2 HALF, 2 HALF + 1} of k-group G, i.e. the 16 columns of ONE Cholesky panel (2 G + HALF)
+// -- the streamed finalize launch multiplies panel by panel as the factor arrives.  The two halves in order are mfma_group: the
+// same fragments, the same MFMAs in the same order on the same accumulators.
+template <int G, int HALF, int MASK = 15>
+__device__ __forceinline__ void mfma_half(const float *__restrict__ La, const BGroup &b, f32x16 (&acc)[4])
+{
+    if ((MASK >> G) == 0) return;
+    AFrag<G> cur = load_afrag<G, MASK>(La, 2 * HALF);
+#pragma unroll
+    for (int i = 2 * HALF; i < 2 * HALF + 2; ++i) {
+        AFrag<G> nxt = cur;
+        if (i < 2 * HALF + 1) nxt = load_afrag<G, MASK>(La, i + 1);
+        float x = b.c[i].x, y = b.c[i].y, z = b.c[i].z, w = b.c[i].w;
+        auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(w), false, false);
+        const float bb[4] = {__uint_as_float(r0[0]), __uint_as_float(r1[0]), __uint_as_float(r0[1]), __uint_as_float(r1[1])};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int rt = G; rt < 4; ++rt)
+                if ((MASK >> rt) & 1) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[q][rt], bb[q], acc[rt], 0, 0, 0);
+        }
+        cur = nxt;
+    }
+}
+
 // a row-tile set as a type (generic lambdas take it as a tag)
 template <int M>
 struct RtMask {

@@ -56,6 +56,7 @@
 #include "chol_lds.hpp"
 #include "eps_tiles.hpp"
 #include "sym_stats.hpp"
+#include "noise_gemm_body.hpp"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -1311,12 +1312,14 @@ __device__ void ns_logdetB_workgroup(const double *__restrict__ A, double *__res
 // the launch would send away anyway (linear id 1: another XCD, so it publishes coherently and raises SC_BAR)
 // early_logdet (one matrix): linear id 2 factors B = A + delta I for its log det (ns_logdetB_workgroup; the launch then carries
 // 129 KiB of dynamic LDS: one workgroup per CU, which is how the XCD's 32 CUs host the 32 workgroups of the iterations anyway)
+// (a template argument: the factorisation's registers -- 184 against 122 -- must not cost the batched launches their third wave per SIMD)
+template <bool EARLY_LOGDET>
 __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
-                                                                int batch, int force_agent, int early_logdet)
+                                                                int batch, int force_agent)
 {
     __shared__ double redp[2][4][4][64];
     __shared__ double partp[2][4];
-    if (early_logdet && blockIdx.x == 2) {  // (another of the linear ids the launch sends away: XCD 2)
+    if (EARLY_LOGDET && blockIdx.x == 2) {  // (another of the linear ids the launch sends away: XCD 2)
         extern __shared__ __attribute__((aligned(16))) double ld_sm[];
         ns_logdetB_workgroup<4>(A, scall, ld_sm, &partp[0][0]);
         return;
@@ -1594,6 +1597,332 @@ __global__ __launch_bounds__(512) void ns_finalize_kernel(const double *__restri
     }
 }
 
+
+// ---- the finalize launch with the noise GEMM streamed under the factorisation (round 5; one matrix, fused covo-online step).
+// Rounds 2-3 built this twice and reverted it: the GEMM needs the SCALED factor fp32(sqrt(cz) chol(Z)), cz needed log det, log det
+// needed every pivot -- so every action had to wait for the end of the factorisation and the launch's 33.5 MB of stores drained
+// behind it (54 us fused against 31 + 20 apart).  With log det B known since the Newton-Schulz launch
+// (ns_logdetB_workgroup) cz is there before the first pivot:
+//   workgroup 0     factors Z exactly as ns_finalize_kernel does; as soon as a 16-column panel is final its waves 1-7 write it,
+//                   scaled and rounded to fp32, into L_stream with write-through stores (four complete 64-byte rows per instruction
+//                   and wave, issued before the waves turn to the next panel's updates), wait for the acknowledgement where they
+//                   would wait for wave 0's F phase anyway, and the last of them raises the panel's flag (the step's sequence
+//                   number: no flag is ever cleared);
+//   workgroups 1..  the GEMM's workers, noise_gemm_kernel's arithmetic on the same device functions (noise_gemm_body.hpp: same
+//                   fragments, same MFMA order -> the same bits): a wave owns one 32-sample tile, draws its epsilon up front (the
+//                   launch's first 10 us have nothing else for it), and per 32-column k-group: flag -> the k-group's columns of L
+//                   into the LDS image (coherent loads) -> the k-group's MFMAs -> row tile g stored -- final after k-group g, L
+//                   being lower triangular -- while workgroup 0 factors on.  The first 32 workers also write a_cov.
+// What the launch adds behind the factorisation is one acknowledgement, one flag round trip, one staging and the last panel's
+// 8 MFMAs per tile instead of a whole 18 us GEMM launch.
+struct StreamHook {
+    const double *sm;
+    double sq;
+    float *Lg;
+    unsigned *sync;
+    unsigned seq;
+    int *cnt;        // LDS [8]: writer waves whose stores of panel p are acknowledged
+    double *stamps;
+    int tid;
+    static constexpr int LD = SN + 1;
+    __device__ __forceinline__ void panel_done(int p) const
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        if (tid == 0) stamps[2 + p] = (double)wall_clock64();
+        if (wave == 0) return;  // (wave 0 goes straight on to the next diagonal block)
+        const int rr = lane >> 4, kk = lane & 15, j0 = 16 * p, c = j0 + kk;
+        for (int i0 = j0 + 4 * (wave - 1); i0 < SN; i0 += 28) {
+            const int i = i0 + rr;
+            const float v = (c <= i) ? (float)(sq * sm[c * LD + i]) : 0.0f;  // ns_finalize_kernel's L_out expression
+            __hip_atomic_store(Lg + (size_t)i * SN + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the stores of panel p - 1 are acknowledged -> its flag (by the last writer wave to get here)
+    __device__ __forceinline__ void before_barrier(int p) const
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        if (p == 0 || wave == 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int old = __hip_atomic_fetch_add(cnt + (p - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 6) {
+                __hip_atomic_store(sync + p, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sync[1 + (p - 1)]
+                stamps[11 + (p - 1)] = (double)wall_clock64();
+            }
+        }
+    }
+};
+
+// wait until k-group G of L_stream (its second panel's flag: the flags go up in panel order) carries this step's sequence number
+template <int G>
+__device__ __forceinline__ bool stream_wait_kgroup(const StreamGemmArgs &S, unsigned seq, int *flag_lds)
+{
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        int good = 1;
+        while (__hip_atomic_load(S.sync + 1 + (2 * G + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 20000000LL) {  // 0.2 s: the factoring workgroup is gone
+                good = 0;
+                break;
+            }
+        }
+        *flag_lds = good;
+    }
+    __syncthreads();
+    return *flag_lds != 0;
+}
+// columns [32 G, 32 G + 32) x rows [32 G, 128) of L_stream -> the padded LDS image (ng_stage_factor's layout and masking)
+template <int G>
+__device__ __forceinline__ void stream_stage_kgroup(const float *__restrict__ L, float *__restrict__ Ls, int tid)
+{
+    constexpr int ROWS = COVO_NA - 32 * G, CHUNKS = ROWS * 8;  // float4 chunks
+    unsigned long long lo[(CHUNKS + 511) / 512], hi[(CHUNKS + 511) / 512];
+#pragma unroll
+    for (int u = 0; u < (CHUNKS + 511) / 512; ++u) {  // all loads first: one round trip
+        const int c = 512 * u + tid;
+        if (c < CHUNKS) {
+            const int i = 32 * G + (c >> 3), k4 = 32 * G + 4 * (c & 7);
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(L + (size_t)i * COVO_NA + k4);
+            lo[u] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hi[u] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < (CHUNKS + 511) / 512; ++u) {
+        const int c = 512 * u + tid;
+        if (c < CHUNKS) {
+            const int i = 32 * G + (c >> 3), k4 = 32 * G + 4 * (c & 7);
+            float *d = Ls + i * NG_LDA + k4;
+            d[0] = (k4 + 0 <= i) ? __uint_as_float((unsigned)lo[u]) : 0.0f;
+            d[1] = (k4 + 1 <= i) ? __uint_as_float((unsigned)(lo[u] >> 32)) : 0.0f;
+            d[2] = (k4 + 2 <= i) ? __uint_as_float((unsigned)hi[u]) : 0.0f;
+            d[3] = (k4 + 3 <= i) ? __uint_as_float((unsigned)(hi[u] >> 32)) : 0.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *__restrict__ Z0, const double *__restrict__ Z1,
+                                                                 const double *__restrict__ Zt0, const double *__restrict__ Zt1,
+                                                                 double *__restrict__ s, float sample_sigma, const StreamGemmArgs S,
+                                                                 int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[8];
+    __shared__ int flag_lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int LD = SN + 1;
+    const double n = (double)SN;
+    // ---- cz, every workgroup for itself from the same numbers (ns_finalize_kernel's expression: the same bits)
+    if (tid == 0) {
+        const long long t0 = wall_clock64();
+        int good = 1;
+        while (gld<COH_AGENT>(s + SC_LDFLAG) == 0.0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 20000000LL) {
+                good = 0;
+                break;
+            }
+        }
+        red[0] = gld<COH_AGENT>(s + SC_SUMLOGB);
+        red[1] = good ? 0.0 : 1.0;
+    }
+    __syncthreads();
+    const double sumlogB = red[0];
+    const bool bad = s[SC_BARFAIL] != 0.0 || red[1] != 0.0;
+    const double poison = bad ? __builtin_nan("") : 1.0;
+    const double cz = poison * ((double)sample_sigma * (double)sample_sigma) * exp(sumlogB / n) * qm::rsq64_(s[SC_SCALE]);
+    const double sq = cz * qm::rsq64_(cz);
+    const unsigned seq = __hip_atomic_load(S.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool z1 = s[SC_ZBUF] != 0.0;
+    const double zc = s[SC_ZCOEF];  // deflation: Z = Z~ + zc u u^T (0: off)
+    // time stamps of the launch (100 MHz wall clock, scripts/stream_timeline.py): workgroup 0 [0] entry, [1] Z in LDS, [2 + p] panel p
+    // final, [10] factorisation over, [11 + p] flag p raised; the first and the last worker's wave 0 [24 / 56 + ...]: entry, then per
+    // panel {flag seen, staged, multiplied (and stored)}
+    double *stamps = s + SC_STAMPS;
+
+    if (blockIdx.x == 0) {
+        // ================================================================ the factoring workgroup
+        if (tid == 0) stamps[0] = (double)wall_clock64();
+        if (tid == 0 && bad && status != nullptr)
+            __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) s[SC_CZ] = cz;
+        __shared__ double suv[SN];
+        __shared__ int wcnt[8];
+        if (tid < SN) suv[tid] = s[SC_U + tid];
+        if (tid < 8) wcnt[tid] = 0;
+        const double2 *Z = reinterpret_cast<const double2 *>(z1 ? Z1 : Z0);
+        const double2 *Zt = reinterpret_cast<const double2 *>(z1 ? Zt1 : Zt0);
+        long long tk[3];
+        tk[0] = clock64();
+        {
+            constexpr int TR = NS_TILES * 128 / 512;  // 9 double2 per thread and matrix: all loads in flight first
+            double2 za[TR], zt[TR];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                const int w = __builtin_amdgcn_readfirstlane((tid >> 7) + 4 * t), in = tid & 127;
+                int ti, tj;
+                tri_tile(w, ti, tj);
+                const int e2 = ((16 * ti + (in >> 3)) * SN + 16 * tj + 2 * (in & 7)) >> 1;
+                za[t] = Z[e2];
+                zt[t] = Zt[e2];
+            }
+            __syncthreads();  // suv
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                const int w = __builtin_amdgcn_readfirstlane((tid >> 7) + 4 * t), in = tid & 127;
+                int ti, tj;
+                tri_tile(w, ti, tj);
+                const int r = 16 * ti + (in >> 3), c = 16 * tj + 2 * (in & 7);
+                double v0 = 0.5 * (za[t].x + zt[t].x), v1 = 0.5 * (za[t].y + zt[t].y);  // covo.py:132 symmetrise
+                if (zc != 0.0) {
+                    const double ur = zc * suv[r];
+                    v0 = fma(ur, suv[c], v0);
+                    v1 = fma(ur, suv[c + 1], v1);
+                }
+                sm[c * LD + r] = v0;
+                sm[(c + 1) * LD + r] = v1;
+                if (ti == tj) {
+                    sm[r * LD + c] = v0;
+                    sm[r * LD + c + 1] = v1;
+                }
+            }
+        }
+        __syncthreads();
+        tk[1] = clock64();
+        if (tid == 0) stamps[1] = (double)wall_clock64();
+        StreamHook hook;
+        hook.sm = sm;
+        hook.sq = sq;
+        hook.Lg = S.L_stream;
+        hook.sync = S.sync;
+        hook.seq = seq;
+        hook.cnt = wcnt;
+        hook.stamps = stamps;
+        hook.tid = tid;
+        chol128_lds_mfma<LD, 8>(sm, tid, hook);
+        hook.before_barrier(8);  // the last panel's acknowledgement and flag
+        tk[2] = clock64();
+        if (tid == 0) {
+            stamps[10] = (double)wall_clock64();
+            for (int i = 0; i < 3; ++i) s[SC_PROF + i] = (double)(tk[i] - tk[0]);
+        }
+        return;
+    }
+
+    // ==================================================================== the GEMM's workers
+    // Worker b = blockIdx.x in [1, W] takes the 8 tiles of the stand-alone GEMM's workgroup b -- same XCD (linear id mod 8), so the
+    // rollout's XCD-affine mapping finds the stripes in the L2 it expects -- one per wave.  The 8 tiles of "workgroup 0" have no CU
+    // (the factoring workgroup sits there): each is hosted by one worker on XCD 0 (b = 8, 16, ...; small launches: b = 1, 2, ...),
+    // whose waves draw its epsilon into LDS together and whose waves 1, 2, 3 carry its row tiles {3}, {2}, {0, 1} next to their own
+    // tile (64 / 48 / 48 of its 160 MFMAs on accumulators of their own: every dot product still one ascending-k chain).
+    float *Ls = reinterpret_cast<float *>(sm);   // [128][NG_LDA]: the LDS image of L, filled k-group by k-group
+    float *mus = Ls + COVO_NA * NG_LDA;          // [128]
+    float4 *epsx = reinterpret_cast<float4 *>(mus + COVO_NA);  // [16][64]: the hosted tile's epsilon in B-operand order (16 KiB)
+    const int b = (int)blockIdx.x, W = (int)gridDim.x - 1;
+    double *wst = (tid == 0 && (b == 1 || b == W)) ? stamps + (b == 1 ? 24 : 56) : nullptr;
+    if (wst) wst[0] = (double)wall_clock64();
+    if (tid < COVO_NA) mus[tid] = S.mu[tid];
+    const uint32_t k0 = S.dyn[0], k1 = S.dyn[1];
+    const int N = S.N, ntiles = (N + 31) / 32;
+    const int nextra = ntiles < 8 ? ntiles : 8;
+    const int j = lane & 31, kh = lane >> 5;
+    const int t0 = 8 * b + wave;
+    const bool has0 = t0 < ntiles;  // (wave-uniform)
+    int ex = -1;                    // the tile of "workgroup 0" this worker hosts
+    if (W >= 64) { if ((b & 7) == 0 && (b >> 3) - 1 < nextra) ex = (b >> 3) - 1; }
+    else if (b - 1 < nextra) ex = b - 1;
+    auto id_of = [&](int t) {
+        int row = t * 32 + j;
+        row = row < N ? row : N - 1;
+        return (uint64_t)(S.sample_offset + row);
+    };
+    const uint64_t id0 = id_of(has0 ? t0 : 0);
+    // epsilon of the wave's own tile, all four k-groups, while workgroup 0 loads Z and factors its first panels
+    BGroup bq[4];
+    if (has0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = gen_group(id0, g, kh, k0, k1);
+    }
+    if (ex >= 0) {  // the hosted tile's: wave v draws chunks 2 v, 2 v + 1 (eps_tiles.hpp's order: chunk q, lane -> normal4(2 q + kh, sample j))
+        const uint64_t idx = id_of(ex);
+#pragma unroll
+        for (int q = 2 * wave; q < 2 * wave + 2; ++q) epsx[q * 64 + lane] = rngd::normal4((uint32_t)(2 * q + kh), idx, k0, k1);
+    }
+    const int xrole = ex >= 0 ? wave : 0;  // 1: row tile 3, 2: row tile 2, 3: row tiles 0 and 1 of the hosted tile
+    // a_cov = cz sym(Z) (+ the deflated eigenpair): covo.py:132, the expression of ns_finalize_kernel / the noise GEMM's CovDeferred
+    if (S.a_cov_out != nullptr && b - 1 < SN * SN / 512) {
+        const double *Zb = z1 ? Z1 : Z0, *Ztb = z1 ? Zt1 : Zt0;
+        const int wstride = W < SN * SN / 512 ? W : SN * SN / 512;  // (small launches: the workers there are stride over the matrix)
+        for (int e = (b - 1) * 512 + tid; e < SN * SN; e += wstride * 512) {
+            double v = 0.5 * (Zb[e] + Ztb[e]);
+            if (zc != 0.0) v = fma(zc * s[SC_U + e / SN], s[SC_U + e % SN], v);
+            S.a_cov_out[e] = (float)(cz * v);
+        }
+    }
+    f32x16 acc0[4], accx[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[rt][e] = 0.0f; accx[rt][e] = 0.0f; }
+    const float *__restrict__ La = Ls + j * NG_LDA + kh;
+    float4 *__restrict__ a_out = reinterpret_cast<float4 *>(S.a_out);
+    bool ok = true;
+    auto store_rt = [&](int rt, int tile, const f32x16 (&acc)[4]) {
+        const int nn = tile * 32 + j;
+        if (nn < N) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int t = 8 * rt + 2 * g + kh;
+                const float4 m4 = *reinterpret_cast<const float4 *>(mus + 4 * t);
+                float4 v;
+                if (S.nanp) {  // COVO_FLAG_PROPAGATE_NAN (covo.py:224 under jnp.clip)
+                    v.x = qm::clip11_nan_(m4.x + acc[rt][4 * g + 0]);
+                    v.y = qm::clip11_nan_(m4.y + acc[rt][4 * g + 1]);
+                    v.z = qm::clip11_nan_(m4.z + acc[rt][4 * g + 2]);
+                    v.w = qm::clip11_nan_(m4.w + acc[rt][4 * g + 3]);
+                } else {
+                    v.x = qm::clip11_(m4.x + acc[rt][4 * g + 0]);
+                    v.y = qm::clip11_(m4.y + acc[rt][4 * g + 1]);
+                    v.z = qm::clip11_(m4.z + acc[rt][4 * g + 2]);
+                    v.w = qm::clip11_(m4.w + acc[rt][4 * g + 3]);
+                }
+                if (!ok) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                a_out[(size_t)t * N + nn] = v;
+            }
+        }
+    };
+    auto xgroup = [&](int g) {  // the hosted tile's k-group g from LDS, in the lane's B-operand image
+        BGroup bx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bx.c[i] = epsx[(4 * g + i) * 64 + lane];
+        return bx;
+    };
+#define STREAM_KGROUP(G)                                                                                          \
+    do {                                                                                                          \
+        ok = stream_wait_kgroup<G>(S, seq, &flag_lds) && ok;                                                      \
+        if (wst) wst[1 + 3 * (G)] = (double)wall_clock64();                                                       \
+        stream_stage_kgroup<G>(S.L_stream, Ls, tid);                                                              \
+        __syncthreads();                                                                                          \
+        if (wst) wst[2 + 3 * (G)] = (double)wall_clock64();                                                       \
+        if (has0) mfma_group<G, 15>(La, bq[G], acc0);                                                             \
+        if (xrole == 1) mfma_group<G, 8>(La, xgroup(G), accx);                                                    \
+        else if (xrole == 2) mfma_group<G, 4>(La, xgroup(G), accx);                                               \
+        else if (xrole == 3) mfma_group<G, 3>(La, xgroup(G), accx);                                               \
+        if (has0) store_rt(G, t0, acc0);                                                                          \
+        if ((G == 3 && xrole == 1) || (G == 2 && xrole == 2) || (G < 2 && xrole == 3)) store_rt(G, ex, accx);    \
+        if (wst) wst[3 + 3 * (G)] = (double)wall_clock64();                                                       \
+    } while (0)
+    STREAM_KGROUP(0);
+    STREAM_KGROUP(1);
+    STREAM_KGROUP(2);
+    STREAM_KGROUP(3);
+#undef STREAM_KGROUP
+    if (!ok && tid == 0 && status != nullptr)
+        __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // how many of the chain's last squarings / Newton-Schulz iterations run inside the persistent launches; covo_debug_set_ns_tail.
 // Rounds 2-3 (persistent launches spread over the XCDs, every access sc1, one counter): a folded phase cost nothing once the
 // chain had converged (a separate launch: 1.6 us) but, while live, +0.4 us per squaring / +1.4 us per iteration over its
@@ -1645,8 +1974,10 @@ SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
-                    hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok, CovDeferred *cov, bool r_has_stats)
+                    hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok, CovDeferred *cov, bool r_has_stats,
+                    const StreamGemmArgs *stream, bool *streamed)
 {
+    if (streamed != nullptr) *streamed = false;
     double *ws = reinterpret_cast<double *>(workspace);
     const size_t M = (size_t)batch * SN * SN;
     double *A = ws, *X0 = ws + M, *X1 = ws + 2 * M;
@@ -1659,7 +1990,9 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (!attr_set) {
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_finalize_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_iter_tail_pair_kernel),
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_iter_tail_pair_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_finalize_stream_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -1716,10 +2049,27 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         B.Tt = Tt;
         // one matrix: log det B rides in this launch (ns_logdetB_workgroup), ~50 us before the finalize launch wants it
         early_logdet = batch == 1;
-        hipLaunchKernelGGL(ns_iter_tail_pair_kernel, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), early_logdet ? lds : 0, s, A, B, sc,
-                           fold_iter0 ? 0 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent, early_logdet ? 1 : 0);
+        if (early_logdet)
+            hipLaunchKernelGGL(ns_iter_tail_pair_kernel<true>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), lds, s, A, B, sc,
+                               fold_iter0 ? 0 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent);
+        else
+            hipLaunchKernelGGL(ns_iter_tail_pair_kernel<false>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 0, s, A, B, sc,
+                               fold_iter0 ? 0 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent);
     }
     if (g_dbg_sigma_stages < 4) return 0;
+    if (stream != nullptr && early_logdet && batch == 1) {
+        // the noise GEMM rides in the finalize launch (ns_finalize_stream_kernel): one workgroup factors, the others multiply
+        // workers b = 1 .. W take the tiles [8 b, 8 b + 8); the tiles [0, 8) are hosted one per worker (ns_finalize_stream_kernel)
+        const int ntiles = (stream->N + 31) / 32;
+        const int workers = (ntiles - 8 + 7) / 8;
+        if (ntiles >= 72 && workers <= 255) {
+            hipLaunchKernelGGL(ns_finalize_stream_kernel, dim3(1 + workers), dim3(512), lds, s, Z[0], Z[1], Zt[0], Zt[1], sc, sample_sigma,
+                               *stream, status);
+            COVO_CHECK_HIP(hipGetLastError());
+            if (streamed != nullptr) *streamed = true;
+            return 0;
+        }
+    }
     EpsGenArgs g;
     g.eps_tiled = nullptr;
     g.dyn = nullptr;

@@ -27,8 +27,9 @@
 __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__restrict__ a_mean_shift,
                                   uint32_t *__restrict__ dyn, float *__restrict__ state_buf, int derive_keys,
                                   float shared_noise_scale, const DynBlock blk, float *__restrict__ mppi_cov,
-                                  float *__restrict__ mppi_Ls)
+                                  float *__restrict__ mppi_Ls, unsigned *__restrict__ seq)
 {
+    if (threadIdx.x == 0 && seq != nullptr) seq[0] = seq[0] + 1u;  // the step's sequence number (the streamed finalize launch's flags)
     // MPPI (mppi_cov != null): the covariance shift + the 4x4 block factors ride in this launch (one launch less on a path
     // that is host bound at small N)
     if (mppi_cov != nullptr) mppi_prep(mppi_cov, mppi_Ls);
@@ -43,6 +44,10 @@ __global__ void step_begin_kernel(const float *__restrict__ a_mean, float *__res
         step_begin_derive(i - (COVO_NA + COVO_STATE_FLOATS), blk, derive_keys, shared_noise_scale, dyn);
     }
 }
+
+// covo_debug_time_step's copies of a step have no begin launch between them: the streamed finalize launch's flags would still
+// carry the previous copy's sequence number (its workers would not wait for anything): one bump per copy
+__global__ void stream_seq_bump_kernel(unsigned *seq) { seq[0] = seq[0] + 1u; }
 
 struct StepKey {
     covo_step_args args;
@@ -61,6 +66,7 @@ struct StepState {
     float4 *eps_tiled;    // covo-online: this step's epsilon in tile order, drawn under the Sigma chain (eps_tiles.hpp); or null
     float *f_tab_rollout, *f_tab_hess;  // [H][4] per-step disturbance tables of the sampling rollouts / the Hessian (disturb.hip)
     unsigned *ticket;     // arrival counter of the fused small step (step_small.hip); 0 between launches
+    unsigned *sync;       // [16] the streamed finalize launch's sequence number and panel flags (StreamGemmArgs::sync)
     // graph cache
     bool have_key, have_graph;
     StepKey key;
@@ -87,6 +93,8 @@ static int step_state_init(covo_ctx *h)
     COVO_CHECK_HIP(hipMalloc(&st->f_tab_hess, COVO_H * 4 * sizeof(float)));
     COVO_CHECK_HIP(hipMalloc(&st->ticket, sizeof(unsigned)));
     COVO_CHECK_HIP(hipMemset(st->ticket, 0, sizeof(unsigned)));
+    COVO_CHECK_HIP(hipMalloc(&st->sync, 16 * sizeof(unsigned)));
+    COVO_CHECK_HIP(hipMemset(st->sync, 0, 16 * sizeof(unsigned)));
     if (h->cfg.n_local <= EPS_AHEAD_MAX_N)
         COVO_CHECK_HIP(hipMalloc(&st->eps_tiled, (size_t)((h->cfg.n_local + 31) / 32) * 16 * 64 * sizeof(float4)));
     h->step = st;
@@ -112,6 +120,7 @@ void step_state_destroy(covo_ctx *h)
     (void)hipFree(st->f_tab_rollout);
     (void)hipFree(st->f_tab_hess);
     (void)hipFree(st->ticket);
+    (void)hipFree(st->sync);
     delete st;
     h->step = nullptr;
 }
@@ -138,6 +147,12 @@ int g_fuse_small = [] {
 int g_merge_in_rollout = [] {
     const char *v = std::getenv("COVO_MERGE_IN_ROLLOUT");
     return v ? std::atoi(v) : 0;
+}();
+// COVO_STREAM_GEMM=0 / covo_debug_set_stream_gemm(0): covo-online's noise GEMM as a launch of its own behind the Sigma chain's
+// finalize launch (rounds 1-4) instead of streamed under the factorisation inside it (sigma_ns.hip: ns_finalize_stream_kernel)
+int g_stream_gemm = [] {
+    const char *v = std::getenv("COVO_STREAM_GEMM");
+    return v ? std::atoi(v) : 1;
 }();
 static int g_dbg_step_mask = 63;  // (1: unused, the begin launch is not part of the graph) 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
 
@@ -181,9 +196,24 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         CovDeferred cov;
         std::memset(&cov, 0, sizeof(cov));
         const bool defer = (M & 8) && g_dbg_sigma_stages >= 4;
+        // the GEMM streamed under the factorisation, inside the chain's last launch (one matrix, persistent launches allowed)
+        StreamGemmArgs sg;
+        sg.mu = am_shift;
+        sg.dyn = st->dyn;
+        sg.sample_offset = a.sample_offset;
+        sg.N = N;
+        sg.a_out = a.a;
+        sg.L_stream = st->L;
+        sg.sync = st->sync;
+        sg.a_cov_out = Sig;
+        sg.nanp = covo_propagate_nan(h) ? 1 : 0;
+        const bool want_stream = g_stream_gemm && (M & 4) && (M & 8) && g_dbg_sigma_stages >= 4;
+        bool streamed = false;
         if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen, h->status_dev,
-                                             (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, defer ? &cov : nullptr, stats))) return rc;
-        if (ahead) {
+                                             (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, defer ? &cov : nullptr, stats,
+                                             want_stream ? &sg : nullptr, &streamed))) return rc;
+        if (streamed) {
+        } else if (ahead) {
             if ((M & 8) && (rc = launch_noise_gemm(st->L, am_shift, reinterpret_cast<const float *>(st->eps_tiled), 0, 0,
                                                    a.sample_offset, N, a.a, s, nullptr, nullptr, 0, 1, true, &cov, covo_propagate_nan(h))))
                 return rc;
@@ -274,7 +304,7 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s,
                        args->a_mean_in ? args->a_mean_in : args->a_mean,
                        args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
-                       shared_noise_scale, blk, (args->mode == COVO_MODE_MPPI && !small) ? args->a_cov : (float *)nullptr, st->Ls);
+                       shared_noise_scale, blk, (args->mode == COVO_MODE_MPPI && !small) ? args->a_cov : (float *)nullptr, st->Ls, st->sync);
 
     StepKey k;
     std::memset(&k, 0, sizeof(k));
@@ -342,7 +372,7 @@ int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const 
         hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, run,
                            args->a_mean_in ? args->a_mean_in : args->a_mean,
                            args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys, 0.0f,
-                           blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls);
+                           blk, args->mode == COVO_MODE_MPPI ? args->a_cov : (float *)nullptr, st->Ls, st->sync);
         COVO_CHECK_HIP(hipStreamSynchronize(run));
     }
     g_dbg_step_mask = step_mask;
@@ -353,7 +383,11 @@ int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const 
     int rc = 0;
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-        for (int r = 0; r < reps && !rc; ++r) rc = enqueue_step(h, st, *params, *args, cs);
+        for (int r = 0; r < reps && !rc; ++r) {
+            if (args->mode == COVO_MODE_COVO_ONLINE && g_stream_gemm && (step_mask & 12) == 12)
+                hipLaunchKernelGGL(stream_seq_bump_kernel, dim3(1), dim3(1), 0, cs, st->sync);
+            rc = enqueue_step(h, st, *params, *args, cs);
+        }
         e = hipStreamEndCapture(cs, &g);
     }
     g_dbg_step_mask = 63;

@@ -372,6 +372,11 @@ int covo_debug_set_fuse_small(int on);
  * captured step graphs. */
 int covo_debug_set_merge_in_rollout(int on);
 
+/* 0: covo-online's noise GEMM runs as a launch of its own behind the Sigma chain (rounds 1-4) instead of streamed under the
+ * factorisation inside the chain's finalize launch (the default for one matrix on a GPU of one's own; COVO_STREAM_GEMM=0 in the
+ * environment).  Same actions, a_cov and means bit for bit.  Drops captured step graphs. */
+int covo_debug_set_stream_gemm(int on);
+
 /* Debug aid: copy `count` doubles from offset `offset_doubles` of the Sigma pipeline's scratch (layout in
  * sigma_ns.hip: 12 matrices [batch][128][128], then 64 scalars per matrix) to `out` (device). */
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);

@@ -1271,3 +1271,43 @@ def test_merge_inside_the_rollout_launch_equals_the_merge_launch(name, N, lam, g
     for step, (f, s) in enumerate(zip(*res)):
         assert torch.equal(f[0], s[0]) and torch.equal(f[1], s[1]), (name, N, graph, step, (f[0] - s[0]).abs().max().item())
     assert torch.isfinite(res[0][-1][0]).all()
+
+
+@pytest.mark.parametrize("N,lam", [(65536, "0.01"), (4096, "0.01"), (1000, "1.0"), (70000, "0.01")])
+@pytest.mark.parametrize("graph", ["graph", "eager"])
+def test_streamed_gemm_equals_the_gemm_launch(N, lam, graph, monkeypatch):
+    """covo-online's noise GEMM streamed under the factorisation inside the Sigma chain's finalize launch (the default for one
+    matrix; sigma_ns.hip: ns_finalize_stream_kernel -- one workgroup factors and sends panel after panel, the others multiply)
+    against the GEMM as a launch of its own behind the chain (covo_debug_set_stream_gemm(0)): actions, costs, a_cov and the new
+    mean bit for bit -- at the headline size (8 worker waves own two tiles), a small one (most workers idle), a ragged count, one
+    beyond 65 536, eager and as a captured graph, with and without the position statistics."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
+    lib = _lib.load_library()
+    params = env.default_params
+    res = []
+    try:
+        for on in (1, 0):
+            _lib.check(lib.covo_debug_set_stream_gemm(on), "stream_gemm")
+            c, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam{lam}", device=DEV, compute_info=(N == 4096))
+            obs, info, state = env.reset(cr.PRNGKey(34), params)
+            cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
+            key = cr.PRNGKey(36)
+            out = []
+            for step in range(4):
+                key, k_act, k_step = cr.split(key, 3)
+                u, cp, _ = c(obs, state, params, k_act, cp, info)
+                out.append((cp.a_mean.clone(), c.core.a.clone(), c.core.cost.clone(), cp.a_cov.clone()))
+                obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
+            assert c.core.device_status() == 0
+            res.append(out)
+            c.core.close()
+    finally:
+        _lib.check(lib.covo_debug_set_stream_gemm(1), "stream_gemm")
+    for step, (f, s) in enumerate(zip(*res)):
+        for what, x, y in zip(("a_mean", "a", "cost", "a_cov"), f, s):
+            assert torch.equal(x, y), (N, graph, step, what, (x - y).abs().max().item())
+    assert torch.isfinite(res[0][-1][0]).all() and torch.isfinite(res[0][-1][3]).all()
