@@ -1653,14 +1653,14 @@ struct StreamHook {
     }
 };
 
-// wait until k-group G of L_stream (its second panel's flag: the flags go up in panel order) carries this step's sequence number
-template <int G>
-__device__ __forceinline__ bool stream_wait_kgroup(const StreamGemmArgs &S, unsigned seq, int *flag_lds)
+// wait until panel P of L_stream carries this step's sequence number (the flags go up in panel order: panel 2 G + 1 = k-group G)
+template <int P>
+__device__ __forceinline__ bool stream_wait_panel(const StreamGemmArgs &S, unsigned seq, int *flag_lds)
 {
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
         int good = 1;
-        while (__hip_atomic_load(S.sync + 1 + (2 * G + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+        while (__hip_atomic_load(S.sync + 1 + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 20000000LL) {  // 0.2 s: the factoring workgroup is gone
                 good = 0;
@@ -1671,6 +1671,23 @@ __device__ __forceinline__ bool stream_wait_kgroup(const StreamGemmArgs &S, unsi
     }
     __syncthreads();
     return *flag_lds != 0;
+}
+// panel P alone: columns [16 P, 16 P + 16), rows from the k-group's first row on (<= 512 float4 chunks: one per thread)
+template <int P>
+__device__ __forceinline__ void stream_stage_panel(const float *__restrict__ L, float *__restrict__ Ls, int tid)
+{
+    constexpr int R0 = 32 * (P / 2), CHUNKS = (COVO_NA - R0) * 4;
+    if (tid < CHUNKS) {
+        const int i = R0 + (tid >> 2), k4 = 16 * P + 4 * (tid & 3);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(L + (size_t)i * COVO_NA + k4);
+        const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float *d = Ls + i * NG_LDA + k4;
+        d[0] = (k4 + 0 <= i) ? __uint_as_float((unsigned)lo) : 0.0f;
+        d[1] = (k4 + 1 <= i) ? __uint_as_float((unsigned)(lo >> 32)) : 0.0f;
+        d[2] = (k4 + 2 <= i) ? __uint_as_float((unsigned)hi) : 0.0f;
+        d[3] = (k4 + 3 <= i) ? __uint_as_float((unsigned)(hi >> 32)) : 0.0f;
+    }
 }
 // columns [32 G, 32 G + 32) x rows [32 G, 128) of L_stream -> the padded LDS image (ng_stage_factor's layout and masking)
 template <int G>
@@ -1899,26 +1916,36 @@ __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *_
         for (int i = 0; i < 4; ++i) bx.c[i] = epsx[(4 * g + i) * 64 + lane];
         return bx;
     };
-#define STREAM_KGROUP(G)                                                                                          \
+    // panel by panel: a sync point costs ~1 us of flag + staging latency, but a worker that is through with panel p before panel
+    // p + 1 is final -- epsilon is in registers, a panel's share of the MFMAs takes less than the panel's factorisation -- pays it
+    // while it would wait anyway; behind the LAST panel there are then 8 MFMAs per tile instead of 16
+#define STREAM_PANEL(P)                                                                                           \
     do {                                                                                                          \
-        ok = stream_wait_kgroup<G>(S, seq, &flag_lds) && ok;                                                      \
-        if (wst) wst[1 + 3 * (G)] = (double)wall_clock64();                                                       \
-        stream_stage_kgroup<G>(S.L_stream, Ls, tid);                                                              \
+        constexpr int G_ = (P) / 2, H_ = (P) & 1;                                                                 \
+        ok = stream_wait_panel<P>(S, seq, &flag_lds) && ok;                                                       \
+        if (wst) wst[1 + 3 * (P)] = (double)wall_clock64();                                                       \
+        stream_stage_panel<P>(S.L_stream, Ls, tid);                                                               \
         __syncthreads();                                                                                          \
-        if (wst) wst[2 + 3 * (G)] = (double)wall_clock64();                                                       \
-        if (has0) mfma_group<G, 15>(La, bq[G], acc0);                                                             \
-        if (xrole == 1) mfma_group<G, 8>(La, xgroup(G), accx);                                                    \
-        else if (xrole == 2) mfma_group<G, 4>(La, xgroup(G), accx);                                               \
-        else if (xrole == 3) mfma_group<G, 3>(La, xgroup(G), accx);                                               \
-        if (has0) store_rt(G, t0, acc0);                                                                          \
-        if ((G == 3 && xrole == 1) || (G == 2 && xrole == 2) || (G < 2 && xrole == 3)) store_rt(G, ex, accx);    \
-        if (wst) wst[3 + 3 * (G)] = (double)wall_clock64();                                                       \
+        if (wst) wst[2 + 3 * (P)] = (double)wall_clock64();                                                       \
+        if (has0) mfma_half<G_, H_, 15>(La, bq[G_], acc0);                                                        \
+        if (xrole == 1) mfma_half<G_, H_, 8>(La, xgroup(G_), accx);                                               \
+        else if (xrole == 2) mfma_half<G_, H_, 4>(La, xgroup(G_), accx);                                          \
+        else if (xrole == 3) mfma_half<G_, H_, 3>(La, xgroup(G_), accx);                                          \
+        if (H_ == 1) {                                                                                            \
+            if (has0) store_rt(G_, t0, acc0);                                                                     \
+            if ((G_ == 3 && xrole == 1) || (G_ == 2 && xrole == 2) || (G_ < 2 && xrole == 3)) store_rt(G_, ex, accx); \
+        }                                                                                                         \
+        if (wst) wst[3 + 3 * (P)] = (double)wall_clock64();                                                       \
     } while (0)
-    STREAM_KGROUP(0);
-    STREAM_KGROUP(1);
-    STREAM_KGROUP(2);
-    STREAM_KGROUP(3);
-#undef STREAM_KGROUP
+    STREAM_PANEL(0);
+    STREAM_PANEL(1);
+    STREAM_PANEL(2);
+    STREAM_PANEL(3);
+    STREAM_PANEL(4);
+    STREAM_PANEL(5);
+    STREAM_PANEL(6);
+    STREAM_PANEL(7);
+#undef STREAM_PANEL
     if (!ok && tid == 0 && status != nullptr)
         __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
