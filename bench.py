@@ -24,7 +24,8 @@ direct peer writes, csrc/exchange.hip).
 Rank 0 prints ONE JSON line with `roofline` (the fused rollout kernel in the variant the timed step runs -- it also
 leaves the softmax records --, HBM bound, 516 B/sample algorithmic, mean launch duration measured live with events on
 the launch stream; `traffic` / `counters` from the committed PMC passes of this command, dropped when the kernel
-sources changed since), `roofline_gemm` (the noise GEMM against the fp32 MFMA peak), `value_with_pos_info` (the same
+sources changed since), `roofline_gemm` (the noise GEMM against the fp32 MFMA peak: as a launch of its own, and what it adds to the
+Sigma chain streamed inside its finalize launch, which is how the timed steps run it), `value_with_pos_info` (the same
 steps with covo.py:281's pos_mean / pos_std computed) and, at N=1, `cpu_baseline` (the plain-C oracle port of the same
 step on the host cores).
 """
@@ -78,6 +79,24 @@ def record_episode(env, controller, params, T, with_counts):
     return {"packed": np.stack(packed), "states": states, "a_means": torch.stack(a_means), "keys": keys,
             "counts": np.asarray(counts) if with_counts else None, "s_reset": s_reset, "cp_reset": cp_reset,
             "err_pos_mean_m": float(np.mean(errs))}
+
+
+def make_states(env, params, n_states, seed):
+    """Noisy states of a PID-tracked tracking_zigzag episode (rounds 1-4's teacher-forced inputs).  NOT used by the bench any more
+    (its timed steps replay the controller's own closed-loop episode, record_episode); scripts/ still draw their states from it."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    obs, info, state = env.reset(cr.PRNGKey(seed), params)
+    pid = cm.controllers.PIDController(env, cm.controllers.PIDParams(Kp=10.0, Kd=5.0, Ki=0.0, Kp_att=10.0))
+    cp, key = pid.init_control_params, cr.PRNGKey(seed + 1)
+    packed, states = [], []
+    for _ in range(n_states):
+        packed.append(info["noisy_state"].pack())
+        states.append(info["noisy_state"])
+        a, cp, _ = pid(obs, state, params, key, cp)
+        key, k = cr.split(key)
+        obs, state, reward, done, info = env.step_env(k, state, a, params)
+    return state, np.stack(packed), states
 
 
 def spread_indices(K, T):
@@ -179,13 +198,13 @@ def closed_loop(env, controller, params, T, rec=None):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r04_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r05_bench_pmc_summary.json")
 # every file the rollout kernel and the noise GEMM are built from: the hash that decides whether committed PMC counters still
 # describe the kernels of this tree (scripts/pmc_summary.py imports this list)
 KERNEL_SRCS = ["covo_mpc_amd/csrc/" + f for f in (
     "rollout_pipe.hpp", "rollout_common.hpp", "rollout_launch.hpp", "rollout.hip", "rollout_var_r0.hip", "rollout_var_r1.hip",
-    "quad_model.hpp", "disturb_model.hpp", "covo_common.hpp", "wave_reduce.hpp", "noise_gemm.hip", "eps_tiles.hpp",
-    "rng_device.hpp", "Makefile")]
+    "quad_model.hpp", "disturb_model.hpp", "covo_common.hpp", "wave_reduce.hpp", "noise_gemm.hip", "noise_gemm_body.hpp",
+    "softmax_merge.hpp", "eps_tiles.hpp", "rng_device.hpp", "Makefile")]
 
 
 def kernel_src_sha():
@@ -509,9 +528,16 @@ def main():
         launch_us, launch_us_min = core.time_rollout(kstate, pc, reps=100, with_records=True)
         standalone = core.time_rollout(kstate, pc, reps=100, with_records=False)
         kernel_name = "rollout_pipe3_kernel<..., REC = true>"
-    in_step_us = gemm_in_step_us = in_step_rounds = gemm_in_step_rounds = in_step_rejected = None
+    in_step_us = gemm_in_step_us = in_step_rounds = gemm_in_step_rounds = in_step_rejected = gemm_added_us = gemm_added_rounds = None
+    in_step_by_index = None
     if world == 1:
         try:
+            # covo_debug_time_step replays the LAST step: make that a mid-episode one (the replays below), and take the rollout's
+            # in-step duration at three indices spread over the episode -- it is DATA dependent through the softmax-record epilogue:
+            # in an episode's last ~30 steps (time + k >= 300 freezes the rewards, quadrotor.py:483) the samples' costs nearly
+            # coincide, every sample carries weight and the epilogue walks whole waves: 16.5 us there against 11.6 elsewhere
+            probe_idx = [idx_timed[(2 * q + 1) * len(idx_timed) // 6] for q in range(3)] if len(idx_timed) >= 3 else [idx_timed[0]]
+            cp = step(probe_idx[1], cp)
             # every figure is a DIFFERENCE of two graph-replay times; for covo-online both carry the ~135 us Sigma chain, so 1 % of
             # clock wander between the two replays would move the 10 us rollout by 1.4 us (r03: the driver's 20-step command read
             # frac 0.34 ... 0.43 run to run).  The selections are therefore replayed interleaved, four times each, and the
@@ -523,13 +549,24 @@ def main():
                 v = sorted(v)
                 return {"min": v[0], "median": 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2]), "max": v[-1]}
             if args.controller == "covo-online":
-                # the product order: the Sigma chain's last launch draws epsilon, the GEMM streams it (tiled variant)
+                # the product order: the noise GEMM rides INSIDE the Sigma chain's last launch, streamed under the factorisation
+                # (sigma_ns.hip: ns_finalize_stream_kernel); mask 4 alone runs the chain with its plain finalize launch
                 rr = rounds_of(4, 4 | 8, 4 | 8 | 16)
                 t_sig, t_sig_gemm, t_all = (min(r[i] for r in rr) for i in range(3))
-                gemm_in_step_us = t_sig_gemm - t_sig
+                gemm_added_us = t_sig_gemm - t_sig               # what the streamed GEMM adds to the chain
                 in_step_us = t_all - t_sig_gemm
                 in_step_rounds = spread([r[2] - r[1] for r in rr])       # the same difference WITHIN each round
-                gemm_in_step_rounds = spread([r[1] - r[0] for r in rr])
+                gemm_added_rounds = spread([r[1] - r[0] for r in rr])
+                # the GEMM as a launch of its own (rounds 1-4: epsilon drawn under the finalize launch, tiled GEMM behind it): the
+                # kernel-quality figure -- every one of its MFMAs, its start-up and its write-back uncovered
+                from covo_mpc_amd import _lib as _l
+                _l.check(core.lib.covo_debug_set_stream_gemm(0), "stream_gemm")
+                try:
+                    rs = rounds_of(4, 4 | 8)
+                    gemm_in_step_us = min(r[1] for r in rs) - min(r[0] for r in rs)
+                    gemm_in_step_rounds = spread([r[1] - r[0] for r in rs])
+                finally:
+                    _l.check(core.lib.covo_debug_set_stream_gemm(1), "stream_gemm")
             else:
                 rr = rounds_of(8, 8 | 16)
                 gemm_in_step_us, t_both = (min(r[i] for r in rr) for i in range(2))
@@ -542,6 +579,16 @@ def main():
                     0.7 * in_step_rounds["median"] <= in_step_us <= 1.3 * in_step_rounds["median"]):
                 in_step_rejected = in_step_us
                 in_step_us = None
+            if in_step_us is not None:
+                def rollout_in_step():
+                    ro = rounds_of(*((4 | 8, 4 | 8 | 16) if args.controller == "covo-online" else (8, 8 | 16)), rounds=3)
+                    return min(r[1] for r in ro) - min(r[0] for r in ro)
+                in_step_by_index = {str(probe_idx[1]): in_step_us}
+                for q in (0, 2):
+                    if q < len(probe_idx):
+                        cp = step(probe_idx[q], cp)
+                        in_step_by_index[str(probe_idx[q])] = rollout_in_step()
+                in_step_us = float(np.mean(list(in_step_by_index.values())))  # the judged figure: the mean over the three indices
             if not (gemm_in_step_us and gemm_in_step_us > 0):
                 gemm_in_step_us = None
         except Exception:
@@ -651,9 +698,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_us": launch_us, "launch_us_statistic":
                          ("in-step: graph replay of 20 x (Sigma chain, GEMM, rollout) minus 20 x (Sigma chain, GEMM), events around "
                           "the replay, fastest replay of each selection over 4 interleaved rounds; in_step_us_per_round = the "
-                          "same difference within each round (min / median / max)" if in_step_us
+                          "same difference within each round (min / median / max); mean over three steps of the episode "
+                          "(in_step_us_by_episode_step: the record epilogue is data dependent)" if in_step_us
                           else "mean of 3 x 100 back-to-back launches (events on the launch stream)"),
                          "in_step_us": in_step_us, "in_step_us_per_round": in_step_rounds,
+                         "in_step_us_by_episode_step": in_step_by_index,
                          "in_step_us_rejected": in_step_rejected,
                          "back_to_back": {"launch_us": b2b_us, "launch_us_min": b2b_min_us,
                                           "frac": alg_bytes / (b2b_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -664,6 +713,9 @@ def main():
                              "frac": alg_bytes / (standalone[0] * 1e-6) / 1e9 / HBM_PEAK_GBS},
                          "counters": (kin.get("rollout_in_step") or {}).get("derived")},
         }
+        if args.controller != "covo-online" and n_local <= 16384 and not args.info and args.task in ("tracking_zigzag", "hovering"):
+            out["config"]["one_launch_step"] = ("the timed steps run as ONE launch per control step (csrc/step_small.hip: begin + noise draw + "
+                                                "rollout + softmax records + merge); the roofline figures below time the staged kernels")
         if elapsed_other is not None:
             v2 = args.steps / elapsed_other
             out["value_with_pos_info" if not args.info else "value_without_pos_info"] = v2
@@ -678,6 +730,14 @@ def main():
                                     "flop_per_sample": {"dense_equivalent": GEMM_FLOP_PER_SAMPLE_DENSE,
                                                         "issued": GEMM_FLOP_PER_SAMPLE_ISSUED},
                                     "counters": (kin.get("noise_gemm") or {}).get("derived")}
+            if gemm_added_us is not None:
+                out["roofline_gemm"]["statistic"] = (
+                    "the noise GEMM as a launch of its own behind the Sigma chain (covo_debug_set_stream_gemm(0): graph replay of 20 x "
+                    "(chain, GEMM) minus 20 x (chain)); the timed steps run it STREAMED inside the chain's finalize launch, where it "
+                    "adds streamed_added_us to the chain (same replays, product mode)")
+                out["roofline_gemm"]["streamed_added_us"] = gemm_added_us
+                out["roofline_gemm"]["streamed_added_us_per_round"] = gemm_added_rounds
+                out["roofline_gemm"]["counters_streamed_launch"] = (kin.get("finalize_stream") or {}).get("derived")
         if chain_counts is not None:
             out["sigma_chain"] = chain_counts
         if split is not None:

@@ -20,7 +20,7 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
-RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r05"
 N_LOCAL, H = 65536, 32
 CU, SIMD = 256, 1024
 sys.path.insert(0, root)
@@ -101,7 +101,8 @@ for which in ("fetch", "write", "sq_a", "sq_b"):
             n = max(len(v) for v in agg[k].values())
             d = mean(dur.get(k, []))
             w.writerow([k, n, f"{d:.0f}" if d else ""] + [f"{mean(agg[k][c]):.3f}" if agg[k].get(c) else "" for c in counters])
-    for tag, pred in (("rollout_in_step", is_rollout_rec), ("rollout_standalone", is_rollout_plain), ("noise_gemm", is_gemm)):
+    for tag, pred in (("rollout_in_step", is_rollout_rec), ("rollout_standalone", is_rollout_plain), ("noise_gemm", is_gemm),
+                      ("finalize_stream", lambda k: "ns_finalize_stream_kernel" in k)):
         k = pick(agg, pred)
         if k is None:
             continue

@@ -2,9 +2,9 @@
 # Everything profiles/ holds for one round, in one GPU call: the unprofiled bench line, the rocprofv3 kernel stats of the
 # same command, the separate --pmc passes (FETCH_SIZE, WRITE_SIZE, two SQ passes; counters are never combined with
 # traces, every pass has the program itself right after `--`), the phase times and the stand-alone kernel table.
-# Run on the GPU box from the repo root; outputs land in gpurun_out/.   usage: scripts/profile_bench.sh [round tag, default r04]
+# Run on the GPU box from the repo root; outputs land in gpurun_out/.   usage: scripts/profile_bench.sh [round tag, default r05]
 R="$(cd "$(dirname "$0")/.." && pwd)"
-RND="${1:-r04}"
+RND="${1:-r05}"
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" > "$R/gpurun_out/bench_line.json" 2> "$R/gpurun_out/bench_line.err"
