@@ -1311,3 +1311,33 @@ def test_streamed_gemm_equals_the_gemm_launch(N, lam, graph, monkeypatch):
         for what, x, y in zip(("a_mean", "a", "cost", "a_cov"), f, s):
             assert torch.equal(x, y), (N, graph, step, what, (x - y).abs().max().item())
     assert torch.isfinite(res[0][-1][0]).all() and torch.isfinite(res[0][-1][3]).all()
+
+
+def test_sigma_batch_beyond_residency_persistent_equals_shared_device():
+    """the batched persistent launches of the Sigma chain (and, since round 5, the sibling factorisations of B inside the
+    finalize launch: 2 x 300 single-CU workgroups) rely on in-order dispatch once the grid exceeds what is resident -- covo-offline's
+    300-row table is such a batch.  300 matrices, persistent launches against COVO_FLAG_SHARED_DEVICE (every phase its own launch):
+    Sigma and L bit for bit, finite, and a clean device status (no barrier / flag time-out)."""
+    rng = np.random.default_rng(11)
+    n = 128
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    base = []
+    G = rng.standard_normal((n, n)); base.append(0.05 * (G + G.T))
+    w = np.concatenate([[-2.0, -1.1, -0.7], np.geomspace(0.01, 900.0, n - 3)]); base.append((Q * w) @ Q.T)
+    w = np.concatenate([np.abs(rng.standard_normal(20)) * 50, rng.standard_normal(108) * 0.05]); base.append((Q * w) @ Q.T)
+    mats = np.stack([base[i % 3] * (1.0 + 0.01 * i) + 0.003 * i * np.eye(n) for i in range(300)])
+    R_d = torch.from_numpy(np.ascontiguousarray(mats)).to(DEV)
+    outs = []
+    for shared in (False, True):
+        core = SamplingCore(256, 32, 0.01, 1.0, device=DEV, shared_device=shared)
+        Sig, L = core.sigma(R_d, 0.5, batch=300)
+        torch.cuda.synchronize()
+        assert core.device_status() == 0
+        outs.append((Sig.clone(), L.clone()))
+        core.close()
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = np.linalg.eigh(mats[7])
+    lam = ref[0] - ref[0].min() + 1e-2
+    S7 = (ref[1] * np.exp(0.5 * (2 * np.log(0.5) * 2 + np.log(lam).sum() / n) - 0.5 * np.log(lam))) @ ref[1].T
+    assert np.linalg.norm(outs[0][0][7].cpu().numpy() - S7) / np.linalg.norm(S7) < 1e-6
