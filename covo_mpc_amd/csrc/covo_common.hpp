@@ -176,13 +176,24 @@ int launch_merge_cov(const float *records, int G, int stride, float lam, const f
 int launch_shift_mean(const float *in, float *out, hipStream_t s);
 size_t hessian_workspace_bytes(int batch);
 struct SymStatsOut;  // sym_stats.hpp
+// the step's begin work folded into the Hessian's first launch (eager covo-online steps; hessian_adj.hip: AdjArgs): the
+// caller's unshifted mean, where the per-step scalars and the sequence number live, and the 48-byte block of step_begin.hpp
+struct HessBegin {
+    const float *a_mean_raw;
+    uint32_t *dyn_out;
+    unsigned *seq;
+    const void *blk;  // DynBlock
+    int derive_keys;
+    float shared_noise_scale;
+};
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev = nullptr,
                    size_t traj_stride = 0,
                    const SymStatsOut *stats = nullptr,   // KD also leaves the Sigma chain's input statistics (sym_stats.hpp)
                    const float *f_tab = nullptr,         // [batch][H][4] per-step disturbance table (disturb.hip), device
                    const void *models_dev = nullptr,     // dm::Model[batch] next to consts_dev (drag / mixed with per-instance parameters)
-                   int *status_dev = nullptr);           // the handle's sticky status word: COVO_DEVSTAT_ADJOINT on a costate time-out
+                   int *status_dev = nullptr,            // the handle's sticky status word: COVO_DEVSTAT_ADJOINT on a costate time-out
+                   const HessBegin *begin = nullptr);    // batch 1: KB also does the step's begin work (a_mean = where the shifted mean goes)
 // true: launch_hessian leaves R's Sigma-chain statistics when asked to (the adjoint kernels do, for every disturbance model;
 // launch_hessian_pairs does not)
 inline bool hessian_leaves_stats(const covo_env_params &p)

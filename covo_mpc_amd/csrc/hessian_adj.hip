@@ -31,8 +31,10 @@
 #include "covo_common.hpp"
 #include "wave_reduce.hpp"
 #include <cstdlib>
+#include <cstring>
 #include "sym_stats.hpp"
 #include "disturb_model.hpp"
+#include "step_begin.hpp"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -56,6 +58,16 @@ struct AdjArgs {
     double drag_off[3];              // disturb_params[:3] / 2
     const dm::Model *models;         // per batch entry next to cs (device, nullable): overrides drag_k / drag_off
     int *status;                     // the handle's sticky device status (nullable): COVO_DEVSTAT_ADJOINT when a costate wait times out
+    // the step's begin work folded into KB (eager covo-online steps; launch_hessian's HessBegin): a_mean_raw != null -> KB reads the
+    // UNSHIFTED mean through the shift's index map (covo.py:201-203) and its workgroup (0, 0) leaves what step_begin_kernel would
+    // have left for the launches that follow: the shifted mean (a_mean points there: KC / KD read it a launch later), the per-step
+    // scalars derived from the raw rng_act (step_begin.hpp) and the bumped sequence number
+    const float *a_mean_raw;
+    uint32_t *dyn_out;
+    unsigned *seq;
+    DynBlock blk;
+    int derive_keys;
+    float shared_noise_scale;
 };
 
 __host__ __device__ inline double adj_drag_coeff(const dm::Model &m)
@@ -85,7 +97,8 @@ size_t hessian_workspace_bytes(int batch) { return (size_t)batch * WS_COUNT_MAX 
 
 int launch_hessian(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *a_mean, int batch, double *R, void *workspace, hipStream_t s, const void *consts_dev,
-                   size_t traj_stride, const SymStatsOut *stats, const float *f_tab, const void *models_dev, int *status_dev)
+                   size_t traj_stride, const SymStatsOut *stats, const float *f_tab, const void *models_dev, int *status_dev,
+                   const HessBegin *begin)
 {
     const bool fs = p.disturb_kind == COVO_DISTURB_DRAG || p.disturb_kind == COVO_DISTURB_MIXED;
     if (fs && (consts_dev != nullptr) != (models_dev != nullptr)) {
@@ -112,6 +125,20 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.pos_traj = pos_traj;
     A.vel_traj = vel_traj;
     A.a_mean = a_mean;
+    A.a_mean_raw = nullptr;
+    A.dyn_out = nullptr;
+    A.seq = nullptr;
+    std::memset(&A.blk, 0, sizeof(A.blk));
+    A.derive_keys = 0;
+    A.shared_noise_scale = 0.0f;
+    if (begin != nullptr && batch == 1 && (g_dbg_hess_mask & 1)) {
+        A.a_mean_raw = begin->a_mean_raw;
+        A.dyn_out = begin->dyn_out;
+        A.seq = begin->seq;
+        std::memcpy(&A.blk, begin->blk, sizeof(A.blk));
+        A.derive_keys = begin->derive_keys;
+        A.shared_noise_scale = begin->shared_noise_scale;
+    }
     A.R = R;
     A.ws = reinterpret_cast<double *>(workspace);
     A.T = T;

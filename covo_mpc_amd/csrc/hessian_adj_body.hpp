@@ -151,7 +151,18 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
 {
     const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const float *__restrict__ st = A.state + (size_t)b * COVO_STATE_FLOATS;
-    const float *__restrict__ am = A.a_mean + (size_t)b * NA;
+    // the mean this step plans around: the shifted one from memory, or (begin work folded in) the caller's unshifted one read through
+    // the shift's index map -- entry i of the shifted mean is entry i + 4 of the old one, the last four repeat (covo.py:201-203)
+    const bool raw = A.a_mean_raw != nullptr;
+    const float *__restrict__ am_base = raw ? A.a_mean_raw : A.a_mean + (size_t)b * NA;
+    auto am = [&](int i) { return am_base[(raw && i < NA - 4) ? i + 4 : i]; };
+    if (raw && k == 0) {  // what step_begin_kernel leaves for the launches behind this one
+        float *shift_out = const_cast<float *>(A.a_mean);
+        shift_out[lane] = am(lane);
+        shift_out[lane + 64] = am(lane + 64);
+        if (lane < 4) step_begin_derive(lane, A.blk, A.derive_keys, A.shared_noise_scale, A.dyn_out);
+        if (lane == 4 && A.seq != nullptr) A.seq[0] = A.seq[0] + 1u;
+    }
     double *__restrict__ ws = A.ws + (size_t)b * WS_COUNT;
     if (lane < 16) {  // rows k (and 32, by the last wave) of the costate buffer: "not yet stored" for KC's launch (ADJ_LAM_UNSET)
         reinterpret_cast<unsigned long long *>(ws + WS_LAM)[16 * k + lane] = ADJ_LAM_UNSET;
@@ -179,8 +190,8 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
         sfd[lane][0] = f[0]; sfd[lane][1] = f[1]; sfd[lane][2] = f[2];
     }
     if (lane < HH) {
-        const double a0 = qm::clip11_((double)am[4 * lane + 0]), a1 = qm::clip11_((double)am[4 * lane + 1]);
-        const double a2 = qm::clip11_((double)am[4 * lane + 2]), a3 = qm::clip11_((double)am[4 * lane + 3]);
+        const double a0 = qm::clip11_((double)am(4 * lane + 0)), a1 = qm::clip11_((double)am(4 * lane + 1));
+        const double a2 = qm::clip11_((double)am(4 * lane + 2)), a3 = qm::clip11_((double)am(4 * lane + 3));
         sact[lane][0] = (a0 + 1.0) * c.thrust_half;
         sact[lane][1] = a1 * c.komega[0];
         sact[lane][2] = a2 * c.komega[1];
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
         qm::D1 act[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const qm::D1 x{(double)am[4 * k + d], lane == NX + d ? 1.0 : 0.0};
+            const qm::D1 x{(double)am(4 * k + d), lane == NX + d ? 1.0 : 0.0};
             act[d] = qm::clip11_(qm::clip11_(x));  // quadrotor.py:223 and :258
         }
 #if ADJ_FS

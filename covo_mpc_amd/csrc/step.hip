@@ -154,17 +154,24 @@ int g_stream_gemm = [] {
     const char *v = std::getenv("COVO_STREAM_GEMM");
     return v ? std::atoi(v) : 1;
 }();
+int g_fold_begin = [] {
+    const char *v = std::getenv("COVO_FOLD_BEGIN");
+    return v ? std::atoi(v) : 1;
+}();
 static int g_dbg_step_mask = 63;  // (1: unused, the begin launch is not part of the graph) 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
 
 // the launch sequence of one step (everything reads per-step scalars from st->dyn)
-static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, const covo_step_args &a, hipStream_t s)
+// begin != null (eager covo-online steps): no begin launch ran -- the Hessian's first launch does its work (HessBegin) and every
+// launch reads the caller's state where it lies (state_direct) instead of the fixed-address copy
+static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, const covo_step_args &a, hipStream_t s,
+                        const HessBegin *begin = nullptr, const float *state_direct = nullptr)
 {
     const int M = g_dbg_step_mask;
     const int N = a.n_samples;
     const float *fdev = reinterpret_cast<const float *>(st->dyn + 2);
     float *am_shift = a.a_mean_shift ? a.a_mean_shift : st->a_mean_shift;
     int rc;
-    const float *state = st->state_buf;
+    const float *state = state_direct ? state_direct : st->state_buf;
     // covo-offline / MPPI at small N: noise -> rollout -> records -> merge as ONE launch (the begin launch has left the step's
     // scalars in st->dyn and the state in st->state_buf; MPPI: it has NOT touched a_cov, the fused launch shifts and factors)
     if (M == 63 && g_fuse_small && step_small_eligible(h, p, a))
@@ -179,7 +186,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         const bool stats = (M & 2) && (M & 4) && (g_dbg_hess_mask & 15) == 15 && hessian_leaves_stats(p);
         const SymStatsOut so = sigma_ns_stats_out(h->ws_sigma);
         if ((M & 2) && (rc = launch_hessian(state, a.pos_traj, a.vel_traj, a.T, p, am_shift, 1, st->R, h->ws_hess, s, nullptr, 0,
-                                            stats ? &so : nullptr, tables ? st->f_tab_hess : nullptr, nullptr, h->status_dev)))
+                                            stats ? &so : nullptr, tables ? st->f_tab_hess : nullptr, nullptr, h->status_dev, begin)))
             return rc;  // :134-185
         float *Sig = a.a_cov ? a.a_cov : st->Sigma;
         // epsilon needs only the act key: it is drawn under the chain's single-workgroup finalize launch, the GEMM loads it
@@ -301,6 +308,20 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
         return launch_step_small(h, *params, *args, args->state, args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, &blk,
                                  nullptr, shared_noise_scale, st->ticket, s);
     }
+    // eager covo-online steps (no per-step force tables, whose launch precedes the Hessian and reads the scalars): the begin work
+    // rides in the Hessian's first launch -- one launch boundary less (COVO_FOLD_BEGIN=0 keeps the begin launch)
+    if (g_fold_begin && args->mode == COVO_MODE_COVO_ONLINE && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 && g_dbg_hess_mask == 15 &&
+        !(params->disturb_kind >= COVO_DISTURB_PERIODIC && params->disturb_kind <= COVO_DISTURB_MIXED)) {
+        HessBegin hb;
+        hb.a_mean_raw = args->a_mean_in ? args->a_mean_in : args->a_mean;
+        hb.dyn_out = st->dyn;
+        hb.seq = st->sync;
+        hb.blk = &blk;
+        hb.derive_keys = args->derive_keys;
+        hb.shared_noise_scale = shared_noise_scale;
+        st->have_key = false;
+        return enqueue_step(h, st, *params, *args, s, &hb, args->state);
+    }
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(COVO_NA + COVO_STATE_FLOATS + 4), 0, s,
                        args->a_mean_in ? args->a_mean_in : args->a_mean,
                        args->a_mean_shift ? args->a_mean_shift : st->a_mean_shift, st->dyn, st->state_buf, args->derive_keys,
@@ -363,9 +384,13 @@ int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const 
     }
     StepState *st = reinterpret_cast<StepState *>(h->step);
     hipStream_t cs = h->side_stream;
-    if (g_fuse_small && step_small_eligible(h, *params, *args) && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 && args->state != nullptr) {
-        // the last step ran as ONE fused launch and never filled the scratch the staged launches read (state copy, shifted
-        // mean, keys; MPPI: shifted covariance + block factors): one begin launch does, with the key the step would derive from (0, 0)
+    const bool folded_online = g_fold_begin && args->mode == COVO_MODE_COVO_ONLINE &&
+                               !(params->disturb_kind >= COVO_DISTURB_PERIODIC && params->disturb_kind <= COVO_DISTURB_MIXED);
+    if (((g_fuse_small && step_small_eligible(h, *params, *args)) || folded_online) && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 &&
+        args->state != nullptr) {
+        // the last step ran without a begin launch (the one-launch small step; covo-online with the begin work folded into the
+        // Hessian) and never filled the scratch the replayed launches read (state copy, shifted mean, keys; MPPI: shifted
+        // covariance + block factors): one begin launch does, with the key the step would derive from (0, 0)
         DynBlock blk;
         std::memset(&blk, 0, sizeof(blk));
         std::memcpy(&blk.w[8], &args->state, sizeof(const float *));
