@@ -333,10 +333,23 @@ def bench_envs(args, world, rank, device, backend):
                        "controller": "covo-online", "envs_total": world * E, "envs_per_gpu": E, "N_per_env": N, "H": H},
             "phases_us_per_batched_step": phases,
         }
+        traffic = traffic_src = None
+        try:  # the committed counter passes of THIS command (scripts/profile_bench.sh), dropped when the kernel sources changed
+            with open(os.path.join(ROOT, "profiles", "r05_bench_envs_pmc_summary.json")) as f:
+                pm = json.load(f)
+            traffic_src = {"kind": "committed_profile", "file": "profiles/r05_bench_envs_pmc_summary.json", "commit": pm.get("commit"),
+                           "kernel_src_sha": pm.get("kernel_src_sha")}
+            if pm.get("kernel_src_sha") == kernel_src_sha() and E == 32 and N == 4096:
+                traffic = pm.get("traffic_bytes_per_launch")
+            else:
+                traffic_src["stale"] = "kernel sources or workload changed since the profile was taken: counters dropped"
+        except Exception:
+            pass
         if ro_us:
             ach = alg_bytes / (ro_us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "rollout_pipe3_kernel<..., BATCHED = true, REC = true> (all instances, one launch)",
-                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "counters_source": traffic_src,
                                "algorithmic_bytes_per_launch": alg_bytes, "launch_us": ro_us,
                                "launch_us_statistic": "graph replay of 10 copies of the batched rollout launch on the step's buffers "
                                                       "(covo_debug_time_batched), fastest of 3 replays"}

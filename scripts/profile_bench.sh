@@ -27,14 +27,25 @@ python3 "$R/bench.py" --config envs > "$R/gpurun_out/bench_envs_line.json" 2> /d
 rm -rf "$R/gpurun_out/prof_envs"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_envs" -o envs -- python3 "$R/bench.py" --config envs --steps 50 --warmup 5 \
     > /dev/null 2> "$R/gpurun_out/prof_envs.err"
+# config [4]'s counter passes: the batched rollout's HBM traffic and the batched Sigma chain's launches
+ENVS_ARGS="--config envs --steps 30 --warmup 5 --no-closed-loop"
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+            "sq SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVES"; do
+    set -- $pass
+    name=$1; shift
+    rm -rf "$R/gpurun_out/pmc_envs_$name"
+    rocprofv3 --pmc "$@" --output-format csv -d "$R/gpurun_out/pmc_envs_$name" -o envs -- python3 "$R/bench.py" $ENVS_ARGS \
+        > /dev/null 2> "$R/gpurun_out/pmc_envs_$name.err"
+done
 cd "$R"
+python3 scripts/pmc_summary_envs.py gpurun_out "$RND" > gpurun_out/pmc_summary_envs.log 2>&1
 python3 scripts/phase_times.py > gpurun_out/phase_times.log 2>/dev/null
 python3 scripts/kbench.py > gpurun_out/kbench.log 2>/dev/null
 python3 scripts/pmc_summary.py gpurun_out "$RND" > gpurun_out/pmc_summary.log 2>&1
 # gpurun merges at most 64 MiB back: the per-dispatch counter dumps (4 x ~14 MB) and the kernel trace stay on the box, their
 # per-kernel means (profiles/<round>_bench_pmc_*.csv, *_summary.json: written above) and the kernel stats travel
 mkdir -p gpurun_out/profiles_out
-cp profiles/"$RND"_bench_pmc_* gpurun_out/profiles_out/
+cp profiles/"$RND"_bench_pmc_* profiles/"$RND"_bench_envs_pmc_summary.json gpurun_out/profiles_out/
 cp gpurun_out/prof_stats/bench_kernel_stats.csv gpurun_out/profiles_out/"$RND"_bench_kernel_stats.csv
 find gpurun_out/prof_envs -name "*kernel_stats.csv" -exec cp {} gpurun_out/profiles_out/"$RND"_bench_envs_kernel_stats.csv \;
 cp gpurun_out/bench_envs_line.json gpurun_out/profiles_out/"$RND"_bench_envs_line.json
@@ -42,7 +53,7 @@ cp gpurun_out/bench_line.json gpurun_out/profiles_out/"$RND"_bench_line.json
 cp gpurun_out/bench_line_under_rocprof.json gpurun_out/profiles_out/"$RND"_bench_line_under_rocprof.json
 cp gpurun_out/phase_times.log gpurun_out/profiles_out/"$RND"_phase_times.log
 cp gpurun_out/kbench.log gpurun_out/profiles_out/"$RND"_kbench.log
-rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b gpurun_out/prof_stats gpurun_out/prof_envs
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b gpurun_out/prof_stats gpurun_out/prof_envs gpurun_out/pmc_envs_*
 ls gpurun_out/profiles_out
 tail -c 1500 gpurun_out/bench_line.json
 tail -5 gpurun_out/pmc_summary.log
