@@ -1689,36 +1689,6 @@ __device__ __forceinline__ void stream_stage_panel(const float *__restrict__ L, 
         d[3] = (k4 + 3 <= i) ? __uint_as_float((unsigned)(hi >> 32)) : 0.0f;
     }
 }
-// columns [32 G, 32 G + 32) x rows [32 G, 128) of L_stream -> the padded LDS image (ng_stage_factor's layout and masking)
-template <int G>
-__device__ __forceinline__ void stream_stage_kgroup(const float *__restrict__ L, float *__restrict__ Ls, int tid)
-{
-    constexpr int ROWS = COVO_NA - 32 * G, CHUNKS = ROWS * 8;  // float4 chunks
-    unsigned long long lo[(CHUNKS + 511) / 512], hi[(CHUNKS + 511) / 512];
-#pragma unroll
-    for (int u = 0; u < (CHUNKS + 511) / 512; ++u) {  // all loads first: one round trip
-        const int c = 512 * u + tid;
-        if (c < CHUNKS) {
-            const int i = 32 * G + (c >> 3), k4 = 32 * G + 4 * (c & 7);
-            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(L + (size_t)i * COVO_NA + k4);
-            lo[u] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hi[u] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < (CHUNKS + 511) / 512; ++u) {
-        const int c = 512 * u + tid;
-        if (c < CHUNKS) {
-            const int i = 32 * G + (c >> 3), k4 = 32 * G + 4 * (c & 7);
-            float *d = Ls + i * NG_LDA + k4;
-            d[0] = (k4 + 0 <= i) ? __uint_as_float((unsigned)lo[u]) : 0.0f;
-            d[1] = (k4 + 1 <= i) ? __uint_as_float((unsigned)(lo[u] >> 32)) : 0.0f;
-            d[2] = (k4 + 2 <= i) ? __uint_as_float((unsigned)hi[u]) : 0.0f;
-            d[3] = (k4 + 3 <= i) ? __uint_as_float((unsigned)(hi[u] >> 32)) : 0.0f;
-        }
-    }
-}
-
 __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *__restrict__ Z0, const double *__restrict__ Z1,
                                                                  const double *__restrict__ Zt0, const double *__restrict__ Zt1,
                                                                  double *__restrict__ s, float sample_sigma, const StreamGemmArgs S,
