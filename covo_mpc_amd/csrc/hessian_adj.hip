@@ -68,6 +68,7 @@ struct AdjArgs {
     DynBlock blk;
     int derive_keys;
     float shared_noise_scale;
+    int scan_prefix;                 // KB forms its primal prefix by parallel scans (adj13; COVO_HESS_SCAN=0: the sequential rollout)
 };
 
 __host__ __device__ inline double adj_drag_coeff(const dm::Model &m)
@@ -139,6 +140,8 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
         A.derive_keys = begin->derive_keys;
         A.shared_noise_scale = begin->shared_noise_scale;
     }
+    static const int scan_prefix = [] { const char *v = std::getenv("COVO_HESS_SCAN"); return v ? std::atoi(v) : 1; }();
+    A.scan_prefix = scan_prefix;
     A.R = R;
     A.ws = reinterpret_cast<double *>(workspace);
     A.T = T;

@@ -97,6 +97,120 @@ __device__ __forceinline__ void adj_next_force(const AdjArgs &A, const AdjDrag &
 }
 #endif
 
+
+#if !ADJ_FS
+// ---- KB's primal prefix as parallel scans (round 5).  x_k by a sequential fp64 rollout was the launch's critical path (wave 31: 31
+// steps of ~52 dependent-issue instructions, 4.7 us).  With the force of a step a constant of that step (none / gaussian / periodic /
+// sin) every recurrence of the step is ASSOCIATIVE over the horizon, so lane k of one wave gets x_k in five scan levels:
+//   body rate   w_(k+1) = alpha w_k + (1 - alpha) wt_k           an affine recurrence with a constant factor: a weighted prefix sum;
+//   attitude    q_(k+1) = normalise(q_k (x) (dt/2 w_k, 1))        (free.py:96,104,139: q + dt/2 L(q) H w IS that quaternion product, and
+//               the re-normalisations are scalars, which commute): q_k = normalise(q_0 (x) r_0 (x) ... (x) r_(k-1)), a prefix PRODUCT;
+//   velocity    v_(k+1) = v_k + dt vdot(q_k, thrust_k, f_k), position p_(k+1) = p_k + dt v_k: two prefix sums.
+// Every wave of the launch runs the same scan and takes lane k's state.  The operation ORDER differs from the sequential rollout
+// (fp64: ~1e-15, against a 1e-9 bar on the Hessian); drag / mixed (the next force depends on the velocity) keep the sequential prefix.
+struct AdjQuat {
+    double x, y, z, w;
+};
+__device__ __forceinline__ AdjQuat adj_qmul(const AdjQuat &a, const AdjQuat &b)  // Hamilton product, (x, y, z) vector part, w scalar
+{
+    AdjQuat r;
+    r.x = fma(a.w, b.x, fma(a.x, b.w, fma(a.y, b.z, -(a.z * b.y))));
+    r.y = fma(a.w, b.y, fma(a.y, b.w, fma(a.z, b.x, -(a.x * b.z))));
+    r.z = fma(a.w, b.z, fma(a.z, b.w, fma(a.x, b.y, -(a.y * b.x))));
+    r.w = fma(a.w, b.w, -fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)));
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ AdjQuat adj_qdpp(const AdjQuat &q)
+{
+    return AdjQuat{wr::dpp_f64<CTRL>(q.x), wr::dpp_f64<CTRL>(q.y), wr::dpp_f64<CTRL>(q.z), wr::dpp_f64<CTRL>(q.w)};
+}
+// inclusive prefix sum over lanes 0 .. 31 of v_j weighted by fac^(k - j) (fac = 1: a plain sum).  pw[i] = fac^(2^i), i = 0 .. 3;
+// pr = fac^((lane & 15) + 1) (what row 0's total is worth in row 1).  DPP row shifts return 0 where there is no source lane.
+__device__ __forceinline__ double adj_scan_sum(double v, const double (&pw)[4], double pr, int lane)
+{
+    v = fma(wr::dpp_f64<0x111>(v), pw[0], v);   // row_shr:1
+    v = fma(wr::dpp_f64<0x112>(v), pw[1], v);   // row_shr:2
+    v = fma(wr::dpp_f64<0x114>(v), pw[2], v);   // row_shr:4
+    v = fma(wr::dpp_f64<0x118>(v), pw[3], v);   // row_shr:8
+    const double t = wr::dpp_f64<0x142>(v);     // row_bcast:15 -- lane 15 of the previous row
+    return ((lane & 16) != 0) ? fma(t, pr, v) : v;
+}
+// -> lane k (< 32): the state BEFORE step k (what `for t < k: dyn_core` leaves), p0 = the state before step 0
+template <bool FT>
+__device__ __forceinline__ qm::State<double> adj_prefix_scan(const qm::State<double> &p0, const double (*sact)[4], const double (*sfd)[3],
+                                                             const qm::Consts<double> &c, int lane)
+{
+    const int k = lane & 31, lo = lane & 15;
+    const double one[4] = {1.0, 1.0, 1.0, 1.0};
+    // powers of alpha: alpha^(2^i), alpha^(lo + 1), alpha^k
+    double pa[4];
+    pa[0] = c.alpha;
+    pa[1] = pa[0] * pa[0];
+    pa[2] = pa[1] * pa[1];
+    pa[3] = pa[2] * pa[2];
+    const double a16 = pa[3] * pa[3];
+    double alo = 1.0;  // alpha^lo
+    if (lo & 1) alo *= pa[0];
+    if (lo & 2) alo *= pa[1];
+    if (lo & 4) alo *= pa[2];
+    if (lo & 8) alo *= pa[3];
+    const double ak = (k & 16) ? alo * a16 : alo, apr = alo * c.alpha;
+    // body rates: w_k = alpha^k w_0 + sum_(j < k) alpha^(k - 1 - j) (1 - alpha) wt_j
+    const double th = sact[k][0];
+    double cx = sact[k][1] * c.one_m_alpha, cy = sact[k][2] * c.one_m_alpha, cz = sact[k][3] * c.one_m_alpha;
+    cx = adj_scan_sum(cx, pa, apr, lane);
+    cy = adj_scan_sum(cy, pa, apr, lane);
+    cz = adj_scan_sum(cz, pa, apr, lane);
+    const double ox = fma(ak, p0.ox, wr::dpp_f64<0x138>(cx));  // wave_shr:1: the exclusive sum (lane 0: 0)
+    const double oy = fma(ak, p0.oy, wr::dpp_f64<0x138>(cy));
+    const double oz = fma(ak, p0.oz, wr::dpp_f64<0x138>(cz));
+    // attitude: inclusive prefix product of r_j = (dt/2 w_j, 1), then q_k = normalise(q0 (x) r_0 ... r_(k-1))
+    AdjQuat P{ox * c.half_dt, oy * c.half_dt, oz * c.half_dt, 1.0};
+    {
+        AdjQuat t = adj_qdpp<0x111>(P);
+        if (lo >= 1) P = adj_qmul(t, P);
+        t = adj_qdpp<0x112>(P);
+        if (lo >= 2) P = adj_qmul(t, P);
+        t = adj_qdpp<0x114>(P);
+        if (lo >= 4) P = adj_qmul(t, P);
+        t = adj_qdpp<0x118>(P);
+        if (lo >= 8) P = adj_qmul(t, P);
+        t = adj_qdpp<0x142>(P);
+        if (lane & 16) P = adj_qmul(t, P);
+    }
+    AdjQuat E = adj_qdpp<0x138>(P);  // exclusive
+    if (lane == 0) E = AdjQuat{0.0, 0.0, 0.0, 1.0};
+    AdjQuat q0{p0.qx, p0.qy, p0.qz, p0.qw};
+    {
+        const double rn = qm::rsq64_(fma(q0.x, q0.x, fma(q0.y, q0.y, fma(q0.z, q0.z, q0.w * q0.w))));  // free.py:88 (the noisy state is not unit)
+        q0.x *= rn; q0.y *= rn; q0.z *= rn; q0.w *= rn;
+    }
+    AdjQuat q = adj_qmul(q0, E);
+    if (k > 0) {  // (step 0's state is the stored one, un-normalised: dyn_core normalises it at entry itself)
+        const double rn = qm::rsq64_(fma(q.x, q.x, fma(q.y, q.y, fma(q.z, q.z, q.w * q.w))));
+        q.x *= rn; q.y *= rn; q.z *= rn; q.w *= rn;
+    }
+    // velocity increments of step k from the UNIT attitude of step k (free.py:97-99,103), then the two prefix sums
+    const double fx = (FT || k == 0) ? sfd[k][0] : 0.0, fy = (FT || k == 0) ? sfd[k][1] : 0.0, fz = (FT || k == 0) ? sfd[k][2] : 0.0;
+    const double Qz0 = 2.0 * (q.x * q.z + q.y * q.w), Qz1 = 2.0 * (q.y * q.z - q.x * q.w), Qz2 = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+    double dvx = ((Qz0 * th + fx) * c.inv_m) * c.dt, dvy = ((Qz1 * th + fy) * c.inv_m) * c.dt, dvz = ((Qz2 * th + fz) * c.inv_m + c.neg_g) * c.dt;
+    dvx = adj_scan_sum(dvx, one, 1.0, lane);
+    dvy = adj_scan_sum(dvy, one, 1.0, lane);
+    dvz = adj_scan_sum(dvz, one, 1.0, lane);
+    const double vx = p0.vx + wr::dpp_f64<0x138>(dvx), vy = p0.vy + wr::dpp_f64<0x138>(dvy), vz = p0.vz + wr::dpp_f64<0x138>(dvz);
+    double dpx = adj_scan_sum(vx * c.dt, one, 1.0, lane), dpy = adj_scan_sum(vy * c.dt, one, 1.0, lane), dpz = adj_scan_sum(vz * c.dt, one, 1.0, lane);
+    qm::State<double> r;
+    r.px = p0.px + wr::dpp_f64<0x138>(dpx);
+    r.py = p0.py + wr::dpp_f64<0x138>(dpy);
+    r.pz = p0.pz + wr::dpp_f64<0x138>(dpz);
+    r.vx = vx; r.vy = vy; r.vz = vz;
+    r.qx = (k == 0) ? p0.qx : q.x; r.qy = (k == 0) ? p0.qy : q.y; r.qz = (k == 0) ? p0.qz : q.z; r.qw = (k == 0) ? p0.qw : q.w;
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    return r;
+}
+#endif
+
 // one step on hyper-dual numbers: z_a carries e1, z_b carries e2 (an index outside 0..16 seeds nothing).
 // r = r_k(x) (0 for k = 0), s = f_k(z) (left at x_k for k = H-1, whose dynamics never reach a reward).
 __device__ __forceinline__ void adj_hd_step(const float *__restrict__ st, const float *__restrict__ am, const AdjArgs &A, int bi,
@@ -214,11 +328,19 @@ __global__ __launch_bounds__(64) void adj_jac_kernel(const AdjArgs A)
         ws[WS_X + 16 * k + 13] = pf[0]; ws[WS_X + 16 * k + 14] = pf[1]; ws[WS_X + 16 * k + 15] = pf[2];
     }
 #else
-    for (int t = 0; t < k; ++t) {
-        const double th = sact[t][0], w0 = sact[t][1], w1 = sact[t][2], w2 = sact[t][3];
-        if (t == 0) qm::dyn_core<double, double>(p, th, w0, w1, w2, c, sfd[0][0], sfd[0][1], sfd[0][2]);
-        else if (FT) qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, sfd[t][0], sfd[t][1], sfd[t][2]);
-        else qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, 0.0, 0.0, 0.0);
+    if (A.scan_prefix) {
+        // x_k as lane k of five-level scans (adj_prefix_scan) instead of k sequential steps
+        const qm::State<double> ps = adj_prefix_scan<FT>(p, sact, sfd, c, lane);
+#define OP(m, i) p.m = wr::bcast_lane(ps.m, k);
+        ADJ_FOR_STATE(OP)
+#undef OP
+    } else {
+        for (int t = 0; t < k; ++t) {
+            const double th = sact[t][0], w0 = sact[t][1], w1 = sact[t][2], w2 = sact[t][3];
+            if (t == 0) qm::dyn_core<double, double>(p, th, w0, w1, w2, c, sfd[0][0], sfd[0][1], sfd[0][2]);
+            else if (FT) qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, sfd[t][0], sfd[t][1], sfd[t][2]);
+            else qm::dyn_core<double, double, false>(p, th, w0, w1, w2, c, 0.0, 0.0, 0.0);
+        }
     }
     if (lane == 0) adj_store_state(p, ws + WS_X + 16 * k);
 #endif
