@@ -142,15 +142,17 @@ def cpu_baseline(states, params, N, H, lam, budget_s=15.0):
 
 
 def sigma_chain_counts(core):
-    """(squarings, Newton-Schulz iterations) the Sigma chain of the LAST covo-online step ran (scalar slots of its workspace;
-    synchronises).  The launch count of a step is data dependent: these are what make two values comparable."""
+    """(squarings, Newton-Schulz iterations) of the Sigma chain of the LAST covo-online step (scalar slots of its workspace;
+    synchronises).  The length of a step's chain is data dependent: these are what make two values comparable.  `squarings` =
+    the filter iterate lambda_min was taken from (SC_KWIN: the first one whose Ritz pair passes its residual test); the chain
+    itself runs up to two squarings further while that iterate is being evaluated."""
     import torch
     from covo_mpc_amd import _lib
     out = torch.zeros(24, dtype=torch.float64).pin_memory()
     _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out), 11 * 128 * 128, 24, core.stream()), "sigma workspace")
     torch.cuda.synchronize()
     o = out.numpy()
-    return float(o[8]), float(o[6])  # SC_SQ, SC_ITERS (csrc/sigma_ns.hip)
+    return float(o[7]), float(o[6])  # SC_KWIN, SC_ITERS (csrc/sigma_ns.hip)
 
 
 def closed_loop(env, controller, params, T, rec=None):

@@ -134,6 +134,7 @@ _SIGS = {
                                            C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, _P]),
     "covo_debug_set_ns_tail": (C.c_int, [C.c_int, C.c_int]),
     "covo_debug_set_ns_deflate": (C.c_int, [C.c_int]),
+    "covo_debug_set_ns_ritz_inside": (C.c_int, [C.c_int]),
     "covo_debug_set_fuse_small": (C.c_int, [C.c_int]),
     "covo_debug_set_merge_in_rollout": (C.c_int, [C.c_int]),
     "covo_debug_set_stream_gemm": (C.c_int, [C.c_int]),

@@ -537,6 +537,13 @@ int covo_debug_set_fuse_small(int on)
     return 0;
 }
 
+int covo_debug_set_ns_ritz_inside(int on)
+{
+    g_ns_ritz_inside = (on == 2) ? 2 : (on ? 1 : 0);  // (2: timing reference, the last iterate only)
+    ++g_dbg_epoch;  // a captured step graph holds one launch set or the other
+    return 0;
+}
+
 int covo_debug_set_ns_deflate(int on)
 {
     g_ns_deflate = on ? 1 : 0;

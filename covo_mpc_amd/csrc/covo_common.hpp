@@ -39,7 +39,7 @@ void covo_set_error(const char *fmt, ...);
 // many stages of the Sigma pipeline (1 prep+squarings, 2 +Ritz, 3 +Newton-Schulz, 4 +finalize) are enqueued.
 // Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
-extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate, g_ns_force_agent;  // sigma_ns.hip
+extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate, g_ns_force_agent, g_ns_ritz_inside;  // sigma_ns.hip
 void sigma_ns_tail_defaults();  // sigma_ns.hip: the four tail lengths back to their defaults
 extern int g_stream_gemm;  // step.hip: covo-online's noise GEMM streamed inside the Sigma chain's finalize launch
 extern int g_merge_in_rollout;  // step.hip: fused single-instance steps finish the softmax update inside the rollout launch

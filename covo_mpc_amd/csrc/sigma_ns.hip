@@ -72,6 +72,14 @@ __shared__ int g_nstamp;
 #define NS_STAMP() do { } while (0)
 #endif
 
+// -DNS_EVAL_STAMPS: wall_clock64() (10 ns ticks) of the squaring launch's seams into SC_STAMPS + 96 ..: [0] chain workgroup 0 enters,
+// [1] leaves; per k = 2 .. 16 at [2 + 3 (k - 2)]: X_k seen complete, evaluated, decided; [70 ..]: the seams inside the evaluation of X_8 (scripts/ritz_timeline.py)
+#ifdef NS_EVAL_STAMPS
+#define EV_STAMP(s, i) do { if (threadIdx.x == 0) (s)[SC_STAMPS + 96 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define EV_STAMP(s, i) do { } while (0)
+#endif
+#define EV_STAMP8(s, k, i) do { if ((k) == 8) EV_STAMP(s, 70 + (i)); } while (0)
 constexpr int SN = COVO_NA;  // 128
 constexpr int NS_SQUARINGS = 16;   // cap: Chebyshev degree 2^16.  Real CoVO Hessians stop at 6..12; the cap matters for bottoms
                                    // that sit within 1e-5 of the spectrum's width of the next eigenvalues (round 3's fuzz sweep:
@@ -90,9 +98,11 @@ constexpr int RITZ = 4;            // Rayleigh-Ritz block: exact lambda_min for 
 
 // per-matrix scratch (doubles): scalars, the Newton-Schulz coefficient table, per-row data of A, and the
 // per-workgroup reduction slots (no atomics anywhere: fixed summation order, bit-reproducible)
-enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_SUMLOGB, SC_ZBUF, SC_ITERS, SC_XBUF, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
+enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_SUMLOGB, SC_ZBUF, SC_ITERS, SC_KWIN, SC_SQ, SC_SQ_DONE, SC_NS_DONE,
        SC_FRO2, SC_TRACE, SC_GERSH, SC_N0,
        // (SC_SUMLOGB = 4: sum_i log diag(chol(B)), B = A + delta I: log det B = 2 SC_SUMLOGB -- ns_logdetB_workgroup)
+       // (SC_KWIN = 7: the squaring count k whose Rayleigh-Ritz evaluation the chain took lambda_min from -- ritz_decide;
+       //  SC_SQ: squarings started, which the early evaluations let run ahead of SC_KWIN)
        SC_PROF = 16,           // clock64() stamps of the finalize kernel (debug; 16-20), the persistent launches' modes (21, 22)
        SC_LDFLAG = 23,         // != 0: SC_SUMLOGB is there (zeroed with the scalars at the head of the chain)
        SC_BAR = 24,            // grid-barrier counters of the two persistent launches (unsigned in slots 24, 25; zeroed with the scalars)
@@ -107,6 +117,11 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_SUMLOGB, SC_ZBUF, SC_ITERS,
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
        SC_PREP = 320,          // prep partials: 8 x {max rowabs, sum v^2, trace, min diag}
+       // the Rayleigh-Ritz evaluations of X_2 .. X_16 (slot + k - 2; all zeroed by the first squaring):
+       SC_VERD = 320,          // verdicts: 0 not yet, 1 not taken, 2 taken (ritz_decide)
+       SC_HAVE_DIAG = 336,     // != 0: X_k's evaluation has read the diagonal of X_(k-1) (its column picks) ...
+       SC_HAVE_COLS = 352,     // ... and its columns of X_k: the chain may come round to those buffers again (ns_square_evaluator)
+       SC_SQ_FINAL = 368,      // != 0: the filter stopped by itself (stationary / cap) and X_(SC_SQ_FINAL) is its last iterate
        SC_SQN = 384,           // |X_i|_F^2 partials: (NS_SQUARINGS + 1) x 64 (36 used)
        SC_ERR = SC_SQN + (NS_SQUARINGS + 1) * 64,  // |Z_k Y_k - I|_F^2 partials: NS_ITERS x 64
        SC_RPART = SC_ERR + NS_ITERS * 64,          // sym_stats.hpp: per-row, per-column-block |.|-sums (128 x 8)
@@ -309,13 +324,14 @@ __device__ __forceinline__ void ns_square_first_stats(double *s, int w, int tid,
                                                       double &beta, double &nrm)
 {
     if (w == 0 && tid < SC_COEF) gst<COH>(s + tid, 0.0);
+    if (w == 0 && tid < 49) gst<COH>(s + SC_VERD + tid, 0.0);  // the evaluations' slots and SC_SQ_FINAL
     if (COH == COH_NONE && w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
     double ra = 0.0, dgv = 0.0;
     if (tid < SN) {
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) ra += s[SC_RPART + tid * 8 + cb];
         dgv = s[SC_DIAG + tid];
-        if (w == 0) s[SC_ROWABS + tid] = ra;
+        if (w == 0) gst<COH>(s + SC_ROWABS + tid, ra);  // (read by the evaluating workgroups of the same launch: ritz_eval)
     }
     const double fp = (lane < NS_TILES) ? s[SC_FPART + lane] : 0.0;
     const double f2 = wr::wave64_allsum(fp);
@@ -337,11 +353,11 @@ __device__ __forceinline__ void ns_square_first_stats(double *s, int w, int tid,
     beta = 2.0 * inv;
     nrm = fma((double)SN * alpha, alpha, fma(-2.0 * alpha * beta, tr, beta * beta * f2));  // |alpha I - beta A|_F^2
     if (w == 0 && tid == 0) {
-        s[SC_SHIFT] = hi;
-        s[SC_FRO2] = f2;
-        s[SC_TRACE] = tr;
-        s[SC_GERSH] = gm;
-        s[SC_N0] = nrm;
+        gst<COH>(s + SC_SHIFT, hi);
+        gst<COH>(s + SC_FRO2, f2);
+        gst<COH>(s + SC_TRACE, tr);
+        gst<COH>(s + SC_GERSH, gm);
+        gst<COH>(s + SC_N0, nrm);
     }
 }
 
@@ -350,7 +366,7 @@ __device__ __forceinline__ void ns_square_first_stats(double *s, int w, int tid,
 // FIRST: Xin is A and the operand is Y0 = alpha I - beta A (see the header), t_in = 1.
 // Returns false when the filter is found stationary (nothing was written).  Workgroup w of matrix b.
 template <bool FIRST, int COH>
-__device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, double *scall, int step, int xbuf_out, int b, int w,
+__device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, double *scall, int step, int b, int w,
                                                double (*red)[4][64], double *part)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -380,7 +396,10 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
             // onto the bottom eigenspace up to scale)
             const double prev = wr::wave64_allsum(p0);
             if (fabs(nrm - prev) <= NS_SQ_TOL * nrm) {
-                if (w == 0 && tid == 0) gst<COH>(s + SC_SQ_DONE, 1.0);
+                if (w == 0 && tid == 0) {
+                    gst<COH>(s + SC_SQ_FINAL, (double)step);  // X_step is the filter's last iterate
+                    gst<COH>(s + SC_SQ_DONE, 1.0);
+                }
                 return false;
             }
         }
@@ -388,7 +407,6 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
     const double t_out = 2.0 * t_in * t_in * nrm;  // overflows to +inf once the filter has separated: 1 / t_out = 0
     const double inv_t = 1.0 / t_out;
     if (w == 0 && tid == 0) {
-        gst<COH>(s + SC_XBUF, (double)xbuf_out);
         gst<COH>(s + SC_SQ, (double)(step + 1));
         gst<COH>(s + SC_SQN + (step + 1) * 64 + 63, t_out);
     }
@@ -403,132 +421,235 @@ __device__ __forceinline__ bool ns_square_body(const double *Xin, double *Xout, 
 
 template <bool FIRST>
 __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict__ Xin, double *__restrict__ Xout,
-                                                        double *__restrict__ scall, int step, int xbuf_out, int batch)
+                                                        double *__restrict__ scall, int step, int batch)
 {
     __shared__ double red[4][4][64];
     __shared__ double part[4];
     int b, w;
     if (!ns_block(batch, b, w)) return;
-    (void)ns_square_body<FIRST, COH_NONE>(Xin, Xout, scall, step, xbuf_out, b, w, red, part);
+    (void)ns_square_body<FIRST, COH_NONE>(Xin, Xout, scall, step, b, w, red, part);
 }
 
-// ---- Rayleigh-Ritz on the RITZ largest-diagonal columns of X: lambda_min(A), delta; then the scale s of
-// B = A + delta I (min of its Gershgorin and Frobenius bounds, from the per-row data of prep) and the
-// Newton-Schulz coefficient table.
-__global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__ Aall, const double *__restrict__ X0all,
-                                                      const double *__restrict__ X1all, double *__restrict__ scall,
-                                                      const int g_ns_deflate_dev)
+// ---- Rayleigh-Ritz on the RITZ largest-diagonal columns of X_k, the filter after k squarings: lambda_min(A), delta; then the
+// scale s of B = A + delta I (min of its Gershgorin and Frobenius bounds, from the per-row data of prep) and the deflation data.
+//
+// Round 5 -- WHICH X_k.  Rounds 1-4 ran this once, on the iterate at which the filter's norm had become stationary (|X_k|_F^2 moving
+// by < 1e-7: the second eigenvalue suppressed to ~5e-8).  But a RITZ-column block recovers the bottom eigenvector as soon as the
+// FIFTH eigenvalue is suppressed, and the Ritz pair says so itself: its residual |A u - theta u| is a guaranteed error bound.  On the
+// Hessians of closed-loop episodes (scripts/analysis/filter_emul.py on scripts/dump_hessians.py's dump) the pair of X_k passes the
+// deflation's own acceptance test -- residual <= 1e-8 x (0.7 x the gap bound), gap bound > 2e-2 -- 2.5 squarings before the norm
+// goes stationary (k = 8.6 against 11.1; |lambda error| <= 5e-14 at that k).  So the chain's lambda_min is DEFINED as
+//     the Ritz value of X_kwin,  kwin = the first k in [2, 16] whose pair passes (ritz_eval: pass), else the filter's last iterate,
+// a pure function of A: every path evaluates the same X_k with the same code (ritz_eval) and takes the same kwin (ritz_decide) --
+//   * one matrix, persistent launch: evaluating workgroups ride in the squaring launch (ns_square_tail_pair_kernel<true>), read X_k
+//     the moment its barrier has passed, and stop the chain; the chain meanwhile runs ahead (every X_k keeps a buffer of its own),
+//     so an evaluation costs the chain nothing and the separate Ritz launch is gone;
+//   * batches / shared-device handles / the debug splits: the squarings run to their own stop as before and ONE launch evaluates
+//     every k of every matrix (ns_ritz_scan_kernel).
+constexpr int RITZ_K0 = 2;                          // first evaluated iterate (the stationarity test needs two norms: the filter never stops before X_2)
+constexpr int RITZ_NK = NS_SQUARINGS - RITZ_K0 + 1;  // evaluations per matrix: X_2 .. X_16
+struct XBufs {  // X_1 -> x0, X_2 -> x1 (T and T^T of the iterations later), X_3 .. X_16 -> the history;  hist == nullptr: no history,
+    double *x0, *x1, *hist;  // odd k -> x0, even k -> x1 (the launch with the evaluations inside: they take what they need of X_k
+    size_t M;                // before the chain comes round to its buffer again -- ns_square_evaluator).
+                             // M: doubles between the buffers of consecutive k (batch x 128 x 128)
+};
+__host__ __device__ __forceinline__ double *ns_xk(const XBufs xb, int k)
 {
-    __shared__ double V[RITZ][SN];
-    __shared__ double AVp[4][RITZ][SN];  // partial A V over the four column quarters
-    __shared__ double H[RITZ][RITZ];
-    __shared__ double red[2];
-    __shared__ double sh_delta;
-    __shared__ double sh_nrm[NS_SQUARINGS + 1];  // |X_j|_F^2 of every filter step
-    __shared__ double sh_cvec[RITZ], sh_lmin, sh_gap, sh_md[2], sh_r2[2];
-    __shared__ int sh_has_null, sh_null_is_min;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double *A = Aall + (size_t)b * SN * SN;
-    double *s = scall + (size_t)b * SC_COUNT;
-    const double *X = ((s[SC_XBUF] != 0.0) ? X1all : X0all) + (size_t)b * SN * SN;
-    // A V, first half of the work: thread (r = tid & 127, cq = tid >> 7) owns A[32 cq .. 32 cq + 31][r]; the 32 loads
-    // are issued now and land while wave 0 builds V
-    const int r_av = tid & (SN - 1), cq = tid >> 7;
-    double acol[32];
+    if (xb.hist == nullptr) return (k & 1) ? xb.x0 : xb.x1;
+    return (k == 1) ? xb.x0 : (k == 2) ? xb.x1 : xb.hist + (size_t)(k - 3) * xb.M;
+}
+struct RitzLds {
+    double V[RITZ][SN];
+    double AVp[4][RITZ][SN];  // partial A V over the four column quarters
+    double H[RITZ][RITZ];
+    double red[2];
+    double nrm[NS_SQUARINGS + 1];  // |X_j|_F^2 of every filter step
+    double cvec[RITZ], lmin, gap, md[2], r2[2];
+    int has_null, null_is_min;
+    // the evaluation's results (ritz_publish)
+    double o_lmin, o_scale, o_lo, o_gam, o_zc, o_gapest, o_resid2;
+    int o_pass;
+    int decide, abort;
+    int pick[RITZ];
+};
+// what an evaluating workgroup keeps of A and of the chain's input statistics (loaded once per matrix; 256 threads)
+struct RitzIn {
+    double acol[2][32];  // thread (r = tid & 63, g = tid >> 6): A[32 g .. 32 g + 31][r] and [..][r + 64] -- two rows share every V they read
+    double dg, ra;    // tid < 128: A[tid][tid], sum_c |A[tid][c]|
+    double tr, f2, hi;
+};
+// (two parts: A and its diagonal are there when the launch starts; the row sums and bounds are left by the first squaring)
+__device__ __forceinline__ void ritz_load_matrix(RitzIn &in, const double *__restrict__ A, const double *s, int tid)
+{
+    const int r_av = tid & 63, g = tid >> 6;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acol[c] = A[(size_t)(32 * cq + c) * SN + r_av];  // A symmetric: coalesced in r
-    // the per-row data of the Gershgorin bound at the end: requested now, one round trip to HBM less on the serial tail
-    const double pre_dg = (tid < SN) ? s[SC_DIAG + tid] : 0.0, pre_ra = (tid < SN) ? s[SC_ROWABS + tid] : 0.0;
-    const double pre_tr = s[SC_TRACE], pre_f2 = s[SC_FRO2];
-    // the filter's norm history (rows 1 .. squarings done: 36 partials each, fixed order) for the gap bound below
-    const int n_sq = (int)s[SC_SQ];
-    for (int j = 1 + wave; j <= NS_SQUARINGS; j += 8) {
-        const double v = (j <= n_sq) ? slot_sum(s + SC_SQN + j * 64, NS_TILES, lane) : 1.0;
-        if (lane == 0) sh_nrm[j] = v;
+    for (int c = 0; c < 32; ++c) {  // A symmetric: coalesced in r
+        in.acol[0][c] = A[(size_t)(32 * g + c) * SN + r_av];
+        in.acol[1][c] = A[(size_t)(32 * g + c) * SN + r_av + 64];
     }
-    if (tid < SN) {
-        const double m = -wr::wave64_allmax(-pre_dg);
-        if (lane == 0) sh_md[wave] = m;
+    in.dg = (tid < SN) ? s[SC_DIAG + tid] : 0.0;  // (written a launch earlier: KD / ns_prep_kernel)
+}
+template <int COH>
+__device__ __forceinline__ void ritz_load_inputs(RitzIn &in, const double *s, int tid)
+{
+    in.ra = (tid < SN) ? gld<COH>(s + SC_ROWABS + tid) : 0.0;
+    in.tr = gld<COH>(s + SC_TRACE);
+    in.f2 = gld<COH>(s + SC_FRO2);
+    in.hi = gld<COH>(s + SC_SHIFT);
+}
+// One evaluation (256 threads; barriers inside): the bottom Ritz pair of X = X_k and everything the iterations need from it, left
+// in L.o_*; returns this thread's component of u (tid < 128).  COH: how X and the norm slots are read (the chain may still be running).
+// ABORT (the evaluations inside the squaring launch): every seam looks at SC_KWIN -- once another evaluation has been taken this
+// one is void and the workgroup must leave (the launch ends when its last workgroup does): returns with L.abort != 0.
+// The RITZ columns are PICKED on the diagonal of the iterate BEFORE (X_(k-1): the largest entries; the same eigenvectors, weights one
+// squaring younger): an evaluating workgroup of the squaring launch does this while X_k is still being computed, and X_k then costs
+// one round trip (the four columns), not two.  Wave 0 only; leaves L.pick[] and L.has_null.
+template <int COH>
+__device__ __forceinline__ void ritz_picks(const double *__restrict__ Xp, const double *s, RitzLds &L)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid >= 64) return;
+    double d0 = gld<COH>(Xp + (size_t)lane * SN + lane), d1 = gld<COH>(Xp + (size_t)(lane + 64) * SN + lane + 64);
+    // Rows of A that are exactly zero (always the last four of a CoVO Hessian: a_(H-1) never reaches a reward) are unit
+    // eigenvectors of eigenvalue 0.  While the filter has not yet separated lambda_min < 0 from them they own the largest
+    // diagonal entries of X and would take all RITZ picks (round 3's fuzz sweep: lambda_min = -0.015 reported as 0, B
+    // indefinite, NaN): they are left out of the picks and enter as the known eigenvalue 0 below.
+    const bool null0 = gld<COH>(s + SC_ROWABS + lane) == 0.0, null1 = gld<COH>(s + SC_ROWABS + lane + 64) == 0.0;
+    const int n_null = __builtin_popcountll(__ballot(null0)) + __builtin_popcountll(__ballot(null1));
+    const bool skip_null = n_null > 0 && n_null <= SN - RITZ;
+    if (skip_null) {
+        if (null0) d0 = -1e300;
+        if (null1) d1 = -1e300;
     }
+    if (lane == 0) L.has_null = skip_null ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < RITZ; ++q) {
+        // argmax over 128 values: wave maximum (DPP), then the first lane/slot holding it
+        const double mx = wr::wave64_allmax(fmax(d0, d1));
+        const unsigned long long m0 = __ballot(d0 == mx), m1 = __ballot(d1 == mx);
+        const int bi = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
+        if (lane == 0) L.pick[q] = bi;
+        if (bi == lane) d0 = -1e300;
+        if (bi == lane + 64) d1 = -1e300;
+    }
+}
+// One evaluation (256 threads; barriers inside): the bottom Ritz pair of X = X_k on the columns L.pick[] (ritz_picks on X_(k-1),
+// same workgroup) and everything the iterations need from it, left in L.o_*; returns this thread's component of u (tid < 128).
+// COH: how X and the norm slots are read (the chain may still be running).
+// ABORT (the evaluations inside the squaring launch): every seam looks at SC_KWIN -- once another evaluation has been taken this
+// one is void and the workgroup must leave (the launch ends when its last workgroup does): returns with L.abort != 0.
+// have_cols != nullptr: raised (coherently) once the columns of X_k are in registers -- the chain may then reuse X_k's buffer.
+template <int COH, bool ABORT = false>
+__device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__restrict__ X, const double *s, int k, RitzLds &L,
+                                            double *have_cols = nullptr)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double kw = 0.0;  // (each seam's load is issued a phase ahead of its use)
+    if (ABORT) kw = gld<COH_AGENT>(s + SC_KWIN);
+    const double t_k = gld<COH>(s + SC_SQN + k * 64 + 63);  // (wanted at the very end)
+    __syncthreads();  // (L is reused from the evaluation before; L.pick is there)
+    if (ABORT && tid == 0) L.abort = 0;
+    EV_STAMP8(const_cast<double *>(s), k, 0);
     if (tid < 64) {
-        // ---- wave 0: pick the RITZ largest diagonal entries, orthonormalise those columns (two-pass MGS,
-        // everything in registers: lane l owns rows l and l+64; reductions on the VALU)
-        double d0 = X[(size_t)lane * SN + lane], d1 = X[(size_t)(lane + 64) * SN + lane + 64];
-        // Rows of A that are exactly zero (always the last four of a CoVO Hessian: a_(H-1) never reaches a reward) are unit
-        // eigenvectors of eigenvalue 0.  While the filter has not yet separated lambda_min < 0 from them they own the largest
-        // diagonal entries of X and would take all RITZ picks (round 3's fuzz sweep: lambda_min = -0.015 reported as 0, B
-        // indefinite, NaN): they are left out of the picks and enter as the known eigenvalue 0 below.
-        const bool null0 = s[SC_ROWABS + lane] == 0.0, null1 = s[SC_ROWABS + lane + 64] == 0.0;
-        const int n_null = __builtin_popcountll(__ballot(null0)) + __builtin_popcountll(__ballot(null1));
-        const bool skip_null = n_null > 0 && n_null <= SN - RITZ;
-        if (skip_null) {
-            if (null0) d0 = -1e300;
-            if (null1) d1 = -1e300;
-        }
-        if (lane == 0) sh_has_null = skip_null ? 1 : 0;
+        // ---- wave 0: the picked columns, orthonormalised (classical Gram-Schmidt, twice -- the dot products of a pass are
+        // independent reductions; everything in registers: lane l owns rows l and l+64; reductions on the VALU)
         double v[RITZ][2];
         int pick_k[RITZ];
 #pragma unroll
-        for (int k = 0; k < RITZ; ++k) {
-            // argmax over 128 values: wave maximum (DPP), then the first lane/slot holding it
-            const double mx = wr::wave64_allmax(fmax(d0, d1));
-            const unsigned long long m0 = __ballot(d0 == mx), m1 = __ballot(d1 == mx);
-            const int bi = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
-            pick_k[k] = bi;
-            if (bi == lane) d0 = -1e300;
-            if (bi == lane + 64) d1 = -1e300;
-        }
-        // the four picks need only the diagonal: all eight column loads go out together (one L2 round trip, not four)
+        for (int q = 0; q < RITZ; ++q) pick_k[q] = L.pick[q];
 #pragma unroll
-        for (int k = 0; k < RITZ; ++k) {
-            v[k][0] = X[(size_t)lane * SN + pick_k[k]];
-            v[k][1] = X[(size_t)(lane + 64) * SN + pick_k[k]];
+        for (int q = 0; q < RITZ; ++q) {
+            v[q][0] = gld<COH>(X + (size_t)lane * SN + pick_k[q]);
+            v[q][1] = gld<COH>(X + (size_t)(lane + 64) * SN + pick_k[q]);
+        }
+        if (have_cols != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gst<COH_AGENT>(have_cols, 1.0);
         }
 #pragma unroll
-        for (int k = 0; k < RITZ; ++k) {
+        for (int q = 0; q < RITZ; ++q) {
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
+            for (int pass = 0; pass < 2; ++pass) {
+                double dot[RITZ];
 #pragma unroll
-                for (int j = 0; j < k; ++j) {
-                    const double dot = wr::wave64_allsum(fma(v[k][0], v[j][0], v[k][1] * v[j][1]));
-                    v[k][0] = fma(-dot, v[j][0], v[k][0]);
-                    v[k][1] = fma(-dot, v[j][1], v[k][1]);
+                for (int j = 0; j < q; ++j) dot[j] = wr::wave64_allsum(fma(v[q][0], v[j][0], v[q][1] * v[j][1]));
+#pragma unroll
+                for (int j = 0; j < q; ++j) {
+                    v[q][0] = fma(-dot[j], v[j][0], v[q][0]);
+                    v[q][1] = fma(-dot[j], v[j][1], v[q][1]);
                 }
-            const double n2 = wr::wave64_allsum(fma(v[k][0], v[k][0], v[k][1] * v[k][1]));
+            }
+            const double n2 = wr::wave64_allsum(fma(v[q][0], v[q][0], v[q][1] * v[q][1]));
             if (n2 > 1e-280) {
                 const double inv = qm::rsq64_(n2);
-                v[k][0] *= inv;
-                v[k][1] *= inv;
+                v[q][0] *= inv;
+                v[q][1] *= inv;
             } else {  // column numerically inside the span of the previous ones: any unit vector will do
-                v[k][0] = (pick_k[k] == lane) ? 1.0 : 0.0;
-                v[k][1] = (pick_k[k] == lane + 64) ? 1.0 : 0.0;
+                v[q][0] = (pick_k[q] == lane) ? 1.0 : 0.0;
+                v[q][1] = (pick_k[q] == lane + 64) ? 1.0 : 0.0;
             }
-            V[k][lane] = v[k][0];
-            V[k][lane + 64] = v[k][1];
+            L.V[q][lane] = v[q][0];
+            L.V[q][lane + 64] = v[q][1];
+        }
+    } else {
+        // waves 1 .. 3 meanwhile: the filter's norm history (rows 1 .. k: 36 partials each, fixed order) for the gap bound below
+        for (int j = wave; j <= NS_SQUARINGS; j += 3) {
+            const double p = (j <= k && lane < NS_TILES) ? gld<COH>(s + SC_SQN + j * 64 + lane) : 0.0;
+            const double vv = (j <= k) ? wr::wave64_allsum(p) : 1.0;
+            if (lane == 0) L.nrm[j] = vv;
+        }
+        if (wave == 1) {
+            const double m = -wr::wave64_allmax(-in.dg);  // (rows 64 .. 127; rows 0 .. 63 below)
+            if (lane == 0) L.md[1] = m;
         }
     }
+    if (wave == 0) {
+        const double m = -wr::wave64_allmax(-in.dg);
+        if (lane == 0) L.md[0] = m;
+    }
+    if (ABORT && tid == 0 && kw != 0.0) L.abort = 1;
+    if (ABORT) kw = gld<COH_AGENT>(s + SC_KWIN);
     __syncthreads();
-    // A V: partial sums over this thread's column quarter, then H = V^T A V from the four partials
+    EV_STAMP8(const_cast<double *>(s), k, 1);
+    if (ABORT && L.abort) return 0.0;
+    // A V: this thread's column quarter for its two rows (the LDS reads of V are what this phase waits for: each feeds two
+    // fused multiply-adds), then H = V^T A V from the four partials
     {
-        double av[RITZ] = {0.0, 0.0, 0.0, 0.0};
+        const int r_av = tid & 63, g = tid >> 6;
+        double av[2][RITZ] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
 #pragma unroll
-            for (int k = 0; k < RITZ; ++k) av[k] = fma(acol[c], V[k][32 * cq + c], av[k]);
+            for (int q = 0; q < RITZ; ++q) {
+                const double vq = L.V[q][32 * g + c];
+                av[0][q] = fma(in.acol[0][c], vq, av[0][q]);
+                av[1][q] = fma(in.acol[1][c], vq, av[1][q]);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < RITZ; ++k) AVp[cq][k][r_av] = av[k];
+        for (int q = 0; q < RITZ; ++q) {
+            L.AVp[g][q][r_av] = av[0][q];
+            L.AVp[g][q][r_av + 64] = av[1][q];
+        }
     }
+    if (ABORT && tid == 0 && kw != 0.0) L.abort = 1;
+    if (ABORT) kw = gld<COH_AGENT>(s + SC_KWIN);
     __syncthreads();
+    EV_STAMP8(const_cast<double *>(s), k, 2);
+    if (ABORT && L.abort) return 0.0;
 #pragma unroll
-    for (int e = 2 * wave; e < 2 * wave + 2; ++e) {  // 8 waves x 2 entries of H
+    for (int e = 4 * wave; e < 4 * wave + 4; ++e) {  // 4 waves x 4 entries of H
         const int i = e / RITZ, j = e % RITZ;
-        const double a0 = (AVp[0][j][lane] + AVp[1][j][lane]) + (AVp[2][j][lane] + AVp[3][j][lane]);
-        const double a1 = (AVp[0][j][lane + 64] + AVp[1][j][lane + 64]) + (AVp[2][j][lane + 64] + AVp[3][j][lane + 64]);
-        const double d = wr::wave64_allsum(fma(V[i][lane], a0, V[i][lane + 64] * a1));
-        if (lane == 0) H[i][j] = d;
+        const double a0 = (L.AVp[0][j][lane] + L.AVp[1][j][lane]) + (L.AVp[2][j][lane] + L.AVp[3][j][lane]);
+        const double a1 = (L.AVp[0][j][lane + 64] + L.AVp[1][j][lane + 64]) + (L.AVp[2][j][lane + 64] + L.AVp[3][j][lane + 64]);
+        const double d = wr::wave64_allsum(fma(L.V[i][lane], a0, L.V[i][lane + 64] * a1));
+        if (lane == 0) L.H[i][j] = d;
     }
+    if (ABORT && tid == 0 && kw != 0.0) L.abort = 1;
+    if (ABORT) kw = gld<COH_AGENT>(s + SC_KWIN);
     __syncthreads();
+    EV_STAMP8(const_cast<double *>(s), k, 3);
+    if (ABORT && L.abort) return 0.0;
     if (tid == 64) {
         // ---- a LOWER bound of the bottom gap lambda_2 - lambda_1 from the filter's norm history, on another wave while lane 0
         // diagonalises H.  X_k = sigma_k (v1 v1^T + sum_(i>=2) r_i v_i v_i^T), r_i = T_(2^k)(y_i) / T_(2^k)(y_1) (y = alpha -
@@ -537,12 +658,12 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         // D = acosh y_1 - acosh y_2:  D >= -ln(e) / 2^j, hence y_2 <= cosh(acosh y_1 - D_est) and lambda_2 >= (alpha - y_2) / beta.
         // lambda_1 enters through y_1 only to ~1 %: the Rayleigh quotient H[0][0] of the dominant column serves.
         double gap = 0.0;
-        const double hi = s[SC_SHIFT], md = fmin(sh_md[0], sh_md[1]);
+        const double hi = in.hi, md = fmin(L.md[0], L.md[1]);
         const double cut = fma(NS_CUT_MARGIN, hi - md, md), inv = 1.0 / (hi - cut);
-        const double alpha = (hi + cut) * inv, beta = 2.0 * inv, l1 = H[0][0];
+        const double alpha = (hi + cut) * inv, beta = 2.0 * inv, l1 = L.H[0][0];
         const double y1 = fma(-beta, l1, alpha);
-        for (int j = 1; j <= n_sq && j <= NS_SQUARINGS; ++j) {
-            const double e = 0.5 * (1.0 - sh_nrm[j]);
+        for (int j = 1; j <= k && j <= NS_SQUARINGS; ++j) {
+            const double e = 0.5 * (1.0 - L.nrm[j]);
             if (e > 1e-13 && e < 0.05 && y1 > 1.0) {  // the earliest step at which the linearisation holds
                 const double D = -log(e) * exp2(-(double)j);
                 const double ac = log(y1 + sqrt(fma(y1, y1, -1.0))) - D;
@@ -552,7 +673,7 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
                 break;
             }
         }
-        sh_gap = gap;
+        L.gap = gap;
     }
     if (tid < RITZ) {
         // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, exits when diagonal); reciprocals / square roots by hardware seed +
@@ -560,7 +681,7 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         // carries ONE row of the accumulated rotation -- the eigenvectors for 4 extra operations per rotation instead of 16
         double h[RITZ][RITZ], jrow[RITZ];
         for (int i = 0; i < RITZ; ++i) {
-            for (int j = 0; j < RITZ; ++j) h[i][j] = 0.5 * (H[i][j] + H[j][i]);
+            for (int j = 0; j < RITZ; ++j) h[i][j] = 0.5 * (L.H[i][j] + L.H[j][i]);
             jrow[i] = (i == tid) ? 1.0 : 0.0;
         }
         for (int sweep = 0; sweep < 12; ++sweep) {
@@ -571,10 +692,15 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
             for (int p = 0; p < RITZ - 1; ++p)
                 for (int q2 = p + 1; q2 < RITZ; ++q2) {
                     if (h[p][q2] * h[p][q2] <= 1e-34 * fabs(h[p][p] * h[q2][q2])) continue;
-                    const double zeta = (h[q2][q2] - h[p][p]) * 0.5 * qm::rcp64_(h[p][q2]);
-                    const double z2 = fma(zeta, zeta, 1.0);
-                    const double t = copysign(1.0, zeta) * qm::rcp64_(fabs(zeta) + z2 * qm::rsq64_(z2));
-                    const double c = qm::rsq64_(fma(t, t, 1.0)), sn = c * t;
+                    // the small rotation that zeroes h_pq: tan(2 theta) = b / a, a = h_qq - h_pp, b = 2 h_pq;  cos(2 theta) = |a| / r,
+                    // r = sqrt(a^2 + b^2);  c^2 = (1 + cos 2 theta) / 2;  s = sign(a) b / (2 r c);  t = s / c -- two rsqrt chains
+                    const double ja = h[q2][q2] - h[p][p], jb = 2.0 * h[p][q2];
+                    const double inv_r = qm::rsq64_(fma(ja, ja, jb * jb));
+                    const double c2 = fma(0.5 * fabs(ja), inv_r, 0.5);
+                    const double inv_c = qm::rsq64_(c2);
+                    const double c = c2 * inv_c;
+                    const double sn = copysign(0.5, ja) * jb * inv_r * inv_c;
+                    const double t = sn * inv_c;
                     // J^T h J for the symmetric h, written out: the 2 x 2 pivot block in closed form (h_pq -> 0), the other rows
                     // and columns once, mirrored (two full 4 x 4 products cost three times the arithmetic on this one serial lane)
                     const double hpq = h[p][q2] * t;
@@ -582,14 +708,14 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
                     h[q2][q2] += hpq;
                     h[p][q2] = 0.0;
                     h[q2][p] = 0.0;
-                    for (int k = 0; k < RITZ; ++k) {
-                        if (k == p || k == q2) continue;
-                        const double hp = h[k][p], hq = h[k][q2];
+                    for (int kk = 0; kk < RITZ; ++kk) {
+                        if (kk == p || kk == q2) continue;
+                        const double hp = h[kk][p], hq = h[kk][q2];
                         const double np_ = c * hp - sn * hq, nq_ = sn * hp + c * hq;
-                        h[k][p] = np_;
-                        h[p][k] = np_;
-                        h[k][q2] = nq_;
-                        h[q2][k] = nq_;
+                        h[kk][p] = np_;
+                        h[p][kk] = np_;
+                        h[kk][q2] = nq_;
+                        h[q2][kk] = nq_;
                     }
                     {   // this lane's row of the accumulated rotation: columns p, q2
                         const double jp = jrow[p], jq = jrow[q2];
@@ -601,62 +727,156 @@ __global__ __launch_bounds__(512) void ns_ritz_kernel(const double *__restrict__
         double lmin = h[0][0], cmin = jrow[0];
         for (int i = 1; i < RITZ; ++i)
             if (h[i][i] < lmin) { lmin = h[i][i]; cmin = jrow[i]; }
-        sh_cvec[tid] = cmin;  // component `tid` of the bottom eigenvector of H
+        L.cvec[tid] = cmin;  // component `tid` of the bottom eigenvector of H
         if (tid == 0) {
-            sh_lmin = lmin;  // (the Ritz pair's own value: what its residual is taken against)
-            sh_null_is_min = 0;
-            if (sh_has_null && lmin > 0.0) {  // the exact zeros of the null rows are the bottom of the spectrum
+            L.lmin = lmin;  // (the Ritz pair's own value: what its residual is taken against)
+            L.null_is_min = 0;
+            if (L.has_null && lmin > 0.0) {  // the exact zeros of the null rows are the bottom of the spectrum
                 lmin = 0.0;
-                sh_null_is_min = 1;
+                L.null_is_min = 1;
             }
-            s[SC_LMIN] = lmin;
-            s[SC_DELTA] = -lmin + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
-            sh_delta = -lmin + 1e-2;
+            L.o_lmin = lmin;
         }
+    }
+    if (ABORT && tid == 0 && kw != 0.0) L.abort = 1;
+    if (ABORT) kw = gld<COH_AGENT>(s + SC_KWIN);
+    __syncthreads();
+    EV_STAMP8(const_cast<double *>(s), k, 4);
+    if (ABORT && L.abort) return 0.0;
+    // the bottom Ritz pair (theta, u = V c) and its residual |A u - theta u| (A V is in the partials of H)
+    double u = 0.0;
+    if (tid < SN) {
+        double au = 0.0;
+#pragma unroll
+        for (int q = 0; q < RITZ; ++q) {
+            u = fma(L.cvec[q], L.V[q][tid], u);
+            au = fma(L.cvec[q], (L.AVp[0][q][tid] + L.AVp[1][q][tid]) + (L.AVp[2][q][tid] + L.AVp[3][q][tid]), au);
+        }
+        const double d = fma(-L.lmin, u, au);
+        const double r2 = wr::wave64_allsum(d * d);
+        if (lane == 0) L.r2[wave] = r2;
     }
     __syncthreads();
-    const double delta = sh_delta;
-    // the bottom Ritz pair (theta, u = V c) and its residual |A u - theta u| (A V is in the partials of H)
-    if (tid < SN) {
-        double u = 0.0, au = 0.0;
-#pragma unroll
-        for (int k = 0; k < RITZ; ++k) {
-            u = fma(sh_cvec[k], V[k][tid], u);
-            au = fma(sh_cvec[k], (AVp[0][k][tid] + AVp[1][k][tid]) + (AVp[2][k][tid] + AVp[3][k][tid]), au);
-        }
-        s[SC_U + tid] = u;
-        const double d = fma(-sh_lmin, u, au);
-        const double r2 = wr::wave64_allsum(d * d);
-        if (lane == 0) sh_r2[wave] = r2;
-    }
+    // An iterate that is taken although its pair has NOT converged (the filter's last one: the cap of 16 squarings -- bottoms whose
+    // gaps are ~1e-8 of the spectrum's width, e.g. covo-offline's table on `hovering`: lambda_max 9e4, gaps 4e-3) over-estimates
+    // lambda_min by up to its residual; B = A + delta I would then be INDEFINITE (NaN from its factorisation) as soon as that
+    // exceeds 1e-2.  There is an eigenvalue within |residual| of theta: theta - |residual| is used instead -- B stays positive
+    // definite, its floor is then 1e-2 .. 1e-2 + |residual| instead of 1e-2.  A converged pair (residual <= 1e-8 gap) is not touched.
+    const double resid2 = L.r2[0] + L.r2[1];
+    const double gap = NS_DEFL_SAFETY * L.gap, rtol = NS_DEFL_RESID * gap;
+    const bool small_resid = !L.null_is_min && gap > NS_DEFL_MIN_GAP && resid2 <= rtol * rtol;
+    const double lmin_used = (small_resid || L.null_is_min) ? L.o_lmin : L.o_lmin - resid2 * qm::rsq64_(fmax(resid2, 1e-300));
+    const double delta = -lmin_used + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
     // Gershgorin bound of B = A + delta I from the row sums of A: only the diagonal term changes
     if (tid < SN) {
-        const double m = wr::wave64_allmax(pre_ra - fabs(pre_dg) + fabs(pre_dg + delta));
-        if (lane == 0) red[wave] = m;
+        const double m = wr::wave64_allmax(in.ra - fabs(in.dg) + fabs(in.dg + delta));
+        if (lane == 0) L.red[wave] = m;
     }
     __syncthreads();
     if (tid == 0) {
-        const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, pre_tr, pre_f2));  // |A + delta I|_F^2
-        const double scale = fmin(fmax(red[0], red[1]), sqrt(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
-        s[SC_SCALE] = scale;  // the Newton-Schulz coefficient table follows from it: ns_first_kernel's extra workgroup
-        // deflate the bottom eigenpair when its gap bound is worth it and the pair is converged (see the header)
-        const double gap = NS_DEFL_SAFETY * sh_gap, resid2 = sh_r2[0] + sh_r2[1], rtol = NS_DEFL_RESID * gap;
-        const bool defl = g_ns_deflate_dev && !sh_null_is_min && gap > NS_DEFL_MIN_GAP && resid2 <= rtol * rtol &&
-                          1e-2 + gap < 0.25 * scale;
-        double lo = 1e-2, gam = 0.0, zc = 0.0;
-        if (defl) {
-            lo = 1e-2 + gap;
+        const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, in.tr, in.f2));  // |A + delta I|_F^2
+        const double scale = fmin(fmax(L.red[0], L.red[1]), fro2 * qm::rsq64_(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
+        // the bottom eigenpair is CONVERGED when its residual is small against the gap bound: the evaluation then "passes" (the
+        // chain stops here) and the iterations may deflate the pair (see the header)
+        const bool conv = small_resid && 1e-2 + gap < 0.25 * scale;
+        L.o_pass = (conv && t_k > NS_SQ_TGUARD) ? 1 : 0;
+        L.o_lmin = lmin_used;
+        L.o_scale = scale;
+        L.o_lo = 1e-2;
+        L.o_gam = 0.0;
+        L.o_zc = 0.0;
+        if (conv) {
+            const double lo = 1e-2 + gap;
             const double ls = lo * scale;
             const double tau = ls * qm::rsq64_(ls);  // sqrt(lo scale): anywhere inside [lo, scale] serves
-            gam = (tau - 1e-2) / scale;
-            zc = scale * qm::rsq64_(scale) * (10.0 - qm::rsq64_(tau));  // sqrt(scale) ((1e-2)^(-1/2) - tau^(-1/2))
+            L.o_lo = lo;
+            L.o_gam = (tau - 1e-2) / scale;
+            L.o_zc = scale * qm::rsq64_(scale) * (10.0 - qm::rsq64_(tau));  // sqrt(scale) ((1e-2)^(-1/2) - tau^(-1/2))
         }
-        s[SC_LO] = lo;
-        s[SC_GAM] = gam;
-        s[SC_ZCOEF] = zc;
-        s[SC_GAPEST] = sh_gap;
-        s[SC_RESID] = resid2;  // squared
+        L.o_gapest = L.gap;
+        L.o_resid2 = resid2;  // squared
     }
+    __syncthreads();
+    return u;
+}
+// the evaluation of X_k becomes the chain's result (slots read by the launches that follow; written coherently: the chain's
+// workgroups poll SC_SQ_DONE)
+__device__ __forceinline__ void ritz_publish(const RitzLds &L, double u, double *s, int k, int deflate)
+{
+    const int tid = threadIdx.x;
+    if (tid < SN) gst<COH_AGENT>(s + SC_U + tid, u);
+    if (tid == 0) {
+        const bool defl = deflate && L.o_gam != 0.0;
+        gst<COH_AGENT>(s + SC_LMIN, L.o_lmin);
+        gst<COH_AGENT>(s + SC_DELTA, -L.o_lmin + 1e-2);
+        gst<COH_AGENT>(s + SC_SCALE, L.o_scale);
+        gst<COH_AGENT>(s + SC_LO, defl ? L.o_lo : 1e-2);
+        gst<COH_AGENT>(s + SC_GAM, defl ? L.o_gam : 0.0);
+        gst<COH_AGENT>(s + SC_ZCOEF, defl ? L.o_zc : 0.0);
+        gst<COH_AGENT>(s + SC_GAPEST, L.o_gapest);
+        gst<COH_AGENT>(s + SC_RESID, L.o_resid2);
+        gst<COH_AGENT>(s + SC_KWIN, (double)k);
+    }
+}
+// The verdict on X_k, in k order (kwin = the FIRST k that passes, whatever order the evaluations finish in): waits for the verdict
+// on X_(k-1); `final` = X_k is the filter's last iterate (taken if nothing passed before).  Returns true when the chain's result
+// is decided (by this k or an earlier one): the caller leaves.  Uniform over the workgroup.
+__device__ __forceinline__ bool ritz_decide(RitzLds &L, double u, double *s, int k, bool final, int deflate)
+{
+    if (threadIdx.x == 0) {
+        int prev = 1;
+        if (k > RITZ_K0) {
+            const long long t0 = wall_clock64();
+            while ((prev = (int)gld<COH_AGENT>(s + SC_VERD + k - 1 - RITZ_K0)) == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 20000000LL) {
+                    gst<COH_AGENT>(s + SC_BARFAIL, 1.0);
+                    prev = 2;  // leave; the finalize launch turns the flag into NaN outputs
+                    break;
+                }
+            }
+        }
+        L.decide = (prev == 2) ? 2 : ((L.o_pass || final) ? 1 : 0);  // 2: decided before; 1: this one is taken; 0: not taken
+        if (L.decide == 1) gst<COH_AGENT>(s + SC_SQ_DONE, 1.0);  // stops the chain (it may be two squarings further by now)
+    }
+    __syncthreads();
+    const int d = L.decide;
+    if (d == 1) ritz_publish(L, u, s, k, deflate);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the results have been acknowledged before the flags go out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, d == 0 ? 1.0 : 2.0);
+    }
+    return d != 0;
+}
+
+// every k of every matrix in ONE launch (the paths whose squarings are launches of their own / run batched): workgroup
+// (k - RITZ_K0) + RITZ_NK * b -- X_(k-1)'s workgroup has the id before it, so the verdict it waits for is always being worked on
+// (dispatch is in id order; the wait is bounded anyway)
+__global__ __launch_bounds__(256) void ns_ritz_scan_kernel(const double *__restrict__ Aall, const XBufs xb, double *__restrict__ scall,
+                                                           const int deflate, const int final_only)
+{
+    __shared__ RitzLds L;
+    const int b = blockIdx.x / RITZ_NK, k = RITZ_K0 + (int)(blockIdx.x % RITZ_NK), tid = threadIdx.x;
+    double *s = scall + (size_t)b * SC_COUNT;
+    const int k_final = (int)s[SC_SQ];  // (a launch boundary ago)
+    if (k > k_final) return;
+    const bool final = k == k_final;
+    if (final_only) {  // timing reference (COVO_NS_RITZ_INSIDE=2): rounds 1-4's rule -- the filter's last iterate, nothing else
+        if (tid == 0 && k == k_final - 1) gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, 1.0);
+        if (!final) return;
+    }
+    // a cheap "not taken": the bounded part of the spectrum is still there (an iterate that cannot pass and is not the last)
+    if (!final && !(s[SC_SQN + k * 64 + 63] > NS_SQ_TGUARD)) {
+        if (tid == 0) gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, 1.0);
+        return;
+    }
+    RitzIn in;
+    ritz_load_matrix(in, Aall + (size_t)b * SN * SN, s, tid);
+    ritz_load_inputs<COH_NONE>(in, s, tid);
+    ritz_picks<COH_NONE>(ns_xk(xb, k - 1) + (size_t)b * SN * SN, s, L);
+    const double u = ritz_eval<COH_NONE>(in, ns_xk(xb, k) + (size_t)b * SN * SN, s, k, L);
+    (void)ritz_decide(L, u, s, k, final, deflate);
 }
 
 // Chen-Chow scaled Newton-Schulz: x -> x (a + b x^2) on [l, 1] with a = 1.5 rho, b = -0.5 rho^3, rho^2 = 3/(1 + l + l^2) (equal
@@ -1012,27 +1232,52 @@ __device__ __forceinline__ unsigned ns_xcc_id()
     return x & 7u;
 }
 // Returns 0: timed out (the fail flag is raised); 1: passed; 2: passed and every workgroup of the launch reported the XCC id
-// `xcc`.  flags[w] = (XCC id << 24) | phase; nw <= 64 workgroups (20 for the squarings, 32 for the iterations).  COH as the phase before it stored.
+// `xcc`; + 4: workgroup 0 announced with THIS phase that the launch is to stop (the squaring launch with evaluations inside: the
+// stop comes from outside the chain, so it must reach every workgroup at the same phase -- workgroup 0 alone looks at the outside
+// flag and passes it on in its flag word, which everybody holds when the barrier opens; a workgroup 0 that stops never writes again).
+// flags[w] = (XCC id << 24) | (stop << 23) | phase; nw <= 64 workgroups.  COH as the phase before it stored.
+constexpr unsigned NS_FLAG_STOP = 0x800000u, NS_FLAG_PHASE = 0x7fffffu;
 template <int COH>
-__device__ __forceinline__ int ns_flag_barrier(unsigned *flags, unsigned phase, int w, int nw, unsigned xcc, double *fail_flag)
+__device__ __forceinline__ int ns_flag_barrier(unsigned *flags, unsigned phase, int w, int nw, unsigned xcc, double *fail_flag,
+                                               const double *stop_src = nullptr, const double *guard0 = nullptr,
+                                               const double *guard1 = nullptr)
 {
     __shared__ int res;
+    // (workgroup 0 of a launch that can be stopped from outside: the outside flag is asked for here, behind this phase's stores --
+    // its round trip runs under the wait for their acknowledgements)
+    double stop_v = 0.0;
+    if (stop_src != nullptr && threadIdx.x == 0) {
+        stop_v = gld<COH_AGENT>(stop_src);
+        // ... and so are the evaluations' "I have what I need of the buffer the next squaring writes" flags (normally long up)
+        double g0 = guard0 ? gld<COH_AGENT>(guard0) : 1.0, g1 = guard1 ? gld<COH_AGENT>(guard1) : 1.0;
+        const long long t0 = wall_clock64();
+        while ((g0 == 0.0 || g1 == 0.0) && stop_v == 0.0) {
+            __builtin_amdgcn_s_sleep(NS_POLL_SLEEP);
+            stop_v = gld<COH_AGENT>(stop_src);
+            if (guard0) g0 = gld<COH_AGENT>(guard0);
+            if (guard1) g1 = gld<COH_AGENT>(guard1);
+            if (wall_clock64() - t0 > 20000000LL) {
+                gst<COH_AGENT>(fail_flag, 1.0);
+                stop_v = 1.0;
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been acknowledged (by the L2 / by memory)
     __syncthreads();
     NS_STAMP();  // stores acknowledged
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        const unsigned word = (xcc << 24) | phase;
+        const unsigned word = (xcc << 24) | ((stop_v != 0.0) ? NS_FLAG_STOP : 0u) | phase;
         if (lane == 0) {
             if (COH == COH_XCD) asm volatile("global_store_dword %0, %1, off" ::"v"(flags + w), "v"(word) : "memory");
             else __hip_atomic_store(flags + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const long long t0 = wall_clock64();
         int good = 1;
-        unsigned v = word;
+        unsigned v = (xcc << 24) | phase;
         for (;;) {
             if (lane < nw) v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_ballot_w64((v & 0xffffffu) < phase) == 0) break;
+            if (__builtin_amdgcn_ballot_w64((v & NS_FLAG_PHASE) < phase) == 0) break;
             __builtin_amdgcn_s_sleep(NS_POLL_SLEEP);
             if (wall_clock64() - t0 > 20000000LL) {
                 good = 0;
@@ -1041,7 +1286,9 @@ __device__ __forceinline__ int ns_flag_barrier(unsigned *flags, unsigned phase, 
             }
         }
         const bool one_xcd = __builtin_amdgcn_ballot_w64((v >> 24) != xcc) == 0;
-        if (lane == 0) res = good ? (one_xcd ? 2 : 1) : 0;
+        const unsigned v0 = __builtin_amdgcn_readfirstlane(v);  // workgroup 0's word
+        const bool stopped = (v0 & NS_FLAG_PHASE) == phase && (v0 & NS_FLAG_STOP) != 0u;
+        if (lane == 0) res = good ? ((one_xcd ? 2 : 1) | (stopped ? 4 : 0)) : 0;
     }
     __syncthreads();
     NS_STAMP();  // barrier passed
@@ -1108,8 +1355,10 @@ __device__ __forceinline__ void pair_mma_reduce(const PairOps &o, double (*redp)
 // (it runs the pair's code with tile 0 -- an upper tile -- left out).  0.77 MB of operands per squaring instead of 1.15, 20
 // workgroups at the barrier instead of 36.  Per tile the arithmetic of ns_square_body.
 constexpr int NS_SQ_PAIR_WG = 20;
-template <bool FIRST, int COH>
-__device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, double *s, int step, int xbuf_out, int w,
+// EVAL (evaluations ride in the launch): SC_SQ_DONE is raised from OUTSIDE the chain, at any time -- the chain's workgroups do
+// not look at it themselves (they would disagree within a phase); workgroup 0 passes it on through the barrier (ns_flag_barrier)
+template <bool FIRST, int COH, bool EVAL = false>
+__device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, double *s, int step, int w,
                                                     double (*redp)[4][4][64], double (*partp)[4])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1128,12 +1377,15 @@ __device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, 
         const double p1 = (lane < NS_TILES) ? gld<COH>(s + SC_SQN + step * 64 + lane) : 0.0;
         const double p0 = (lane < NS_TILES && step >= 2) ? gld<COH>(s + SC_SQN + (step - 1) * 64 + lane) : 0.0;
         t_in = gld<COH>(s + SC_SQN + step * 64 + 63);
-        if (done != 0.0) return false;
+        if (!EVAL && done != 0.0) return false;
         nrm = wr::wave64_allsum(p1);
         if (step >= 2 && t_in > NS_SQ_TGUARD) {
             const double prev = wr::wave64_allsum(p0);
             if (fabs(nrm - prev) <= NS_SQ_TOL * nrm) {
-                if (w == 0 && tid == 0) gst<COH>(s + SC_SQ_DONE, 1.0);
+                if (w == 0 && tid == 0) {
+                    gst<COH>(s + SC_SQ_FINAL, (double)step);  // X_step is the filter's last iterate
+                    gst<COH>(s + SC_SQ_DONE, 1.0);
+                }
                 return false;
             }
         }
@@ -1141,7 +1393,6 @@ __device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, 
     const double t_out = 2.0 * t_in * t_in * nrm;  // overflows to +inf once the filter has separated: 1 / t_out = 0
     const double inv_t = 1.0 / t_out;
     if (w == 0 && tid == 0) {
-        gst<COH>(s + SC_XBUF, (double)xbuf_out);
         gst<COH>(s + SC_SQ, (double)(step + 1));
         gst<COH>(s + SC_SQN + (step + 1) * 64 + 63, t_out);
     }
@@ -1164,40 +1415,161 @@ __device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, 
     }
     return true;
 }
-template <int COH>
-__device__ __forceinline__ void ns_square_tail_pair_rest(double *X0, double *X1, double *scall, int step_first, int step_last, int w,
+constexpr int NS_SQ_EVAL_WG = 8;  // evaluating workgroups of the one-matrix launch: an evaluation takes three to four squarings
+template <int COH, bool EVAL>
+__device__ __forceinline__ void ns_square_tail_pair_rest(const XBufs xb, double *scall, int step_first, int step_last, int w,
                                                          unsigned xcc, double (*redp)[4][4][64], double (*partp)[4])
 {
+    constexpr int NW = NS_SQ_PAIR_WG + (EVAL ? NS_SQ_EVAL_WG : 0);
     unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS);
     unsigned phase = 1;
-    for (int step = step_first + 1; step <= step_last; ++step) {
-        const bool odd = (step & 1) != 0;  // step i reads the buffer step i-1 wrote: X0 after the first squaring
-        if (!ns_square_pair_body<false, COH>(odd ? X0 : X1, odd ? X1 : X0, scall, step, odd ? 1 : 0, w, redp, partp)) return;
-        if (step < step_last && !ns_flag_barrier<COH>(flags, ++phase, w, NS_SQ_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
+    for (int step = step_first + 1; step <= step_last; ++step) {  // squaring `step` reads X_step, writes X_(step + 1)
+        if (!ns_square_pair_body<false, COH, EVAL>(ns_xk(xb, step), ns_xk(xb, step + 1), scall, step, w, redp, partp)) return;
+        // (with evaluations riding along the last iterate, too, is announced by a barrier: the flag words are what they poll)
+        if (EVAL || step < step_last) {
+            // (the squaring after this barrier, number `phase`, writes X_(phase + 1) over X_(phase - 1): X_(phase - 1)'s evaluation must
+            // have its columns and X_phase's evaluation the diagonal -- workgroup 0 holds the barrier for them)
+            ++phase;
+            const bool gd = EVAL && w == 0;
+            const int r = ns_flag_barrier<COH>(flags, phase, w, NW, xcc, scall + SC_BARFAIL, gd ? scall + SC_SQ_DONE : nullptr,
+                                               (gd && phase >= 2 && phase <= NS_SQUARINGS) ? scall + SC_HAVE_DIAG + phase - RITZ_K0 : nullptr,
+                                               (gd && phase >= 3 && phase <= NS_SQUARINGS + 1) ? scall + SC_HAVE_COLS + phase - 1 - RITZ_K0 : nullptr);
+            if (r == 0 || (r & 4)) return;
+        }
+        if (EVAL && w == 0) EV_STAMP(scall, 48 + step + 1);  // X_(step + 1) complete
+    }
+    if (EVAL && w == 0 && threadIdx.x == 0) gst<COH_AGENT>(scall + SC_SQ_FINAL, (double)(step_last + 1));  // the cap: X_16 is the last
+}
+// ---- an evaluating workgroup of the one-matrix squaring launch (e = 0 .. NS_SQ_EVAL_WG - 1): X_k for k = RITZ_K0 + e, + NS_SQ_EVAL_WG, ...
+// Polls the chain's barrier flag words (X_k is complete once all of them have reached k): picks its columns on X_(k-1) while X_k is
+// being computed, takes them from X_k the moment it is complete, evaluates, decides in k order (ritz_decide) and leaves as soon as
+// the chain's result is decided.  The chain works on TWO buffers (XBufs without history): squaring k + 1 overwrites X_k, so workgroup 0
+// of the chain holds its barrier until this workgroup has said that it has the diagonal / the columns (SC_HAVE_DIAG / SC_HAVE_COLS;
+// normally said microseconds earlier).  Every wait is bounded.
+// Waits until the chain's flag words have all reached `phase`.  Returns 1: they have; 0: the evaluation is not wanted any more
+// (a result has been taken, the filter stopped before iterate k, a barrier failed) -- leave.  Uniform over the workgroup.
+__device__ __forceinline__ int ns_eval_wait(unsigned *flags, double *s, unsigned phase, int k, int *ev_state)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        const long long t0 = wall_clock64();
+        int st;
+        for (;;) {
+            const unsigned v = (lane < NS_SQ_PAIR_WG) ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NS_FLAG_PHASE;
+            const double kw = gld<COH_AGENT>(s + SC_KWIN), fin = gld<COH_AGENT>(s + SC_SQ_FINAL), bf = gld<COH_AGENT>(s + SC_BARFAIL);
+            const bool ready = __builtin_amdgcn_ballot_w64((v & NS_FLAG_PHASE) < phase) == 0;
+            // (the slots are zeroed by the first squaring: trusted only once the chain's own flags are past phase 1)
+            const bool live = __builtin_amdgcn_ballot_w64((v & NS_FLAG_PHASE) < 1u) == 0;
+            if (live && (kw != 0.0 || bf != 0.0 || (fin != 0.0 && (double)k > fin))) { st = 0; break; }
+            if (ready) { st = 1; break; }
+            __builtin_amdgcn_s_sleep(NS_POLL_SLEEP);
+            if (wall_clock64() - t0 > 20000000LL) {
+                if (lane == 0) gst<COH_AGENT>(s + SC_BARFAIL, 1.0);
+                st = 0;
+                break;
+            }
+        }
+        if (lane == 0) *ev_state = st;
+    }
+    __syncthreads();
+    const int st = *ev_state;
+    __syncthreads();
+    return st;
+}
+__device__ __forceinline__ void ns_square_evaluator(const double *__restrict__ A, const XBufs xb, double *s, int e, unsigned xcc,
+                                                    int deflate, RitzLds &L)
+{
+    __shared__ int ev_state;
+    unsigned *flags = reinterpret_cast<unsigned *>(s + SC_FLAGS);
+    const int tid = threadIdx.x;
+    // takes part in the first barrier (the placement check reads its XCC id) and never holds up a later one
+    if (tid == 0) __hip_atomic_store(flags + NS_SQ_PAIR_WG + e, (xcc << 24) | NS_FLAG_PHASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RitzIn in;
+    ritz_load_matrix(in, A, s, tid);  // (depends on nothing in this launch: in flight while the first squarings run)
+    bool have_in = false;
+    for (int k = RITZ_K0 + e; k <= NS_SQUARINGS; k += NS_SQ_EVAL_WG) {
+        // ---- X_(k-1) is complete: the picks
+        if (!ns_eval_wait(flags, s, (unsigned)(k - 1), k, &ev_state)) return;
+        if (!have_in) {  // (after the first barrier: the first squaring has left the row sums and the bounds)
+            ritz_load_inputs<COH_AGENT>(in, s, tid);
+            have_in = true;
+        }
+        ritz_picks<COH_AGENT>(ns_xk(xb, k - 1), s, L);
+        if (tid == 0) gst<COH_AGENT>(s + SC_HAVE_DIAG + k - RITZ_K0, 1.0);  // (the picks have consumed the diagonal)
+        // ---- X_k is complete
+        if (!ns_eval_wait(flags, s, (unsigned)k, k, &ev_state)) return;
+        EV_STAMP(s, 2 + 3 * (k - 2));
+        // an iterate that cannot pass and cannot be the last (the filter stops by itself only beyond the guard, or at the cap)
+        if (k < NS_SQUARINGS && !(gld<COH_AGENT>(s + SC_SQN + k * 64 + 63) > NS_SQ_TGUARD)) {
+            if (tid == 0) {
+                gst<COH_AGENT>(s + SC_HAVE_COLS + k - RITZ_K0, 1.0);
+                gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, 1.0);
+            }
+            continue;
+        }
+        const double u = ritz_eval<COH_AGENT, true>(in, ns_xk(xb, k), s, k, L, s + SC_HAVE_COLS + k - RITZ_K0);
+        if (L.abort) return;
+        EV_STAMP(s, 3 + 3 * (k - 2));
+        // is X_k the filter's last iterate?  The chain says so when it looks at X_k's norm: SC_SQ_FINAL = k, or squaring k starts
+        // (SC_SQ = k + 1).  Only an evaluation that did not pass needs to know.
+        if (tid == 0) {
+            int st = 1;  // 1: not the last; 2: the last; 0: leave
+            if (!L.o_pass) {
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    const double fin = gld<COH_AGENT>(s + SC_SQ_FINAL), sq = gld<COH_AGENT>(s + SC_SQ), kw = gld<COH_AGENT>(s + SC_KWIN);
+                    if (kw != 0.0) { st = 0; break; }
+                    if (fin != 0.0) { st = ((double)k == fin) ? 2 : ((double)k < fin ? 1 : 0); break; }
+                    if (sq >= (double)(k + 1)) { st = 1; break; }
+                    __builtin_amdgcn_s_sleep(NS_POLL_SLEEP);
+                    if (wall_clock64() - t0 > 20000000LL) {
+                        gst<COH_AGENT>(s + SC_BARFAIL, 1.0);
+                        st = 0;
+                        break;
+                    }
+                }
+            }
+            ev_state = st;
+        }
+        __syncthreads();
+        const int st = ev_state;
+        if (st == 0) return;
+        const bool decided = ritz_decide(L, u, s, k, st == 2, deflate);
+        EV_STAMP(s, 4 + 3 * (k - 2));
+        if (decided) return;
     }
 }
-__global__ __launch_bounds__(256) void ns_square_tail_pair_kernel(const double *A, double *X0, double *X1, double *scall, int step_first,
-                                                                  int step_last, int batch, int force_agent)
+template <bool EVAL>
+__global__ __launch_bounds__(256) void ns_square_tail_pair_kernel(const double *A, const XBufs xb_all, double *scall, int step_first,
+                                                                  int step_last, int batch, int force_agent, int deflate)
 {
     __shared__ double redp[2][4][4][64];
     __shared__ double partp[2][4];
+    constexpr int NW = NS_SQ_PAIR_WG + (EVAL ? NS_SQ_EVAL_WG : 0);
     int b, w;
-    if (!ns_tail_block(NS_SQ_PAIR_WG, batch, b, w)) return;
-    X0 += (size_t)b * SN * SN;
-    X1 += (size_t)b * SN * SN;
+    if (!ns_tail_block(NW, batch, b, w)) return;
+    // (EVAL: two buffers -- ns_square_evaluator)
+    const XBufs xb{xb_all.x0 + (size_t)b * SN * SN, xb_all.x1 + (size_t)b * SN * SN,
+                   EVAL ? nullptr : xb_all.hist + (size_t)b * SN * SN, xb_all.M};
     scall += (size_t)b * SC_COUNT;
     const unsigned xcc = ns_xcc_id();
-    const bool odd = (step_first & 1) != 0;
+    if (EVAL && w >= NS_SQ_PAIR_WG) {
+        __shared__ RitzLds L;
+        ns_square_evaluator(A + (size_t)b * SN * SN, xb, scall, w - NS_SQ_PAIR_WG, xcc, deflate, L);
+        return;
+    }
+    if (EVAL && w == 0) EV_STAMP(scall, 0);
     if (step_first == 0) {
-        (void)ns_square_pair_body<true, COH_AGENT>(A + (size_t)b * SN * SN, X0, scall, 0, 0, w, redp, partp);
-    } else if (!ns_square_pair_body<false, COH_AGENT>(odd ? X0 : X1, odd ? X1 : X0, scall, step_first, odd ? 1 : 0, w, redp, partp))
+        (void)ns_square_pair_body<true, COH_AGENT>(A + (size_t)b * SN * SN, ns_xk(xb, 1), scall, 0, w, redp, partp);
+    } else if (!ns_square_pair_body<false, COH_AGENT>(ns_xk(xb, step_first), ns_xk(xb, step_first + 1), scall, step_first, w, redp, partp))
         return;
     if (step_first == step_last) return;
-    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, NS_SQ_PAIR_WG, xcc, scall + SC_BARFAIL);
+    int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, NW, xcc, scall + SC_BARFAIL);
     if (r == 2 && force_agent) r = 1;
     if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 5] = (double)r;  // diagnostics: which mode the squaring launch ran in
-    if (r == 2) ns_square_tail_pair_rest<COH_XCD>(X0, X1, scall, step_first, step_last, w, xcc, redp, partp);
-    else if (r == 1) ns_square_tail_pair_rest<COH_AGENT>(X0, X1, scall, step_first, step_last, w, xcc, redp, partp);
+    if (r == 2) ns_square_tail_pair_rest<COH_XCD, EVAL>(xb, scall, step_first, step_last, w, xcc, redp, partp);
+    else if (r == 1) ns_square_tail_pair_rest<COH_AGENT, EVAL>(xb, scall, step_first, step_last, w, xcc, redp, partp);
+    if (EVAL && w == 0) EV_STAMP(scall, 1);
 }
 
 constexpr int NS_PAIR_WG = 32;
@@ -1970,7 +2342,10 @@ SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
     o.flags = sc + SC_FLAGS;
     return o;
 }
-size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * (11 * SN * SN + SC_COUNT) * sizeof(double); }
+// 11 matrices, the slots, then the filter's history X_3 .. X_16 (XBufs)
+size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * ((11 + NS_SQUARINGS - 2) * SN * SN + SC_COUNT) * sizeof(double); }
+// COVO_NS_RITZ_INSIDE=0 / covo_debug_set_ns_ritz_inside(0): the one-matrix chain, too, evaluates after its squarings (ns_ritz_scan_kernel)
+int g_ns_ritz_inside = [] { const char *e = std::getenv("COVO_NS_RITZ_INSIDE"); return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1; }();
 
 int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
                     hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok, CovDeferred *cov, bool r_has_stats,
@@ -1997,22 +2372,27 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     }
     if (r_has_stats) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
     else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
+    XBufs xb{X0, X1, sc + (size_t)batch * SC_COUNT, M};
     const bool fold_first = persistent_ok && (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) >= NS_SQUARINGS - 1;
-    if (!fold_first) hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, X0, sc, 0, 0, batch);
+    if (!fold_first) hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, ns_xk(xb, 1), sc, 0, batch);
     // the remaining squarings / iterations run inside persistent launches (20 / 32 workgroups per matrix, one XCD per matrix)
     int sq_tail = persistent_ok ? (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) : 0;
     if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
     const int sq_sep = NS_SQUARINGS - sq_tail;
-    double *xi = X0, *xo = X1;
-    for (int i = 1; i < sq_sep; ++i) {
-        hipLaunchKernelGGL(ns_square_kernel<false>, ns_grid(NS_TILES, batch), dim3(256), 0, s, xi, xo, sc, i, (xo == X1) ? 1 : 0, batch);
-        double *t = xi; xi = xo; xo = t;
+    for (int i = 1; i < sq_sep; ++i)
+        hipLaunchKernelGGL(ns_square_kernel<false>, ns_grid(NS_TILES, batch), dim3(256), 0, s, ns_xk(xb, i), ns_xk(xb, i + 1), sc, i, batch);
+    // one matrix, every squaring folded: the Rayleigh-Ritz evaluations ride in the squaring launch and stop it (ns_square_evaluator)
+    const bool eval_inside = fold_first && batch == 1 && g_ns_ritz_inside == 1;
+    if (sq_tail > 0) {
+        if (eval_inside)
+            hipLaunchKernelGGL(ns_square_tail_pair_kernel<true>, ns_tail_grid(NS_SQ_PAIR_WG + NS_SQ_EVAL_WG, batch), dim3(256), 0, s, A, xb, sc,
+                               0, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
+        else
+            hipLaunchKernelGGL(ns_square_tail_pair_kernel<false>, ns_tail_grid(NS_SQ_PAIR_WG, batch), dim3(256), 0, s, A, xb, sc,
+                               fold_first ? 0 : sq_sep, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
     }
-    if (sq_tail > 0)
-        hipLaunchKernelGGL(ns_square_tail_pair_kernel, ns_tail_grid(NS_SQ_PAIR_WG, batch), dim3(256), 0, s, A, X0, X1, sc,
-                           fold_first ? 0 : sq_sep, NS_SQUARINGS - 1, batch, g_ns_force_agent);
     if (g_dbg_sigma_stages < 2) return 0;
-    hipLaunchKernelGGL(ns_ritz_kernel, dim3(batch), dim3(512), 0, s, A, X0, X1, sc, g_ns_deflate);
+    if (!eval_inside) hipLaunchKernelGGL(ns_ritz_scan_kernel, dim3(batch * RITZ_NK), dim3(256), 0, s, A, xb, sc, g_ns_deflate, g_ns_ritz_inside == 2 ? 1 : 0);
     if (g_dbg_sigma_stages < 3) return 0;
     // one matrix with every iteration folded: iteration 0 is phase 0 of the persistent launch (ns_iter_tail_pair_kernel)
     // (same box, three runs each: 5 464-5 467 / 4 888-4 900 steps/s bench / closed loop against 5 442-5 445 / 4 859-4 870 with its own launch)

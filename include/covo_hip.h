@@ -394,6 +394,10 @@ int covo_debug_set_ns_deflate(int on);
  * XCD (sigma_ns.hip: every access stays an agent-scope atomic, COH_AGENT) -- the fallback of the placement check, which no
  * MI355X box takes by itself; 0 (default): as detected.  Same Sigma and L bit for bit. */
 int covo_debug_set_ns_coherence(int force_agent);
+/* Test hook (process-wide): 0 makes the one-matrix Sigma chain evaluate its Rayleigh-Ritz pairs AFTER the squaring launch
+ * (ns_ritz_scan_kernel, what batches and shared-device handles do) instead of inside it; default 1.  Same Sigma and L bit for
+ * bit: lambda_min is a function of the matrix alone (sigma_ns.hip: ritz_decide).  Also COVO_NS_RITZ_INSIDE=0 in the environment. */
+int covo_debug_set_ns_ritz_inside(int on);
 int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 
 /* Profiling aid: covo_sigma for ONE matrix that also stores shader-clock ticks (s_memtime) at the kernel's

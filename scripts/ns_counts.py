@@ -25,7 +25,7 @@ for task in ("tracking_zigzag", "tracking"):
         u, cp, _ = c(obs, state, params, ka, cp, info)
         _lib.check(c.core.lib.covo_debug_sigma_workspace(c.core.h, _lib.ptr(out_t), SC0, 16, c.core.stream()))
         torch.cuda.synchronize()
-        sq.append(int(out_t[8])); it.append(int(out_t[6]))
+        sq.append(int(out_t[7])); it.append(int(out_t[6]))
         obs, state, _, _, info = env.step(ks, state, u.cpu().numpy(), params)
     print(task, "squarings:", sorted(collections.Counter(sq).items()), " NS iterations:", sorted(collections.Counter(it).items()))
     print("  first 60 squarings:", sq[:60])

@@ -32,7 +32,7 @@ for tail in ((0, 0), (0, 2), (0, 64), (64, 0), (64, 64)):
     out_t = torch.zeros(24, dtype=torch.float64).pin_memory()
     _lib.check(lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out_t), 11 * n * n, 24, core.stream()))
     torch.cuda.synchronize()
-    print(f"tail (squarings, iterations) = {tail}: covo_sigma {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us in a graph  (squarings {int(out_t[8])}, NS iterations {int(out_t[6])}; tail modes {int(out_t[21])} / {int(out_t[22])} [2 = one XCD])")
+    print(f"tail (squarings, iterations) = {tail}: covo_sigma {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us in a graph  (squarings {int(out_t[7])}, NS iterations {int(out_t[6])}; tail modes {int(out_t[21])} / {int(out_t[22])} [2 = one XCD])")
     if os.environ.get("NS_STAMPS") and tail[1]:  # library built with -DNS_STAMPS: the seams of workgroup 0's phases, 10 ns ticks
         SC_STAMPS = int(os.environ["NS_STAMPS"])
         st = torch.zeros(192, dtype=torch.float64).pin_memory()

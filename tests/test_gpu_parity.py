@@ -1043,7 +1043,53 @@ def _sigma_chain_iters(core):
     out = torch.zeros(32, dtype=torch.float64, device=DEV)
     _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out), 11 * 128 * 128, 32, core.stream()))
     o = out.cpu().numpy()
-    return int(o[8]), int(o[6]), bool(o[29] != 0.0)  # SC_SQ, SC_ITERS, SC_GAM
+    return int(o[7]), int(o[6]), bool(o[29] != 0.0)  # SC_KWIN, SC_ITERS, SC_GAM
+
+
+def test_sigma_early_ritz_inside_equals_scan_equals_batch():
+    """lambda_min is the Ritz value of X_kwin, kwin = the first filter iterate whose bottom Ritz pair passes its own residual
+    test (sigma_ns.hip: ritz_eval / ritz_decide) -- a function of the matrix alone.  The evaluations riding inside the
+    squaring launch (one matrix), the scan launch after the squarings (covo_debug_set_ns_ritz_inside(0)) and the batched chain
+    give the same Sigma and L bit for bit; on real Hessians kwin comes well before the filter's own stop."""
+    g = np.load(os.path.join(HERE, "golden", "hessians_r03.npz"))
+    mats = [m for k in g.files for m in g[k]]
+    n_real = len(mats)
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(128, 128))
+    w, U = np.linalg.eigh(0.05 * (A + A.T))
+    for w01 in (1e-9, 1e-3, 3.0):
+        ww = w.copy()
+        ww[0] = ww[1] - w01
+        mats.append((U * ww) @ U.T)
+    mats.append(np.load(os.path.join(HERE, "golden", "sigma_nullblock_small_lmin.npy")))
+    mats.append(np.eye(128))
+    core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
+    out = torch.zeros(32, dtype=torch.float64, device=DEV)
+    res, kwin, ksq = {}, [], []
+    try:
+        for inside in (1, 0):
+            core.lib.covo_debug_set_ns_ritz_inside(inside)
+            for i, Rm in enumerate(mats):
+                Sigma, L = core.sigma(torch.from_numpy(Rm[None].copy()).to(DEV), 0.5)
+                res[inside, i] = (Sigma[0].cpu().numpy(), L[0].cpu().numpy())
+                _lib.check(core.lib.covo_debug_sigma_workspace(core.h, _lib.ptr(out), 11 * 128 * 128, 32, core.stream()))
+                o = out.cpu().numpy()
+                assert o[26] == 0.0, (inside, i)  # SC_BARFAIL
+                if inside == 0:  # the scan path runs the filter to its own stop: SC_KWIN against SC_SQ
+                    kwin.append(int(o[7]))
+                    ksq.append(int(o[8]))
+                    assert 2 <= o[7] <= o[8] <= 16, (i, o[7], o[8])
+                ref = R.optimize_sigma(Rm, 0.5, 32, 4)
+                assert np.linalg.norm(res[inside, i][0] - ref) / np.linalg.norm(ref) < 1e-6, (inside, i)
+    finally:
+        core.lib.covo_debug_set_ns_ritz_inside(1)
+    for i in range(len(mats)):
+        assert np.array_equal(res[1, i][0], res[0, i][0]) and np.array_equal(res[1, i][1], res[0, i][1]), i
+    kwin, ksq = np.array(kwin), np.array(ksq)
+    assert np.mean(ksq[:n_real] - kwin[:n_real]) >= 1.5, (kwin, ksq)  # real Hessians: the pair is there ~2.5 squarings early
+    Sb, Lb = core.sigma(torch.from_numpy(np.stack(mats)).to(DEV), 0.5, batch=len(mats))
+    for i in range(len(mats)):
+        assert np.array_equal(Sb[i].cpu().numpy(), res[1, i][0]) and np.array_equal(Lb[i].cpu().numpy(), res[1, i][1]), i
 
 
 def test_sigma_deflation_on_real_hessians():
