@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
 //     so an evaluation costs the chain nothing and the separate Ritz launch is gone;
 //   * batches / shared-device handles / the debug splits: the squarings run to their own stop as before and ONE launch evaluates
 //     every k of every matrix (ns_ritz_scan_kernel).
+constexpr double RITZ_PASS_E = 0.05;  // e_k = (1 - |X_k|_F^2) / 2 below this: the gap bound's linearisation holds (ritz_eval)
 constexpr int RITZ_K0 = 2;                          // first evaluated iterate (the stationarity test needs two norms: the filter never stops before X_2)
 constexpr int RITZ_NK = NS_SQUARINGS - RITZ_K0 + 1;  // evaluations per matrix: X_2 .. X_16
 struct XBufs {  // X_1 -> x0, X_2 -> x1 (T and T^T of the iterations later), X_3 .. X_16 -> the history;  hist == nullptr: no history,
@@ -473,24 +474,31 @@ struct RitzLds {
     int pick[RITZ];
 };
 // what an evaluating workgroup keeps of A and of the chain's input statistics (loaded once per matrix; 256 threads)
-struct RitzIn {
-    double acol[2][32];  // thread (r = tid & 63, g = tid >> 6): A[32 g .. 32 g + 31][r] and [..][r + 64] -- two rows share every V they read
+template <bool LEAN = false>
+struct RitzInT {
+    double acol[2][LEAN ? 1 : 32];  // thread (r = tid & 63, g = tid >> 6): A[32 g .. 32 g + 31][r] and [..][r + 64] -- two rows share every V they read
     double dg, ra;    // tid < 128: A[tid][tid], sum_c |A[tid][c]|
     double tr, f2, hi;
+    const double *A;  // LEAN evaluations (the batched squaring launch: three workgroups per CU, <= 168 VGPRs) read A where it lies
 };
+typedef RitzInT<false> RitzIn;
 // (two parts: A and its diagonal are there when the launch starts; the row sums and bounds are left by the first squaring)
-__device__ __forceinline__ void ritz_load_matrix(RitzIn &in, const double *__restrict__ A, const double *s, int tid)
+template <bool LEAN = false>
+__device__ __forceinline__ void ritz_load_matrix(RitzInT<LEAN> &in, const double *__restrict__ A, const double *s, int tid)
 {
     const int r_av = tid & 63, g = tid >> 6;
+    in.A = A;
+    if (!LEAN) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {  // A symmetric: coalesced in r
-        in.acol[0][c] = A[(size_t)(32 * g + c) * SN + r_av];
-        in.acol[1][c] = A[(size_t)(32 * g + c) * SN + r_av + 64];
+        for (int c = 0; c < 32; ++c) {  // A symmetric: coalesced in r
+            in.acol[0][c] = A[(size_t)(32 * g + c) * SN + r_av];
+            in.acol[1][c] = A[(size_t)(32 * g + c) * SN + r_av + 64];
+        }
     }
     in.dg = (tid < SN) ? s[SC_DIAG + tid] : 0.0;  // (written a launch earlier: KD / ns_prep_kernel)
 }
-template <int COH>
-__device__ __forceinline__ void ritz_load_inputs(RitzIn &in, const double *s, int tid)
+template <int COH, bool LEAN = false>
+__device__ __forceinline__ void ritz_load_inputs(RitzInT<LEAN> &in, const double *s, int tid)
 {
     in.ra = (tid < SN) ? gld<COH>(s + SC_ROWABS + tid) : 0.0;
     in.tr = gld<COH>(s + SC_TRACE);
@@ -539,8 +547,8 @@ __device__ __forceinline__ void ritz_picks(const double *__restrict__ Xp, const 
 // ABORT (the evaluations inside the squaring launch): every seam looks at SC_KWIN -- once another evaluation has been taken this
 // one is void and the workgroup must leave (the launch ends when its last workgroup does): returns with L.abort != 0.
 // have_cols != nullptr: raised (coherently) once the columns of X_k are in registers -- the chain may then reuse X_k's buffer.
-template <int COH, bool ABORT = false>
-__device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__restrict__ X, const double *s, int k, RitzLds &L,
+template <int COH, bool ABORT = false, bool LEAN = false>
+__device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const double *__restrict__ X, const double *s, int k, RitzLds &L,
                                             double *have_cols = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -617,13 +625,47 @@ __device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__re
     {
         const int r_av = tid & 63, g = tid >> 6;
         double av[2][RITZ] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        if (LEAN) {  // the same sums, A from memory in chunks of eight columns (the next chunk in flight)
+            double a[2][2][8];
+            // (the chunk's base address goes through an opaque asm: left alone the compiler forms all 64 addresses of all chunks
+            // ahead of the workgroup's evaluation loop and spills them)
+            const double *Ap = in.A + (size_t)(32 * g) * SN + r_av;
+            asm volatile("" : "+v"(Ap));
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
+            for (int c = 0; c < 8; ++c) {
+                a[0][0][c] = Ap[(size_t)c * SN];
+                a[0][1][c] = Ap[(size_t)c * SN + 64];
+            }
 #pragma unroll
-            for (int q = 0; q < RITZ; ++q) {
-                const double vq = L.V[q][32 * g + c];
-                av[0][q] = fma(in.acol[0][c], vq, av[0][q]);
-                av[1][q] = fma(in.acol[1][c], vq, av[1][q]);
+            for (int ch = 0; ch < 4; ++ch) {
+                if (ch < 3) {
+                    const double *An = Ap + (size_t)(8 * (ch + 1)) * SN;
+                    asm volatile("" : "+v"(An));
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        a[(ch + 1) & 1][0][c] = An[(size_t)c * SN];
+                        a[(ch + 1) & 1][1][c] = An[(size_t)c * SN + 64];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                    for (int q = 0; q < RITZ; ++q) {
+                        const double vq = L.V[q][32 * g + 8 * ch + c];
+                        av[0][q] = fma(a[ch & 1][0][c], vq, av[0][q]);
+                        av[1][q] = fma(a[ch & 1][1][c], vq, av[1][q]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+#pragma unroll
+                for (int q = 0; q < RITZ; ++q) {
+                    const double vq = L.V[q][32 * g + c];
+                    av[0][q] = fma(in.acol[0][c], vq, av[0][q]);
+                    av[1][q] = fma(in.acol[1][c], vq, av[1][q]);
+                }
             }
         }
 #pragma unroll
@@ -664,7 +706,7 @@ __device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__re
         const double y1 = fma(-beta, l1, alpha);
         for (int j = 1; j <= k && j <= NS_SQUARINGS; ++j) {
             const double e = 0.5 * (1.0 - L.nrm[j]);
-            if (e > 1e-13 && e < 0.05 && y1 > 1.0) {  // the earliest step at which the linearisation holds
+            if (e > 1e-13 && e < RITZ_PASS_E && y1 > 1.0) {  // the earliest step at which the linearisation holds
                 const double D = -log(e) * exp2(-(double)j);
                 const double ac = log(y1 + sqrt(fma(y1, y1, -1.0))) - D;
                 const double ex = exp(fmax(ac, 0.0));
@@ -680,16 +722,23 @@ __device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__re
         // Newton (qm::rcp64_, qm::rsq64_), not libm.  Lanes 0..3 run it in lockstep (the same issue slots as one lane): each also
         // carries ONE row of the accumulated rotation -- the eigenvectors for 4 extra operations per rotation instead of 16
         double h[RITZ][RITZ], jrow[RITZ];
+#pragma unroll
         for (int i = 0; i < RITZ; ++i) {
+#pragma unroll
             for (int j = 0; j < RITZ; ++j) h[i][j] = 0.5 * (L.H[i][j] + L.H[j][i]);
             jrow[i] = (i == tid) ? 1.0 : 0.0;
         }
-        for (int sweep = 0; sweep < 12; ++sweep) {
+#pragma unroll 1
+        for (int sweep = 0; sweep < 12; ++sweep) {  // (h and jrow stay in registers: every inner loop is unrolled)
             double off = 0.0, dia = 0.0;
+#pragma unroll
             for (int p = 0; p < RITZ; ++p)
+#pragma unroll
                 for (int q2 = 0; q2 < RITZ; ++q2) (p == q2 ? dia : off) += h[p][q2] * h[p][q2];
             if (off <= 1e-26 * dia) break;  // off^2 / gap bounds the eigenvalue error: far below the 1e-13 the chain needs
+#pragma unroll
             for (int p = 0; p < RITZ - 1; ++p)
+#pragma unroll
                 for (int q2 = p + 1; q2 < RITZ; ++q2) {
                     if (h[p][q2] * h[p][q2] <= 1e-34 * fabs(h[p][p] * h[q2][q2])) continue;
                     // the small rotation that zeroes h_pq: tan(2 theta) = b / a, a = h_qq - h_pp, b = 2 h_pq;  cos(2 theta) = |a| / r,
@@ -708,6 +757,7 @@ __device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__re
                     h[q2][q2] += hpq;
                     h[p][q2] = 0.0;
                     h[q2][p] = 0.0;
+#pragma unroll
                     for (int kk = 0; kk < RITZ; ++kk) {
                         if (kk == p || kk == q2) continue;
                         const double hp = h[kk][p], hq = h[kk][q2];
@@ -725,6 +775,7 @@ __device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__re
                 }
         }
         double lmin = h[0][0], cmin = jrow[0];
+#pragma unroll
         for (int i = 1; i < RITZ; ++i)
             if (h[i][i] < lmin) { lmin = h[i][i]; cmin = jrow[i]; }
         L.cvec[tid] = cmin;  // component `tid` of the bottom eigenvector of H
@@ -779,7 +830,8 @@ __device__ __forceinline__ double ritz_eval(const RitzIn &in, const double *__re
         // the bottom eigenpair is CONVERGED when its residual is small against the gap bound: the evaluation then "passes" (the
         // chain stops here) and the iterations may deflate the pair (see the header)
         const bool conv = small_resid && 1e-2 + gap < 0.25 * scale;
-        L.o_pass = (conv && t_k > NS_SQ_TGUARD) ? 1 : 0;
+        // (... and only an iterate whose norm is already in the gap bound's linear range: what lets the scan launch skip the others)
+        L.o_pass = (conv && t_k > NS_SQ_TGUARD && 0.5 * (1.0 - L.nrm[k]) < RITZ_PASS_E) ? 1 : 0;
         L.o_lmin = lmin_used;
         L.o_scale = scale;
         L.o_lo = 1e-2;
@@ -866,15 +918,17 @@ __global__ __launch_bounds__(256) void ns_ritz_scan_kernel(const double *__restr
         if (tid == 0 && k == k_final - 1) gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, 1.0);
         if (!final) return;
     }
-    // a cheap "not taken": the bounded part of the spectrum is still there (an iterate that cannot pass and is not the last)
-    if (!final && !(s[SC_SQN + k * 64 + 63] > NS_SQ_TGUARD)) {
+    // a cheap "not taken": the bounded part of the spectrum is still there, or the norm is not yet in the range in which an
+    // evaluation can pass (ritz_eval: o_pass) -- an iterate that cannot pass and is not the last
+    const double e_k = 0.5 * (1.0 - slot_sum(s + SC_SQN + k * 64, NS_TILES, tid & 63));
+    if (!final && (!(s[SC_SQN + k * 64 + 63] > NS_SQ_TGUARD) || !(e_k < RITZ_PASS_E))) {
         if (tid == 0) gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, 1.0);
         return;
     }
+    ritz_picks<COH_NONE>(ns_xk(xb, k - 1) + (size_t)b * SN * SN, s, L);  // (first: its loads are waited for in issue order)
     RitzIn in;
     ritz_load_matrix(in, Aall + (size_t)b * SN * SN, s, tid);
     ritz_load_inputs<COH_NONE>(in, s, tid);
-    ritz_picks<COH_NONE>(ns_xk(xb, k - 1) + (size_t)b * SN * SN, s, L);
     const double u = ritz_eval<COH_NONE>(in, ns_xk(xb, k) + (size_t)b * SN * SN, s, k, L);
     (void)ritz_decide(L, u, s, k, final, deflate);
 }
@@ -1415,12 +1469,14 @@ __device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, 
     }
     return true;
 }
-constexpr int NS_SQ_EVAL_WG = 8;  // evaluating workgroups of the one-matrix launch: an evaluation takes three to four squarings
-template <int COH, bool EVAL>
+constexpr int NS_SQ_EVAL_WG = 8;        // evaluating workgroups of the one-matrix launch: an evaluation takes three squarings
+constexpr int NS_SQ_EVAL_WG_BATCH = 3;  // ... per matrix of a batched launch (its squarings take twice as long; LEAN evaluations)
+template <int COH, int NEVAL>
 __device__ __forceinline__ void ns_square_tail_pair_rest(const XBufs xb, double *scall, int step_first, int step_last, int w,
                                                          unsigned xcc, double (*redp)[4][4][64], double (*partp)[4])
 {
-    constexpr int NW = NS_SQ_PAIR_WG + (EVAL ? NS_SQ_EVAL_WG : 0);
+    constexpr bool EVAL = NEVAL > 0;
+    constexpr int NW = NS_SQ_PAIR_WG + NEVAL;
     unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS);
     unsigned phase = 1;
     for (int step = step_first + 1; step <= step_last; ++step) {  // squaring `step` reads X_step, writes X_(step + 1)
@@ -1476,6 +1532,7 @@ __device__ __forceinline__ int ns_eval_wait(unsigned *flags, double *s, unsigned
     __syncthreads();
     return st;
 }
+template <int NEVAL, bool LEAN>
 __device__ __forceinline__ void ns_square_evaluator(const double *__restrict__ A, const XBufs xb, double *s, int e, unsigned xcc,
                                                     int deflate, RitzLds &L)
 {
@@ -1484,14 +1541,15 @@ __device__ __forceinline__ void ns_square_evaluator(const double *__restrict__ A
     const int tid = threadIdx.x;
     // takes part in the first barrier (the placement check reads its XCC id) and never holds up a later one
     if (tid == 0) __hip_atomic_store(flags + NS_SQ_PAIR_WG + e, (xcc << 24) | NS_FLAG_PHASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    RitzIn in;
-    ritz_load_matrix(in, A, s, tid);  // (depends on nothing in this launch: in flight while the first squarings run)
+    RitzInT<LEAN> in;
+    ritz_load_matrix<LEAN>(in, A, s, tid);  // (depends on nothing in this launch: in flight while the first squarings run)
     bool have_in = false;
-    for (int k = RITZ_K0 + e; k <= NS_SQUARINGS; k += NS_SQ_EVAL_WG) {
+#pragma unroll 1
+    for (int k = RITZ_K0 + e; k <= NS_SQUARINGS; k += NEVAL) {
         // ---- X_(k-1) is complete: the picks
         if (!ns_eval_wait(flags, s, (unsigned)(k - 1), k, &ev_state)) return;
         if (!have_in) {  // (after the first barrier: the first squaring has left the row sums and the bounds)
-            ritz_load_inputs<COH_AGENT>(in, s, tid);
+            ritz_load_inputs<COH_AGENT, LEAN>(in, s, tid);
             have_in = true;
         }
         ritz_picks<COH_AGENT>(ns_xk(xb, k - 1), s, L);
@@ -1507,7 +1565,7 @@ __device__ __forceinline__ void ns_square_evaluator(const double *__restrict__ A
             }
             continue;
         }
-        const double u = ritz_eval<COH_AGENT, true>(in, ns_xk(xb, k), s, k, L, s + SC_HAVE_COLS + k - RITZ_K0);
+        const double u = ritz_eval<COH_AGENT, true, LEAN>(in, ns_xk(xb, k), s, k, L, s + SC_HAVE_COLS + k - RITZ_K0);
         if (L.abort) return;
         EV_STAMP(s, 3 + 3 * (k - 2));
         // is X_k the filter's last iterate?  The chain says so when it looks at X_k's norm: SC_SQ_FINAL = k, or squaring k starts
@@ -1539,13 +1597,15 @@ __device__ __forceinline__ void ns_square_evaluator(const double *__restrict__ A
         if (decided) return;
     }
 }
-template <bool EVAL>
-__global__ __launch_bounds__(256) void ns_square_tail_pair_kernel(const double *A, const XBufs xb_all, double *scall, int step_first,
-                                                                  int step_last, int batch, int force_agent, int deflate)
+// NEVAL: evaluating workgroups per matrix (0: none -- the evaluations are a launch of their own, ns_ritz_scan_kernel)
+template <int NEVAL, bool LEAN>
+__device__ __forceinline__ void ns_square_tail_pair_impl(const double *A, const XBufs xb_all, double *scall, int step_first, int step_last,
+                                                         int batch, int force_agent, int deflate)
 {
     __shared__ double redp[2][4][4][64];
     __shared__ double partp[2][4];
-    constexpr int NW = NS_SQ_PAIR_WG + (EVAL ? NS_SQ_EVAL_WG : 0);
+    constexpr bool EVAL = NEVAL > 0;
+    constexpr int NW = NS_SQ_PAIR_WG + NEVAL;
     int b, w;
     if (!ns_tail_block(NW, batch, b, w)) return;
     // (EVAL: two buffers -- ns_square_evaluator)
@@ -1555,7 +1615,7 @@ __global__ __launch_bounds__(256) void ns_square_tail_pair_kernel(const double *
     const unsigned xcc = ns_xcc_id();
     if (EVAL && w >= NS_SQ_PAIR_WG) {
         __shared__ RitzLds L;
-        ns_square_evaluator(A + (size_t)b * SN * SN, xb, scall, w - NS_SQ_PAIR_WG, xcc, deflate, L);
+        ns_square_evaluator<NEVAL, LEAN>(A + (size_t)b * SN * SN, xb, scall, w - NS_SQ_PAIR_WG, xcc, deflate, L);
         return;
     }
     if (EVAL && w == 0) EV_STAMP(scall, 0);
@@ -1567,9 +1627,22 @@ __global__ __launch_bounds__(256) void ns_square_tail_pair_kernel(const double *
     int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS), 1u, w, NW, xcc, scall + SC_BARFAIL);
     if (r == 2 && force_agent) r = 1;
     if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 5] = (double)r;  // diagnostics: which mode the squaring launch ran in
-    if (r == 2) ns_square_tail_pair_rest<COH_XCD, EVAL>(xb, scall, step_first, step_last, w, xcc, redp, partp);
-    else if (r == 1) ns_square_tail_pair_rest<COH_AGENT, EVAL>(xb, scall, step_first, step_last, w, xcc, redp, partp);
+    if (r == 2) ns_square_tail_pair_rest<COH_XCD, NEVAL>(xb, scall, step_first, step_last, w, xcc, redp, partp);
+    else if (r == 1) ns_square_tail_pair_rest<COH_AGENT, NEVAL>(xb, scall, step_first, step_last, w, xcc, redp, partp);
     if (EVAL && w == 0) EV_STAMP(scall, 1);
+}
+template <int NEVAL>
+__global__ __launch_bounds__(256) void ns_square_tail_pair_kernel(const double *A, const XBufs xb_all, double *scall, int step_first,
+                                                                  int step_last, int batch, int force_agent, int deflate)
+{
+    ns_square_tail_pair_impl<NEVAL, false>(A, xb_all, scall, step_first, step_last, batch, force_agent, deflate);
+}
+// batched, evaluations inside: four matrices per XCD = 92 workgroups on its 32 CUs -- three per CU, i.e. three waves per SIMD
+// (<= 168 VGPRs: the LEAN evaluation keeps A in memory)
+__global__ __launch_bounds__(256, 3) void ns_square_tail_pair_lean_kernel(const double *A, const XBufs xb_all, double *scall, int step_first,
+                                                                          int step_last, int batch, int force_agent, int deflate)
+{
+    ns_square_tail_pair_impl<NS_SQ_EVAL_WG_BATCH, true>(A, xb_all, scall, step_first, step_last, batch, force_agent, deflate);
 }
 
 constexpr int NS_PAIR_WG = 32;
@@ -2381,14 +2454,17 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     const int sq_sep = NS_SQUARINGS - sq_tail;
     for (int i = 1; i < sq_sep; ++i)
         hipLaunchKernelGGL(ns_square_kernel<false>, ns_grid(NS_TILES, batch), dim3(256), 0, s, ns_xk(xb, i), ns_xk(xb, i + 1), sc, i, batch);
-    // one matrix, every squaring folded: the Rayleigh-Ritz evaluations ride in the squaring launch and stop it (ns_square_evaluator)
-    const bool eval_inside = fold_first && batch == 1 && g_ns_ritz_inside == 1;
+    // every squaring folded: the Rayleigh-Ritz evaluations ride in the squaring launch and stop it (ns_square_evaluator)
+    const bool eval_inside = fold_first && g_ns_ritz_inside == 1;
     if (sq_tail > 0) {
-        if (eval_inside)
-            hipLaunchKernelGGL(ns_square_tail_pair_kernel<true>, ns_tail_grid(NS_SQ_PAIR_WG + NS_SQ_EVAL_WG, batch), dim3(256), 0, s, A, xb, sc,
-                               0, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
+        if (eval_inside && batch == 1)
+            hipLaunchKernelGGL((ns_square_tail_pair_kernel<NS_SQ_EVAL_WG>), ns_tail_grid(NS_SQ_PAIR_WG + NS_SQ_EVAL_WG, batch), dim3(256), 0,
+                               s, A, xb, sc, 0, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
+        else if (eval_inside)
+            hipLaunchKernelGGL(ns_square_tail_pair_lean_kernel, ns_tail_grid(NS_SQ_PAIR_WG + NS_SQ_EVAL_WG_BATCH, batch),
+                               dim3(256), 0, s, A, xb, sc, 0, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
         else
-            hipLaunchKernelGGL(ns_square_tail_pair_kernel<false>, ns_tail_grid(NS_SQ_PAIR_WG, batch), dim3(256), 0, s, A, xb, sc,
+            hipLaunchKernelGGL((ns_square_tail_pair_kernel<0>), ns_tail_grid(NS_SQ_PAIR_WG, batch), dim3(256), 0, s, A, xb, sc,
                                fold_first ? 0 : sq_sep, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
     }
     if (g_dbg_sigma_stages < 2) return 0;
