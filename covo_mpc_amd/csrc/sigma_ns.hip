@@ -718,9 +718,11 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
         L.gap = gap;
     }
     if (tid < RITZ) {
-        // cyclic Jacobi on the RITZ x RITZ symmetric H (serial, exits when diagonal); reciprocals / square roots by hardware seed +
-        // Newton (qm::rcp64_, qm::rsq64_), not libm.  Lanes 0..3 run it in lockstep (the same issue slots as one lane): each also
-        // carries ONE row of the accumulated rotation -- the eigenvectors for 4 extra operations per rotation instead of 16
+        // Jacobi on the RITZ x RITZ symmetric H (exits when diagonal); square roots by hardware seed + Newton (qm::rsq64_), not libm.
+        // Lanes 0..3 run it in lockstep, each with the whole of h and ONE row of the accumulated rotation (the eigenvectors for 4
+        // extra operations per rotation instead of 16).  Round-robin order -- {(0,1),(2,3)}, {(0,2),(1,3)}, {(0,3),(1,2)}: the two
+        // rotations of a round touch disjoint pivots, so their angles are ONE chain of dependent instructions (even lanes work out
+        // the first pair's, odd lanes the second's; the results travel by v_readlane) -- the chain is what a sweep costs.
         double h[RITZ][RITZ], jrow[RITZ];
 #pragma unroll
         for (int i = 0; i < RITZ; ++i) {
@@ -728,6 +730,33 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
             for (int j = 0; j < RITZ; ++j) h[i][j] = 0.5 * (L.H[i][j] + L.H[j][i]);
             jrow[i] = (i == tid) ? 1.0 : 0.0;
         }
+        const bool second = (tid & 1) != 0;
+        auto bcast = [](double x, int l) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+            return __hiloint2double(hi, lo);
+        };
+        auto rotate = [&](int p, int q2, double c, double sn, double t) {
+            // J^T h J for the symmetric h, written out: the 2 x 2 pivot block in closed form (h_pq -> 0), the other rows and
+            // columns once, mirrored
+            const double hpq = h[p][q2] * t;
+            h[p][p] -= hpq;
+            h[q2][q2] += hpq;
+            h[p][q2] = 0.0;
+            h[q2][p] = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < RITZ; ++kk) {
+                if (kk == p || kk == q2) continue;
+                const double hp = h[kk][p], hq = h[kk][q2];
+                const double np_ = c * hp - sn * hq, nq_ = sn * hp + c * hq;
+                h[kk][p] = np_;
+                h[p][kk] = np_;
+                h[kk][q2] = nq_;
+                h[q2][kk] = nq_;
+            }
+            const double jp = jrow[p], jq = jrow[q2];  // this lane's row of the accumulated rotation: columns p, q2
+            jrow[p] = c * jp - sn * jq;
+            jrow[q2] = sn * jp + c * jq;
+        };
 #pragma unroll 1
         for (int sweep = 0; sweep < 12; ++sweep) {  // (h and jrow stay in registers: every inner loop is unrolled)
             double off = 0.0, dia = 0.0;
@@ -737,42 +766,25 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
                 for (int q2 = 0; q2 < RITZ; ++q2) (p == q2 ? dia : off) += h[p][q2] * h[p][q2];
             if (off <= 1e-26 * dia) break;  // off^2 / gap bounds the eigenvalue error: far below the 1e-13 the chain needs
 #pragma unroll
-            for (int p = 0; p < RITZ - 1; ++p)
-#pragma unroll
-                for (int q2 = p + 1; q2 < RITZ; ++q2) {
-                    if (h[p][q2] * h[p][q2] <= 1e-34 * fabs(h[p][p] * h[q2][q2])) continue;
-                    // the small rotation that zeroes h_pq: tan(2 theta) = b / a, a = h_qq - h_pp, b = 2 h_pq;  cos(2 theta) = |a| / r,
-                    // r = sqrt(a^2 + b^2);  c^2 = (1 + cos 2 theta) / 2;  s = sign(a) b / (2 r c);  t = s / c -- two rsqrt chains
-                    const double ja = h[q2][q2] - h[p][p], jb = 2.0 * h[p][q2];
-                    const double inv_r = qm::rsq64_(fma(ja, ja, jb * jb));
-                    const double c2 = fma(0.5 * fabs(ja), inv_r, 0.5);
-                    const double inv_c = qm::rsq64_(c2);
-                    const double c = c2 * inv_c;
-                    const double sn = copysign(0.5, ja) * jb * inv_r * inv_c;
-                    const double t = sn * inv_c;
-                    // J^T h J for the symmetric h, written out: the 2 x 2 pivot block in closed form (h_pq -> 0), the other rows
-                    // and columns once, mirrored (two full 4 x 4 products cost three times the arithmetic on this one serial lane)
-                    const double hpq = h[p][q2] * t;
-                    h[p][p] -= hpq;
-                    h[q2][q2] += hpq;
-                    h[p][q2] = 0.0;
-                    h[q2][p] = 0.0;
-#pragma unroll
-                    for (int kk = 0; kk < RITZ; ++kk) {
-                        if (kk == p || kk == q2) continue;
-                        const double hp = h[kk][p], hq = h[kk][q2];
-                        const double np_ = c * hp - sn * hq, nq_ = sn * hp + c * hq;
-                        h[kk][p] = np_;
-                        h[p][kk] = np_;
-                        h[kk][q2] = nq_;
-                        h[q2][kk] = nq_;
-                    }
-                    {   // this lane's row of the accumulated rotation: columns p, q2
-                        const double jp = jrow[p], jq = jrow[q2];
-                        jrow[p] = c * jp - sn * jq;
-                        jrow[q2] = sn * jp + c * jq;
-                    }
-                }
+            for (int r = 0; r < 3; ++r) {
+                const int p1 = 0, q1 = r + 1, p2 = (r == 0) ? 2 : 1, q2 = (r == 2) ? 2 : 3;
+                const double hpp = second ? h[p2][p2] : h[p1][p1], hqq = second ? h[q2][q2] : h[q1][q1];
+                const double hpq = second ? h[p2][q2] : h[p1][q1];
+                const bool skip = hpq * hpq <= 1e-34 * fabs(hpp * hqq);  // (-> the identity: c = 1, s = t = 0)
+                // the small rotation that zeroes h_pq: tan(2 theta) = b / a, a = h_qq - h_pp, b = 2 h_pq;  cos(2 theta) = |a| / r,
+                // r = sqrt(a^2 + b^2);  c^2 = (1 + cos 2 theta) / 2;  s = sign(a) b / (2 r c);  t = s / c -- two rsqrt chains
+                const double ja = skip ? 1.0 : hqq - hpp, jb = skip ? 0.0 : 2.0 * hpq;
+                const double inv_r = qm::rsq64_(fma(ja, ja, jb * jb));
+                const double c2 = fma(0.5 * fabs(ja), inv_r, 0.5);
+                const double inv_c = qm::rsq64_(c2);
+                const double c = c2 * inv_c;
+                const double sn = copysign(0.5, ja) * jb * inv_r * inv_c;
+                const double t = sn * inv_c;
+                const double ca = bcast(c, 0), sa = bcast(sn, 0), ta = bcast(t, 0);
+                const double cb = bcast(c, 1), sb = bcast(sn, 1), tb = bcast(t, 1);
+                rotate(p1, q1, ca, sa, ta);
+                rotate(p2, q2, cb, sb, tb);
+            }
         }
         double lmin = h[0][0], cmin = jrow[0];
 #pragma unroll
@@ -805,7 +817,13 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
         }
         const double d = fma(-L.lmin, u, au);
         const double r2 = wr::wave64_allsum(d * d);
-        if (lane == 0) L.r2[wave] = r2;
+        // Gershgorin bound of B = A + delta I from the row sums of A (only the diagonal term changes), for delta0 = 1e-2 - theta:
+        // the delta used below is never smaller, and the bound grows by at most the difference
+        const double m = wr::wave64_allmax(in.ra - fabs(in.dg) + fabs(in.dg + (1e-2 - L.o_lmin)));
+        if (lane == 0) {
+            L.r2[wave] = r2;
+            L.red[wave] = m;
+        }
     }
     __syncthreads();
     // An iterate that is taken although its pair has NOT converged (the filter's last one: the cap of 16 squarings -- bottoms whose
@@ -818,15 +836,10 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
     const bool small_resid = !L.null_is_min && gap > NS_DEFL_MIN_GAP && resid2 <= rtol * rtol;
     const double lmin_used = (small_resid || L.null_is_min) ? L.o_lmin : L.o_lmin - resid2 * qm::rsq64_(fmax(resid2, 1e-300));
     const double delta = -lmin_used + 1e-2;  // covo.py:120-122: offset = -min_eign + 1e-2
-    // Gershgorin bound of B = A + delta I from the row sums of A: only the diagonal term changes
-    if (tid < SN) {
-        const double m = wr::wave64_allmax(in.ra - fabs(in.dg) + fabs(in.dg + delta));
-        if (lane == 0) L.red[wave] = m;
-    }
-    __syncthreads();
     if (tid == 0) {
         const double fro2 = fma((double)SN * delta, delta, fma(2.0 * delta, in.tr, in.f2));  // |A + delta I|_F^2
-        const double scale = fmin(fmax(L.red[0], L.red[1]), fro2 * qm::rsq64_(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
+        const double gersh = fmax(L.red[0], L.red[1]) + (delta - (1e-2 - L.o_lmin));
+        const double scale = fmin(gersh, fro2 * qm::rsq64_(fro2)) * (1.0 + 1e-12);  // >= lambda_max(B): eigenvalues of Y0 in (0, 1]
         // the bottom eigenpair is CONVERGED when its residual is small against the gap bound: the evaluation then "passes" (the
         // chain stops here) and the iterations may deflate the pair (see the header)
         const bool conv = small_resid && 1e-2 + gap < 0.25 * scale;
@@ -880,6 +893,12 @@ __device__ __forceinline__ bool ritz_decide(RitzLds &L, double u, double *s, int
         if (k > RITZ_K0) {
             const long long t0 = wall_clock64();
             while ((prev = (int)gld<COH_AGENT>(s + SC_VERD + k - 1 - RITZ_K0)) == 0) {
+                // (an evaluation that notices a taken result at one of its seams leaves WITHOUT a verdict: the taken result
+                // itself is the other thing to look for)
+                if (gld<COH_AGENT>(s + SC_KWIN) != 0.0) {
+                    prev = 2;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
                 if (wall_clock64() - t0 > 20000000LL) {
                     gst<COH_AGENT>(s + SC_BARFAIL, 1.0);
@@ -888,17 +907,16 @@ __device__ __forceinline__ bool ritz_decide(RitzLds &L, double u, double *s, int
                 }
             }
         }
-        L.decide = (prev == 2) ? 2 : ((L.o_pass || final) ? 1 : 0);  // 2: decided before; 1: this one is taken; 0: not taken
-        if (L.decide == 1) gst<COH_AGENT>(s + SC_SQ_DONE, 1.0);  // stops the chain (it may be two squarings further by now)
+        const int d = (prev == 2) ? 2 : ((L.o_pass || final) ? 1 : 0);  // 2: decided before; 1: this one is taken; 0: not taken
+        L.decide = d;
+        // the flags first (nothing in this launch reads the results themselves; the launches that do come after its end): the
+        // chain stops (it may be two squarings further by now), the evaluation of X_(k+1) has its answer
+        if (d == 1) gst<COH_AGENT>(s + SC_SQ_DONE, 1.0);
+        gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, d == 0 ? 1.0 : 2.0);
     }
     __syncthreads();
     const int d = L.decide;
     if (d == 1) ritz_publish(L, u, s, k, deflate);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the results have been acknowledged before the flags go out
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        gst<COH_AGENT>(s + SC_VERD + k - RITZ_K0, d == 0 ? 1.0 : 2.0);
-    }
     return d != 0;
 }
 
@@ -1417,15 +1435,27 @@ __device__ __forceinline__ bool ns_square_pair_body(const double *X, double *O, 
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double nrm, t_in = 1.0, alpha = 0.0, beta = 0.0;
-    if (FIRST) ns_square_first_stats<COH>(s, w, tid, lane, wv, &redp[0][0][0][0], alpha, beta, nrm);
     // w -> (m, local): group m holds 2m + 2 workgroups (offsets 0, 2, 6, 12)
     const int m = (w >= 12) ? 3 : (w >= 6) ? 2 : (w >= 2) ? 1 : 0;
     const int local = w - m * (m + 1);
     const bool single = local == 2 * m + 1;
     const int tj = single ? 2 * m + 1 : local;
     PairOps ops;
-    if (FIRST) pair_load<COH>(ops, X, X, m, tj, lane, wv, LoadAffine{alpha, beta});
-    else pair_load<COH>(ops, X, X, m, tj, lane, wv, LoadPlain{});
+    // (the operands of A are asked for BEFORE the statistics that make Y0 = alpha I - beta A out of them: the chain's first round
+    // trip -- A comes from memory, the Hessian's launches wrote it from other XCDs -- runs under the statistics' two barriers)
+    pair_load<COH>(ops, X, X, m, tj, lane, wv, LoadPlain{});
+    if (FIRST) {
+        ns_square_first_stats<COH>(s, w, tid, lane, wv, &redp[0][0][0][0], alpha, beta, nrm);
+        const LoadAffine f{alpha, beta};
+        const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = 32 * wv + 4 * kk + hi;
+            ops.a[0][kk] = f(ops.a[0][kk], k, 32 * m + lo);
+            ops.a[1][kk] = f(ops.a[1][kk], k, 32 * m + 16 + lo);
+            ops.b[kk] = f(ops.b[kk], k, 16 * tj + lo);
+        }
+    }
     if (!FIRST) {
         const double done = gld<COH>(s + SC_SQ_DONE);
         const double p1 = (lane < NS_TILES) ? gld<COH>(s + SC_SQN + step * 64 + lane) : 0.0;

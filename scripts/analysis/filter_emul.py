@@ -110,3 +110,30 @@ if __name__ == "__main__":
             print(task, "r=%d" % r, "mean stop %.2f  mean kwin %.2f  max |lambda err| %.2e  max res/gap %.2e" %
                   (o[:, 0].mean(), o[:, 1].mean(), np.abs(o[:, 2]).max(), (o[:, 3] / o[:, 4]).max()),
                   " hist(stop-kwin):", np.bincount((o[:, 0] - o[:, 1]).astype(int)))
+
+def more_pairs(task_R):
+    """at kwin (first iterate whose bottom pair passes): how good are Ritz pairs 2 .. 4?"""
+    rows = []
+    for A in task_R:
+        A = 0.5 * (A + A.T)
+        ev = np.linalg.eigvalsh(A)
+        hi, md = stats(A); cut = md + (hi - md) / 1024
+        Xs, norms, ts, stop = run_filter(A, cut, hi)
+        for k in range(2, stop + 1):
+            if ts[k] <= 1e10: continue
+            d = Xs[k - 2].diagonal().copy(); d[np.abs(A).sum(1) == 0] = -1e300
+            idx = np.argsort(-d)[:4]
+            V, _ = np.linalg.qr(Xs[k - 1][:, idx])
+            Hm = V.T @ A @ V; w, c = np.linalg.eigh(0.5 * (Hm + Hm.T)); U = V @ c
+            res = np.linalg.norm(A @ U - U * w, axis=0)
+            g = 0.7 * gap_bound(norms, k, hi, cut, w[0])
+            if g > 2e-2 and res[0] <= 1e-8 * g:
+                rows.append((k, *(res / np.maximum(ev[1:5] - ev[0:4], 1e-9)), *(w - ev[:4]), ev[1] - ev[0], ev[3] - ev[0], ev[4] - ev[0], ev[-1] - ev[0]))
+                break
+    return np.array(rows)
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "pairs":
+    for task in z.files:
+        r = more_pairs(z[task])
+        print(task, "residual/gap of Ritz pairs 1..4 at kwin (median, max):", np.median(r[:, 1:5], 0), r[:, 1:5].max(0))
+        print("   gap12 / gap14 / gap15 medians:", np.median(r[:, 9]), np.median(r[:, 10]), np.median(r[:, 11]))
