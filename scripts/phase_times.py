@@ -29,7 +29,7 @@ core = controller.core
 T = core.time_phases
 rows = [("whole step (graph)", T()), ("hessian (3 kernels)", T(2)),
         ("  jac", T(2, 1)), ("  chain + hyper-dual pairs + contraction", T(2, 2)), ("  gemm", T(2, 8)),
-        ("sigma (all)", T(4)), ("  prep+squarings", T(4, 15, 1)), ("  +ritz", T(4, 15, 2)), ("  +newton-schulz", T(4, 15, 3)),
+        ("sigma (all)", T(4)), ("  squarings with the Ritz evaluations inside", T(4, 15, 1)), ("  (+ scan launch: none on this path)", T(4, 15, 2)), ("  +newton-schulz", T(4, 15, 3)),
         ("sigma + gemm (product: eps drawn under finalize, tiled GEMM)", T(12)),
         ("noise gemm, in-kernel Philox (offline/MPPI path)", T(8)), ("rollout (+ softmax records)", T(16)),
         ("merge (softmax update)", T(32)), ("empty graph (floor)", T(0))]
@@ -55,7 +55,7 @@ print("whole step via tool again", T())
 
 from covo_mpc_amd import _lib
 M = 128 * 128
-names = ["SHIFT", "LMIN", "DELTA", "SCALE", "LOGDET", "ZBUF", "ITERS", "XBUF", "SQ", "SQ_DONE", "NS_DONE"]
+names = ["SHIFT", "LMIN", "DELTA", "SCALE", "SUMLOGB", "ZBUF", "ITERS", "KWIN", "SQ", "SQ_DONE", "NS_DONE"]
 for i in [5, 20, 44, 100, 200, 290]:
     ds_i = DeviceState(packed=packed_d[i % 60], pos_traj=dref.pos_traj, vel_traj=dref.vel_traj, time=int(host_states[i % 60].time))
     key, k = cr.split(key)
