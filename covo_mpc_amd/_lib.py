@@ -121,6 +121,7 @@ _SIGS = {
     "covo_sigma": (C.c_int, [_P, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "covo_debug_sigma_workspace": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "covo_debug_hess_workspace": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "covo_debug_batched_hessians": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "covo_env_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), _P, C.POINTER(C.c_uint32),
                                 C.c_int32, C.c_float, _P, C.c_int32, _P]),
     "covo_pid_nominal": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(EnvParamsC), C.POINTER(EnvParamsC), C.c_float,

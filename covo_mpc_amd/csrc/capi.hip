@@ -785,6 +785,12 @@ int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubl
     return 0;
 }
 
+int covo_debug_batched_hessians(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream)
+{
+    REQUIRE(h && out && offset_doubles >= 0 && count > 0, "covo_debug_batched_hessians: bad argument");
+    return covo_debug_batched_hessians_impl(h, out, offset_doubles, count, (hipStream_t)stream);
+}
+
 int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out, float *L_out,
                       void *stream)
 {

@@ -805,3 +805,15 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
     }
     return batch_enqueue(h, b, *args, s);
 }
+
+// test hook: the Hessians of the LAST batched step (E x 128 x 128 doubles), device -> host
+int covo_debug_batched_hessians_impl(covo_ctx *h, double *out, int64_t offset_doubles, int64_t count, hipStream_t s)
+{
+    BatchState *b = reinterpret_cast<BatchState *>(h->batch);
+    if (b == nullptr || b->R == nullptr) {
+        covo_set_error("covo_debug_batched_hessians: no batched step has run on this handle");
+        return COVO_E_BADARG;
+    }
+    COVO_CHECK_HIP(hipMemcpyAsync(out, b->R + offset_doubles, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s));
+    return 0;
+}

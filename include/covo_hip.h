@@ -399,6 +399,9 @@ int covo_debug_set_ns_coherence(int force_agent);
  * bit: lambda_min is a function of the matrix alone (sigma_ns.hip: ritz_decide).  Also COVO_NS_RITZ_INSIDE=0 in the environment. */
 int covo_debug_set_ns_ritz_inside(int on);
 int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
+/* Test hook: `count` doubles at `offset_doubles` of the Hessians of the LAST covo_mpc_step_batched on this handle
+ * ([n_envs][128][128], the Sigma chain's input), copied to the HOST buffer `out` (asynchronously on `stream`). */
+int covo_debug_batched_hessians(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 
 /* Profiling aid: covo_sigma for ONE matrix that also stores shader-clock ticks (s_memtime) at the kernel's
  * phase boundaries into ticks_out (device uint64[32]): [0] start, [1] loaded+shifted, [2+i] end of sweep i,

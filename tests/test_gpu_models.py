@@ -696,6 +696,39 @@ def test_env_instances_32_batched_step_vs_fp64_oracle():
     assert np.abs(b.a_mean[0].cpu().numpy() - b.a_mean[13].cpu().numpy()).max() > 1e-4  # different plans
 
 
+def test_batched_closed_loop_sigma_tracks_lapack_on_its_own_hessians():
+    """Every step of a batched closed-loop episode (E = 32 domain-randomised instances, control + env step on the device): the
+    Sigma an instance sampled from against LAPACK eigh on THAT step's Hessian (covo_debug_batched_hessians: the Sigma chain's
+    input), <= 1e-6 -- the early Ritz evaluations inside the batched squaring launch take lambda_min from whichever filter
+    iterate passes first, step after step, on the matrices a closed loop really produces."""
+    import covo_mpc_amd as cm
+    N, E = 4096, 32
+    env = _dr_env()
+    params = [env.sample_params(cr.PRNGKey(1000 + e)) for e in range(E)]
+    c0, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device=DEV, compute_info=False)
+    cp0 = c0.init_control_params
+    b = cm.controllers.BatchedCoVOController(env, E, N, 32, 0.01, discount=cp0.discount, gamma_mean=cp0.gamma_mean,
+                                             sample_sigma=cp0.sample_sigma, a_mean_init=cp0.a_mean, device=DEV)
+    ep = cm.envs.BatchedDeviceEpisode(env, [cr.PRNGKey(5000 + e) for e in range(E)], params, (b.core.lib, b.core.h), DEV)
+    rngs = np.stack([np.asarray(cr.PRNGKey(6000 + e)) for e in range(E)])
+    Rh = torch.zeros((2, 128 * 128), dtype=torch.float64).pin_memory()
+    sl = torch.zeros(16, dtype=torch.float64, device=DEV)
+    kwins = []
+    for t in range(40):
+        rngs = b.run_episode(ep, rngs, 1)
+        for i, e in enumerate((4, 19)):
+            _lib.check(b.core.lib.covo_debug_batched_hessians(b.core.h, _lib.ptr(Rh[i]), e * 128 * 128, 128 * 128, b.core.stream()))
+        _lib.check(b.core.lib.covo_debug_sigma_workspace(b.core.h, _lib.ptr(sl), 11 * E * 128 * 128 + 4 * 3712, 16, b.core.stream()))
+        torch.cuda.synchronize()
+        kwins.append((int(sl[7]), int(sl[8])))  # SC_KWIN, SC_SQ of instance 4
+        for i, e in enumerate((4, 19)):
+            ref = R.optimize_sigma(Rh[i].numpy().reshape(128, 128), 0.5, 32, 4)
+            S = b.a_cov[e].cpu().numpy()
+            assert np.linalg.norm(S - ref) / np.linalg.norm(ref) < 1e-6, (t, e)
+    assert b.core.device_status() == 0
+    assert all(2 <= k <= s <= 16 for k, s in kwins), kwins
+
+
 def test_batched_env_step_vs_oracle_and_single_instance_kernel():
     """covo_env_step_batched (E = 32, one launch): every instance's step equals covo_env_step on that instance alone bit for bit,
     and three sampled instances land where oracle/ref_np.py::step_env + noisy_state (fp64, THEIR parameters, the draws their
