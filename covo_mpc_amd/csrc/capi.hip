@@ -67,6 +67,8 @@ __global__ void raise_status_kernel(int *status, int bits)
     __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+int covo_debug_batched_hessians_impl(covo_ctx *h, double *out, int64_t offset_doubles, int64_t count, hipStream_t s);  // step.hip
+
 extern "C" {
 
 const char *covo_last_error(void) { return g_err; }

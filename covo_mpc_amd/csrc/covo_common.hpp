@@ -210,7 +210,6 @@ int launch_hessian_pairs(const float *state, const float *pos_traj, const float 
 int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, float *L, unsigned long long *prof,
                  hipStream_t s);
 size_t sigma_ns_workspace_bytes(int batch);
-int covo_debug_batched_hessians_impl(covo_ctx *h, double *out, int64_t offset_doubles, int64_t count, hipStream_t s);  // step.hip
 struct EpsGenArgs;  // eps_tiles.hpp
 // gen != null (fused step): the finalize launch also draws the step's epsilon in tile order (eps_tiles.hpp)
 // status: the handle's sticky status word (a timed-out grid barrier raises COVO_DEVSTAT_GRID_BARRIER there, next to the NaN
