@@ -114,6 +114,7 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_SUMLOGB, SC_ZBUF, SC_ITERS,
        SC_GAPEST = 31,         // the gap bound lambda_2 - lambda_1 >= ... (diagnostics)
        SC_RESID = 15,          // |A u - theta u|^2 of the bottom Ritz pair (diagnostics)
        SC_COEF = 32,           // a_k, b_k   (2 * NS_ITERS)
+       SC_ALPHA = 56, SC_BETA = 57,  // the filter's affine map Y0f = alpha I - beta A (first squaring; ns_first_setup rebuilds A^2 from X_1)
        SC_ROWABS = 64,         // sum_c |A[r][c]|            (128)
        SC_DIAG = 192,          // A[r][r]                    (128)
        SC_PREP = 320,          // prep partials: 8 x {max rowabs, sum v^2, trace, min diag}
@@ -187,16 +188,21 @@ struct TileOps {
 };
 // issue the 16 operand loads of this wave's K-quarter (callers issue them BEFORE looking at any flag: every
 // launch of the chain then pays one memory latency, not one per dependent scalar)
-template <int COH = COH_NONE, class F>
-__device__ __forceinline__ void tile_load(TileOps &o, const double *A, const double *B, int ti, int tj, int lane, int kq, F f)
+template <int COH = COH_NONE, class FA, class FB>
+__device__ __forceinline__ void tile_load2(TileOps &o, const double *A, const double *B, int ti, int tj, int lane, int kq, FA fa, FB fb)
 {
     const int lo = lane & 15, hi = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const int k = 32 * kq + 4 * kk + hi;
-        o.a[kk] = f(gld<COH>(A + (size_t)k * SN + 16 * ti + lo), k, 16 * ti + lo);
-        o.b[kk] = f(gld<COH>(B + (size_t)k * SN + 16 * tj + lo), k, 16 * tj + lo);
+        o.a[kk] = fa(gld<COH>(A + (size_t)k * SN + 16 * ti + lo), k, 16 * ti + lo);
+        o.b[kk] = fb(gld<COH>(B + (size_t)k * SN + 16 * tj + lo), k, 16 * tj + lo);
     }
+}
+template <int COH = COH_NONE, class F>
+__device__ __forceinline__ void tile_load(TileOps &o, const double *A, const double *B, int ti, int tj, int lane, int kq, F f)
+{
+    tile_load2<COH>(o, A, B, ti, tj, lane, kq, f, f);
 }
 __device__ __forceinline__ f64x4 tile_mma(const TileOps &o)
 {
@@ -358,6 +364,8 @@ __device__ __forceinline__ void ns_square_first_stats(double *s, int w, int tid,
         gst<COH>(s + SC_TRACE, tr);
         gst<COH>(s + SC_GERSH, gm);
         gst<COH>(s + SC_N0, nrm);
+        gst<COH>(s + SC_ALPHA, alpha);
+        gst<COH>(s + SC_BETA, beta);
     }
 }
 
@@ -449,15 +457,17 @@ __global__ __launch_bounds__(256) void ns_square_kernel(const double *__restrict
 constexpr double RITZ_PASS_E = 0.05;  // e_k = (1 - |X_k|_F^2) / 2 below this: the gap bound's linearisation holds (ritz_eval)
 constexpr int RITZ_K0 = 2;                          // first evaluated iterate (the stationarity test needs two norms: the filter never stops before X_2)
 constexpr int RITZ_NK = NS_SQUARINGS - RITZ_K0 + 1;  // evaluations per matrix: X_2 .. X_16
-struct XBufs {  // X_1 -> x0, X_2 -> x1 (T and T^T of the iterations later), X_3 .. X_16 -> the history;  hist == nullptr: no history,
-    double *x0, *x1, *hist;  // odd k -> x0, even k -> x1 (the launch with the evaluations inside: they take what they need of X_k
-    size_t M;                // before the chain comes round to its buffer again -- ns_square_evaluator).
-                             // M: doubles between the buffers of consecutive k (batch x 128 x 128)
+struct XBufs {  // X_1 -> xq (it outlives the filter: iteration 1 of the Newton-Schulz part rebuilds A^2 from it, NsFirst); X_2 -> x1, and then
+    double *x0, *x1, *hist, *xq;  // X_3 .. X_16 -> the history;  hist == nullptr: no history, odd k -> x0, even k -> x1 (the launch with the
+    size_t M;                     // evaluations inside: they take what they need of X_k before the chain comes round to its buffer
+                                  // again -- ns_square_evaluator).  x0, x1 are T and T^T of the iterations later.
+                                  // M: doubles between the buffers of consecutive k (batch x 128 x 128)
 };
 __host__ __device__ __forceinline__ double *ns_xk(const XBufs xb, int k)
 {
+    if (k == 1) return xb.xq;
     if (xb.hist == nullptr) return (k & 1) ? xb.x0 : xb.x1;
-    return (k == 1) ? xb.x0 : (k == 2) ? xb.x1 : xb.hist + (size_t)(k - 3) * xb.M;
+    return (k == 2) ? xb.x1 : xb.hist + (size_t)(k - 3) * xb.M;
 }
 struct RitzLds {
     double V[RITZ][SN];
@@ -960,59 +970,71 @@ __device__ __forceinline__ void ns_coef(double l, double &a, double &bq)
     bq = -0.5 * rho * rho * rho;
 }
 
-// ---- Newton-Schulz iteration 0 (Z0 = I, Y0 = B/s read from A on load):  Y1 = a0 Y0 + b0 Y0^2,  Z1 = a0 I + b0 Y0
-__global__ __launch_bounds__(256) void ns_first_kernel(const double *__restrict__ Aall, double *__restrict__ Yout,
-                                                       double *__restrict__ Ytout, double *__restrict__ Zout,
-                                                       double *__restrict__ Ztout, double *__restrict__ scall, int zbuf_out,
-                                                       int batch)
+// ---- Iteration 0 (Z0 = I, Y0 = B/s + gam u u^T):  Y1 = a0 Y0 + b0 Y0^2,  Z1 = a0 I + b0 Y0.  Rounds 1-4 ran it as a launch / phase of its
+// own (one product: Y0^2).  Round 5: Y0^2 is ALREADY THERE -- the filter's first squaring formed X_1 = (alpha I - beta A)^2 / n0 -
+// I / t_1, i.e. A^2 = (n0 (X_1 + I / t_1) - alpha^2 I + 2 alpha beta A) / beta^2 -- so Y1 and Z1 are affine in {A, X_1, I, u u^T}:
+//     Y1 = ya A + yx X_1 + yi I + yu u u^T,      Z1 = za A + zi I + zu u u^T
+// (B u = 1e-2 u for the deflated pair), and iteration 1 forms them ON LOAD: no iteration-0 product, no launch / phase for it (X_1
+// keeps a buffer of its own for that: XBufs::xq).  Both are exactly symmetric (A and X_1 are stored so), whichever way they are read.
+struct NsFirst {
+    const double *X1, *u;
+    double ya, yx, yi, yu, za, zi, zu;
+    double a1, b1;  // iteration 1's own coefficients (the table's second entry: the same recurrence, so that nobody waits for the table)
+};
+__device__ __forceinline__ NsFirst ns_first_setup(const double *X1, const double *s)
 {
-    __shared__ double red[4][4][64];
-    int b, w;
-    if (!ns_block(batch, b, w)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t off = (size_t)b * SN * SN;
-    const double *A = Aall + off;
-    double *s = scall + (size_t)b * SC_COUNT;
-    const double scale = s[SC_SCALE];
-    const double delta = s[SC_DELTA], inv = 1.0 / scale;
-    const double lo = s[SC_LO], gam = s[SC_GAM];  // deflation (ns_ritz_kernel): table from lo, Y0 = B/s + gam u u^T
-    if (w == 64) {
-        // the extra workgroup: the coefficient table of the iterations to come (a serial recurrence, ~1 us on one lane -- under
-        // this launch's GEMM instead of on the tail of the single-workgroup Ritz launch before it)
-        if (tid == 0) {
-            double l = sqrt(lo / scale);
-            for (int k = 0; k < NS_ITERS; ++k) {
-                double a, bq;
-                ns_coef(l, a, bq);
-                s[SC_COEF + 2 * k] = a;
-                s[SC_COEF + 2 * k + 1] = bq;
-                l = fmin(1.0, l * fma(bq * l, l, a));
-            }
-        }
-        return;
+#pragma clang fp contract(off)  // (every launch that forms these operands must form the same bits)
+    NsFirst f;
+    const double scale = s[SC_SCALE], delta = s[SC_DELTA], lo = s[SC_LO], gam = s[SC_GAM];
+    const double alpha = s[SC_ALPHA], beta = s[SC_BETA], n0 = s[SC_N0], t1 = s[SC_SQN + 64 + 63];
+    const double inv = 1.0 / scale, ib2 = 1.0 / (beta * beta), is2 = inv * inv;
+    double l = sqrt(lo / scale), a0, b0;
+    ns_coef(l, a0, b0);
+    l = fmin(1.0, l * fma(b0 * l, l, a0));
+    ns_coef(l, f.a1, f.b1);
+    // Y0^2 = qx X_1 + qa A + qi I + qu u u^T
+    const double qx = n0 * ib2 * is2, qa = (2.0 * alpha * beta * ib2 + 2.0 * delta) * is2;
+    const double qi = ((n0 / t1 - alpha * alpha) * ib2 + delta * delta) * is2, qu = gam * (2.0 * (1e-2 * inv) + gam);
+    f.ya = fma(b0, qa, a0 * inv);
+    f.yx = b0 * qx;
+    f.yi = fma(b0, qi, a0 * delta * inv);
+    f.yu = fma(b0, qu, a0 * gam);
+    f.za = b0 * inv;
+    f.zi = fma(b0, delta * inv, a0);
+    f.zu = b0 * gam;
+    f.X1 = X1;
+    f.u = s + SC_U;
+    return f;
+}
+struct LoadY1 {  // applied to an element of A
+    NsFirst f;
+    __device__ __forceinline__ double operator()(double v, int r, int c) const
+    {
+#pragma clang fp contract(off)
+        return fma(f.ya, v, fma(f.yx, f.X1[(size_t)r * SN + c], fma(f.yu * f.u[r], f.u[c], (r == c) ? f.yi : 0.0)));
     }
-    double a0, b0;
-    ns_coef(sqrt(lo / scale), a0, b0);
-    if (w == 0 && tid == 0) {
-        s[SC_ZBUF] = (double)zbuf_out;
-        s[SC_ITERS] = 1.0;
+};
+struct LoadZ1 {  // applied to an element of A
+    NsFirst f;
+    __device__ __forceinline__ double operator()(double v, int r, int c) const
+    {
+#pragma clang fp contract(off)
+        return fma(f.za, v, fma(f.zu * f.u[r], f.u[c], (r == c) ? f.zi : 0.0));
     }
-    const int ti = w >> 3, tj = w & 7;
-    const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-    double y2, y0;
-    if (gam != 0.0) {  // (uniform)
-        const LoadScaledBDefl ld{delta, inv, gam, s + SC_U};
-        const f64x4 acc = tile_mm_q(A, A, ti, tj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
-        y2 = tile_reduce(acc, red, wv, lane);
-        y0 = ld(A[(size_t)row * SN + col], row, col);
-    } else {
-        const LoadScaledB ld{delta, inv};
-        const f64x4 acc = tile_mm_q(A, A, ti, tj, lane, wv, ld);
-        y2 = tile_reduce(acc, red, wv, lane);
-        y0 = ld(A[(size_t)row * SN + col], row, col);
+};
+// the coefficient table of the iterations (a serial recurrence, ~1.5 us on one lane: an extra workgroup of iteration 1's first launch)
+template <int COH>
+__device__ __forceinline__ void ns_coef_table(double *s)
+{
+    const double scale = s[SC_SCALE], lo = s[SC_LO];
+    double l = sqrt(lo / scale);
+    for (int k = 0; k < NS_ITERS; ++k) {
+        double a, bq;
+        ns_coef(l, a, bq);
+        gst<COH>(s + SC_COEF + 2 * k, a);
+        gst<COH>(s + SC_COEF + 2 * k + 1, bq);
+        l = fmin(1.0, l * fma(bq * l, l, a));
     }
-    store_both(Yout + off, Ytout + off, row, col, fma(b0, y2, a0 * y0));
-    store_both(Zout + off, Ztout + off, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
 }
 
 template <int COH>
@@ -1031,9 +1053,10 @@ __device__ __forceinline__ bool ns_converged(double *s, int iter, int lane, bool
 
 // ---- Newton-Schulz step k >= 1, part 1:  T = a_k I + b_k Z.Y  (64 tiles; T and T^T are stored).
 // Returns false when the iteration has converged (nothing was written).  Workgroup w of matrix b.
-template <int COH>
-__device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztall, double *Tall, double *Ttall, double *scall,
-                                          int iter, int b, int w, double (*red)[4][64], double *part)
+// iter == 1: Z1 and Y1 are formed on load from A and X_1 (NsFirst; Aall / X1all: the chain's input and the filter's first iterate)
+template <int COH, bool FIRST_OK = true>
+__device__ __forceinline__ bool ns_T_body(const double *Aall, const double *X1all, const double *Yall, const double *Ztall, double *Tall,
+                                          double *Ttall, double *scall, int iter, int b, int w, double (*red)[4][64], double *part)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -1041,8 +1064,17 @@ __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztal
     const int ti = w >> 3, tj = w & 7;
     if (!COH && gridDim.y > 1 && s[SC_NS_DONE] != 0.0) return false;  // batched: the flag before the operands (see ns_square_body)
     TileOps ops;
-    tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // written by ns_first_kernel's extra workgroup
+    double a, bq;
+    if (FIRST_OK && iter == 1) {  // (uniform)
+        const NsFirst f = ns_first_setup(X1all + off, s);
+        tile_load2<COH_NONE>(ops, Aall + off, Aall + off, ti, tj, lane, wv, LoadZ1{f}, LoadY1{f});  // Z1 . Y1
+        a = f.a1;
+        bq = f.b1;
+    } else {
+        tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+        a = s[SC_COEF + 2 * iter];  // (the table: an extra workgroup of iteration 1's first launch)
+        bq = s[SC_COEF + 2 * iter + 1];
+    }
     if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
     const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
@@ -1055,10 +1087,10 @@ __device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztal
 }
 
 // ---- part 2:  Y' = Y.T (tiles 0..63),  Z' = T.Z (tiles 64..127); each with its transpose.  Workgroup wx in 0..127.
-template <int COH>
-__device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
-                                           double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
-                                           int zbuf_out, int b, int wx, double (*red)[4][64])
+template <int COH, bool FIRST_OK = true>
+__device__ __forceinline__ bool ns_YZ_body(const double *Aall, const double *X1all, const double *Ytall, const double *Zall,
+                                           const double *Tall, const double *Ttall, double *Yout, double *Ytout, double *Zout,
+                                           double *Ztout, double *scall, int iter, int zbuf_out, int b, int wx, double (*red)[4][64])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -1069,7 +1101,13 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Za
     // Y' = Y.T : left factor Y -> pass Y^T;   Z' = T.Z : left factor T -> pass T^T
     if (!COH && gridDim.y > 1 && s[SC_NS_DONE] != 0.0) return false;  // batched: the flag before the operands (see ns_square_body)
     TileOps ops;
-    tile_load<COH>(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
+    if (FIRST_OK && iter == 1) {  // (uniform) Y' = Y1 . T (Y1 symmetric: its own transpose),  Z' = T . Z1
+        const NsFirst f = ns_first_setup(X1all + off, s);
+        if (isZ) tile_load2<COH>(ops, Ttall + off, Aall + off, ti, tj, lane, wv, LoadPlain{}, LoadZ1{f});
+        else tile_load2<COH>(ops, Aall + off, Tall + off, ti, tj, lane, wv, LoadY1{f}, LoadPlain{});
+    } else {
+        tile_load<COH>(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
+    }
     if (ns_converged<COH>(s, iter, lane, false)) return false;  // part 1 of this iteration raised the flag
     if (wx == 0 && tid == 0) {
         gst<COH>(s + SC_ZBUF, (double)zbuf_out);  // which Z buffer holds the newest iterate
@@ -1082,7 +1120,11 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Za
     return true;
 }
 
-__global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
+// (FIRST <=> iter == 1: grid 64 tiles + one workgroup for the coefficient table, which iteration 2 reads first; a template argument:
+// the on-load operands' registers must not cost the other iterations' launches their occupancy)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
+                                                   const double *__restrict__ Yall, const double *__restrict__ Ztall,
                                                    double *__restrict__ Tall, double *__restrict__ Ttall,
                                                    double *__restrict__ scall, int iter, int batch)
 {
@@ -1090,10 +1132,16 @@ __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Ya
     __shared__ double part[4];
     int b, w;
     if (!ns_block(batch, b, w)) return;
-    (void)ns_T_body<COH_NONE>(Yall, Ztall, Tall, Ttall, scall, iter, b, w, red, part);
+    if (FIRST && w == 64) {
+        if (threadIdx.x == 0) ns_coef_table<COH_NONE>(scall + (size_t)b * SC_COUNT);
+        return;
+    }
+    (void)ns_T_body<COH_NONE, FIRST>(Aall, X1all, Yall, Ztall, Tall, Ttall, scall, iter, b, w, red, part);
 }
 
-__global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
+template <bool FIRST>
+__global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
+                                                    const double *__restrict__ Ytall, const double *__restrict__ Zall,
                                                     const double *__restrict__ Tall, const double *__restrict__ Ttall,
                                                     double *__restrict__ Yout, double *__restrict__ Ytout,
                                                     double *__restrict__ Zout, double *__restrict__ Ztout,
@@ -1102,7 +1150,7 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
     __shared__ double red[4][4][64];
     int b, w;
     if (!ns_block(batch, b, w)) return;
-    (void)ns_YZ_body<COH_NONE>(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, b, w, red);
+    (void)ns_YZ_body<COH_NONE, FIRST>(Aall, X1all, Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, b, w, red);
 }
 
 // ---- batched launches of the Newton-Schulz phases: one workgroup = a 2 x 2 block of 16 x 16 tiles (round 4).  With one tile per
@@ -1114,8 +1162,8 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Y
 struct QuadOps {
     double a[2][8], b[2][8];
 };
-template <class F>
-__device__ __forceinline__ void quad_load(QuadOps &o, const double *A, const double *B, int mi, int mj, int lane, int kq, F f)
+template <class FA, class FB>
+__device__ __forceinline__ void quad_load2(QuadOps &o, const double *A, const double *B, int mi, int mj, int lane, int kq, FA fa, FB fb)
 {
     const int lo = lane & 15, hi = lane >> 4;
 #pragma unroll
@@ -1123,10 +1171,15 @@ __device__ __forceinline__ void quad_load(QuadOps &o, const double *A, const dou
         const int k = 32 * kq + 4 * kk + hi;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            o.a[h][kk] = f(A[(size_t)k * SN + 32 * mi + 16 * h + lo], k, 32 * mi + 16 * h + lo);
-            o.b[h][kk] = f(B[(size_t)k * SN + 32 * mj + 16 * h + lo], k, 32 * mj + 16 * h + lo);
+            o.a[h][kk] = fa(A[(size_t)k * SN + 32 * mi + 16 * h + lo], k, 32 * mi + 16 * h + lo);
+            o.b[h][kk] = fb(B[(size_t)k * SN + 32 * mj + 16 * h + lo], k, 32 * mj + 16 * h + lo);
         }
     }
+}
+template <class F>
+__device__ __forceinline__ void quad_load(QuadOps &o, const double *A, const double *B, int mi, int mj, int lane, int kq, F f)
+{
+    quad_load2(o, A, B, mi, mj, lane, kq, f, f);
 }
 // the four tiles (ia, ib): this wave's element (row (lane >> 4) + 4 wv, col lane & 15) of each, v[2 ia + ib]
 __device__ __forceinline__ void quad_mma_reduce(const QuadOps &o, double (*redq)[4][4][64], int wv, int lane, double v[4])
@@ -1148,7 +1201,10 @@ __device__ __forceinline__ void quad_mma_reduce(const QuadOps &o, double (*redq)
 }
 
 // part 1 (ns_T_body): grid (16 blocks, batch)
-__global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
+// (FIRST <=> iter == 1: grid 16 blocks + one workgroup for the coefficient table; operands formed on load, see ns_T_body)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
+                                                        const double *__restrict__ Yall, const double *__restrict__ Ztall,
                                                         double *__restrict__ Tall, double *__restrict__ Ttall,
                                                         double *__restrict__ scall, int iter, int batch)
 {
@@ -1158,12 +1214,25 @@ __global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict
     if (!ns_block(batch, b, w)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
+    if (FIRST && w == 16) {
+        if (tid == 0) ns_coef_table<COH_NONE>(s);
+        return;
+    }
     const size_t off = (size_t)b * SN * SN;
     const int mi = w >> 2, mj = w & 3;
     if (s[SC_NS_DONE] != 0.0) return;  // the flag before the operands (see ns_square_body)
     QuadOps ops;
-    quad_load(ops, Ztall + off, Yall + off, mi, mj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
+    double a, bq;
+    if (FIRST) {
+        const NsFirst f = ns_first_setup(X1all + off, s);
+        quad_load2(ops, Aall + off, Aall + off, mi, mj, lane, wv, LoadZ1{f}, LoadY1{f});  // Z1 . Y1
+        a = f.a1;
+        bq = f.b1;
+    } else {
+        quad_load(ops, Ztall + off, Yall + off, mi, mj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+        a = s[SC_COEF + 2 * iter];
+        bq = s[SC_COEF + 2 * iter + 1];
+    }
     if (ns_converged<COH_NONE>(s, iter, lane, w == 0 && tid == 0)) return;
     double p[4];
     quad_mma_reduce(ops, redq, wv, lane, p);
@@ -1184,7 +1253,9 @@ __global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict
 }
 
 // part 2 (ns_YZ_body): grid (32 blocks, batch): blocks 0..15 of Y' = Y.T, 16..31 of Z' = T.Z
-__global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
+template <bool FIRST>
+__global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
+                                                         const double *__restrict__ Ytall, const double *__restrict__ Zall,
                                                          const double *__restrict__ Tall, const double *__restrict__ Ttall,
                                                          double *__restrict__ Yout, double *__restrict__ Ytout,
                                                          double *__restrict__ Zout, double *__restrict__ Ztout,
@@ -1200,7 +1271,13 @@ __global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restric
     const size_t off = (size_t)b * SN * SN;
     if (s[SC_NS_DONE] != 0.0) return;
     QuadOps ops;
-    quad_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, mi, mj, lane, wv, LoadPlain{});
+    if (FIRST) {  // Y' = Y1 . T,  Z' = T . Z1
+        const NsFirst f = ns_first_setup(X1all + off, s);
+        if (isZ) quad_load2(ops, Ttall + off, Aall + off, mi, mj, lane, wv, LoadPlain{}, LoadZ1{f});
+        else quad_load2(ops, Aall + off, Tall + off, mi, mj, lane, wv, LoadY1{f}, LoadPlain{});
+    } else {
+        quad_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, mi, mj, lane, wv, LoadPlain{});
+    }
     if (ns_converged<COH_NONE>(s, iter, lane, false)) return;  // part 1 of this iteration raised the flag
     if (wx == 0 && tid == 0) {
         s[SC_ZBUF] = (double)zbuf_out;
@@ -1214,67 +1291,6 @@ __global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restric
         const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
         store_both((isZ ? Zout : Yout) + off, (isZ ? Ztout : Ytout) + off, row, col, v[t]);
     }
-}
-
-// iteration 0 (ns_first_kernel) the same way: grid (16 blocks + the table's workgroup, batch)
-template <class LD>
-__device__ __forceinline__ void ns_first_quad_tiles(const LD &ld, const double *A, double *Yout, double *Ytout, double *Zout,
-                                                    double *Ztout, double a0, double b0, int mi, int mj, int lane, int wv,
-                                                    double (*redq)[4][4][64])
-{
-    QuadOps ops;
-    quad_load(ops, A, A, mi, mj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
-    double y2[4];
-    quad_mma_reduce(ops, redq, wv, lane, y2);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ti = 2 * mi + (t >> 1), tj = 2 * mj + (t & 1);
-        const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-        const double y0 = ld(A[(size_t)row * SN + col], row, col);
-        store_both(Yout, Ytout, row, col, fma(b0, y2[t], a0 * y0));
-        store_both(Zout, Ztout, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
-    }
-}
-__global__ __launch_bounds__(256) void ns_first_quad_kernel(const double *__restrict__ Aall, double *__restrict__ Yout,
-                                                            double *__restrict__ Ytout, double *__restrict__ Zout,
-                                                            double *__restrict__ Ztout, double *__restrict__ scall, int zbuf_out,
-                                                            int batch)
-{
-    __shared__ double redq[4][4][4][64];
-    int b, w;
-    if (!ns_block(batch, b, w)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t off = (size_t)b * SN * SN;
-    const double *A = Aall + off;
-    double *s = scall + (size_t)b * SC_COUNT;
-    const double scale = s[SC_SCALE];
-    const double delta = s[SC_DELTA], inv = 1.0 / scale;
-    const double lo = s[SC_LO], gam = s[SC_GAM];
-    if (w == 16) {  // the coefficient table (see ns_first_kernel)
-        if (tid == 0) {
-            double l = sqrt(lo / scale);
-            for (int k = 0; k < NS_ITERS; ++k) {
-                double a, bq;
-                ns_coef(l, a, bq);
-                s[SC_COEF + 2 * k] = a;
-                s[SC_COEF + 2 * k + 1] = bq;
-                l = fmin(1.0, l * fma(bq * l, l, a));
-            }
-        }
-        return;
-    }
-    double a0, b0;
-    ns_coef(sqrt(lo / scale), a0, b0);
-    if (w == 0 && tid == 0) {
-        s[SC_ZBUF] = (double)zbuf_out;
-        s[SC_ITERS] = 1.0;
-    }
-    const int mi = w >> 2, mj = w & 3;
-    if (gam != 0.0)  // (uniform)
-        ns_first_quad_tiles(LoadScaledBDefl{delta, inv, gam, s + SC_U}, A, Yout + off, Ytout + off, Zout + off, Ztout + off, a0, b0, mi, mj,
-                            lane, wv, redq);
-    else
-        ns_first_quad_tiles(LoadScaledB{delta, inv}, A, Yout + off, Ytout + off, Zout + off, Ztout + off, a0, b0, mi, mj, lane, wv, redq);
 }
 
 // ---- the chain's dependent phases inside ONE persistent launch (batch 1 only: the launch's workgroups must be
@@ -1383,6 +1399,7 @@ static inline dim3 ns_tail_grid(int nw, int batch) { return dim3(8 * nw * ((batc
 
 struct NsBufs {
     double *Y[2], *Yt[2], *Z[2], *Zt[2], *T, *Tt;
+    const double *A, *X1;  // iteration 1 forms its operands from the chain's input and the filter's first iterate (NsFirst)
 };
 
 // ---- the iteration tail on PAIRS of tiles (round 4): workgroup w of 32 forms the tiles (2 p, tj) and (2 p + 1, tj), p = w >> 3,
@@ -1393,17 +1410,22 @@ struct NsBufs {
 struct PairOps {
     double a[2][8], b[8];
 };
-template <int COH, class F>
-__device__ __forceinline__ void pair_load(PairOps &o, const double *A, const double *B, int p, int tj, int lane, int kq, F f)
+template <int COH, class FA, class FB>
+__device__ __forceinline__ void pair_load2(PairOps &o, const double *A, const double *B, int p, int tj, int lane, int kq, FA fa, FB fb)
 {
     const int lo = lane & 15, hi = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const int k = 32 * kq + 4 * kk + hi;
-        o.a[0][kk] = f(gld<COH>(A + (size_t)k * SN + 32 * p + lo), k, 32 * p + lo);
-        o.a[1][kk] = f(gld<COH>(A + (size_t)k * SN + 32 * p + 16 + lo), k, 32 * p + 16 + lo);
-        o.b[kk] = f(gld<COH>(B + (size_t)k * SN + 16 * tj + lo), k, 16 * tj + lo);
+        o.a[0][kk] = fa(gld<COH>(A + (size_t)k * SN + 32 * p + lo), k, 32 * p + lo);
+        o.a[1][kk] = fa(gld<COH>(A + (size_t)k * SN + 32 * p + 16 + lo), k, 32 * p + 16 + lo);
+        o.b[kk] = fb(gld<COH>(B + (size_t)k * SN + 16 * tj + lo), k, 16 * tj + lo);
     }
+}
+template <int COH, class F>
+__device__ __forceinline__ void pair_load(PairOps &o, const double *A, const double *B, int p, int tj, int lane, int kq, F f)
+{
+    pair_load2<COH>(o, A, B, p, tj, lane, kq, f, f);
 }
 // (skip0: tile 0 of the pair is not wanted; v[0] is then meaningless)
 __device__ __forceinline__ void pair_mma_reduce(const PairOps &o, double (*redp)[4][4][64], int wv, int lane, double v[2],
@@ -1640,7 +1662,7 @@ __device__ __forceinline__ void ns_square_tail_pair_impl(const double *A, const 
     if (!ns_tail_block(NW, batch, b, w)) return;
     // (EVAL: two buffers -- ns_square_evaluator)
     const XBufs xb{xb_all.x0 + (size_t)b * SN * SN, xb_all.x1 + (size_t)b * SN * SN,
-                   EVAL ? nullptr : xb_all.hist + (size_t)b * SN * SN, xb_all.M};
+                   EVAL ? nullptr : xb_all.hist + (size_t)b * SN * SN, xb_all.xq + (size_t)b * SN * SN, xb_all.M};
     scall += (size_t)b * SC_COUNT;
     const unsigned xcc = ns_xcc_id();
     if (EVAL && w >= NS_SQ_PAIR_WG) {
@@ -1676,15 +1698,25 @@ __global__ __launch_bounds__(256, 3) void ns_square_tail_pair_lean_kernel(const 
 }
 
 constexpr int NS_PAIR_WG = 32;
-template <int COH>
-__device__ __forceinline__ bool ns_T_pair_body(const double *Y, const double *Zt, double *T, double *Tt, double *s, int iter, int w,
-                                               double (*redp)[4][4][64], double (*partp)[4])
+// (A1, X1: this matrix's A and X_1 -- iteration 1's operands are formed on load, see ns_T_body)
+template <int COH, bool FIRST_OK>
+__device__ __forceinline__ bool ns_T_pair_body(const double *A1, const double *X1, const double *Y, const double *Zt, double *T, double *Tt,
+                                               double *s, int iter, int w, double (*redp)[4][4][64], double (*partp)[4])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = w >> 3, tj = w & 7;
     PairOps ops;
-    pair_load<COH>(ops, Zt, Y, p, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-    const double a = gld<COH>(s + SC_COEF + 2 * iter), bq = gld<COH>(s + SC_COEF + 2 * iter + 1);
+    double a, bq;
+    if (FIRST_OK && iter == 1) {  // (uniform)
+        const NsFirst f = ns_first_setup(X1, s);
+        pair_load2<COH_NONE>(ops, A1, A1, p, tj, lane, wv, LoadZ1{f}, LoadY1{f});  // Z1 . Y1
+        a = f.a1;
+        bq = f.b1;
+    } else {
+        pair_load<COH>(ops, Zt, Y, p, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+        a = gld<COH>(s + SC_COEF + 2 * iter);
+        bq = gld<COH>(s + SC_COEF + 2 * iter + 1);
+    }
     if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;
     NS_STAMP();  // operands + slots have arrived
     double pv[2];
@@ -1706,15 +1738,21 @@ __device__ __forceinline__ bool ns_T_pair_body(const double *Y, const double *Zt
 // (all 48 operand loads of part 2 in flight together -- 190 VGPRs -- instead of pair after pair: measured for one matrix, no
 // difference: 5 449 / 5 459 / 5 435 against 5 425 / 5 470 / 5 432 steps/s on one box -- the phase waits for the L2's bytes, not for a
 // second latency)
-template <int COH>
-__device__ __forceinline__ bool ns_YZ_pair_body(const double *Yt, const double *Z, const double *T, const double *Tt, double *Yo, double *Yto,
-                                                double *Zo, double *Zto, double *s, int iter, int zbuf_out, int w,
-                                                double (*redp)[4][4][64])
+template <int COH, bool FIRST_OK>
+__device__ __forceinline__ bool ns_YZ_pair_body(const double *A1, const double *X1, const double *Yt, const double *Z, const double *T,
+                                                const double *Tt, double *Yo, double *Yto, double *Zo, double *Zto, double *s, int iter,
+                                                int zbuf_out, int w, double (*redp)[4][4][64])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = w >> 3, tj = w & 7;
     PairOps ops;
-    pair_load<COH>(ops, Yt, T, p, tj, lane, wv, LoadPlain{});  // Y' = Y.T
+    NsFirst f;
+    if (FIRST_OK && iter == 1) {  // (uniform) Y' = Y1 . T (Y1 symmetric: its own transpose)
+        f = ns_first_setup(X1, s);
+        pair_load2<COH>(ops, A1, T, p, tj, lane, wv, LoadY1{f}, LoadPlain{});
+    } else {
+        pair_load<COH>(ops, Yt, T, p, tj, lane, wv, LoadPlain{});  // Y' = Y.T
+    }
     if (ns_converged<COH>(s, iter, lane, false)) return false;
     if (w == 0 && tid == 0) {
         gst<COH>(s + SC_ZBUF, (double)zbuf_out);
@@ -1729,7 +1767,8 @@ __device__ __forceinline__ bool ns_YZ_pair_body(const double *Yt, const double *
         store_both<COH>(Yo, Yto, row, col, v[h]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    pair_load<COH>(ops, Tt, Z, p, tj, lane, wv, LoadPlain{});  // Z' = T.Z
+    if (FIRST_OK && iter == 1) pair_load2<COH>(ops, Tt, A1, p, tj, lane, wv, LoadPlain{}, LoadZ1{f});  // Z' = T . Z1
+    else pair_load<COH>(ops, Tt, Z, p, tj, lane, wv, LoadPlain{});  // Z' = T.Z
     __syncthreads();  // redp is reused
     pair_mma_reduce(ops, redp, wv, lane, v);
     NS_STAMP();  // both products reduced
@@ -1740,11 +1779,11 @@ __device__ __forceinline__ bool ns_YZ_pair_body(const double *Yt, const double *
     }
     return true;
 }
-template <int COH>
+template <int COH, bool FIRST_OK>
 __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t off, double *scall, int iter_first, int iter_last, int w,
                                                        unsigned xcc, double (*redp)[4][4][64], double (*partp)[4], bool t_first)
 {
-    // t_first: part 1 of iteration iter_first is still to do (the launch began with iteration 0); else the launch's first phase was it
+    // t_first: part 1 of iteration iter_first is still to do (the launch began by writing Y1, Z1 out); else the launch's first phase was it
     unsigned *flags = reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64;
     unsigned phase = 1;
     for (int iter = iter_first; iter <= iter_last; ++iter) {
@@ -1754,43 +1793,24 @@ __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t o
         double *Yo = (odd ? B.Y[0] : B.Y[1]) + off, *Yto = (odd ? B.Yt[0] : B.Yt[1]) + off;
         double *Zo = (odd ? B.Z[0] : B.Z[1]) + off, *Zto = (odd ? B.Zt[0] : B.Zt[1]) + off;
         if (iter > iter_first || t_first) {
-            if (!ns_T_pair_body<COH>(Yi, Zti, B.T + off, B.Tt + off, scall, iter, w, redp, partp)) return;
+            if (!ns_T_pair_body<COH, FIRST_OK>(B.A + off, B.X1 + off, Yi, Zti, B.T + off, B.Tt + off, scall, iter, w, redp, partp)) return;
             if (!ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
         }
-        (void)ns_YZ_pair_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, redp);
+        (void)ns_YZ_pair_body<COH, FIRST_OK>(B.A + off, B.X1 + off, Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, redp);
         if (iter < iter_last && !ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
-    }
-}
-// iteration 0 (ns_first_kernel's tiles) on a pair, coherent stores: phase 0 of the launch when every iteration is folded
-template <class LD>
-__device__ __forceinline__ void ns_first_pair_tiles(const LD &ld, const double *A, double *Yo, double *Yto, double *Zo, double *Zto, double a0,
-                                                    double b0, int w, double (*redp)[4][4][64])
-{
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p = w >> 3, tj = w & 7;
-    PairOps ops;
-    pair_load<COH_AGENT>(ops, A, A, p, tj, lane, wv, ld);  // Y0 symmetric: Y0^T = Y0
-    double y2[2];
-    pair_mma_reduce(ops, redp, wv, lane, y2);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = 16 * (2 * p + h) + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-        const double y0 = ld(A[(size_t)row * SN + col], row, col);
-        store_both<COH_AGENT>(Yo, Yto, row, col, fma(b0, y2[h], a0 * y0));
-        store_both<COH_AGENT>(Zo, Zto, row, col, fma(b0, y0, (row == col) ? a0 : 0.0));
     }
 }
 template <int NWAVES>
 __device__ void ns_logdetB_workgroup(const double *__restrict__ A, double *__restrict__ s, double *__restrict__ sm, double *__restrict__ red);
-// iter_first = 0 (one matrix, every iteration folded): the launch begins with iteration 0 (A: the chain's input), and the
-// coefficient table of the iterations to come -- a serial recurrence, ~1.5 us on one lane -- is the work of one of the workgroups
-// the launch would send away anyway (linear id 1: another XCD, so it publishes coherently and raises SC_BAR)
+// with_table (one matrix, every iteration folded: iter_first = 1): the coefficient table of the iterations to come -- a serial
+// recurrence, ~1.5 us on one lane -- is the work of one of the workgroups the launch would send away anyway (linear id 1: another
+// XCD, so it publishes coherently and raises SC_BAR); iteration 1 itself does not need it (NsFirst carries its coefficients)
 // early_logdet (one matrix): linear id 2 factors B = A + delta I for its log det (ns_logdetB_workgroup; the launch then carries
 // 129 KiB of dynamic LDS: one workgroup per CU, which is how the XCD's 32 CUs host the 32 workgroups of the iterations anyway)
 // (a template argument: the factorisation's registers -- 184 against 122 -- must not cost the batched launches their third wave per SIMD)
 template <bool EARLY_LOGDET>
 __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
-                                                                int batch, int force_agent)
+                                                                int batch, int force_agent, int with_table)
 {
     __shared__ double redp[2][4][4][64];
     __shared__ double partp[2][4];
@@ -1799,20 +1819,11 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
         ns_logdetB_workgroup<4>(A, scall, ld_sm, &partp[0][0]);
         return;
     }
-    if (iter_first == 0 && blockIdx.x == 1) {
+    if (with_table && blockIdx.x == 1) {
         if (threadIdx.x == 0) {
-            double *s = scall;
-            const double scale = s[SC_SCALE], lo = s[SC_LO];
-            double l = sqrt(lo / scale);
-            for (int k = 0; k < NS_ITERS; ++k) {
-                double a, bq;
-                ns_coef(l, a, bq);
-                gst<COH_AGENT>(s + SC_COEF + 2 * k, a);
-                gst<COH_AGENT>(s + SC_COEF + 2 * k + 1, bq);
-                l = fmin(1.0, l * fma(bq * l, l, a));
-            }
+            ns_coef_table<COH_AGENT>(scall);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            gst<COH_AGENT>(s + SC_BAR, 1.0);
+            gst<COH_AGENT>(scall + SC_BAR, 1.0);
         }
         return;
     }
@@ -1827,28 +1838,34 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
     __syncthreads();
     NS_STAMP();
 #endif
-    if (iter_first == 0) {
-        double *s = scall;
-        const double scale = s[SC_SCALE], delta = s[SC_DELTA], inv = 1.0 / scale, lo = s[SC_LO], gam = s[SC_GAM];
-        double a0, b0;
-        ns_coef(sqrt(lo / scale), a0, b0);
-        if (w == 0 && threadIdx.x == 0) {
-            gst<COH_AGENT>(s + SC_ZBUF, 1.0);
-            gst<COH_AGENT>(s + SC_ITERS, 1.0);
+    // the launch's first phase (agent-scope stores: the placement check comes with the barrier behind it)
+    if (with_table) {
+        // every iteration folded: Y1 and Z1 written out once (element-wise: NsFirst, no product), so that iteration 1's two phases
+        // load plain tiles like every other iteration's.  (The batched and the launch-per-phase paths form the same values on load
+        // instead -- for them a phase more is a launch more; here forming them on load cost 3.3 us over the phase it saved.)
+        const NsFirst f = ns_first_setup(B.X1 + off, scall);
+        const LoadY1 fy{f};
+        const LoadZ1 fz{f};
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = w >> 3, tj = w & 7;
+        if (w == 0 && tid == 0) {
+            gst<COH_AGENT>(scall + SC_ZBUF, 1.0);
+            gst<COH_AGENT>(scall + SC_ITERS, 1.0);
         }
-        if (gam != 0.0)  // (uniform)
-            ns_first_pair_tiles(LoadScaledBDefl{delta, inv, gam, s + SC_U}, A + off, B.Y[1] + off, B.Yt[1] + off, B.Z[1] + off, B.Zt[1] + off, a0,
-                                b0, w, redp);
-        else
-            ns_first_pair_tiles(LoadScaledB{delta, inv}, A + off, B.Y[1] + off, B.Yt[1] + off, B.Z[1] + off, B.Zt[1] + off, a0, b0, w, redp);
-    } else if (!ns_T_pair_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall,
-                                          iter_first, w, redp, partp))
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = 16 * (2 * p + h) + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+            const double av = (B.A + off)[(size_t)row * SN + col];
+            store_both<COH_AGENT>(B.Y[1] + off, B.Yt[1] + off, row, col, fy(av, row, col));
+            store_both<COH_AGENT>(B.Z[1] + off, B.Zt[1] + off, row, col, fz(av, row, col));
+        }
+    } else if (!ns_T_pair_body<COH_AGENT, false>(B.A + off, B.X1 + off, (odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off,
+                                                 B.Tt + off, scall, iter_first, w, redp, partp))
         return;
     int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL);
     if (r == 2 && force_agent) r = 1;
     if (w == 0 && threadIdx.x == 0) scall[SC_PROF + 6] = (double)r;
-    if (iter_first == 0) {
-        // the coefficient table must be there before part 1 of iteration 1 reads it (it normally is: ~2 us against this launch's ~4)
+    if (with_table) {
+        // the coefficient table must be there before part 1 of iteration 2 reads it (it normally is: ~2 us against this launch's ~4)
         __shared__ int tab_ok;
         if (threadIdx.x == 0) {
             const long long t0 = wall_clock64();
@@ -1866,9 +1883,8 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
         __syncthreads();
         if (!tab_ok) return;
     }
-    const int it0 = iter_first == 0 ? 1 : iter_first;
-    if (r == 2) ns_iter_tail_pair_rest<COH_XCD>(B, off, scall, it0, iter_last, w, xcc, redp, partp, iter_first == 0);
-    else if (r == 1) ns_iter_tail_pair_rest<COH_AGENT>(B, off, scall, it0, iter_last, w, xcc, redp, partp, iter_first == 0);
+    if (r == 2) ns_iter_tail_pair_rest<COH_XCD, false>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp, with_table != 0);
+    else if (r == 1) ns_iter_tail_pair_rest<COH_AGENT, false>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp, with_table != 0);
 #ifdef NS_STAMPS
     if (b == 0 && w == 0 && threadIdx.x == 0)
         for (int i = 0; i < 192; ++i) scall[SC_STAMPS + i] = (i < g_nstamp) ? (double)(g_stamp[i] - g_stamp[0]) : -1.0;
@@ -2445,8 +2461,8 @@ SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
     o.flags = sc + SC_FLAGS;
     return o;
 }
-// 11 matrices, the slots, then the filter's history X_3 .. X_16 (XBufs)
-size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * ((11 + NS_SQUARINGS - 2) * SN * SN + SC_COUNT) * sizeof(double); }
+// 11 matrices, the slots, then the filter's history X_3 .. X_16 and X_1 (XBufs)
+size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * ((11 + NS_SQUARINGS - 1) * SN * SN + SC_COUNT) * sizeof(double); }
 // COVO_NS_RITZ_INSIDE=0 / covo_debug_set_ns_ritz_inside(0): the one-matrix chain, too, evaluates after its squarings (ns_ritz_scan_kernel)
 int g_ns_ritz_inside = [] { const char *e = std::getenv("COVO_NS_RITZ_INSIDE"); return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1; }();
 
@@ -2475,7 +2491,8 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     }
     if (r_has_stats) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
     else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
-    XBufs xb{X0, X1, sc + (size_t)batch * SC_COUNT, M};
+    double *hist0 = sc + (size_t)batch * SC_COUNT;
+    const XBufs xb{X0, X1, hist0, hist0 + (size_t)(NS_SQUARINGS - 2) * M, M};
     const bool fold_first = persistent_ok && (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) >= NS_SQUARINGS - 1;
     if (!fold_first) hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, ns_xk(xb, 1), sc, 0, batch);
     // the remaining squarings / iterations run inside persistent launches (20 / 32 workgroups per matrix, one XCD per matrix)
@@ -2500,27 +2517,38 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (g_dbg_sigma_stages < 2) return 0;
     if (!eval_inside) hipLaunchKernelGGL(ns_ritz_scan_kernel, dim3(batch * RITZ_NK), dim3(256), 0, s, A, xb, sc, g_ns_deflate, g_ns_ritz_inside == 2 ? 1 : 0);
     if (g_dbg_sigma_stages < 3) return 0;
-    // one matrix with every iteration folded: iteration 0 is phase 0 of the persistent launch (ns_iter_tail_pair_kernel)
-    // (same box, three runs each: 5 464-5 467 / 4 888-4 900 steps/s bench / closed loop against 5 442-5 445 / 4 859-4 870 with its own launch)
-    const bool fold_iter0 = batch == 1 && persistent_ok && g_ns_tail_iters >= NS_ITERS - 1;
-    if (fold_iter0) {
-    } else if (batch > 1) hipLaunchKernelGGL(ns_first_quad_kernel, ns_grid(17, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
-    else hipLaunchKernelGGL(ns_first_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);  // 64 tiles + the table
+    // Iteration 0 is no product and no launch (NsFirst): iteration 1 forms Y1 and Z1 on load from A and X_1.  One matrix with every
+    // iteration folded: the persistent launch begins with iteration 1 and carries the coefficient table's workgroup.
+    const double *Xq = ns_xk(xb, 1);  // X_1
+    const bool fold_all = batch == 1 && persistent_ok && g_ns_tail_iters >= NS_ITERS - 1;
     bool early_logdet = false;
     int n_tail = persistent_ok ? (batch == 1 ? g_ns_tail_iters : g_ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
+    if (!fold_all && n_tail > NS_ITERS - 2) n_tail = NS_ITERS - 2;  // (iteration 1 as launches: its first one also makes the table)
     const int n_sep = NS_ITERS - n_tail;
     for (int i = 1; i < n_sep; ++i) {
         const int in = i & 1, out = in ^ 1;
         if (batch > 1) {  // 2 x 2 tile blocks per workgroup: same tiles, same bits, half the operand traffic
-            hipLaunchKernelGGL(ns_T_quad_kernel, ns_grid(16, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i, batch);
-            hipLaunchKernelGGL(ns_YZ_quad_kernel, ns_grid(32, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
-                               Zt[out], sc, i, out, batch);
+            if (i == 1) {
+                hipLaunchKernelGGL(ns_T_quad_kernel<true>, ns_grid(17, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
+                hipLaunchKernelGGL(ns_YZ_quad_kernel<true>, ns_grid(32, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out],
+                                   Z[out], Zt[out], sc, i, out, batch);
+            } else {
+                hipLaunchKernelGGL(ns_T_quad_kernel<false>, ns_grid(16, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
+                hipLaunchKernelGGL(ns_YZ_quad_kernel<false>, ns_grid(32, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out],
+                                   Z[out], Zt[out], sc, i, out, batch);
+            }
             continue;
         }
-        hipLaunchKernelGGL(ns_T_kernel, ns_grid(64, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i, batch);
-        hipLaunchKernelGGL(ns_YZ_kernel, ns_grid(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
-                           Zt[out], sc, i, out, batch);
+        if (i == 1) {
+            hipLaunchKernelGGL(ns_T_kernel<true>, ns_grid(65, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
+            hipLaunchKernelGGL(ns_YZ_kernel<true>, ns_grid(128, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
+                               Zt[out], sc, i, out, batch);
+        } else {
+            hipLaunchKernelGGL(ns_T_kernel<false>, ns_grid(64, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
+            hipLaunchKernelGGL(ns_YZ_kernel<false>, ns_grid(128, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
+                               Zt[out], sc, i, out, batch);
+        }
     }
     if (n_tail > 0) {
         NsBufs B;
@@ -2532,14 +2560,16 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         }
         B.T = T;
         B.Tt = Tt;
+        B.A = A;
+        B.X1 = Xq;
         // one matrix: log det B rides in this launch (ns_logdetB_workgroup), ~50 us before the finalize launch wants it
         early_logdet = batch == 1;
         if (early_logdet)
             hipLaunchKernelGGL(ns_iter_tail_pair_kernel<true>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), lds, s, A, B, sc,
-                               fold_iter0 ? 0 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent);
+                               fold_all ? 1 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent, fold_all ? 1 : 0);
         else
             hipLaunchKernelGGL(ns_iter_tail_pair_kernel<false>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 0, s, A, B, sc,
-                               fold_iter0 ? 0 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent);
+                               n_sep, NS_ITERS - 1, batch, g_ns_force_agent, 0);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     if (stream != nullptr && early_logdet && batch == 1) {
