@@ -974,8 +974,9 @@ __device__ __forceinline__ void ns_coef(double l, double &a, double &bq)
 // own (one product: Y0^2).  Round 5: Y0^2 is ALREADY THERE -- the filter's first squaring formed X_1 = (alpha I - beta A)^2 / n0 -
 // I / t_1, i.e. A^2 = (n0 (X_1 + I / t_1) - alpha^2 I + 2 alpha beta A) / beta^2 -- so Y1 and Z1 are affine in {A, X_1, I, u u^T}:
 //     Y1 = ya A + yx X_1 + yi I + yu u u^T,      Z1 = za A + zi I + zu u u^T
-// (B u = 1e-2 u for the deflated pair), and iteration 1 forms them ON LOAD: no iteration-0 product, no launch / phase for it (X_1
-// keeps a buffer of its own for that: XBufs::xq).  Both are exactly symmetric (A and X_1 are stored so), whichever way they are read.
+// (B u = 1e-2 u for the deflated pair): they are written out element-wise, no product (X_1 keeps a buffer of its own for that:
+// XBufs::xq) -- by ns_first_elem_kernel, or by the first phase of the one-matrix persistent launch.  Forming them ON LOAD inside
+// iteration 1's two products was measured too: + 10 us over two regular batched launches, + 3.3 us on the persistent launch.
 struct NsFirst {
     const double *X1, *u;
     double ya, yx, yi, yu, za, zi, zu;
@@ -1053,10 +1054,9 @@ __device__ __forceinline__ bool ns_converged(double *s, int iter, int lane, bool
 
 // ---- Newton-Schulz step k >= 1, part 1:  T = a_k I + b_k Z.Y  (64 tiles; T and T^T are stored).
 // Returns false when the iteration has converged (nothing was written).  Workgroup w of matrix b.
-// iter == 1: Z1 and Y1 are formed on load from A and X_1 (NsFirst; Aall / X1all: the chain's input and the filter's first iterate)
-template <int COH, bool FIRST_OK = true>
-__device__ __forceinline__ bool ns_T_body(const double *Aall, const double *X1all, const double *Yall, const double *Ztall, double *Tall,
-                                          double *Ttall, double *scall, int iter, int b, int w, double (*red)[4][64], double *part)
+template <int COH>
+__device__ __forceinline__ bool ns_T_body(const double *Yall, const double *Ztall, double *Tall, double *Ttall, double *scall,
+                                          int iter, int b, int w, double (*red)[4][64], double *part)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -1064,17 +1064,8 @@ __device__ __forceinline__ bool ns_T_body(const double *Aall, const double *X1al
     const int ti = w >> 3, tj = w & 7;
     if (!COH && gridDim.y > 1 && s[SC_NS_DONE] != 0.0) return false;  // batched: the flag before the operands (see ns_square_body)
     TileOps ops;
-    double a, bq;
-    if (FIRST_OK && iter == 1) {  // (uniform)
-        const NsFirst f = ns_first_setup(X1all + off, s);
-        tile_load2<COH_NONE>(ops, Aall + off, Aall + off, ti, tj, lane, wv, LoadZ1{f}, LoadY1{f});  // Z1 . Y1
-        a = f.a1;
-        bq = f.b1;
-    } else {
-        tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-        a = s[SC_COEF + 2 * iter];  // (the table: an extra workgroup of iteration 1's first launch)
-        bq = s[SC_COEF + 2 * iter + 1];
-    }
+    tile_load<COH>(ops, Ztall + off, Yall + off, ti, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];  // (the table: ns_first_elem_kernel's extra workgroup)
     if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;  // Y, Z are final
     const f64x4 acc = tile_mma(ops);
     const double p = tile_reduce(acc, red, wv, lane);
@@ -1087,10 +1078,10 @@ __device__ __forceinline__ bool ns_T_body(const double *Aall, const double *X1al
 }
 
 // ---- part 2:  Y' = Y.T (tiles 0..63),  Z' = T.Z (tiles 64..127); each with its transpose.  Workgroup wx in 0..127.
-template <int COH, bool FIRST_OK = true>
-__device__ __forceinline__ bool ns_YZ_body(const double *Aall, const double *X1all, const double *Ytall, const double *Zall,
-                                           const double *Tall, const double *Ttall, double *Yout, double *Ytout, double *Zout,
-                                           double *Ztout, double *scall, int iter, int zbuf_out, int b, int wx, double (*red)[4][64])
+template <int COH>
+__device__ __forceinline__ bool ns_YZ_body(const double *Ytall, const double *Zall, const double *Tall, const double *Ttall,
+                                           double *Yout, double *Ytout, double *Zout, double *Ztout, double *scall, int iter,
+                                           int zbuf_out, int b, int wx, double (*red)[4][64])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
@@ -1101,13 +1092,7 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Aall, const double *X1a
     // Y' = Y.T : left factor Y -> pass Y^T;   Z' = T.Z : left factor T -> pass T^T
     if (!COH && gridDim.y > 1 && s[SC_NS_DONE] != 0.0) return false;  // batched: the flag before the operands (see ns_square_body)
     TileOps ops;
-    if (FIRST_OK && iter == 1) {  // (uniform) Y' = Y1 . T (Y1 symmetric: its own transpose),  Z' = T . Z1
-        const NsFirst f = ns_first_setup(X1all + off, s);
-        if (isZ) tile_load2<COH>(ops, Ttall + off, Aall + off, ti, tj, lane, wv, LoadPlain{}, LoadZ1{f});
-        else tile_load2<COH>(ops, Aall + off, Tall + off, ti, tj, lane, wv, LoadY1{f}, LoadPlain{});
-    } else {
-        tile_load<COH>(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
-    }
+    tile_load<COH>(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, ti, tj, lane, wv, LoadPlain{});
     if (ns_converged<COH>(s, iter, lane, false)) return false;  // part 1 of this iteration raised the flag
     if (wx == 0 && tid == 0) {
         gst<COH>(s + SC_ZBUF, (double)zbuf_out);  // which Z buffer holds the newest iterate
@@ -1120,11 +1105,7 @@ __device__ __forceinline__ bool ns_YZ_body(const double *Aall, const double *X1a
     return true;
 }
 
-// (FIRST <=> iter == 1: grid 64 tiles + one workgroup for the coefficient table, which iteration 2 reads first; a template argument:
-// the on-load operands' registers must not cost the other iterations' launches their occupancy)
-template <bool FIRST>
-__global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
-                                                   const double *__restrict__ Yall, const double *__restrict__ Ztall,
+__global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
                                                    double *__restrict__ Tall, double *__restrict__ Ttall,
                                                    double *__restrict__ scall, int iter, int batch)
 {
@@ -1132,16 +1113,10 @@ __global__ __launch_bounds__(256) void ns_T_kernel(const double *__restrict__ Aa
     __shared__ double part[4];
     int b, w;
     if (!ns_block(batch, b, w)) return;
-    if (FIRST && w == 64) {
-        if (threadIdx.x == 0) ns_coef_table<COH_NONE>(scall + (size_t)b * SC_COUNT);
-        return;
-    }
-    (void)ns_T_body<COH_NONE, FIRST>(Aall, X1all, Yall, Ztall, Tall, Ttall, scall, iter, b, w, red, part);
+    (void)ns_T_body<COH_NONE>(Yall, Ztall, Tall, Ttall, scall, iter, b, w, red, part);
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
-                                                    const double *__restrict__ Ytall, const double *__restrict__ Zall,
+__global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
                                                     const double *__restrict__ Tall, const double *__restrict__ Ttall,
                                                     double *__restrict__ Yout, double *__restrict__ Ytout,
                                                     double *__restrict__ Zout, double *__restrict__ Ztout,
@@ -1150,7 +1125,36 @@ __global__ __launch_bounds__(256) void ns_YZ_kernel(const double *__restrict__ A
     __shared__ double red[4][4][64];
     int b, w;
     if (!ns_block(batch, b, w)) return;
-    (void)ns_YZ_body<COH_NONE, FIRST>(Aall, X1all, Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, b, w, red);
+    (void)ns_YZ_body<COH_NONE>(Ytall, Zall, Tall, Ttall, Yout, Ytout, Zout, Ztout, scall, iter, zbuf_out, b, w, red);
+}
+
+// ---- "iteration 0" of the launch-per-phase and the batched paths: Y1, Z1 (and their transposes) written out element-wise (NsFirst:
+// no product) -- grid (64 tiles + one workgroup for the coefficient table, batch); the one-matrix persistent launch does the same as
+// its first phase.  Same functors, same bits.
+__global__ __launch_bounds__(256) void ns_first_elem_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
+                                                            double *__restrict__ Yout, double *__restrict__ Ytout,
+                                                            double *__restrict__ Zout, double *__restrict__ Ztout,
+                                                            double *__restrict__ scall, int zbuf_out, int batch)
+{
+    int b, w;
+    if (!ns_block(batch, b, w)) return;
+    const int tid = threadIdx.x;
+    double *s = scall + (size_t)b * SC_COUNT;
+    if (w == 64) {
+        if (tid == 0) ns_coef_table<COH_NONE>(s);
+        return;
+    }
+    const size_t off = (size_t)b * SN * SN;
+    const NsFirst f = ns_first_setup(X1all + off, s);
+    if (w == 0 && tid == 0) {
+        s[SC_ZBUF] = (double)zbuf_out;
+        s[SC_ITERS] = 1.0;
+    }
+    const int ti = w >> 3, tj = w & 7;
+    const int row = 16 * ti + (tid >> 4), col = 16 * tj + (tid & 15);
+    const double av = Aall[off + (size_t)row * SN + col];
+    store_both(Yout + off, Ytout + off, row, col, LoadY1{f}(av, row, col));
+    store_both(Zout + off, Ztout + off, row, col, LoadZ1{f}(av, row, col));
 }
 
 // ---- batched launches of the Newton-Schulz phases: one workgroup = a 2 x 2 block of 16 x 16 tiles (round 4).  With one tile per
@@ -1201,10 +1205,7 @@ __device__ __forceinline__ void quad_mma_reduce(const QuadOps &o, double (*redq)
 }
 
 // part 1 (ns_T_body): grid (16 blocks, batch)
-// (FIRST <=> iter == 1: grid 16 blocks + one workgroup for the coefficient table; operands formed on load, see ns_T_body)
-template <bool FIRST>
-__global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
-                                                        const double *__restrict__ Yall, const double *__restrict__ Ztall,
+__global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict__ Yall, const double *__restrict__ Ztall,
                                                         double *__restrict__ Tall, double *__restrict__ Ttall,
                                                         double *__restrict__ scall, int iter, int batch)
 {
@@ -1214,25 +1215,12 @@ __global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict
     if (!ns_block(batch, b, w)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *s = scall + (size_t)b * SC_COUNT;
-    if (FIRST && w == 16) {
-        if (tid == 0) ns_coef_table<COH_NONE>(s);
-        return;
-    }
     const size_t off = (size_t)b * SN * SN;
     const int mi = w >> 2, mj = w & 3;
     if (s[SC_NS_DONE] != 0.0) return;  // the flag before the operands (see ns_square_body)
     QuadOps ops;
-    double a, bq;
-    if (FIRST) {
-        const NsFirst f = ns_first_setup(X1all + off, s);
-        quad_load2(ops, Aall + off, Aall + off, mi, mj, lane, wv, LoadZ1{f}, LoadY1{f});  // Z1 . Y1
-        a = f.a1;
-        bq = f.b1;
-    } else {
-        quad_load(ops, Ztall + off, Yall + off, mi, mj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-        a = s[SC_COEF + 2 * iter];
-        bq = s[SC_COEF + 2 * iter + 1];
-    }
+    quad_load(ops, Ztall + off, Yall + off, mi, mj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double a = s[SC_COEF + 2 * iter], bq = s[SC_COEF + 2 * iter + 1];
     if (ns_converged<COH_NONE>(s, iter, lane, w == 0 && tid == 0)) return;
     double p[4];
     quad_mma_reduce(ops, redq, wv, lane, p);
@@ -1253,9 +1241,7 @@ __global__ __launch_bounds__(256) void ns_T_quad_kernel(const double *__restrict
 }
 
 // part 2 (ns_YZ_body): grid (32 blocks, batch): blocks 0..15 of Y' = Y.T, 16..31 of Z' = T.Z
-template <bool FIRST>
-__global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restrict__ Aall, const double *__restrict__ X1all,
-                                                         const double *__restrict__ Ytall, const double *__restrict__ Zall,
+__global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restrict__ Ytall, const double *__restrict__ Zall,
                                                          const double *__restrict__ Tall, const double *__restrict__ Ttall,
                                                          double *__restrict__ Yout, double *__restrict__ Ytout,
                                                          double *__restrict__ Zout, double *__restrict__ Ztout,
@@ -1271,13 +1257,7 @@ __global__ __launch_bounds__(256) void ns_YZ_quad_kernel(const double *__restric
     const size_t off = (size_t)b * SN * SN;
     if (s[SC_NS_DONE] != 0.0) return;
     QuadOps ops;
-    if (FIRST) {  // Y' = Y1 . T,  Z' = T . Z1
-        const NsFirst f = ns_first_setup(X1all + off, s);
-        if (isZ) quad_load2(ops, Ttall + off, Aall + off, mi, mj, lane, wv, LoadPlain{}, LoadZ1{f});
-        else quad_load2(ops, Aall + off, Tall + off, mi, mj, lane, wv, LoadY1{f}, LoadPlain{});
-    } else {
-        quad_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, mi, mj, lane, wv, LoadPlain{});
-    }
+    quad_load(ops, (isZ ? Ttall : Ytall) + off, (isZ ? Zall : Tall) + off, mi, mj, lane, wv, LoadPlain{});
     if (ns_converged<COH_NONE>(s, iter, lane, false)) return;  // part 1 of this iteration raised the flag
     if (wx == 0 && tid == 0) {
         s[SC_ZBUF] = (double)zbuf_out;
@@ -1698,25 +1678,15 @@ __global__ __launch_bounds__(256, 3) void ns_square_tail_pair_lean_kernel(const 
 }
 
 constexpr int NS_PAIR_WG = 32;
-// (A1, X1: this matrix's A and X_1 -- iteration 1's operands are formed on load, see ns_T_body)
-template <int COH, bool FIRST_OK>
-__device__ __forceinline__ bool ns_T_pair_body(const double *A1, const double *X1, const double *Y, const double *Zt, double *T, double *Tt,
-                                               double *s, int iter, int w, double (*redp)[4][4][64], double (*partp)[4])
+template <int COH>
+__device__ __forceinline__ bool ns_T_pair_body(const double *Y, const double *Zt, double *T, double *Tt, double *s, int iter, int w,
+                                               double (*redp)[4][4][64], double (*partp)[4])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = w >> 3, tj = w & 7;
     PairOps ops;
-    double a, bq;
-    if (FIRST_OK && iter == 1) {  // (uniform)
-        const NsFirst f = ns_first_setup(X1, s);
-        pair_load2<COH_NONE>(ops, A1, A1, p, tj, lane, wv, LoadZ1{f}, LoadY1{f});  // Z1 . Y1
-        a = f.a1;
-        bq = f.b1;
-    } else {
-        pair_load<COH>(ops, Zt, Y, p, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
-        a = gld<COH>(s + SC_COEF + 2 * iter);
-        bq = gld<COH>(s + SC_COEF + 2 * iter + 1);
-    }
+    pair_load<COH>(ops, Zt, Y, p, tj, lane, wv, LoadPlain{});  // (Z^T)^T . Y = Z.Y
+    const double a = gld<COH>(s + SC_COEF + 2 * iter), bq = gld<COH>(s + SC_COEF + 2 * iter + 1);
     if (ns_converged<COH>(s, iter, lane, w == 0 && tid == 0)) return false;
     NS_STAMP();  // operands + slots have arrived
     double pv[2];
@@ -1738,21 +1708,15 @@ __device__ __forceinline__ bool ns_T_pair_body(const double *A1, const double *X
 // (all 48 operand loads of part 2 in flight together -- 190 VGPRs -- instead of pair after pair: measured for one matrix, no
 // difference: 5 449 / 5 459 / 5 435 against 5 425 / 5 470 / 5 432 steps/s on one box -- the phase waits for the L2's bytes, not for a
 // second latency)
-template <int COH, bool FIRST_OK>
-__device__ __forceinline__ bool ns_YZ_pair_body(const double *A1, const double *X1, const double *Yt, const double *Z, const double *T,
-                                                const double *Tt, double *Yo, double *Yto, double *Zo, double *Zto, double *s, int iter,
-                                                int zbuf_out, int w, double (*redp)[4][4][64])
+template <int COH>
+__device__ __forceinline__ bool ns_YZ_pair_body(const double *Yt, const double *Z, const double *T, const double *Tt, double *Yo, double *Yto,
+                                                double *Zo, double *Zto, double *s, int iter, int zbuf_out, int w,
+                                                double (*redp)[4][4][64])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = w >> 3, tj = w & 7;
     PairOps ops;
-    NsFirst f;
-    if (FIRST_OK && iter == 1) {  // (uniform) Y' = Y1 . T (Y1 symmetric: its own transpose)
-        f = ns_first_setup(X1, s);
-        pair_load2<COH>(ops, A1, T, p, tj, lane, wv, LoadY1{f}, LoadPlain{});
-    } else {
-        pair_load<COH>(ops, Yt, T, p, tj, lane, wv, LoadPlain{});  // Y' = Y.T
-    }
+    pair_load<COH>(ops, Yt, T, p, tj, lane, wv, LoadPlain{});  // Y' = Y.T
     if (ns_converged<COH>(s, iter, lane, false)) return false;
     if (w == 0 && tid == 0) {
         gst<COH>(s + SC_ZBUF, (double)zbuf_out);
@@ -1767,8 +1731,7 @@ __device__ __forceinline__ bool ns_YZ_pair_body(const double *A1, const double *
         store_both<COH>(Yo, Yto, row, col, v[h]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (FIRST_OK && iter == 1) pair_load2<COH>(ops, Tt, A1, p, tj, lane, wv, LoadPlain{}, LoadZ1{f});  // Z' = T . Z1
-    else pair_load<COH>(ops, Tt, Z, p, tj, lane, wv, LoadPlain{});  // Z' = T.Z
+    pair_load<COH>(ops, Tt, Z, p, tj, lane, wv, LoadPlain{});  // Z' = T.Z
     __syncthreads();  // redp is reused
     pair_mma_reduce(ops, redp, wv, lane, v);
     NS_STAMP();  // both products reduced
@@ -1779,7 +1742,7 @@ __device__ __forceinline__ bool ns_YZ_pair_body(const double *A1, const double *
     }
     return true;
 }
-template <int COH, bool FIRST_OK>
+template <int COH>
 __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t off, double *scall, int iter_first, int iter_last, int w,
                                                        unsigned xcc, double (*redp)[4][4][64], double (*partp)[4], bool t_first)
 {
@@ -1793,10 +1756,10 @@ __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t o
         double *Yo = (odd ? B.Y[0] : B.Y[1]) + off, *Yto = (odd ? B.Yt[0] : B.Yt[1]) + off;
         double *Zo = (odd ? B.Z[0] : B.Z[1]) + off, *Zto = (odd ? B.Zt[0] : B.Zt[1]) + off;
         if (iter > iter_first || t_first) {
-            if (!ns_T_pair_body<COH, FIRST_OK>(B.A + off, B.X1 + off, Yi, Zti, B.T + off, B.Tt + off, scall, iter, w, redp, partp)) return;
+            if (!ns_T_pair_body<COH>(Yi, Zti, B.T + off, B.Tt + off, scall, iter, w, redp, partp)) return;
             if (!ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
         }
-        (void)ns_YZ_pair_body<COH, FIRST_OK>(B.A + off, B.X1 + off, Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, redp);
+        (void)ns_YZ_pair_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, redp);
         if (iter < iter_last && !ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
     }
 }
@@ -1858,8 +1821,8 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
             store_both<COH_AGENT>(B.Y[1] + off, B.Yt[1] + off, row, col, fy(av, row, col));
             store_both<COH_AGENT>(B.Z[1] + off, B.Zt[1] + off, row, col, fz(av, row, col));
         }
-    } else if (!ns_T_pair_body<COH_AGENT, false>(B.A + off, B.X1 + off, (odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off,
-                                                 B.Tt + off, scall, iter_first, w, redp, partp))
+    } else if (!ns_T_pair_body<COH_AGENT>((odd ? B.Y[1] : B.Y[0]) + off, (odd ? B.Zt[1] : B.Zt[0]) + off, B.T + off, B.Tt + off, scall,
+                                          iter_first, w, redp, partp))
         return;
     int r = ns_flag_barrier<COH_AGENT>(reinterpret_cast<unsigned *>(scall + SC_FLAGS) + 64, 1u, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL);
     if (r == 2 && force_agent) r = 1;
@@ -1883,8 +1846,8 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
         __syncthreads();
         if (!tab_ok) return;
     }
-    if (r == 2) ns_iter_tail_pair_rest<COH_XCD, false>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp, with_table != 0);
-    else if (r == 1) ns_iter_tail_pair_rest<COH_AGENT, false>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp, with_table != 0);
+    if (r == 2) ns_iter_tail_pair_rest<COH_XCD>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp, with_table != 0);
+    else if (r == 1) ns_iter_tail_pair_rest<COH_AGENT>(B, off, scall, iter_first, iter_last, w, xcc, redp, partp, with_table != 0);
 #ifdef NS_STAMPS
     if (b == 0 && w == 0 && threadIdx.x == 0)
         for (int i = 0; i < 192; ++i) scall[SC_STAMPS + i] = (i < g_nstamp) ? (double)(g_stamp[i] - g_stamp[0]) : -1.0;
@@ -2517,38 +2480,26 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     if (g_dbg_sigma_stages < 2) return 0;
     if (!eval_inside) hipLaunchKernelGGL(ns_ritz_scan_kernel, dim3(batch * RITZ_NK), dim3(256), 0, s, A, xb, sc, g_ns_deflate, g_ns_ritz_inside == 2 ? 1 : 0);
     if (g_dbg_sigma_stages < 3) return 0;
-    // Iteration 0 is no product and no launch (NsFirst): iteration 1 forms Y1 and Z1 on load from A and X_1.  One matrix with every
-    // iteration folded: the persistent launch begins with iteration 1 and carries the coefficient table's workgroup.
+    // Iteration 0 is no product (NsFirst): Y1 and Z1 are written out element-wise from A and X_1 -- by the first phase of the persistent
+    // launch when one matrix folds every iteration into it, else by a launch of their own (which also makes the coefficient table).
     const double *Xq = ns_xk(xb, 1);  // X_1
     const bool fold_all = batch == 1 && persistent_ok && g_ns_tail_iters >= NS_ITERS - 1;
+    if (!fold_all) hipLaunchKernelGGL(ns_first_elem_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Xq, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
     bool early_logdet = false;
     int n_tail = persistent_ok ? (batch == 1 ? g_ns_tail_iters : g_ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
-    if (!fold_all && n_tail > NS_ITERS - 2) n_tail = NS_ITERS - 2;  // (iteration 1 as launches: its first one also makes the table)
     const int n_sep = NS_ITERS - n_tail;
     for (int i = 1; i < n_sep; ++i) {
         const int in = i & 1, out = in ^ 1;
         if (batch > 1) {  // 2 x 2 tile blocks per workgroup: same tiles, same bits, half the operand traffic
-            if (i == 1) {
-                hipLaunchKernelGGL(ns_T_quad_kernel<true>, ns_grid(17, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
-                hipLaunchKernelGGL(ns_YZ_quad_kernel<true>, ns_grid(32, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out],
-                                   Z[out], Zt[out], sc, i, out, batch);
-            } else {
-                hipLaunchKernelGGL(ns_T_quad_kernel<false>, ns_grid(16, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
-                hipLaunchKernelGGL(ns_YZ_quad_kernel<false>, ns_grid(32, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out],
-                                   Z[out], Zt[out], sc, i, out, batch);
-            }
+            hipLaunchKernelGGL(ns_T_quad_kernel, ns_grid(16, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i, batch);
+            hipLaunchKernelGGL(ns_YZ_quad_kernel, ns_grid(32, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
+                               Zt[out], sc, i, out, batch);
             continue;
         }
-        if (i == 1) {
-            hipLaunchKernelGGL(ns_T_kernel<true>, ns_grid(65, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
-            hipLaunchKernelGGL(ns_YZ_kernel<true>, ns_grid(128, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
-                               Zt[out], sc, i, out, batch);
-        } else {
-            hipLaunchKernelGGL(ns_T_kernel<false>, ns_grid(64, batch), dim3(256), 0, s, A, Xq, Y[in], Zt[in], T, Tt, sc, i, batch);
-            hipLaunchKernelGGL(ns_YZ_kernel<false>, ns_grid(128, batch), dim3(256), 0, s, A, Xq, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
-                               Zt[out], sc, i, out, batch);
-        }
+        hipLaunchKernelGGL(ns_T_kernel, ns_grid(64, batch), dim3(256), 0, s, Y[in], Zt[in], T, Tt, sc, i, batch);
+        hipLaunchKernelGGL(ns_YZ_kernel, ns_grid(128, batch), dim3(256), 0, s, Yt[in], Z[in], T, Tt, Y[out], Yt[out], Z[out],
+                           Zt[out], sc, i, out, batch);
     }
     if (n_tail > 0) {
         NsBufs B;
