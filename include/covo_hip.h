@@ -378,7 +378,9 @@ int covo_debug_set_merge_in_rollout(int on);
 int covo_debug_set_stream_gemm(int on);
 
 /* Debug aid: copy `count` doubles from offset `offset_doubles` of the Sigma pipeline's scratch (layout in
- * sigma_ns.hip: 12 matrices [batch][128][128], then 64 scalars per matrix) to `out` (device). */
+ * sigma_ns.hip: 11 matrices [batch][128][128], then 3 712 doubles of slots per matrix -- SC_* in sigma_ns.hip: lambda_min, delta,
+ * scale, the iterate the result was taken from, iteration counts, barrier status ... --, then the filter's iterate buffers) to
+ * `out` (device or pinned host). */
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 /* Test hook (process-wide): how many of the eigh-free Sigma chain's last Chebyshev squarings / Newton-Schulz iterations
  * run inside the two persistent launches (phases separated by barriers inside the launch) instead of as one / two launches
