@@ -456,7 +456,7 @@ struct RitzLds {
     // the evaluation's results (ritz_publish)
     double o_lmin, o_scale, o_lo, o_gam, o_zc, o_gapest, o_resid2;
     int o_pass;
-    int decide, abort;
+    int decide, abort, prev_hint;  // prev_hint: the verdict on X_(k-1) as ritz_eval saw it (0: not yet)
     int pick[RITZ];
 };
 // what an evaluating workgroup keeps of A and of the chain's input statistics (loaded once per matrix; 256 threads)
@@ -792,6 +792,9 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
     __syncthreads();
     EV_STAMP8(const_cast<double *>(s), k, 4);
     if (ABORT && L.abort) return 0.0;
+    // (the verdict on X_(k-1), which the decision will ask for first: its round trip runs under the residual)
+    double prev_v = 0.0;
+    if (ABORT && tid == 0 && k > RITZ_K0) prev_v = gld<COH_AGENT>(s + SC_VERD + k - 1 - RITZ_K0);
     // the bottom Ritz pair (theta, u = V c) and its residual |A u - theta u| (A V is in the partials of H)
     double u = 0.0;
     if (tid < SN) {
@@ -846,6 +849,7 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
         }
         L.o_gapest = L.gap;
         L.o_resid2 = resid2;  // squared
+        L.prev_hint = (int)prev_v;
     }
     __syncthreads();
     return u;
@@ -876,7 +880,8 @@ __device__ __forceinline__ bool ritz_decide(RitzLds &L, double u, double *s, int
 {
     if (threadIdx.x == 0) {
         int prev = 1;
-        if (k > RITZ_K0) {
+        if (k > RITZ_K0 && L.prev_hint != 0) prev = L.prev_hint;
+        else if (k > RITZ_K0) {
             const long long t0 = wall_clock64();
             while ((prev = (int)gld<COH_AGENT>(s + SC_VERD + k - 1 - RITZ_K0)) == 0) {
                 // (an evaluation that notices a taken result at one of its seams leaves WITHOUT a verdict: the taken result
