@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(256) void ns_first_elem_kernel(const double *__rest
 struct QuadOps {
     double a[2][8], b[2][8];
 };
-template <class F>
+template <int COH = COH_NONE, class F>
 __device__ __forceinline__ void quad_load(QuadOps &o, const double *A, const double *B, int mi, int mj, int lane, int kq, F f)
 {
     const int lo = lane & 15, hi = lane >> 4;
@@ -1156,8 +1156,8 @@ __device__ __forceinline__ void quad_load(QuadOps &o, const double *A, const dou
         const int k = 32 * kq + 4 * kk + hi;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            o.a[h][kk] = f(A[(size_t)k * SN + 32 * mi + 16 * h + lo], k, 32 * mi + 16 * h + lo);
-            o.b[h][kk] = f(B[(size_t)k * SN + 32 * mj + 16 * h + lo], k, 32 * mj + 16 * h + lo);
+            o.a[h][kk] = f(gld<COH>(A + (size_t)k * SN + 32 * mi + 16 * h + lo), k, 32 * mi + 16 * h + lo);
+            o.b[h][kk] = f(gld<COH>(B + (size_t)k * SN + 32 * mj + 16 * h + lo), k, 32 * mj + 16 * h + lo);
         }
     }
 }
@@ -1676,40 +1676,38 @@ __device__ __forceinline__ bool ns_T_pair_body(const double *Y, const double *Zt
     if (tid < 2) gst<COH>(s + SC_ERR + iter * 64 + (2 * p + tid) * 8 + tj, (partp[tid][0] + partp[tid][1]) + (partp[tid][2] + partp[tid][3]));
     return true;
 }
-// (all 48 operand loads of part 2 in flight together -- 190 VGPRs -- instead of pair after pair: measured for one matrix, no
-// difference: 5 449 / 5 459 / 5 435 against 5 425 / 5 470 / 5 432 steps/s on one box -- the phase waits for the L2's bytes, not for a
-// second latency)
+// Part 2 on 2 x 2 tile BLOCKS (round 5): workgroups 0..15 form the blocks of Y' = Y.T, 16..31 those of Z' = T.Z -- one product of four
+// tiles per workgroup instead of two products of two tiles one after the other.  What this phase waits for is the XCD's ONE L2
+// (16 channels x 64 B/clk): pairs pull 4 MB of operands through it (~2 us: the stamps of -DNS_STAMPS show the second product's
+// operands arriving 2.0 us after the first's), blocks 2 MB; the MFMA count per wave is the same (32).  Per tile the arithmetic of
+// ns_YZ_body (quad_mma_reduce), as in the batched launches.  redq: 4 x 4 x 4 x 64 doubles of LDS.  Measured (-DNS_STAMPS, one matrix): the
+// phase 3.9 us against 4.2 (operands 1.4 us against 1.2 + the second product's 1.2 under its own product; product 1.3 against 2.0;
+// four tiles' stores 0.8 against 0.5); same box, whole step 173.3 against 175.2 us.  (Round 4 had tried all 48 operand loads of the
+// two pair products in flight together: no difference -- the bytes, not the second latency.)
 template <int COH>
-__device__ __forceinline__ bool ns_YZ_pair_body(const double *Yt, const double *Z, const double *T, const double *Tt, double *Yo, double *Yto,
+__device__ __forceinline__ bool ns_YZ_quad_body(const double *Yt, const double *Z, const double *T, const double *Tt, double *Yo, double *Yto,
                                                 double *Zo, double *Zto, double *s, int iter, int zbuf_out, int w,
-                                                double (*redp)[4][4][64])
+                                                double (*redq)[4][4][64])
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p = w >> 3, tj = w & 7;
-    PairOps ops;
-    pair_load<COH>(ops, Yt, T, p, tj, lane, wv, LoadPlain{});  // Y' = Y.T
+    const bool isZ = w >= 16;
+    const int q = w & 15, mi = q >> 2, mj = q & 3;
+    QuadOps ops;
+    quad_load<COH>(ops, isZ ? Tt : Yt, isZ ? Z : T, mi, mj, lane, wv, LoadPlain{});
     if (ns_converged<COH>(s, iter, lane, false)) return false;
     if (w == 0 && tid == 0) {
         gst<COH>(s + SC_ZBUF, (double)zbuf_out);
         gst<COH>(s + SC_ITERS, (double)(iter + 1));
     }
     NS_STAMP();  // operands + slots have arrived
-    double v[2];
-    pair_mma_reduce(ops, redp, wv, lane, v);
+    double v[4];
+    quad_mma_reduce(ops, redq, wv, lane, v);
+    NS_STAMP();  // products reduced
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = 16 * (2 * p + h) + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-        store_both<COH>(Yo, Yto, row, col, v[h]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    pair_load<COH>(ops, Tt, Z, p, tj, lane, wv, LoadPlain{});  // Z' = T.Z
-    __syncthreads();  // redp is reused
-    pair_mma_reduce(ops, redp, wv, lane, v);
-    NS_STAMP();  // both products reduced
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = 16 * (2 * p + h) + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
-        store_both<COH>(Zo, Zto, row, col, v[h]);
+    for (int t = 0; t < 4; ++t) {
+        const int ti = 2 * mi + (t >> 1), tj = 2 * mj + (t & 1);
+        const int row = 16 * ti + (lane >> 4) + 4 * wv, col = 16 * tj + (lane & 15);
+        store_both<COH>(isZ ? Zo : Yo, isZ ? Zto : Yto, row, col, v[t]);
     }
     return true;
 }
@@ -1730,7 +1728,7 @@ __device__ __forceinline__ void ns_iter_tail_pair_rest(const NsBufs &B, size_t o
             if (!ns_T_pair_body<COH>(Yi, Zti, B.T + off, B.Tt + off, scall, iter, w, redp, partp)) return;
             if (!ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
         }
-        (void)ns_YZ_pair_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, redp);
+        (void)ns_YZ_quad_body<COH>(Yti, Zi, B.T + off, B.Tt + off, Yo, Yto, Zo, Zto, scall, iter, odd ? 0 : 1, w, redp);
         if (iter < iter_last && !ns_flag_barrier<COH>(flags, ++phase, w, NS_PAIR_WG, xcc, scall + SC_BARFAIL)) return;
     }
 }
@@ -1746,10 +1744,12 @@ template <bool EARLY_LOGDET>
 __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
                                                                 int batch, int force_agent, int with_table)
 {
-    __shared__ double redp[2][4][4][64];
+    // dynamic LDS: the factorisation's matrix (129 KiB, EARLY_LOGDET) / the iterations' reduction buffer (32 KiB: four tiles x four
+    // K-quarters, ns_YZ_quad_body; the pairs of part 1 use half of it) -- static and dynamic together must stay under 160 KiB
+    extern __shared__ __attribute__((aligned(16))) double ld_sm[];
+    double (*redp)[4][4][64] = reinterpret_cast<double (*)[4][4][64]>(ld_sm);
     __shared__ double partp[2][4];
     if (EARLY_LOGDET && blockIdx.x == 2) {  // (another of the linear ids the launch sends away: XCD 2)
-        extern __shared__ __attribute__((aligned(16))) double ld_sm[];
         ns_logdetB_workgroup<4>(A, scall, ld_sm, &partp[0][0]);
         return;
     }
@@ -2490,7 +2490,7 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
             hipLaunchKernelGGL(ns_iter_tail_pair_kernel<true>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), lds, s, A, B, sc,
                                fold_all ? 1 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent, fold_all ? 1 : 0);
         else
-            hipLaunchKernelGGL(ns_iter_tail_pair_kernel<false>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 0, s, A, B, sc,
+            hipLaunchKernelGGL(ns_iter_tail_pair_kernel<false>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 4 * 4 * 4 * 64 * sizeof(double), s, A, B, sc,
                                n_sep, NS_ITERS - 1, batch, g_ns_force_agent, 0);
     }
     if (g_dbg_sigma_stages < 4) return 0;
