@@ -398,7 +398,9 @@ int covo_debug_set_ns_deflate(int on);
 int covo_debug_set_ns_coherence(int force_agent);
 /* Test hook (process-wide): 0 makes the one-matrix Sigma chain evaluate its Rayleigh-Ritz pairs AFTER the squaring launch
  * (ns_ritz_scan_kernel, what batches and shared-device handles do) instead of inside it; default 1.  Same Sigma and L bit for
- * bit: lambda_min is a function of the matrix alone (sigma_ns.hip: ritz_decide).  Also COVO_NS_RITZ_INSIDE=0 in the environment. */
+ * bit: lambda_min is a function of the matrix alone (sigma_ns.hip: ritz_decide).  Also COVO_NS_RITZ_INSIDE=0 in the environment.
+ * 2: a timing reference only -- rounds 1-4's rule (the Ritz step reads the filter's last iterate and nothing else; Sigma then
+ * differs in the last bits). */
 int covo_debug_set_ns_ritz_inside(int on);
 int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 /* Test hook: `count` doubles at `offset_doubles` of the Hessians of the LAST covo_mpc_step_batched on this handle
