@@ -458,6 +458,8 @@ struct RitzLds {
     int o_pass;
     int decide, abort, prev_hint;  // prev_hint: the verdict on X_(k-1) as ritz_eval saw it (0: not yet)
     int pick[RITZ];
+    double C[RITZ][SN];            // the picked columns of X_k as loaded (the dominance test: ritz_eval)
+    double numq[2][RITZ], uq[RITZ];
 };
 // what an evaluating workgroup keeps of A and of the chain's input statistics (loaded once per matrix; 256 threads)
 template <bool LEAN = false>
@@ -559,6 +561,11 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
         if (have_cols != nullptr) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) gst<COH_AGENT>(have_cols, 1.0);
+        }
+#pragma unroll
+        for (int q = 0; q < RITZ; ++q) {
+            L.C[q][lane] = v[q][0];
+            L.C[q][lane + 64] = v[q][1];
         }
 #pragma unroll
         for (int q = 0; q < RITZ; ++q) {
@@ -806,6 +813,13 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
         }
         const double d = fma(-L.lmin, u, au);
         const double r2 = wr::wave64_allsum(d * d);
+        // the dominance test's raw material (below): (X_k u) at the picked coordinates = u^T (column q of X_k), and u there
+#pragma unroll
+        for (int q = 0; q < RITZ; ++q) {
+            const double nq = wr::wave64_allsum(u * L.C[q][tid]);
+            if (lane == 0) L.numq[wave][q] = nq;
+            if (tid == L.pick[q]) L.uq[q] = u;
+        }
         // Gershgorin bound of B = A + delta I from the row sums of A (only the diagonal term changes), for delta0 = 1e-2 - theta:
         // the delta used below is never smaller, and the bound grows by at most the difference
         const double m = wr::wave64_allmax(in.ra - fabs(in.dg) + fabs(in.dg + (1e-2 - L.o_lmin)));
@@ -832,8 +846,19 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
         // the bottom eigenpair is CONVERGED when its residual is small against the gap bound: the evaluation then "passes" (the
         // chain stops here) and the iterations may deflate the pair (see the header)
         const bool conv = small_resid && 1e-2 + gap < 0.25 * scale;
+        // A small residual says u is AN eigenvector of A, not that it is the bottom one: four eigenvectors concentrated on single
+        // coordinates, with eigenvalues just above a delocalised bottom eigenvector's, take all four picks for a squaring or two and
+        // are exact eigenpairs.  The bottom eigenvector is the DOMINANT one of X_k (the filter amplifies nothing more than
+        // lambda_min): rho = (X_k u)_j / u_j at the picked coordinate j where u is largest must be X_k's top eigenvalue, ~sqrt(|X_k|_F^2)
+        // -- every other eigenvector's is at most 0.32 of it while e_k < 0.05.  Only such a pair passes early.
+        int qb = 0;
+#pragma unroll
+        for (int q = 1; q < RITZ; ++q)
+            if (fabs(L.uq[q]) > fabs(L.uq[qb])) qb = q;
+        const double rho = (L.numq[0][qb] + L.numq[1][qb]) / L.uq[qb];
+        const bool dominant = rho > 0.0 && rho * rho >= 0.25 * L.nrm[k];
         // (... and only an iterate whose norm is already in the gap bound's linear range: what lets the scan launch skip the others)
-        L.o_pass = (conv && t_k > NS_SQ_TGUARD && 0.5 * (1.0 - L.nrm[k]) < RITZ_PASS_E) ? 1 : 0;
+        L.o_pass = (conv && dominant && t_k > NS_SQ_TGUARD && 0.5 * (1.0 - L.nrm[k]) < RITZ_PASS_E) ? 1 : 0;
         L.o_lmin = lmin_used;
         L.o_scale = scale;
         L.o_lo = 1e-2;
