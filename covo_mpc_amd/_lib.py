@@ -22,7 +22,7 @@ COVO_RANK_RECORD_FLOATS = COVO_PARTIAL_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 51
 COVO_COV_FLOATS = COVO_H * 10
 COVO_RANK_RECORD_COV_FLOATS = COVO_PARTIAL_FLOATS + COVO_COV_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 836: with MPPI's second moments
 COVO_EXCHANGE_HANDLE_BYTES = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 COVO_FLAG_ACTIONS_CLIPPED = 1
 
 
@@ -39,6 +39,7 @@ class EnvParamsC(C.Structure):
         ("rollover_terminate", C.c_int32), ("reward_kind", C.c_int32), ("disturb_kind", C.c_int32),
         ("disturb_period", C.c_int32), ("disturb_scale", C.c_float), ("disturb_params", C.c_float * 6),
         ("dyn_noise_scale", C.c_float),
+        ("reset_traj", C.c_int32), ("reserved0", C.c_int32), ("reset_dt", C.c_double), ("reset_disturb_scale", C.c_double),
     ]
 
 
@@ -70,6 +71,7 @@ class BatchArgsC(C.Structure):
 
 REWARD_KINDS = {"penyaw": 0, "realworld": 1}                 # COVO_REWARD_*
 DISTURB_KINDS = {"none": 0, "gaussian": 1, "periodic": 2, "sin": 3, "drag": 4, "mixed": 5}  # COVO_DISTURB_*
+TRAJ_KINDS = {None: 0, "hovering": 1, "tracking": 2, "tracking_slow": 3, "tracking_zigzag": 4}  # COVO_TRAJ_* by Quad3D task
 TABLE_DISTURB_KINDS = (2, 3, 4, 5)                            # models that need covo_disturb_table's per-step table
 DISTURB_KEYS_SHARED, DISTURB_KEYS_HESSIAN, DISTURB_KEYS_NOMINAL = 0, 1, 2
 COVO_MAX_ENVS = 64

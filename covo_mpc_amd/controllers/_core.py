@@ -478,6 +478,10 @@ class SamplingCore:
         args, am, _, cov_out = self._prepare_step(mode, episode.noisy_state, a_mean, derive_keys=True, carry_only=True, **kw)
         key = (C.c_uint32 * 2)(int(rng[0]), int(rng[1]))
         env = episode.env
+        # the env step's auto-reset (base.py:22-40) is a property of the EPISODE, the model constants come from the controller
+        params_c = type(params_c).from_buffer_copy(params_c)
+        for f in ("reset_traj", "reset_dt", "reset_disturb_scale"):
+            setattr(params_c, f, getattr(episode.params_c, f))
         check(self.lib.covo_run_episode(self.h, C.byref(params_c), C.byref(args), ptr(episode.true), ptr(episode.acc_traj),
                                         1 if env.generate_noisy_state else 0, float(env.default_params.obs_noise_scale),
                                         ptr(episode.log[episode.n_steps:]), key, int(n_steps), self.stream()),

@@ -44,10 +44,16 @@ def env_reward_kind(env) -> str:
                               "(tracking_penyaw_reward_fn, tracking_realworld_reward_fn: quadjax/envs/quadrotor.py:49-84)")
 
 
-def env_model_params_c(env, env_params):
+def env_model_params_c(env, env_params, auto_reset: bool = False):
+    """struct covo_env_params of `env` + `env_params`; auto_reset: the device env resets a finished episode as
+    BaseEnvironment.step does (quadjax/envs/base.py:22-40) with the env's own trajectory generator."""
     from .._lib import DISTURB_KINDS
     disturb = getattr(env, "disturb_type", "none")
     if disturb not in DISTURB_KINDS:
         raise NotImplementedError(f"disturb_type={disturb!r}")
-    return env_params.to_c(rollover_terminate=not getattr(env, "disable_rollover_terminate", True),
-                           reward=env_reward_kind(env), disturb_type=disturb)
+    c = env_params.to_c(rollover_terminate=not getattr(env, "disable_rollover_terminate", True),
+                        reward=env_reward_kind(env), disturb_type=disturb,
+                        reset_task=getattr(env, "task", None) if auto_reset else None)
+    if auto_reset:  # generate_traj is bound to the env's DEFAULT dt (quadrotor.py:50-80), whatever the instance's parameters
+        c.reset_dt = float(env.default_params.dt)
+    return c

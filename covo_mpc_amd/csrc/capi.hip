@@ -671,9 +671,10 @@ static int check_batch_models(const covo_env_params *params, int E, const char *
     for (int e = 0; e < E; ++e) {
         CHECK_MODEL(&params[e], what);
         if (params[e].reward_kind != params[0].reward_kind || params[e].rollover_terminate != params[0].rollover_terminate ||
-            params[e].disturb_kind != params[0].disturb_kind || params[e].max_steps_in_episode != params[0].max_steps_in_episode) {
+            params[e].disturb_kind != params[0].disturb_kind || params[e].max_steps_in_episode != params[0].max_steps_in_episode ||
+            params[e].reset_traj != params[0].reset_traj) {
             covo_set_error("%s: instance %d differs from instance 0 in reward_kind / rollover_terminate / disturb_kind / "
-                           "max_steps_in_episode (one kernel variant per launch)", what, e);
+                           "max_steps_in_episode / reset_traj (one kernel variant per launch)", what, e);
             return COVO_E_BADARG;
         }
     }

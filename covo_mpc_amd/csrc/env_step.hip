@@ -12,16 +12,19 @@
 // ONE host sync at the end.  The kernel derives the five noise keys from the step key exactly as the Python
 // env does (covo_mpc_amd/envs/quadrotor.py, random.py) and evaluates normal(key, (n,)) with the same
 // counter layout: block j = Philox4x32-10(counter (j,0,0,0xB175), key), words b[0..2n), u1 = b[i], u2 = b[n+i],
-// z = sqrt(-2 ln u1) cos(2 pi u2) in fp64, rounded to fp32.  Auto-reset on done (base.py:33-39) stays on the
-// host: the done flag is logged, an episode of max_steps_in_episode steps never raises it before its end.
+// z = sqrt(-2 ln u1) cos(2 pi u2) in fp64, rounded to fp32.
+// Auto-reset on done (BaseEnvironment.step, quadjax/envs/base.py:22-40; round 6): when the PRE-step state is terminal the kernel
+// stores reset_env(key_reset)'s state, noisy copy and NEW reference trajectory instead of the stepped ones (env_reset.hpp), and
+// the log row carries the reset state's errors -- what eval_env reads from info after env.step (quadrotor.py:531-538).
 #include <cstring>
 #include "covo_common.hpp"
 #include "disturb_model.hpp"
+#include "env_reset.hpp"
 
 struct EnvStepArgs {
     float *state;          // [32] true state, updated in place
     float *noisy;          // [32] the noisy copy of the new state (what the controller reads)
-    const float *pos_traj, *vel_traj, *acc_traj;  // [T][3]
+    float *pos_traj, *vel_traj, *acc_traj;  // [T][3]; rewritten by an auto-reset
     const float *action;   // [4] (device): the controller's u = a_mean[0]
     float *log;            // [max_steps][4]: reward, err_pos, err_vel, done of the PRE-step state (nullable)
     int T, log_index, noisy_on;
@@ -32,6 +35,7 @@ struct EnvStepArgs {
     qm::Consts<float> c;
     int max_steps;
     int rollover;  // is_terminal's rollover test (quadrotor.py:486-490)
+    er::ResetArgs reset;   // kind == COVO_TRAJ_NONE: no auto-reset
 };
 
 // element i of normal(key, (n,)) -- host formula (random.py) in fp64
@@ -60,6 +64,7 @@ __device__ __forceinline__ void env_step_body(const EnvStepArgs &A)
     __shared__ float sst[COVO_STATE_FLOATS];   // the state as loaded, then as stepped
     __shared__ float sact[4];
     __shared__ float straj[2][9];              // pos / vel / acc targets of row `guess` (speculative) and of row time + 1
+    __shared__ double skp[16][3];              // an auto-reset's zigzag key points
     const int lane = threadIdx.x;
     // One launch of one wave is latency: everything that does not depend on anything is requested first -- the state (lanes
     // 0..31, one coalesced load), the action, and the trajectory row the NEXT state will point at, guessed from the step count
@@ -118,6 +123,14 @@ __device__ __forceinline__ void env_step_body(const EnvStepArgs &A)
         const float *__restrict__ tr = q < 3 ? A.pos_traj : (q < 6 ? A.vel_traj : A.acc_traj);
         straj[1][q] = tr[3 * idx + q % 3];
     }
+    // ---- termination of the PRE-step state (quadrotor.py:244, 479-490): every lane evaluates it on the same LDS words
+    bool done = (time >= A.max_steps) ||
+                fmaxf(fmaxf(fabsf(sst[ST_POS + 0]), fabsf(sst[ST_POS + 1])), fabsf(sst[ST_POS + 2])) > A.c.pos_limit;
+    if (A.rollover)  // quadrotor.py:486-490
+        done = done || sst[ST_QUAT + 3] < 0.70710678118654752f ||
+               fmaxf(fmaxf(fabsf(sst[ST_OMEGA + 0]), fabsf(sst[ST_OMEGA + 1])), fabsf(sst[ST_OMEGA + 2])) > 100.0f;
+    const bool reset = done && A.reset.kind != COVO_TRAJ_NONE;  // uniform
+    float r_pre = 0.0f;
     if (lane == 0) {
         qm::State<float> s;
         s.px = sst[ST_POS + 0]; s.py = sst[ST_POS + 1]; s.pz = sst[ST_POS + 2];
@@ -127,20 +140,20 @@ __device__ __forceinline__ void env_step_body(const EnvStepArgs &A)
         const float fx = sst[ST_FDIST + 0], fy = sst[ST_FDIST + 1], fz = sst[ST_FDIST + 2];
         const float tx = sst[ST_POSTAR + 0], ty = sst[ST_POSTAR + 1], tz = sst[ST_POSTAR + 2];
         const float tvx = sst[ST_VELTAR + 0], tvy = sst[ST_VELTAR + 1], tvz = sst[ST_VELTAR + 2];
-        // ---- reward / errors / termination of the PRE-step state (quadrotor.py:243-244, 479-490; utils.py:285-294)
+        // ---- reward / errors of the PRE-step state (quadrotor.py:243, 352-353; utils.py:285-294)
         if (A.log != nullptr) {
-            const float r = qm::reward_kind<float, float>(A.reward, s, tx, ty, tz, tvx, tvy, tvz);
-            const float ex = tx - s.px, ey = ty - s.py, ez = tz - s.pz;
-            const float wx = tvx - s.vx, wy = tvy - s.vy, wz = tvz - s.vz;
-            bool done = (time >= A.max_steps) || fmaxf(fmaxf(fabsf(s.px), fabsf(s.py)), fabsf(s.pz)) > A.c.pos_limit;
-            if (A.rollover)  // quadrotor.py:486-490
-                done = done || s.qw < 0.70710678118654752f || fmaxf(fmaxf(fabsf(s.ox), fabsf(s.oy)), fabsf(s.oz)) > 100.0f;
-            float *__restrict__ lg = A.log + 4 * A.log_index;
-            lg[0] = r;
-            lg[1] = sqrtf(ex * ex + ey * ey + ez * ez);
-            lg[2] = sqrtf(wx * wx + wy * wy + wz * wz);
-            lg[3] = done ? 1.0f : 0.0f;
+            r_pre = qm::reward_kind<float, float>(A.reward, s, tx, ty, tz, tvx, tvy, tvz);
+            if (!reset) {
+                const float ex = tx - s.px, ey = ty - s.py, ez = tz - s.pz;
+                const float wx = tvx - s.vx, wy = tvy - s.vy, wz = tvz - s.vz;
+                float *__restrict__ lg = A.log + 4 * A.log_index;
+                lg[0] = r_pre;
+                lg[1] = sqrtf(ex * ex + ey * ey + ez * ez);
+                lg[2] = sqrtf(wx * wx + wy * wy + wz * wz);
+                lg[3] = done ? 1.0f : 0.0f;
+            }
         }
+        if (!reset) {
         // ---- one Euler step with the state's current disturbance (free.py:91,98)
         const float a0 = qm::clip11_(qm::clip11_(sact[0])), a1 = qm::clip11_(qm::clip11_(sact[1]));
         const float a2 = qm::clip11_(qm::clip11_(sact[2])), a3 = qm::clip11_(qm::clip11_(sact[3]));
@@ -170,9 +183,28 @@ __device__ __forceinline__ void env_step_body(const EnvStepArgs &A)
         sst[ST_OMEGA + 0] = s.ox; sst[ST_OMEGA + 1] = s.oy; sst[ST_OMEGA + 2] = s.oz;
         sst[ST_FDIST + 0] = fn[0]; sst[ST_FDIST + 1] = fn[1]; sst[ST_FDIST + 2] = fn[2];
         sst[ST_TIME] = __int_as_float(t1);
+        }
+    }
+    if (reset) {
+        // ---- base.py:26-40: select(done, reset_env(key_reset), stepped) on state and info; the controller's state carries on
+        __syncthreads();  // lane 0 has read the pre-step state
+        const uint32_t sk[2] = {A.step_key[0], A.step_key[1]};
+        er::reset_env(A.reset, sk, A.pos_traj, A.vel_traj, A.acc_traj, sst, z, straj[1], skp);
+        __syncthreads();
+        if (lane == 0 && A.log != nullptr) {  // info_re of get_info(info_key, state_re, state_re): the RESET state's errors
+            const float ex = sst[ST_POSTAR + 0] - sst[ST_POS + 0], ey = sst[ST_POSTAR + 1] - sst[ST_POS + 1],
+                        ez = sst[ST_POSTAR + 2] - sst[ST_POS + 2];
+            const float wx = sst[ST_VELTAR + 0] - sst[ST_VEL + 0], wy = sst[ST_VELTAR + 1] - sst[ST_VEL + 1],
+                        wz = sst[ST_VELTAR + 2] - sst[ST_VEL + 2];
+            float *__restrict__ lg = A.log + 4 * A.log_index;
+            lg[0] = r_pre;
+            lg[1] = sqrtf(ex * ex + ey * ey + ez * ez);
+            lg[2] = sqrtf(wx * wx + wy * wy + wz * wz);
+            lg[3] = 1.0f;
+        }
     }
     __syncthreads();  // also: the re-read row (if any) has landed in straj[1] -- its writers waited for their own loads
-    if (lane < 9) {
+    if (lane < 9 && !reset) {
         const float v = straj[reread ? 1 : 0][lane];
         sst[(lane < 3 ? ST_POSTAR : (lane < 6 ? ST_VELTAR : ST_ACCTAR)) + lane % 3] = v;
     }
@@ -206,6 +238,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(const EnvStepArgs A) { env
 struct EnvInst {            // what domain randomisation varies per instance (device array, built once per episode)
     qm::Consts<float> c;
     dm::Model dist;
+    double reset_dt, reset_disturb_scale;
 };
 struct EnvStepBatchKeys {
     uint32_t k[COVO_MAX_ENVS][2];  // the key Quad3D.step receives, per instance
@@ -213,13 +246,13 @@ struct EnvStepBatchKeys {
 struct EnvStepBatchArgs {
     float *states;         // [E][32] true states, updated in place
     float *noisy;          // [E][32] the noisy copies (the batched controller's `states`)
-    const float *pos_traj, *vel_traj, *acc_traj;  // [E][T][3]
+    float *pos_traj, *vel_traj, *acc_traj;  // [E][T][3]; an instance's block is rewritten by its auto-reset
     const float *a_mean;   // [E][128]: instance e's action = a_mean[e][0..3]
     float *log;            // [E][log_stride][4] or null
     const EnvInst *inst;   // [E]
     int T, log_index, log_stride, noisy_on;
     float obs_noise_scale;
-    int reward, max_steps, rollover;
+    int reward, max_steps, rollover, reset_traj;
 };
 __global__ __launch_bounds__(64) void env_step_batched_kernel(const EnvStepBatchArgs B, const EnvStepBatchKeys K)
 {
@@ -243,6 +276,11 @@ __global__ __launch_bounds__(64) void env_step_batched_kernel(const EnvStepBatch
     A.c = B.inst[e].c;
     A.max_steps = B.max_steps;
     A.rollover = B.rollover;
+    A.reset.kind = B.reset_traj;
+    A.reset.max_steps = B.max_steps;
+    A.reset.T = B.T;
+    A.reset.dt = B.inst[e].reset_dt;
+    A.reset.disturb_scale = B.inst[e].reset_disturb_scale;
     env_step_body(A);
 }
 
@@ -253,10 +291,26 @@ void env_step_fill_inst(const covo_env_params *params, int n, void *out)
     for (int i = 0; i < n; ++i) {
         o[i].c = make_consts<float>(params[i]);
         o[i].dist = dm::make_model(params[i]);
+        o[i].reset_dt = params[i].reset_dt;
+        o[i].reset_disturb_scale = params[i].reset_disturb_scale;
     }
 }
 
-// params0: what all instances share (reward, max_steps, rollover switch); the per-instance constants come from `inst`
+// the auto-reset's preconditions (covo_hip.h: T is the generator's row count)
+static int check_reset(const covo_env_params &p, int T, const char *what)
+{
+    if (p.reset_traj == COVO_TRAJ_NONE) return 0;
+    const int rows = er::traj_rows(p.reset_traj, p.max_steps_in_episode);
+    if (rows < 0 || rows != T || p.max_steps_in_episode / 40 + 2 > 16 || !(p.reset_dt > 0.0) || !(p.reset_disturb_scale >= 0.0)) {
+        covo_set_error("%s: auto-reset (reset_traj=%d) needs T = %d rows for max_steps_in_episode=%d (got T=%d), "
+                       "max_steps_in_episode < 600, reset_dt > 0 (%g) and reset_disturb_scale >= 0 (%g)",
+                       what, p.reset_traj, rows, p.max_steps_in_episode, T, p.reset_dt, p.reset_disturb_scale);
+        return COVO_E_BADARG;
+    }
+    return 0;
+}
+
+// params0: what all instances share (reward, max_steps, rollover switch, reset generator); the per-instance constants come from `inst`
 int launch_env_step_batched(float *states, float *noisy, const float *pos_traj, const float *vel_traj, const float *acc_traj, int T,
                             const covo_env_params &params0, const void *inst_dev, int E, const float *a_mean,
                             const uint32_t *step_keys /* host [E][2] */, int noisy_on, float obs_noise_scale, float *log,
@@ -266,12 +320,14 @@ int launch_env_step_batched(float *states, float *noisy, const float *pos_traj, 
         covo_set_error("env_step_batched: n_envs=%d outside (0, %d]", E, COVO_MAX_ENVS);
         return COVO_E_BADARG;
     }
+    if (int rc = check_reset(params0, T, "env_step_batched")) return rc;
     EnvStepBatchArgs B;
     B.states = states;
     B.noisy = noisy;
-    B.pos_traj = pos_traj;
-    B.vel_traj = vel_traj;
-    B.acc_traj = acc_traj;
+    B.pos_traj = const_cast<float *>(pos_traj);
+    B.vel_traj = const_cast<float *>(vel_traj);
+    B.acc_traj = const_cast<float *>(acc_traj);
+    B.reset_traj = params0.reset_traj;
     B.a_mean = a_mean;
     B.log = log;
     B.inst = reinterpret_cast<const EnvInst *>(inst_dev);
@@ -298,12 +354,18 @@ int launch_env_step(float *state, float *noisy, const float *pos_traj, const flo
                     const covo_env_params &p, const float *action, const uint32_t *step_key, int noisy_on,
                     float obs_noise_scale, float *log, int log_index, hipStream_t s)
 {
+    if (int rc = check_reset(p, T, "env_step")) return rc;
     EnvStepArgs A;
     A.state = state;
     A.noisy = noisy;
-    A.pos_traj = pos_traj;
-    A.vel_traj = vel_traj;
-    A.acc_traj = acc_traj;
+    A.pos_traj = const_cast<float *>(pos_traj);
+    A.vel_traj = const_cast<float *>(vel_traj);
+    A.acc_traj = const_cast<float *>(acc_traj);
+    A.reset.kind = p.reset_traj;
+    A.reset.max_steps = p.max_steps_in_episode;
+    A.reset.T = T;
+    A.reset.dt = p.reset_dt;
+    A.reset.disturb_scale = p.reset_disturb_scale;
     A.action = action;
     A.log = log;
     A.T = T;

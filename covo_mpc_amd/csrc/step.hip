@@ -333,6 +333,8 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     k.args.state = nullptr;  // read through the dyn block: a new state address does not invalidate the graph
     k.args.a_mean_in = nullptr;  // read by the (eager) begin launch only
     k.params = *params;
+    k.params.reset_traj = 0;  // the env step's auto-reset switches: no launch of the control step reads them
+    k.params.reset_dt = k.params.reset_disturb_scale = 0.0;
     k.stream = s;
     const bool same = st->have_key && std::memcmp(&k, &st->key, sizeof(k)) == 0;
     if (same && st->have_graph) {

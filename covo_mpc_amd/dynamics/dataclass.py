@@ -66,12 +66,17 @@ class EnvParams3D:
     def replace(self, **kw) -> "EnvParams3D":
         return dataclasses.replace(self, **kw)
 
-    def to_c(self, rollover_terminate: bool = False, reward: str = "penyaw", disturb_type: str = "none") -> EnvParamsC:
+    def to_c(self, rollover_terminate: bool = False, reward: str = "penyaw", disturb_type: str = "none",
+             reset_task=None) -> EnvParamsC:
         """The rollout-relevant subset as struct covo_env_params.  `rollover_terminate` (the env's `not
         disable_rollover_terminate`, envs/quadrotor.py:486-490), `reward` (which function env.reward_fn is,
-        quadrotor.py:49-84) and `disturb_type` (quadrotor.py:35,87-89) are attributes of Quad3D, not of the parameters."""
-        from .._lib import DISTURB_KINDS, REWARD_KINDS
+        quadrotor.py:49-84) and `disturb_type` (quadrotor.py:35,87-89) are attributes of Quad3D, not of the parameters.
+        `reset_task`: the Quad3D task whose trajectory generator the DEVICE env's auto-reset runs (base.py:22-40); None = no
+        auto-reset (only covo_env_step* / covo_run_episode* read it)."""
+        from .._lib import DISTURB_KINDS, REWARD_KINDS, TRAJ_KINDS
         c = EnvParamsC()
+        c.reset_traj, c.reserved0 = TRAJ_KINDS[reset_task], 0
+        c.reset_dt, c.reset_disturb_scale = float(self.dt), float(self.disturb_scale)
         c.reward_kind, c.disturb_kind = REWARD_KINDS[reward], DISTURB_KINDS[disturb_type]
         c.disturb_period, c.disturb_scale = int(self.disturb_period), float(self.disturb_scale)
         for i in range(6):

@@ -263,9 +263,12 @@ class DeviceEpisode:
     controller plans from), the reference trajectory and the per-step log {reward, err_pos, err_vel, done}.
     `reset` is host plumbing (trajectory generation, quadrotor.py:265-312) followed by one upload; `step` launches
     covo_env_step, which derives the five noise keys of `Quad3D.step` from the step key on the device -- no sync,
-    so an episode is 300 x (controller graph + this launch) with one read-back of the log at the end."""
+    so an episode is 300 x (controller graph + this launch) with one read-back of the log at the end.
+    auto_reset (default, as BaseEnvironment.step: quadjax/envs/base.py:22-40): when the pre-step state is terminal the kernel
+    stores reset_env(key_reset)'s state, noisy copy and a NEW trajectory (written over pos_traj / vel_traj / acc_traj in place);
+    the log row then carries the reset state's errors and done = 1.  `state0` keeps the first reset's host state."""
 
-    def __init__(self, env: "Quad3D", key, params, lib_handle, device):
+    def __init__(self, env: "Quad3D", key, params, lib_handle, device, auto_reset: bool = True):
         import torch
         from .. import _lib
         self.env, self.params, self.device = env, params, device
@@ -281,7 +284,8 @@ class DeviceEpisode:
         self.T = int(state.pos_traj.shape[0])
         self.log = torch.zeros((params.max_steps_in_episode + 1, 4), dtype=torch.float32, device=device)
         from ..controllers.base import env_model_params_c
-        self.params_c = env_model_params_c(env, params)  # incl. the env's reward and disturbance model (env_step.hip runs all of them)
+        # incl. the env's reward, disturbance model and reset generator (env_step.hip runs all of them)
+        self.params_c = env_model_params_c(env, params, auto_reset=auto_reset)
         self.n_steps = 0
 
     @property
@@ -329,9 +333,9 @@ class BatchedDeviceEpisode:
     """E independent env instances on the device (BASELINE configs[4]): instance e has its own (domain-randomised,
     quadrotor.py:132-171) parameters, reset key, true state, noisy copy, reference trajectory and log.  `step` launches
     covo_env_step_batched -- every instance's Quad3D.step in ONE launch; BatchedCoVOController.run_episode enqueues whole
-    episodes (control step + env step for all instances) from one C call."""
+    episodes (control step + env step for all instances) from one C call.  auto_reset: as DeviceEpisode, per instance."""
 
-    def __init__(self, env: "Quad3D", keys, params_list, lib_handle, device):
+    def __init__(self, env: "Quad3D", keys, params_list, lib_handle, device, auto_reset: bool = True):
         import torch
         from .. import _lib
         from ..controllers.base import env_model_params_c
@@ -360,7 +364,7 @@ class BatchedDeviceEpisode:
         self.vel_traj = up(np.stack([s.vel_traj for s in states]))
         self.acc_traj = up(np.stack([s.acc_traj for s in states]))
         self.log = torch.zeros((self.E, self.params[0].max_steps_in_episode + 1, 4), dtype=torch.float32, device=device)
-        self.params_c = (_lib.EnvParamsC * self.E)(*[env_model_params_c(env, p) for p in self.params])
+        self.params_c = (_lib.EnvParamsC * self.E)(*[env_model_params_c(env, p, auto_reset=auto_reset) for p in self.params])
         self.n_steps = 0
 
     def step(self, step_keys, a_mean, stream=None):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define COVO_ABI_VERSION 5
+#define COVO_ABI_VERSION 6
 
 #define COVO_H 32            /* horizon (compile-time in the fused kernels)          */
 #define COVO_DU 4            /* action dim, quadjax/envs/quadrotor.py:198            */
@@ -109,6 +109,15 @@ extern "C" {
 #define COVO_DISTURB_DRAG 4      /* free.py:41-47: -|scale| rel |rel| / 1.5^2, rel = vel - disturb_params[:3] / 2 (per sample) */
 #define COVO_DISTURB_MIXED 5     /* free.py:50-56: (drag + sin + periodic) / 3 */
 
+/* covo_env_params.reset_traj: the trajectory generator Quad3D binds to self.generate_traj (quadjax/envs/quadrotor.py:49-84), i.e.
+ * what reset_env (quadrotor.py:265-312, 363-370) draws when BaseEnvironment.step auto-resets a finished episode
+ * (quadjax/envs/base.py:22-40).  COVO_TRAJ_NONE switches the device env's auto-reset off (done is logged, the state flies on). */
+#define COVO_TRAJ_NONE 0
+#define COVO_TRAJ_FIXED 1        /* generate_fixed_traj (dynamics/utils.py:49-53): task hovering; T = max_steps_in_episode rows of 0 */
+#define COVO_TRAJ_LISSA 2        /* generate_lissa_traj (utils.py:87-130): task tracking; T = max_steps_in_episode + 50 */
+#define COVO_TRAJ_LISSA_SLOW 3   /* generate_lissa_traj_slow (utils.py:133-180): task tracking_slow; T = max_steps_in_episode + 50 */
+#define COVO_TRAJ_ZIGZAG 4       /* generate_zigzag_traj (utils.py:183-251): task tracking_zigzag; T = (max_steps_in_episode / 40 + 1) * 40 */
+
 /* covo_disturb_table key threading (who calls step_env with which key) */
 #define COVO_DISTURB_KEYS_SHARED 0    /* every step uses the SAME step key: the controllers' rollouts (covo.py:225,231; mppi.py:69,74) */
 #define COVO_DISTURB_KEYS_HESSIAN 1   /* per step rng_k, key = split(key); step_env(rng_k): get_hessian (covo.py:150-153) */
@@ -137,6 +146,11 @@ typedef struct covo_env_params {
     float disturb_scale;        /* .2   (dataclass.py:87) */
     float disturb_params[6];    /* 0    (dataclass.py:88; domain randomisation / reset draw them, quadrotor.py:151,171) */
     float dyn_noise_scale;      /* .05  (dataclass.py:93): scale of the gaussian model (zeroed by deterministic=True) */
+    /* ---- auto-reset of the device env (covo_env_step*, covo_run_episode*; base.py:22-40).  Ignored by every other entry point. */
+    int32_t reset_traj;         /* COVO_TRAJ_*; COVO_TRAJ_NONE (0) = no auto-reset */
+    int32_t reserved0;          /* 0 */
+    double reset_dt;            /* dt as the trajectory generators receive it (quadrotor.py:52,60,68,77: the host's double .02) */
+    double reset_disturb_scale; /* f_disturb ~ U(-s, s) at reset (quadrotor.py:300-305): the host's double .2 */
 } covo_env_params;
 
 typedef struct covo_config {
@@ -504,7 +518,14 @@ int covo_cholesky(covo_handle_t h, const float *A, int32_t n, int32_t batch, flo
  * `action` = float[4] on the device (the controller's u); `step_key` = uint32[2] on the HOST: the key Quad3D.step
  * receives -- the kernel derives the (disturbance, pos, vel, quat, omega) noise keys from it like the Python env; log (nullable) float[..][4] gets
  * {reward, err_pos, err_vel, done} of the PRE-step state at row log_index.  acc_traj: float[T][3].  Reward and disturbance
- * model (all six of free.py:9-72, the next step's force from the PRE-step state) follow params->reward_kind / disturb_kind. */
+ * model (all six of free.py:9-72, the next step's force from the PRE-step state) follow params->reward_kind / disturb_kind.
+ * AUTO-RESET (BaseEnvironment.step, quadjax/envs/base.py:22-40; params->reset_traj != COVO_TRAJ_NONE): when the PRE-step state is
+ * terminal (quadrotor.py:479-490) the kernel stores what reset_env(key_reset) gives instead of the stepped state -- key_reset =
+ * split(step_key)[1]; a NEW reference trajectory from params->reset_traj's generator written over pos_traj / vel_traj / acc_traj
+ * (which are therefore written to, despite the const: T must be that generator's row count), the zero state with
+ * f_disturb ~ U(-reset_disturb_scale, reset_disturb_scale), time 0, targets = row 0, and the noisy copy from reset_env's own
+ * info key -- and the log row carries {reward of the pre-step state, err_pos, err_vel of the RESET state, 1}, which is what
+ * eval_env records after env.step (quadrotor.py:531-538).  The controller's state carries on, as in the reference. */
 int covo_env_step(covo_handle_t h, float *state, float *noisy_state, const float *pos_traj, const float *vel_traj,
                   const float *acc_traj, int32_t T, const covo_env_params *params, const float *action,
                   const uint32_t *step_key, int32_t noisy_on, float obs_noise_scale, float *log, int32_t log_index,

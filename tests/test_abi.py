@@ -34,7 +34,9 @@ def test_load_and_abi_version(built):
 
 def test_struct_layouts_match_header(built):
     # + rollover_terminate (ABI 2); + reward_kind, disturb_kind, disturb_period, disturb_scale, disturb_params[6], dyn_noise_scale (ABI 3)
-    assert ctypes.sizeof(built.EnvParamsC) == 4 * (1 + 3 + 3 + 5 + 1 + 1 + 1 + 4 + 6 + 1)
+    # + reset_traj, reserved0, reset_dt (double), reset_disturb_scale (double): the device env's auto-reset (ABI 6)
+    assert ctypes.sizeof(built.EnvParamsC) == 4 * (1 + 3 + 3 + 5 + 1 + 1 + 1 + 4 + 6 + 1) + 4 + 4 + 8 + 8 == 128
+    assert built.EnvParamsC.reset_traj.offset == 104 and built.EnvParamsC.reset_dt.offset == 112
     assert built.EnvParamsC.reward_kind.offset == 60 and built.EnvParamsC.disturb_params.offset == 76
     assert built.StepArgsC.rollout_deterministic.offset == built.StepArgsC.derive_keys.offset + 4
     assert ctypes.sizeof(built.ConfigC) == 24

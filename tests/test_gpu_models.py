@@ -525,7 +525,9 @@ def test_env_step_kernel_vs_oracle_step_env(task, kind, rollover):
     p = R.Params().fp32().replace(disturb_params=DP, disturb_period=6)
     reward_fn = R.REWARD_FNS["realworld" if task == "tracking_slow" else "penyaw"]
     core = SamplingCore(256, 32, 0.01, 1.0, device=DEV)
-    ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(11), params, (core.lib, core.h), DEV)
+    # auto_reset=False: the oracle's step_env has no reset (base.py's select is host plumbing, tests/test_gpu_reset.py), and the
+    # rollover case terminates on purpose
+    ep = cm.envs.DeviceEpisode(env, cr.PRNGKey(11), params, (core.lib, core.h), DEV, auto_reset=False)
     traj = (ep.state0.pos_traj, ep.state0.vel_traj, ep.state0.acc_traj)
     rng = np.random.default_rng(5)
     key = cr.PRNGKey(12)
