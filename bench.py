@@ -321,8 +321,10 @@ def bench_envs(args, world, rank, device, backend):
                   "steps_per_instance": int(T), "err_pos_mean_m": float(log[:, 5:, 1].mean()),
                   "err_pos_median_instance_m": float(np.median(log[:, 5:, 1].mean(axis=1))),
                   "err_pos_max_instance_m": float(log[:, 5:, 1].mean(axis=1).max()),
-                  # the reference's eval protocol calls an episode above 0.3 m a crash; domain-randomised `tracking` episodes crash
-                  # at 0.5-0.8 % (24 / 15 of 3 072 episodes, this build / the build before the early Ritz evaluations: DESIGN.md 5)
+                  # an instance whose lissajous trajectory itself leaves the 3 m box (38 of 3 072 `tracking` trajectories do) terminates
+                  # there (quadrotor.py:484) and is auto-reset on the device as BaseEnvironment.step does (base.py:22-40): counted here
+                  "auto_reset": True, "instances_done_before_T": int((log[:, :, 3].sum(axis=1) > 0).sum()),
+                  "resets": int(log[:, :, 3].sum()),
                   "instances_above_0.3_m": int((log[:, 5:, 1].mean(axis=1) > 0.3).sum())}
     if rank == 0:
         alg_bytes = E * N * ROLLOUT_BYTES_PER_SAMPLE
