@@ -209,6 +209,36 @@ KERNEL_SRCS = ["covo_mpc_amd/csrc/" + f for f in (
     "softmax_merge.hpp", "eps_tiles.hpp", "rng_device.hpp", "Makefile")]
 
 
+def rollout_sweep(kstate, pc, lam, device, sizes=(65536, 131072, 262144, 1048576), reps=100):
+    """SURVEY.md 7 ("configs 2-4 must be reported honestly with a size sweep showing the asymptote"): the judged rollout kernel
+    stand-alone (rollout_pipe3_kernel<..., REC = false>: covo_rollout_cost) at growing sample counts on the timed mid-episode
+    state -- 3 x `reps` back-to-back launches issued from C between HIP events on the launch stream (covo_debug_time_rollout),
+    actions = clip(mean + 0.5 eps) drawn on the device.  516 B per sample / launch duration against 8 TB/s."""
+    import torch
+    from covo_mpc_amd.controllers._core import SamplingCore
+    out = []
+    for n in sizes:
+        core = None
+        try:
+            core = SamplingCore(n, 32, lam, 1.0, device=device, compute_info=False, trust_clipped=True, use_graph=False)
+            am = torch.tensor([-0.3378, 0.0, 0.0, 0.0], device=device).repeat(32)
+            L = (0.5 * torch.eye(128, device=device)).contiguous()
+            core.noise_gemm_philox(L, am, (1, 2))
+            torch.cuda.synchronize()
+            us, us_min = core.time_rollout(kstate, pc, reps=reps, with_records=False)
+            ach = n * ROLLOUT_BYTES_PER_SAMPLE / (us * 1e-6) / 1e9
+            out.append({"N": int(n), "launch_us": us, "launch_us_min": us_min, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                        "frac_fastest_batch": n * ROLLOUT_BYTES_PER_SAMPLE / (us_min * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        except Exception as e:  # noqa: BLE001
+            out.append({"N": int(n), "error": str(e)})
+        finally:
+            if core is not None:
+                core.close()
+                del core
+            torch.cuda.empty_cache()
+    return out
+
+
 def kernel_src_sha():
     import hashlib
     h = hashlib.sha256()
@@ -424,6 +454,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop episodes (profiler counter passes)")
     ap.add_argument("--no-info-leg", action="store_true", help="skip the second timed loop with pos_mean/pos_std on")
+    ap.add_argument("--no-sweep", action="store_true", help="skip roofline.sweep (the stand-alone rollout at 65 536 ... 1 048 576 samples)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--task", default="tracking_zigzag", help="--config samples: the env task (BASELINE configs[0] is `hovering`)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -690,6 +721,12 @@ def main():
             elapsed_other = float(t.item())
         del ctrl2, cp2
 
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_sweep:
+        try:
+            sweep = rollout_sweep(kstate, pc, args.lam, device)
+        except Exception as e:  # noqa: BLE001
+            sweep = [{"error": str(e)}]
     if rank == 0:
         alg_bytes = n_local * ROLLOUT_BYTES_PER_SAMPLE
         # the judged duration is the kernel's IN-STEP duration (what the timed region ran and what the rocprofv3 kernel trace
@@ -732,7 +769,10 @@ def main():
                              "kernel": "rollout_pipe3_kernel<..., REC = false>", "launch_us": standalone[0],
                              "launch_us_min": standalone[1],
                              "frac": alg_bytes / (standalone[0] * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                         "counters": (kin.get("rollout_in_step") or {}).get("derived")},
+                         "counters": (kin.get("rollout_in_step") or {}).get("derived"),
+                         "sweep": sweep, "sweep_statistic": "stand-alone rollout_pipe3_kernel<..., REC = false> on the timed "
+                         "mid-episode state, mean (launch_us) / fastest batch (launch_us_min) of 3 x 100 back-to-back launches "
+                         "between HIP events on the launch stream; frac = 516 B x N / launch_us / 8 TB/s"},
         }
         if args.controller != "covo-online" and n_local <= 16384 and not args.info and args.task in ("tracking_zigzag", "hovering"):
             out["config"]["one_launch_step"] = ("the timed steps run as ONE launch per control step (csrc/step_small.hip: begin + noise draw + "
