@@ -107,7 +107,9 @@ __device__ __forceinline__ float rp3_atan2abs(float y, float x)
 // ([H][64] float4 of THIS group, left there by the launch's own noise draw) instead of A.a in HBM.  Returns this lane's cost
 // (role 2), its sample index n and whether the sample exists.  KEEP_ALL: the A and T waves come back too (the caller has an
 // epilogue for every wave: softmax records, position statistics); otherwise they leave the launch when their stage is done.
-template <bool DISC1, bool ROLL, int CH, int ONLY, bool STATS, bool KEEP_ALL, int REWARD, int FDIST, bool A_LDS, class StatsLds>
+// KSTEPS (scripts/probe/rollout_lab.hip only): the stages stop after KSTEPS steps -- the timing bound of a split-horizon launch.
+template <bool DISC1, bool ROLL, int CH, int ONLY, bool STATS, bool KEEP_ALL, int REWARD, int FDIST, bool A_LDS, class StatsLds,
+          int KSTEPS = COVO_H>
 __device__ __forceinline__ void rp3_stages(const RolloutArgs &A, Rp3Lds<CH> &lds, StatsLds &lds_st, const int role, const int gsub,
                                            const int group, const int lane, const float4 *__restrict__ a_lds, float &cost, bool &valid_out,
                                            int &n_out)
@@ -145,7 +147,7 @@ __device__ __forceinline__ void rp3_stages(const RolloutArgs &A, Rp3Lds<CH> &lds
         float gx = st[ST_OMEGA + 0] * c.half_dt, gy = st[ST_OMEGA + 1] * c.half_dt, gz = st[ST_OMEGA + 2] * c.half_dt;
         const float groll = 100.0f * c.half_dt;
 #pragma unroll
-        for (int k = 0; k < COVO_H; ++k) {
+        for (int k = 0; k < KSTEPS; ++k) {
             float4 a4;
             if (A_LDS) {
                 a4 = a_lds[k * COVO_WAVE + lane];
@@ -287,7 +289,7 @@ __device__ __forceinline__ void rp3_stages(const RolloutArgs &A, Rp3Lds<CH> &lds
         RP3_STAMP(0);
         rp3_barrier<ONLY>();  // interval 0: chunk 0 of ring A is being written
 #pragma unroll
-        for (int k = 0; k < COVO_H; ++k) {
+        for (int k = 0; k < KSTEPS; ++k) {
             if (k % CH == 0) {
                 rp_pin(px, py, pz, vx, vy, vz);
                 if (FDIST == 2) rp_pin(fpx, fpy, fpz);
@@ -373,7 +375,7 @@ __device__ __forceinline__ void rp3_stages(const RolloutArgs &A, Rp3Lds<CH> &lds
     rp3_barrier<ONLY>();
     rp3_barrier<ONLY>();
 #pragma unroll
-    for (int k = 0; k < COVO_H; ++k) {
+    for (int k = 0; k < KSTEPS; ++k) {
         if (k % CH == 0) {
             rp_pin(acc, r_before);
         }

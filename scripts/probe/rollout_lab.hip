@@ -20,6 +20,30 @@ int noise_gemm_groups_per_workgroup(int, int) { return 4; }
 void launch_rollout_variant_r0(const RolloutArgs &, const RolloutArgs *, int, bool, int, bool, hipStream_t) {}
 void launch_rollout_variant_r1(const RolloutArgs &, const RolloutArgs *, int, bool, int, bool, hipStream_t) {}
 
+// ---- round 6: the TIMING BOUND of a split-horizon launch (VERDICT r05 Next 5).  Every 64 samples get SIX waves: two complete
+// three-stage pipelines, each running 16 of the 32 steps on its own rings (the second reads stripes 16 .. 31), no join, no
+// composition arithmetic -- i.e. exactly today's instruction streams and HBM bytes at twice the waves per SIMD.  A real
+// split-horizon kernel adds the relative-to-absolute composition of the second half (+ ~35 VALU per step there) and a join on
+// (q, v, p)_16: it cannot be faster than this.  Costs are garbage.
+template <int CH, int GROUPS>
+__global__ __launch_bounds__(6 * GROUPS * COVO_WAVE) void rollout_split_bound_kernel(const RolloutArgs A_, const size_t half_stride)
+{
+    __shared__ Rp3Lds<CH> lds_all[2 * GROUPS];
+    __shared__ float lds_st[1][1][9];
+    const int lane = threadIdx.x & (COVO_WAVE - 1);
+    const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wave_ / (3 * GROUPS), w = wave_ % (3 * GROUPS);
+    const int role = w / GROUPS, gsub = w % GROUPS;
+    RolloutArgs A = A_;
+    if (half) A.a = A_.a + half_stride;  // stripes 16 .. 31
+    const int group = blockIdx.x * GROUPS + gsub;
+    float cost = 0.0f;
+    bool valid = false;
+    int n = 0;
+    rp3_stages<true, false, CH, -1, false, false, 0, 0, false, decltype(lds_st), COVO_H / 2>(A, lds_all[half * GROUPS + gsub], lds_st, role, gsub,
+                                                                                              group, lane, nullptr, cost, valid, n);
+}
+
 static float time_launches(const std::function<void()> &fn, int reps)
 {
     hipEvent_t e0, e1;
@@ -124,6 +148,10 @@ int main(int argc, char **argv)
         report("pipe3 CH=1 GROUPS=4 +rollover", [&] { hipLaunchKernelGGL((rollout_pipe3_kernel<true, true, 1, 4>), dim3((N + 255) / 256), dim3(768), 0, 0, A2, nullptr); }, false);
         report("pipe3 CH=1 GROUPS=4 discount", [&] { hipLaunchKernelGGL((rollout_pipe3_kernel<false, false, 1, 4>), dim3((N + 255) / 256), dim3(768), 0, 0, A2, nullptr); }, true);
         report("pipe3 CH=2 no barriers (garbage)", [&] { hipLaunchKernelGGL((rollout_pipe3_kernel<true, false, 2, 1, false, -2>), dim3((N + 63) / 64), dim3(192), 0, 0, A2, nullptr); }, false);
+#define SPLIT(CH, G)                                                                                                             \
+        report("split-horizon BOUND CH=" #CH " GROUPS=" #G " (6 waves / 64 samples, garbage)", [&] {                               \
+            hipLaunchKernelGGL((rollout_split_bound_kernel<CH, G>), dim3((N + 64 * G - 1) / (64 * G)), dim3(384 * G), 0, 0, A2, (size_t)16 * N); }, false)
+        SPLIT(2, 1); SPLIT(2, 2); SPLIT(1, 2); SPLIT(4, 2);
 #define STAGE(ROLE, WAVES)                                                                                                       \
         report("stage " #ROLE " alone, " #WAVES " waves/group", [&] {                                                              \
             hipLaunchKernelGGL((rollout_pipe3_kernel<true, false, 1, 1, false, ROLE, WAVES>), dim3((N + 63) / 64), dim3(64 * WAVES), 0, 0, A2, nullptr); }, false)
