@@ -612,13 +612,13 @@ def main():
                 # the GEMM as a launch of its own (rounds 1-4: epsilon drawn under the finalize launch, tiled GEMM behind it): the
                 # kernel-quality figure -- every one of its MFMAs, its start-up and its write-back uncovered
                 from covo_mpc_amd import _lib as _l
-                _l.check(core.lib.covo_debug_set_stream_gemm(0), "stream_gemm")
+                _l.check(core.lib.covo_debug_set_stream_gemm(core.h, 0), "stream_gemm")
                 try:
                     rs = rounds_of(4, 4 | 8)
                     gemm_in_step_us = min(r[1] for r in rs) - min(r[0] for r in rs)
                     gemm_in_step_rounds = spread([r[1] - r[0] for r in rs])
                 finally:
-                    _l.check(core.lib.covo_debug_set_stream_gemm(1), "stream_gemm")
+                    _l.check(core.lib.covo_debug_set_stream_gemm(core.h, 1), "stream_gemm")
             else:
                 rr = rounds_of(8, 8 | 16)
                 gemm_in_step_us, t_both = (min(r[i] for r in rr) for i in range(2))
@@ -793,7 +793,7 @@ def main():
                                     "counters": (kin.get("noise_gemm") or {}).get("derived")}
             if gemm_added_us is not None:
                 out["roofline_gemm"]["statistic"] = (
-                    "the noise GEMM as a launch of its own behind the Sigma chain (covo_debug_set_stream_gemm(0): graph replay of 20 x "
+                    "the noise GEMM as a launch of its own behind the Sigma chain (covo_debug_set_stream_gemm(handle, 0): graph replay of 20 x "
                     "(chain, GEMM) minus 20 x (chain)); the timed steps run it STREAMED inside the chain's finalize launch, where it "
                     "adds streamed_added_us to the chain (same replays, product mode)")
                 out["roofline_gemm"]["streamed_added_us"] = gemm_added_us

@@ -22,7 +22,7 @@ COVO_RANK_RECORD_FLOATS = COVO_PARTIAL_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 51
 COVO_COV_FLOATS = COVO_H * 10
 COVO_RANK_RECORD_COV_FLOATS = COVO_PARTIAL_FLOATS + COVO_COV_FLOATS + 2 * COVO_POS_STATS_DOUBLES  # 836: with MPPI's second moments
 COVO_EXCHANGE_HANDLE_BYTES = 128
-ABI_VERSION = 6
+ABI_VERSION = 7
 COVO_FLAG_ACTIONS_CLIPPED = 1
 
 
@@ -135,13 +135,13 @@ _SIGS = {
                                         C.POINTER(C.c_uint32), C.c_int32, C.c_float, _P, C.c_int32, C.c_int32, _P]),
     "covo_run_episode_batched": (C.c_int, [_P, C.POINTER(BatchArgsC), C.POINTER(EnvParamsC), _P, _P, C.c_int32, C.c_float, _P,
                                            C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, _P]),
-    "covo_debug_set_ns_tail": (C.c_int, [C.c_int, C.c_int]),
-    "covo_debug_set_ns_deflate": (C.c_int, [C.c_int]),
-    "covo_debug_set_ns_ritz_inside": (C.c_int, [C.c_int]),
-    "covo_debug_set_fuse_small": (C.c_int, [C.c_int]),
-    "covo_debug_set_merge_in_rollout": (C.c_int, [C.c_int]),
-    "covo_debug_set_stream_gemm": (C.c_int, [C.c_int]),
-    "covo_debug_set_ns_coherence": (C.c_int, [C.c_int]),
+    "covo_debug_set_ns_tail": (C.c_int, [_P, C.c_int, C.c_int]),       # per-handle experiment switches (covo_hip.h)
+    "covo_debug_set_ns_deflate": (C.c_int, [_P, C.c_int]),
+    "covo_debug_set_ns_ritz_inside": (C.c_int, [_P, C.c_int]),
+    "covo_debug_set_fuse_small": (C.c_int, [_P, C.c_int]),
+    "covo_debug_set_fold_begin": (C.c_int, [_P, C.c_int]),
+    "covo_debug_set_stream_gemm": (C.c_int, [_P, C.c_int]),
+    "covo_debug_set_ns_coherence": (C.c_int, [_P, C.c_int]),
     "covo_debug_time_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_debug_time_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),

@@ -405,8 +405,12 @@ class SamplingCore:
         # it) the step's first launch reads it where it lies (args.a_mean_in) -- no copy launch on the per-step path
         a_mean_in = None
         if a_mean.data_ptr() != am.data_ptr():
-            if not carry_only and a_mean.is_cuda and a_mean.dtype == torch.float32 and a_mean.is_contiguous() and a_mean.numel() == COVO_NA:
+            if (not carry_only and a_mean.is_cuda and a_mean.device == am.device and a_mean.dtype == torch.float32 and
+                    a_mean.is_contiguous() and a_mean.numel() == COVO_NA):  # (another GPU's tensor is copied: ADVICE r05)
                 a_mean_in = a_mean
+                cur = torch.cuda.current_stream(am.device)
+                if cur.cuda_stream != 0:  # the tensor may have been allocated on another stream: keep its block until this one is through
+                    a_mean.record_stream(cur)
             else:
                 am.copy_(a_mean.reshape(-1), non_blocking=True)
         am_shift = self._persistent("a_mean_shift", (COVO_NA,))

@@ -82,7 +82,8 @@ int covo_create(const covo_config *cfg, covo_handle_t *out)
     REQUIRE(cfg->n_local > 0, "covo_create: n_local=%d", cfg->n_local);
     REQUIRE(cfg->lam > 0.0f, "covo_create: lam=%g", (double)cfg->lam);
     covo_ctx *h = new covo_ctx();
-    h->dbg_epoch = g_dbg_epoch;
+    h->opt = covo_default_opts();
+    h->dbg_epoch = h->opt.epoch;
     h->cfg = *cfg;
     COVO_CHECK_HIP(hipGetDevice(&h->device));
     h->max_red_blocks = 256;
@@ -498,65 +499,74 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
         COVO_CHECK_HIP(hipMalloc(&h->ws_sigma, need));
         h->ws_sigma_bytes = need;
     }
-    return launch_sigma_ns(R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream, nullptr, h->status_dev,
+    return launch_sigma_ns(h->opt, R, batch, sample_sigma, Sigma_out, L_out, h->ws_sigma, (hipStream_t)stream, nullptr, h->status_dev,
                            (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0);
 }
 
-int covo_debug_set_ns_tail(int n_squarings, int n_iters)
+// ---- per-HANDLE experiment switches (CovoOpts, covo_common.hpp); every setter bumps the handle's epoch: its captured step graphs
+// hold the old launch set / kernel arguments and are re-captured at the next step
+int covo_debug_set_ns_tail(covo_handle_t h, int n_squarings, int n_iters)
 {
+    REQUIRE(h, "covo_debug_set_ns_tail: null handle");
     if (n_squarings > 64 || n_iters > 64 || (n_squarings < 0) != (n_iters < 0)) {
         covo_set_error("covo_debug_set_ns_tail: (%d, %d) out of range", n_squarings, n_iters);
         return COVO_E_BADARG;
     }
     if (n_squarings < 0) {  // back to the defaults, defined in ONE place (sigma_ns.hip)
-        sigma_ns_tail_defaults();
+        sigma_ns_tail_defaults(h->opt);
     } else {
-        g_ns_tail_squarings = g_ns_tail_squarings_batched = n_squarings;  // batch 1 and batched launches alike
-        g_ns_tail_iters = g_ns_tail_iters_batched = n_iters;
+        h->opt.ns_tail_squarings = h->opt.ns_tail_squarings_batched = n_squarings;  // batch 1 and batched launches alike
+        h->opt.ns_tail_iters = h->opt.ns_tail_iters_batched = n_iters;
     }
-    ++g_dbg_epoch;  // captured step graphs hold the old launch set: every handle re-captures at its next step
+    ++h->opt.epoch;
     return 0;
 }
 
-int covo_debug_set_stream_gemm(int on)
+int covo_debug_set_stream_gemm(covo_handle_t h, int on)
 {
-    g_stream_gemm = on ? 1 : 0;
-    ++g_dbg_epoch;
+    REQUIRE(h, "covo_debug_set_stream_gemm: null handle");
+    h->opt.stream_gemm = on ? 1 : 0;
+    ++h->opt.epoch;
     return 0;
 }
 
-int covo_debug_set_merge_in_rollout(int on)
+int covo_debug_set_fuse_small(covo_handle_t h, int on)
 {
-    g_merge_in_rollout = on ? 1 : 0;
-    ++g_dbg_epoch;
+    REQUIRE(h, "covo_debug_set_fuse_small: null handle");
+    h->opt.fuse_small = on ? 1 : 0;
+    ++h->opt.epoch;
     return 0;
 }
 
-int covo_debug_set_fuse_small(int on)
+int covo_debug_set_fold_begin(covo_handle_t h, int on)
 {
-    g_fuse_small = on ? 1 : 0;
-    ++g_dbg_epoch;  // a captured step graph holds one launch set or the other
+    REQUIRE(h, "covo_debug_set_fold_begin: null handle");
+    h->opt.fold_begin = on ? 1 : 0;
+    ++h->opt.epoch;
     return 0;
 }
 
-int covo_debug_set_ns_ritz_inside(int on)
+int covo_debug_set_ns_ritz_inside(covo_handle_t h, int on)
 {
-    g_ns_ritz_inside = (on == 2) ? 2 : (on ? 1 : 0);  // (2: timing reference, the last iterate only)
-    ++g_dbg_epoch;  // a captured step graph holds one launch set or the other
+    REQUIRE(h, "covo_debug_set_ns_ritz_inside: null handle");
+    h->opt.ns_ritz_inside = (on == 2) ? 2 : (on ? 1 : 0);  // (2: timing reference, the last iterate only)
+    ++h->opt.epoch;
     return 0;
 }
 
-int covo_debug_set_ns_deflate(int on)
+int covo_debug_set_ns_deflate(covo_handle_t h, int on)
 {
-    g_ns_deflate = on ? 1 : 0;
-    ++g_dbg_epoch;  // ... and the old switch as a kernel argument of the Ritz launch
+    REQUIRE(h, "covo_debug_set_ns_deflate: null handle");
+    h->opt.ns_deflate = on ? 1 : 0;
+    ++h->opt.epoch;
     return 0;
 }
 
-int covo_debug_set_ns_coherence(int force_agent)
+int covo_debug_set_ns_coherence(covo_handle_t h, int force_agent)
 {
-    g_ns_force_agent = force_agent ? 1 : 0;
-    ++g_dbg_epoch;  // a kernel argument of the persistent launches
+    REQUIRE(h, "covo_debug_set_ns_coherence: null handle");
+    h->opt.ns_force_agent = force_agent ? 1 : 0;
+    ++h->opt.epoch;
     return 0;
 }
 

@@ -10,8 +10,25 @@
 // state buffer offsets (include/covo_hip.h "Data layouts")
 enum { ST_POS = 0, ST_VEL = 3, ST_QUAT = 6, ST_OMEGA = 10, ST_FDIST = 13, ST_POSTAR = 16, ST_VELTAR = 19, ST_ACCTAR = 22, ST_TIME = 25 };
 
+// Experiment switches of ONE handle (round 6: rounds 1-5 kept them in process-global variables that flipped every handle of the
+// process and were not thread-safe).  covo_create fills them from the environment (covo_default_opts: COVO_STREAM_GEMM,
+// COVO_FUSE_SMALL, COVO_FOLD_BEGIN, COVO_NS_DEFLATE, COVO_NS_RITZ_INSIDE, read once per handle); covo_debug_set_*(handle, ...) change
+// them for that handle only and bump `epoch`, which makes the handle re-capture its step graphs (they bake the launch set in).
+struct CovoOpts {
+    int stream_gemm;   // covo-online's noise GEMM streamed inside the Sigma chain's finalize launch (sigma_ns.hip: ns_finalize_stream_kernel)
+    int fuse_small;    // the fused small step (step_small.hip) is taken where eligible
+    int fold_begin;    // eager covo-online steps: the begin work rides in the Hessian's first launch
+    int ns_tail_iters, ns_tail_squarings, ns_tail_iters_batched, ns_tail_squarings_batched;  // phases folded into the persistent launches
+    int ns_deflate;      // the Newton-Schulz iteration deflates the bottom eigenpair
+    int ns_force_agent;  // take the agent-scope coherence fallback although the placement check passed
+    int ns_ritz_inside;  // 1: the Rayleigh-Ritz evaluations ride in the squaring launch; 0: one scan launch; 2: the last iterate only
+    int epoch;
+};
+CovoOpts covo_default_opts();  // step.hip
+
 struct covo_ctx {
     covo_config cfg;
+    CovoOpts opt;
     int device;
     // workspace (device)
     float *ws_partials;   // [max_blocks][COVO_PARTIAL_FLOATS] stage-1 records of the softmax reduce
@@ -30,21 +47,46 @@ struct covo_ctx {
     int *status_host;         // host-mapped sticky status word (COVO_DEVSTAT_* bits written by kernels), see covo_device_status
     int *status_dev;          // its device address
     void *exchange;           // Exchange (exchange.hip): peer-write exchange of the rank records, or null
-    int dbg_epoch;            // g_dbg_epoch when this handle's step graphs were captured (a debug setter since then: re-capture)
+    int dbg_epoch;            // opt.epoch when this handle's step graphs were captured (a debug setter since then: re-capture)
 };
 
 void covo_set_error(const char *fmt, ...);
+
+// hipFuncSetAttribute is per DEVICE: a one-time opt-in (dynamic LDS above 64 KB) guarded by a process-wide `static bool` was set on
+// the first device only.  Returns true the first time it is called for the current device with this mask.
+static inline bool covo_first_on_device(unsigned long long &mask)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
+// A pointer a kernel LOADS from memory (a field of a per-instance argument block, a table of buffers) is a GENERIC pointer to the
+// compiler: every access through it becomes a flat_load / flat_store, which counts on BOTH vmcnt and lgkmcnt -- an
+// `s_waitcnt lgkmcnt(0)` in front of an LDS hand-off or a barrier then also drains the loads in flight (round 6: the env-batched
+// rollout kept its 12 prefetched stripes for two steps instead of twelve and ran 30 % slower than the same kernel taking its
+// pointers as kernel arguments, which clang knows to be global).  rebase_global re-expresses such a pointer as
+// (a kernel-argument pointer of the same kind) + (byte distance between the two): the address space then follows from the kernel
+// argument.  The distance goes through an empty asm, else InstCombine folds base + (p - base) back into p.  Neither a cast
+// through address space 1 and back nor an llvm.assume(!is.shared && !is.private) survives to InferAddressSpaces here (ROCm 7.2).
+template <class T>
+__device__ __forceinline__ T *rebase_global(T *kernarg_base, T *loaded)
+{
+    long long off = (long long)(uintptr_t)loaded - (long long)(uintptr_t)kernarg_base;
+    int lo = (int)off, hi = (int)(off >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    off = ((long long)hi << 32) | (unsigned)lo;
+    return (T *)((const char *)kernarg_base + off);
+}
 
 // debug/profiling switches (covo_debug_set): which launches of the Hessian (bit k = kernel k of hessian_adj.hip) and how
 // many stages of the Sigma pipeline (1 prep+squarings, 2 +Ritz, 3 +Newton-Schulz, 4 +finalize) are enqueued.
 // Defaults enqueue everything; only covo_debug_time_step changes them, and restores them.
 extern int g_dbg_hess_mask, g_dbg_sigma_stages;
-extern int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched, g_ns_deflate, g_ns_force_agent, g_ns_ritz_inside;  // sigma_ns.hip
-void sigma_ns_tail_defaults();  // sigma_ns.hip: the four tail lengths back to their defaults
-extern int g_stream_gemm;  // step.hip: covo-online's noise GEMM streamed inside the Sigma chain's finalize launch
-extern int g_merge_in_rollout;  // step.hip: fused single-instance steps finish the softmax update inside the rollout launch
-extern int g_fuse_small;  // step.hip: the fused small step (step_small.hip) is taken where eligible
-extern int g_dbg_epoch;  // capi.hip: bumped by every debug setter whose value a captured step graph bakes in as a kernel argument
+void sigma_ns_tail_defaults(CovoOpts &o);  // sigma_ns.hip: the four tail lengths at their defaults (defined in ONE place)
 
 #define COVO_CHECK_HIP(expr)                                                         \
     do {                                                                             \
@@ -114,23 +156,13 @@ int launch_noise_blockdiag(const float *Ls, const float *mu, const float *eps, u
                            int64_t sample_offset, int N, float *a, hipStream_t s, const uint32_t *dyn = nullptr,
                            bool propagate_nan = false);
 static inline bool covo_propagate_nan(const covo_ctx *h) { return (h->cfg.flags & COVO_FLAG_PROPAGATE_NAN) != 0; }
-// the softmax update's merge inside the record-leaving rollout launch (rollout_common.hpp: rollout_merge_last): the arrival counter
-// (0 between launches), where the result goes -- final: the new mean [128] blended with mean_old; else the merged record [130]
-struct RolloutMerge {
-    unsigned *ticket;
-    float *out;
-    const float *mean_old;
-    float gamma;
-    int final;
-};
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev = nullptr,
                    float *records = nullptr, float lam = 0.0f,   // records: one online-softmax record per workgroup (rollout.hip)
                    const float *f_tab = nullptr,                 // [H][4] per-step disturbance table (disturb.hip), device
                    int xcd_groups = 0,    // 64-sample groups per workgroup of the kernel that wrote `a` (0: the noise GEMM's for this N)
-                   bool propagate_nan = false,   // the re-clip of untrusted stripes keeps a NaN (COVO_FLAG_PROPAGATE_NAN)
-                   const RolloutMerge *merge = nullptr);  // with records: the launch's last workgroup merges them (no merge launch)
+                   bool propagate_nan = false);  // the re-clip of untrusted stripes keeps a NaN (COVO_FLAG_PROPAGATE_NAN)
 int launch_disturb_table(const covo_env_params &p, const float *state, int batch, const uint32_t *keys_dev, uint32_t key0,
                          uint32_t key1, int key_mode, int deterministic, float *out, hipStream_t s);
 int launch_disturb_tables_step(const covo_env_params &p, const float *state, const uint32_t *dyn, int rollout_deterministic,
@@ -232,7 +264,7 @@ struct StreamGemmArgs {
     float *a_cov_out;       // nullable: a_cov [128][128]
     int nanp;               // COVO_FLAG_PROPAGATE_NAN
 };
-int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
+int launch_sigma_ns(const CovoOpts &opt, const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
                     hipStream_t s, const EpsGenArgs *gen = nullptr, int *status = nullptr, bool persistent_ok = true,
                     CovDeferred *cov = nullptr, bool r_has_stats = false, const StreamGemmArgs *stream = nullptr,
                     bool *streamed = nullptr);

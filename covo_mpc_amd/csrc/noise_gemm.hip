@@ -343,15 +343,14 @@ int launch_noise_gemm(const float *L, const float *mu, const float *eps, uint32_
     if (grid > 2048 / waves_per_block) grid = 2048 / waves_per_block;  // persistent: 2 waves/SIMD chip-wide, waves stride over tiles
     if (batch > 1 && block == 512 && (long long)grid * batch > 256) grid = (256 + batch - 1) / batch;  // one 8-wave workgroup per CU
     const size_t lds = (size_t)(COVO_NA * NG_LDA + COVO_NA) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devices = 0;  // (per device: covo_first_on_device)
+    if (covo_first_on_device(attr_devices)) {
 #define NG_ATTR(...) COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(noise_gemm_kernel<__VA_ARGS__>), \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
         NG_ATTR(false, false, 256); NG_ATTR(true, false, 256); NG_ATTR(false, true, 256);
         NG_ATTR(false, false, 512); NG_ATTR(true, false, 512); NG_ATTR(false, true, 512);
         NG_ATTR(false, false, 256, true); NG_ATTR(true, false, 256, true); NG_ATTR(false, true, 256, true);
 #undef NG_ATTR
-        attr_set = true;
     }
 #define NG_GO(...)                                                                                                             \
     do {                                                                                                                         \

@@ -71,7 +71,7 @@ void fill_rollout_args(RolloutArgs &A, const float *state, const float *pos_traj
     A.xcd_remap = (N % 2048 == 0 && N / 128 <= 512) ? xcd_groups : 0;
     A.records = nullptr;
     A.inv_lam = 0.0f;
-    A.merge_ticket = nullptr;
+    A.merge_ticket = nullptr;  // (step_small.hip sets these for its own launch)
     A.merge_out = nullptr;
     A.merge_mean_old = nullptr;
     A.merge_gamma = 1.0f;
@@ -121,7 +121,7 @@ static int dispatch_rollout(const RolloutArgs &A, const RolloutArgs *batch, int 
 int launch_rollout(const float *state, const float *pos_traj, const float *vel_traj, int T, const covo_env_params &p,
                    const float *f_shared, const float *a, int N, float discount, bool trust_clipped, float *cost,
                    float *groupmin, double *pos_stats, double *stats_ws, hipStream_t s, const float *f_shared_dev,
-                   float *records, float lam, const float *f_tab, int xcd_groups, bool propagate_nan, const RolloutMerge *merge)
+                   float *records, float lam, const float *f_tab, int xcd_groups, bool propagate_nan)
 {
     RolloutArgs A;
     fill_rollout_args(A, state, pos_traj, vel_traj, T, p, f_shared, a, N, discount, cost, groupmin, stats_ws, f_shared_dev, f_tab,
@@ -137,13 +137,6 @@ int launch_rollout(const float *state, const float *pos_traj, const float *vel_t
     A.clip = trust_clipped ? 0 : (propagate_nan ? 2 : 1);
     A.records = records;
     A.inv_lam = records ? 1.0f / lam : 0.0f;
-    if (records != nullptr && merge != nullptr) {  // the launch finishes the softmax update itself (rollout_merge_last)
-        A.merge_ticket = merge->ticket;
-        A.merge_out = merge->out;
-        A.merge_mean_old = merge->mean_old;
-        A.merge_gamma = merge->gamma;
-        A.merge_final = merge->final;
-    }
     return dispatch_rollout<false>(A, nullptr, 0, pos_stats, s);
 }
 

@@ -29,7 +29,7 @@ struct RolloutArgs {
     float drag_k;         // fdist 2: c_drag * (-|disturb_scale| / 1.5^2)  (free.py:41-47)
     float drag_off[3];    // fdist 2: disturb_params[:3] / 2
     qm::Consts<float> c;
-    // nullable (fused single-instance steps): the workgroup that takes the last ticket also merges all records (softmax_merge.hpp:
+    // the one-launch small step only (step_small.hip; null elsewhere): the workgroup that takes the last ticket also merges all records (softmax_merge.hpp:
     // merge_kernel's arithmetic) -- the softmax update finishes inside this launch, no merge launch follows.  The records are then
     // published with coherent stores.  merge_final: merge_out[128] = the new mean blended with merge_mean_old (covo.py:270-275);
     // else merge_out[130] = the merged record (a sample-sharded rank)
@@ -168,7 +168,8 @@ __device__ __forceinline__ void rollout_record(const RolloutArgs &A, float cost,
     }
 }
 
-// The update's second stage inside the launch that left the records: every workgroup takes a ticket once its (coherently stored)
+// (step_small.hip only since round 6; the same inside the product rollout launch measured slower at every size and was removed:
+// scripts/probe/rollout_merge_in_launch.hpp)  The update's second stage inside the launch that left the records: every workgroup takes a ticket once its (coherently stored)
 // record is acknowledged; the one that takes the last merges all gridDim.x records.  atomicInc wraps to 0 at the last arrival:
 // the counter re-arms itself for the next launch.  Called by every thread of every workgroup (barriers); THREADS = blockDim.x.
 template <int THREADS>

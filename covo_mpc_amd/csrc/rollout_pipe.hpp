@@ -430,7 +430,24 @@ template <bool DISC1, bool ROLL, int CH, int GROUPS, bool BATCHED = false, int O
 __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) void rollout_pipe3_kernel(
     const RolloutArgs A_, const RolloutArgs *__restrict__ batch)
 {
-    const RolloutArgs &A = BATCHED ? batch[blockIdx.y] : A_;
+    // BATCHED: instance y's argument block is loaded from memory; A_ is instance 0's block as a kernel argument.  The pointers
+    // are re-expressed relative to A_'s (covo_common.hpp: rebase_global -- flat accesses would tie the stripe prefetch to the LDS
+    // rings' lgkmcnt waits); all instances alike in which nullable buffers they pass
+    RolloutArgs Ab;
+    if (BATCHED) {
+        Ab = batch[blockIdx.y];
+        Ab.state = rebase_global(A_.state, Ab.state);
+        Ab.pos_traj = rebase_global(A_.pos_traj, Ab.pos_traj);
+        Ab.vel_traj = rebase_global(A_.vel_traj, Ab.vel_traj);
+        Ab.a = rebase_global(A_.a, Ab.a);
+        Ab.cost = rebase_global(A_.cost, Ab.cost);
+        Ab.groupmin = rebase_global(A_.groupmin, Ab.groupmin);
+        Ab.stats_ws = rebase_global(A_.stats_ws, Ab.stats_ws);
+        Ab.f_shared_dev = rebase_global(A_.f_shared_dev, Ab.f_shared_dev);
+        Ab.f_tab = rebase_global(A_.f_tab, Ab.f_tab);
+        Ab.records = rebase_global(A_.records, Ab.records);
+    }
+    const RolloutArgs &A = BATCHED ? Ab : A_;
     __shared__ Rp3Lds<CH> lds_all[ONLY >= 0 ? ONLY_WAVES : GROUPS];
     __shared__ float lds_st[STATS ? GROUPS : 1][STATS ? COVO_H : 1][9];  // STATS: per group and step {sum d, sum d^2, shift} (d: see stage T)
     const int lane = threadIdx.x & (COVO_WAVE - 1);
@@ -453,14 +470,8 @@ __global__ __launch_bounds__((ONLY >= 0 ? ONLY_WAVES : 3 * GROUPS) * COVO_WAVE) 
     if (ONLY == -1 && REC) {  // every wave of the workgroup (the A and T waves carry no cost)
         __shared__ float rec_m[GROUPS], rec_s[GROUPS];
         __shared__ __attribute__((aligned(16))) float rec_v[GROUPS][COVO_NA];
-        const bool merge_here = !BATCHED && A.merge_ticket != nullptr;  // (wave-uniform kernel argument)
         rollout_record<3 * GROUPS, GROUPS>(A, cost, valid && role == 2, n, role == 2 ? gsub : 0, role == 2, lane, blockIdx.x, rec_m,
-                                           rec_s, rec_v, nullptr, merge_here);
-        if (!BATCHED) {
-            __shared__ MergeLds merge_lds;
-            __shared__ int merge_last;
-            if (merge_here) rollout_merge_last<3 * GROUPS * COVO_WAVE>(A, merge_lds, merge_last);
-        }
+                                           rec_s, rec_v);
     }
     if (STATS) {
         // this workgroup's {sum (p - p0), sum (p - p0)^2} per step and axis, in fp64, with each T wave's shift put back:

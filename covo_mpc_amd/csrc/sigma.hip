@@ -360,11 +360,10 @@ int launch_sigma(const double *R, int batch, float sample_sigma, float *Sigma, f
                  hipStream_t s)
 {
     const size_t lds = (size_t)(SG_N * SG_LD + SG_N + 32 + 2) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devices = 0;  // (per device: covo_first_on_device)
+    if (covo_first_on_device(attr_devices)) {
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sigma_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     hipLaunchKernelGGL(sigma_kernel, dim3(batch), dim3(SG_THREADS), lds, s, R, sample_sigma, Sigma, L, prof);
     COVO_CHECK_HIP(hipGetLastError());
@@ -378,11 +377,10 @@ int launch_cholesky(const float *A, int n, int batch, float *L, hipStream_t s)
         return COVO_E_BADARG;
     }
     const size_t lds = (size_t)n * (n + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devices = 0;  // (per device: covo_first_on_device)
+    if (covo_first_on_device(attr_devices)) {
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cholesky_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8));
-        attr_set = true;
     }
     hipLaunchKernelGGL(cholesky_kernel, dim3(batch), dim3(n <= 8 ? 64 : 256), lds, s, A, n, L);
     COVO_CHECK_HIP(hipGetLastError());

@@ -622,8 +622,11 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
             double a[2][2][8];
             // (the chunk's base address goes through an opaque asm: left alone the compiler forms all 64 addresses of all chunks
             // ahead of the workgroup's evaluation loop and spills them)
-            const double *Ap = in.A + (size_t)(32 * g) * SN + r_av;
-            asm volatile("" : "+v"(Ap));
+            // (... the OFFSET, not the pointer: a pointer that has been through an asm is generic to the compiler and its loads become
+            // flat_load, which also count on lgkmcnt -- covo_common.hpp: rebase_global)
+            size_t aoff = (size_t)(32 * g) * SN + r_av;
+            asm volatile("" : "+v"(aoff));
+            const double *Ap = in.A + aoff;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 a[0][0][c] = Ap[(size_t)c * SN];
@@ -632,8 +635,9 @@ __device__ __forceinline__ double ritz_eval(const RitzInT<LEAN> &in, const doubl
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 if (ch < 3) {
-                    const double *An = Ap + (size_t)(8 * (ch + 1)) * SN;
-                    asm volatile("" : "+v"(An));
+                    size_t noff = aoff + (size_t)(8 * (ch + 1)) * SN;
+                    asm volatile("" : "+v"(noff));
+                    const double *An = in.A + noff;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         a[(ch + 1) & 1][0][c] = An[(size_t)c * SN];
@@ -2078,7 +2082,9 @@ struct StreamHook {
     __device__ __forceinline__ void panel_done(int p) const
     {
         const int wave = tid >> 6, lane = tid & 63;
+#ifdef NS_STREAM_STAMPS
         if (tid == 0) stamps[2 + p] = (double)wall_clock64();
+#endif
         if (wave == 0) return;  // (wave 0 goes straight on to the next diagonal block)
         const int rr = lane >> 4, kk = lane & 15, j0 = 16 * p, c = j0 + kk;
         for (int i0 = j0 + 4 * (wave - 1); i0 < SN; i0 += 28) {
@@ -2097,7 +2103,9 @@ struct StreamHook {
             const int old = __hip_atomic_fetch_add(cnt + (p - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (old == 6) {
                 __hip_atomic_store(sync + p, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sync[1 + (p - 1)]
+#ifdef NS_STREAM_STAMPS
                 stamps[11 + (p - 1)] = (double)wall_clock64();
+#endif
             }
         }
     }
@@ -2177,11 +2185,17 @@ __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *_
     // time stamps of the launch (100 MHz wall clock, scripts/stream_timeline.py): workgroup 0 [0] entry, [1] Z in LDS, [2 + p] panel p
     // final, [10] factorisation over, [11 + p] flag p raised; the first and the last worker's wave 0 [24 / 56 + ...]: entry, then per
     // panel {flag seen, staged, multiplied (and stored)}
+    // -DNS_STREAM_STAMPS only (make HIPFLAGS+=-DNS_STREAM_STAMPS: scripts/stream_timeline.py); the product kernel stores none
+#ifdef NS_STREAM_STAMPS
     double *stamps = s + SC_STAMPS;
+#define STREAM_STAMP(i) do { if (tid == 0) stamps[(i)] = (double)wall_clock64(); } while (0)
+#else
+#define STREAM_STAMP(i) do { } while (0)
+#endif
 
     if (blockIdx.x == 0) {
         // ================================================================ the factoring workgroup
-        if (tid == 0) stamps[0] = (double)wall_clock64();
+        STREAM_STAMP(0);
         if (tid == 0 && bad && status != nullptr)
             __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (tid == 0) s[SC_CZ] = cz;
@@ -2228,7 +2242,7 @@ __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *_
         }
         __syncthreads();
         tk[1] = clock64();
-        if (tid == 0) stamps[1] = (double)wall_clock64();
+        STREAM_STAMP(1);
         StreamHook hook;
         hook.sm = sm;
         hook.sq = sq;
@@ -2236,13 +2250,19 @@ __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *_
         hook.sync = S.sync;
         hook.seq = seq;
         hook.cnt = wcnt;
+#ifdef NS_STREAM_STAMPS
         hook.stamps = stamps;
+#else
+        hook.stamps = nullptr;
+#endif
         hook.tid = tid;
         chol128_lds_mfma<LD, 8>(sm, tid, hook);
         hook.before_barrier(8);  // the last panel's acknowledgement and flag
         tk[2] = clock64();
         if (tid == 0) {
+#ifdef NS_STREAM_STAMPS
             stamps[10] = (double)wall_clock64();
+#endif
             for (int i = 0; i < 3; ++i) s[SC_PROF + i] = (double)(tk[i] - tk[0]);
         }
         return;
@@ -2258,7 +2278,11 @@ __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *_
     float *mus = Ls + COVO_NA * NG_LDA;          // [128]
     float4 *epsx = reinterpret_cast<float4 *>(mus + COVO_NA);  // [16][64]: the hosted tile's epsilon in B-operand order (16 KiB)
     const int b = (int)blockIdx.x, W = (int)gridDim.x - 1;
+#ifdef NS_STREAM_STAMPS
     double *wst = (tid == 0 && (b == 1 || b == W)) ? stamps + (b == 1 ? 24 : 56) : nullptr;
+#else
+    double *const wst = nullptr;
+#endif
     if (wst) wst[0] = (double)wall_clock64();
     if (tid < COVO_NA) mus[tid] = S.mu[tid];
     const uint32_t k0 = S.dyn[0], k1 = S.dyn[1];
@@ -2368,6 +2392,12 @@ __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *_
     STREAM_PANEL(6);
     STREAM_PANEL(7);
 #undef STREAM_PANEL
+    if (!ok && S.a_cov_out != nullptr && b - 1 < SN * SN / 512) {
+        // a panel flag timed out: this launch's actions are NaN -- so is the a_cov part this worker wrote before it knew (ADVICE r05:
+        // the outputs of a failed step must not disagree; the sticky device status below makes the next call fail)
+        const int wstride = W < SN * SN / 512 ? W : SN * SN / 512;
+        for (int e = (b - 1) * 512 + tid; e < SN * SN; e += wstride * 512) S.a_cov_out[e] = __builtin_nanf("");
+    }
     if (!ok && tid == 0 && status != nullptr)
         __hip_atomic_fetch_or(status, COVO_DEVSTAT_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -2394,19 +2424,14 @@ __global__ __launch_bounds__(512) void ns_finalize_stream_kernel(const double *_
 // loop: (15, 3) 81 815 / 75 187; (15, 4) 82 553 / 75 641; (15, 5) 82 865 / 74 674; (15, 6) 82 978 / 74 796; (15, 8) 81 889 / 74 194;
 // (15, 11) 80 713 / 73 431 -> the last 4.  The squaring launch on pairs too (20 workgroups per matrix instead of 36, a third fewer
 // operand bytes): one matrix 5 464-5 470 / 4 874-4 886 against 5 428-5 457 / 4 844-4 854, batched 83 663 / 76 231 against 82 535 / 75 461.
-int g_ns_tail_iters, g_ns_tail_squarings, g_ns_tail_iters_batched, g_ns_tail_squarings_batched;
-// THE defaults of the four tail lengths (also what covo_debug_set_ns_tail(-1, -1) restores)
-void sigma_ns_tail_defaults()
+// THE defaults of the four tail lengths (also what covo_debug_set_ns_tail(handle, -1, -1) restores); the other switches of a
+// handle (deflation, forced agent-scope coherence, where the Ritz evaluations run): CovoOpts, covo_default_opts (step.hip)
+void sigma_ns_tail_defaults(CovoOpts &o)
 {
-    g_ns_tail_iters = NS_ITERS - 1;
-    g_ns_tail_squarings = g_ns_tail_squarings_batched = NS_SQUARINGS - 1;
-    g_ns_tail_iters_batched = 4;
+    o.ns_tail_iters = NS_ITERS - 1;
+    o.ns_tail_squarings = o.ns_tail_squarings_batched = NS_SQUARINGS - 1;
+    o.ns_tail_iters_batched = 4;
 }
-static const int g_ns_tail_init = (sigma_ns_tail_defaults(), 0);
-// COVO_NS_DEFLATE=0 in the environment (read once, when the library is loaded) / covo_debug_set_ns_deflate(0): the undeflated
-// iteration (A/B measurements, tests)
-int g_ns_force_agent = 0;  // covo_debug_set_ns_coherence: take the COH_AGENT fallback although the placement check passed
-int g_ns_deflate = [] { const char *e = std::getenv("COVO_NS_DEFLATE"); return (e && e[0] == '0') ? 0 : 1; }();
 
 SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
 {
@@ -2422,10 +2447,10 @@ SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
 }
 // 11 matrices, the slots, then the filter's history X_3 .. X_16 and X_1 (XBufs)
 size_t sigma_ns_workspace_bytes(int batch) { return (size_t)batch * ((11 + NS_SQUARINGS - 1) * SN * SN + SC_COUNT) * sizeof(double); }
-// COVO_NS_RITZ_INSIDE=0 / covo_debug_set_ns_ritz_inside(0): the one-matrix chain, too, evaluates after its squarings (ns_ritz_scan_kernel)
-int g_ns_ritz_inside = [] { const char *e = std::getenv("COVO_NS_RITZ_INSIDE"); return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1; }();
+// (opt.ns_ritz_inside == 0 -- COVO_NS_RITZ_INSIDE=0 / covo_debug_set_ns_ritz_inside(h, 0): the one-matrix chain, too, evaluates after
+// its squarings: ns_ritz_scan_kernel)
 
-int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
+int launch_sigma_ns(const CovoOpts &opt, const double *R, int batch, float sample_sigma, float *Sigma, float *L, void *workspace,
                     hipStream_t s, const EpsGenArgs *gen, int *status, bool persistent_ok, CovDeferred *cov, bool r_has_stats,
                     const StreamGemmArgs *stream, bool *streamed)
 {
@@ -2438,51 +2463,50 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
     double *T = X0, *Tt = X1;  // the squaring buffers are free once lambda_min is known
     double *sc = ws + 11 * M;
     const size_t lds = (size_t)SN * (SN + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devices = 0;  // (per device: covo_first_on_device)
+    if (covo_first_on_device(attr_devices)) {
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_finalize_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_iter_tail_pair_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_finalize_stream_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     if (r_has_stats) A = const_cast<double *>(R);  // exactly symmetric, statistics already in sc (KD): no prep launch
     else hipLaunchKernelGGL(ns_prep_kernel, ns_grid(NS_TILES, batch), dim3(256), 0, s, R, A, sc, batch);
     double *hist0 = sc + (size_t)batch * SC_COUNT;
     const XBufs xb{X0, X1, hist0, hist0 + (size_t)(NS_SQUARINGS - 2) * M, M};
-    const bool fold_first = persistent_ok && (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) >= NS_SQUARINGS - 1;
+    const bool fold_first = persistent_ok && (batch == 1 ? opt.ns_tail_squarings : opt.ns_tail_squarings_batched) >= NS_SQUARINGS - 1;
     if (!fold_first) hipLaunchKernelGGL(ns_square_kernel<true>, ns_grid(NS_TILES, batch), dim3(256), 0, s, A, ns_xk(xb, 1), sc, 0, batch);
     // the remaining squarings / iterations run inside persistent launches (20 / 32 workgroups per matrix, one XCD per matrix)
-    int sq_tail = persistent_ok ? (batch == 1 ? g_ns_tail_squarings : g_ns_tail_squarings_batched) : 0;
+    int sq_tail = persistent_ok ? (batch == 1 ? opt.ns_tail_squarings : opt.ns_tail_squarings_batched) : 0;
     if (sq_tail > NS_SQUARINGS - 1) sq_tail = NS_SQUARINGS - 1;
     const int sq_sep = NS_SQUARINGS - sq_tail;
     for (int i = 1; i < sq_sep; ++i)
         hipLaunchKernelGGL(ns_square_kernel<false>, ns_grid(NS_TILES, batch), dim3(256), 0, s, ns_xk(xb, i), ns_xk(xb, i + 1), sc, i, batch);
     // every squaring folded: the Rayleigh-Ritz evaluations ride in the squaring launch and stop it (ns_square_evaluator)
-    const bool eval_inside = fold_first && g_ns_ritz_inside == 1;
+    const bool eval_inside = fold_first && opt.ns_ritz_inside == 1;
     if (sq_tail > 0) {
         if (eval_inside && batch == 1)
             hipLaunchKernelGGL((ns_square_tail_pair_kernel<NS_SQ_EVAL_WG>), ns_tail_grid(NS_SQ_PAIR_WG + NS_SQ_EVAL_WG, batch), dim3(256), 0,
-                               s, A, xb, sc, 0, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
+                               s, A, xb, sc, 0, NS_SQUARINGS - 1, batch, opt.ns_force_agent, opt.ns_deflate);
         else if (eval_inside)
             hipLaunchKernelGGL(ns_square_tail_pair_lean_kernel, ns_tail_grid(NS_SQ_PAIR_WG + NS_SQ_EVAL_WG_BATCH, batch),
-                               dim3(256), 0, s, A, xb, sc, 0, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
+                               dim3(256), 0, s, A, xb, sc, 0, NS_SQUARINGS - 1, batch, opt.ns_force_agent, opt.ns_deflate);
         else
             hipLaunchKernelGGL((ns_square_tail_pair_kernel<0>), ns_tail_grid(NS_SQ_PAIR_WG, batch), dim3(256), 0, s, A, xb, sc,
-                               fold_first ? 0 : sq_sep, NS_SQUARINGS - 1, batch, g_ns_force_agent, g_ns_deflate);
+                               fold_first ? 0 : sq_sep, NS_SQUARINGS - 1, batch, opt.ns_force_agent, opt.ns_deflate);
     }
     if (g_dbg_sigma_stages < 2) return 0;
-    if (!eval_inside) hipLaunchKernelGGL(ns_ritz_scan_kernel, dim3(batch * RITZ_NK), dim3(256), 0, s, A, xb, sc, g_ns_deflate, g_ns_ritz_inside == 2 ? 1 : 0);
+    if (!eval_inside) hipLaunchKernelGGL(ns_ritz_scan_kernel, dim3(batch * RITZ_NK), dim3(256), 0, s, A, xb, sc, opt.ns_deflate, opt.ns_ritz_inside == 2 ? 1 : 0);
     if (g_dbg_sigma_stages < 3) return 0;
     // Iteration 0 is no product (NsFirst): Y1 and Z1 are written out element-wise from A and X_1 -- by the first phase of the persistent
     // launch when one matrix folds every iteration into it, else by a launch of their own (which also makes the coefficient table).
     const double *Xq = ns_xk(xb, 1);  // X_1
-    const bool fold_all = batch == 1 && persistent_ok && g_ns_tail_iters >= NS_ITERS - 1;
+    const bool fold_all = batch == 1 && persistent_ok && opt.ns_tail_iters >= NS_ITERS - 1;
     if (!fold_all) hipLaunchKernelGGL(ns_first_elem_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Xq, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
     bool early_logdet = false;
-    int n_tail = persistent_ok ? (batch == 1 ? g_ns_tail_iters : g_ns_tail_iters_batched) : 0;
+    int n_tail = persistent_ok ? (batch == 1 ? opt.ns_tail_iters : opt.ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
     const int n_sep = NS_ITERS - n_tail;
     for (int i = 1; i < n_sep; ++i) {
@@ -2513,10 +2537,10 @@ int launch_sigma_ns(const double *R, int batch, float sample_sigma, float *Sigma
         early_logdet = batch == 1;
         if (early_logdet)
             hipLaunchKernelGGL(ns_iter_tail_pair_kernel<true>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), lds, s, A, B, sc,
-                               fold_all ? 1 : n_sep, NS_ITERS - 1, batch, g_ns_force_agent, fold_all ? 1 : 0);
+                               fold_all ? 1 : n_sep, NS_ITERS - 1, batch, opt.ns_force_agent, fold_all ? 1 : 0);
         else
             hipLaunchKernelGGL(ns_iter_tail_pair_kernel<false>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), 4 * 4 * 4 * 64 * sizeof(double), s, A, B, sc,
-                               n_sep, NS_ITERS - 1, batch, g_ns_force_agent, 0);
+                               n_sep, NS_ITERS - 1, batch, opt.ns_force_agent, 0);
     }
     if (g_dbg_sigma_stages < 4) return 0;
     if (stream != nullptr && early_logdet && batch == 1) {

@@ -7,6 +7,7 @@
 // The second call with the same buffers captures the sequence into a hipGraph, later calls replay it.
 // Quantities that change every step (Philox key, MPPI's shared disturbance draw) live in a 32-byte
 // device block refreshed by one async copy before each replay, so the captured kernel arguments stay valid.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -126,38 +127,45 @@ void step_state_destroy(covo_ctx *h)
 }
 
 int g_dbg_hess_mask = 15, g_dbg_sigma_stages = 4;
-int g_dbg_epoch = 0;
 static const int g_dbg_eps_ahead = [] {  // COVO_EPS_AHEAD=0: the GEMM draws epsilon itself (A/B measurements)
     const char *v = std::getenv("COVO_EPS_AHEAD");
     return v ? std::atoi(v) : 1;
 }();
-// COVO_FUSE_SMALL=0 / covo_debug_set_fuse_small(0): covo-offline and MPPI steps of <= 256 sample groups run their staged launches
-// (begin | noise | rollout + records | merge) instead of the one fused launch of step_small.hip (A/B measurements, parity tests)
-int g_fuse_small = [] {
-    const char *v = std::getenv("COVO_FUSE_SMALL");
-    return v ? std::atoi(v) : 1;
-}();
-// COVO_MERGE_IN_ROLLOUT=1 / covo_debug_set_merge_in_rollout(1): the records' merge by the rollout launch's last workgroup
-// (rollout_merge_last) instead of as a launch of its own (merge_kernel).  Same arithmetic, same bits -- and measured SLOWER at every
-// size (round 5, one MI355X: covo-online N = 65 536 5 005 against 5 070 steps/s, the sharded launch group 44.3 against 41.2 us;
-// covo-offline N = 8 192 staged 32.2k against 38.6k): every workgroup's tail gains a write-through acknowledgement and an
-// agent-scope atomic (two fabric round trips), the last one then pulls the records through sc1 loads -- more than the 2 us launch
-// boundary + 2.4-4.3 us merge_kernel it replaces.  Opt-in; the one-launch small step (step_small.hip) keeps it: there it also
-// removes a launch from a host-bound path.
-int g_merge_in_rollout = [] {
-    const char *v = std::getenv("COVO_MERGE_IN_ROLLOUT");
-    return v ? std::atoi(v) : 0;
-}();
-// COVO_STREAM_GEMM=0 / covo_debug_set_stream_gemm(0): covo-online's noise GEMM as a launch of its own behind the Sigma chain's
-// finalize launch (rounds 1-4) instead of streamed under the factorisation inside it (sigma_ns.hip: ns_finalize_stream_kernel)
-int g_stream_gemm = [] {
-    const char *v = std::getenv("COVO_STREAM_GEMM");
-    return v ? std::atoi(v) : 1;
-}();
-int g_fold_begin = [] {
-    const char *v = std::getenv("COVO_FOLD_BEGIN");
-    return v ? std::atoi(v) : 1;
-}();
+// The experiment switches a new handle starts with (CovoOpts, covo_common.hpp), from the environment:
+//   COVO_FUSE_SMALL=0     covo-offline and MPPI steps of <= 256 sample groups run their staged launches (begin | noise | rollout +
+//                         records | merge) instead of the one fused launch of step_small.hip
+//   COVO_STREAM_GEMM=0    covo-online's noise GEMM as a launch of its own behind the Sigma chain's finalize launch (rounds 1-4)
+//                         instead of streamed under the factorisation inside it (sigma_ns.hip: ns_finalize_stream_kernel)
+//   COVO_FOLD_BEGIN=0     eager covo-online steps keep the begin launch (default: its work rides in the Hessian's first launch)
+//   COVO_NS_TAIL=sq,it    phases folded into the Sigma chain's persistent launches, as covo_debug_set_ns_tail
+//   COVO_NS_DEFLATE=0     the undeflated Newton-Schulz iteration;  COVO_NS_RITZ_INSIDE=0 / 2: the Ritz evaluations as one scan
+//                         launch after the squarings / the filter's last iterate only (rounds 1-4's rule, timing reference)
+// covo_debug_set_*(handle, ...) change them per handle afterwards (A/B measurements, parity tests).
+CovoOpts covo_default_opts()
+{
+    auto env_int = [](const char *name, int dflt) {
+        const char *v = std::getenv(name);
+        return v ? std::atoi(v) : dflt;
+    };
+    CovoOpts o;
+    o.fuse_small = env_int("COVO_FUSE_SMALL", 1);
+    o.stream_gemm = env_int("COVO_STREAM_GEMM", 1);
+    o.fold_begin = env_int("COVO_FOLD_BEGIN", 1);
+    sigma_ns_tail_defaults(o);
+    if (const char *v = std::getenv("COVO_NS_TAIL")) {  // "squarings,iterations" as covo_debug_set_ns_tail (scripts/tail_bench.py)
+        int sq = -1, it = -1;
+        if (std::sscanf(v, "%d,%d", &sq, &it) == 2 && sq >= 0 && it >= 0 && sq <= 64 && it <= 64) {
+            o.ns_tail_squarings = o.ns_tail_squarings_batched = sq;
+            o.ns_tail_iters = o.ns_tail_iters_batched = it;
+        }
+    }
+    o.ns_deflate = env_int("COVO_NS_DEFLATE", 1) ? 1 : 0;
+    o.ns_force_agent = 0;
+    const int ri = env_int("COVO_NS_RITZ_INSIDE", 1);
+    o.ns_ritz_inside = ri == 2 ? 2 : (ri ? 1 : 0);
+    o.epoch = 0;
+    return o;
+}
 static int g_dbg_step_mask = 63;  // (1: unused, the begin launch is not part of the graph) 2 Hessian, 4 Sigma, 8 noise GEMM, 16 rollout, 32 softmax update
 
 // the launch sequence of one step (everything reads per-step scalars from st->dyn)
@@ -174,7 +182,7 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     const float *state = state_direct ? state_direct : st->state_buf;
     // covo-offline / MPPI at small N: noise -> rollout -> records -> merge as ONE launch (the begin launch has left the step's
     // scalars in st->dyn and the state in st->state_buf; MPPI: it has NOT touched a_cov, the fused launch shifts and factors)
-    if (M == 63 && g_fuse_small && step_small_eligible(h, p, a))
+    if (M == 63 && h->opt.fuse_small && step_small_eligible(h, p, a))
         return launch_step_small(h, p, a, state, am_shift, nullptr, st->dyn, 0.0f, st->ticket, s);
     // periodic / sin / drag / mixed (free.py:10-58): the wave-uniform part of every rollout step's force, for the sampling
     // rollouts (shared step key) and for the Hessian's deterministic rollout (per-step keys), resolved once per control step
@@ -214,9 +222,9 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
         sg.sync = st->sync;
         sg.a_cov_out = Sig;
         sg.nanp = covo_propagate_nan(h) ? 1 : 0;
-        const bool want_stream = g_stream_gemm && (M & 4) && (M & 8) && g_dbg_sigma_stages >= 4;
+        const bool want_stream = h->opt.stream_gemm && (M & 4) && (M & 8) && g_dbg_sigma_stages >= 4;
         bool streamed = false;
-        if ((M & 4) && (rc = launch_sigma_ns(st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen, h->status_dev,
+        if ((M & 4) && (rc = launch_sigma_ns(h->opt, st->R, 1, a.sample_sigma, Sig, st->L, h->ws_sigma, s, &gen, h->status_dev,
                                              (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, defer ? &cov : nullptr, stats,
                                              want_stream ? &sg : nullptr, &streamed))) return rc;
         if (streamed) {
@@ -243,21 +251,12 @@ static int enqueue_step(covo_ctx *h, StepState *st, const covo_env_params &p, co
     // MPPI's covariance adaptation needs second moments the in-rollout records do not carry: its own stage 1 (reduce.hip)
     const bool cov_adapt = a.mode == COVO_MODE_MPPI && a.gamma_sigma != 0.0f;
     const bool records = G <= h->max_red_blocks && !cov_adapt;
-    // the update's merge inside the rollout launch (its last workgroup; rollout_merge_last) -- when the step runs both anyway
-    const bool merge_in = records && g_merge_in_rollout && (M & 16) && (M & 32);
-    RolloutMerge mg;
-    mg.ticket = st->ticket;
-    mg.final = a.partial_out == nullptr;
-    mg.out = a.partial_out ? a.partial_out : a.a_mean;
-    mg.mean_old = am_shift;
-    mg.gamma = a.gamma_mean;
     if ((M & 16) && (rc = launch_rollout(state, a.pos_traj, a.vel_traj, a.T, p, nullptr, a.a, N, h->cfg.discount, clipped, a.cost,
                                          records ? nullptr : a.groupmin, a.pos_stats, h->ws_stats, s, fdev,
                                          records ? h->ws_partials : nullptr, h->cfg.lam, tables ? st->f_tab_rollout : nullptr,
-                                         a.mode == COVO_MODE_MPPI ? 4 : 0, false,  // MPPI's block-diagonal kernel: 256 samples per workgroup
-                                         merge_in ? &mg : nullptr)))
+                                         a.mode == COVO_MODE_MPPI ? 4 : 0, false)))  // MPPI's block-diagonal kernel: 256 samples per workgroup
         return rc;
-    if (!(M & 32) || merge_in) return 0;
+    if (!(M & 32)) return 0;
     if (cov_adapt && a.partial_out != nullptr)  // a sample-sharded rank: its record with the second moments (836-float kind)
         return launch_softmax_reduce_cov(h, a.cost, a.a, N, a.groupmin, (N + 63) / 64, am_shift, a.partial_out, s);
     if (cov_adapt)  // mppi.py:109-125: new mean, then a_cov (already shifted by the begin launch) adapted in place
@@ -281,9 +280,9 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
         int rc = step_state_init(h);
         if (rc) return rc;
     }
-    if (h->dbg_epoch != g_dbg_epoch) {  // a debug setter changed what a captured graph baked in (launch set, deflation switch)
+    if (h->dbg_epoch != h->opt.epoch) {  // a debug setter changed what a captured graph baked in (launch set, deflation switch)
         step_graphs_drop(h);
-        h->dbg_epoch = g_dbg_epoch;
+        h->dbg_epoch = h->opt.epoch;
     }
     StepState *st = reinterpret_cast<StepState *>(h->step);
     // per-step scalars: kernel arguments of the begin launch
@@ -301,7 +300,7 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     const float shared_noise_scale =
         (params->disturb_kind == COVO_DISTURB_GAUSSIAN && !args->rollout_deterministic) ? params->dyn_noise_scale : 0.0f;
     // control_params.a_mean of this call: the handle's own buffer (a carried mean) or the caller's input (args->a_mean_in)
-    const bool small = g_fuse_small && step_small_eligible(h, *params, *args);
+    const bool small = h->opt.fuse_small && step_small_eligible(h, *params, *args);
     if (small && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0) {
         // an eager handle: the WHOLE step is one launch, the begin launch's work included (per workgroup, step_small.hip)
         st->have_key = false;  // (st->dyn / st->state_buf are not refreshed: a later graph capture starts from an eager call)
@@ -310,7 +309,7 @@ int covo_step_impl(covo_ctx *h, const covo_env_params *params, const covo_step_a
     }
     // eager covo-online steps (no per-step force tables, whose launch precedes the Hessian and reads the scalars): the begin work
     // rides in the Hessian's first launch -- one launch boundary less (COVO_FOLD_BEGIN=0 keeps the begin launch)
-    if (g_fold_begin && args->mode == COVO_MODE_COVO_ONLINE && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 && g_dbg_hess_mask == 15 &&
+    if (h->opt.fold_begin && args->mode == COVO_MODE_COVO_ONLINE && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 && g_dbg_hess_mask == 15 &&
         !(params->disturb_kind >= COVO_DISTURB_PERIODIC && params->disturb_kind <= COVO_DISTURB_MIXED)) {
         HessBegin hb;
         hb.a_mean_raw = args->a_mean_in ? args->a_mean_in : args->a_mean;
@@ -386,9 +385,9 @@ int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const 
     }
     StepState *st = reinterpret_cast<StepState *>(h->step);
     hipStream_t cs = h->side_stream;
-    const bool folded_online = g_fold_begin && args->mode == COVO_MODE_COVO_ONLINE &&
+    const bool folded_online = h->opt.fold_begin && args->mode == COVO_MODE_COVO_ONLINE &&
                                !(params->disturb_kind >= COVO_DISTURB_PERIODIC && params->disturb_kind <= COVO_DISTURB_MIXED);
-    if (((g_fuse_small && step_small_eligible(h, *params, *args)) || folded_online) && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 &&
+    if (((h->opt.fuse_small && step_small_eligible(h, *params, *args)) || folded_online) && (h->cfg.flags & COVO_FLAG_NO_GRAPH) != 0 &&
         args->state != nullptr) {
         // the last step ran without a begin launch (the one-launch small step; covo-online with the begin work folded into the
         // Hessian) and never filled the scratch the replayed launches read (state copy, shifted mean, keys; MPPI: shifted
@@ -411,7 +410,7 @@ int covo_debug_time_step_impl(covo_ctx *h, const covo_env_params *params, const 
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
         for (int r = 0; r < reps && !rc; ++r) {
-            if (args->mode == COVO_MODE_COVO_ONLINE && g_stream_gemm && (step_mask & 12) == 12)
+            if (args->mode == COVO_MODE_COVO_ONLINE && h->opt.stream_gemm && (step_mask & 12) == 12)
                 hipLaunchKernelGGL(stream_seq_bump_kernel, dim3(1), dim3(1), 0, cs, st->sync);
             rc = enqueue_step(h, st, *params, *args, cs);
         }
@@ -623,7 +622,7 @@ static int batch_enqueue(covo_ctx *h, BatchState *b, const covo_batch_args &a, h
     gen.n_inst = E;
     gen.dyn_stride = 12;
     gen.eps_stride = (size_t)((N + 31) / 32) * 16 * 64;
-    if ((M & 4) && (rc = launch_sigma_ns(b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, &gen, h->status_dev,
+    if ((M & 4) && (rc = launch_sigma_ns(h->opt, b->R, E, a.sample_sigma, Sig, b->L, h->ws_sigma, s, &gen, h->status_dev,
                                          (h->cfg.flags & COVO_FLAG_SHARED_DEVICE) == 0, nullptr, stats))) return rc;
     if (ahead) {
         if ((rc = launch_noise_gemm(b->L, b->a_mean_shift, reinterpret_cast<const float *>(b->eps_tiled), 0, 0, 0, N, a.a, s, nullptr,
@@ -691,9 +690,9 @@ int covo_step_batched_impl(covo_ctx *h, const covo_batch_args *args, const covo_
                            hipStream_t s)
 {
     const int E = args->n_envs;
-    if (h->dbg_epoch != g_dbg_epoch) {  // as in covo_step_impl
+    if (h->dbg_epoch != h->opt.epoch) {  // as in covo_step_impl
         step_graphs_drop(h);
-        h->dbg_epoch = g_dbg_epoch;
+        h->dbg_epoch = h->opt.epoch;
     }
     BatchState *b = reinterpret_cast<BatchState *>(h->batch);
     if (!b) {

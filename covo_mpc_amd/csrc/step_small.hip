@@ -262,14 +262,13 @@ int launch_step_small(covo_ctx *h, const covo_env_params &p, const covo_step_arg
     P.shared_noise_scale = shared_noise_scale;
     P.nanp = covo_propagate_nan(h) ? 1 : 0;
     const int ng = (N + COVO_WAVE - 1) / COVO_WAVE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devices = 0;  // (per device: covo_first_on_device)
+    if (covo_first_on_device(attr_devices)) {
 #define SS_ATTR(MPPI, D, R) COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(step_small_kernel<MPPI, D, R>), \
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MPPI ? SS_LDS_MPPI : SS_LDS_GEMM)))
         SS_ATTR(false, false, false); SS_ATTR(false, false, true); SS_ATTR(false, true, false); SS_ATTR(false, true, true);
         SS_ATTR(true, false, false); SS_ATTR(true, false, true); SS_ATTR(true, true, false); SS_ATTR(true, true, true);
 #undef SS_ATTR
-        attr_set = true;
     }
     const bool mppi = a.mode == COVO_MODE_MPPI, disc1 = h->cfg.discount == 1.0f, roll = P.R.rollover != 0;
 #define SS_GO(MPPI, D, R) hipLaunchKernelGGL((step_small_kernel<MPPI, D, R>), dim3(ng), dim3(SS_BLOCK), MPPI ? SS_LDS_MPPI : SS_LDS_GEMM, s, P)

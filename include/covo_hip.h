@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define COVO_ABI_VERSION 6
+#define COVO_ABI_VERSION 7
 
 #define COVO_H 32            /* horizon (compile-time in the fused kernels)          */
 #define COVO_DU 4            /* action dim, quadjax/envs/quadrotor.py:198            */
@@ -375,47 +375,49 @@ int covo_sigma(covo_handle_t h, const double *R, int32_t batch, float sample_sig
 int covo_sigma_jacobi(covo_handle_t h, const double *R, int32_t batch, float sample_sigma, float *Sigma_out,
                       float *L_out, void *stream);
 
-/* 0: covo-offline / MPPI steps of <= 256 sample groups run their staged launches (begin | noise | rollout + records | merge)
- * instead of the ONE fused launch of csrc/step_small.hip (the default where eligible; also COVO_FUSE_SMALL=0 in the environment).
- * Both give the same bits; the switch exists for A/B measurements and the parity test.  Drops captured step graphs. */
-int covo_debug_set_fuse_small(int on);
+/* ---- Experiment switches of ONE handle (round 6; rounds 1-5 kept them process-global).  A new handle takes its defaults from the
+ * environment (COVO_FUSE_SMALL, COVO_STREAM_GEMM, COVO_FOLD_BEGIN, COVO_NS_DEFLATE, COVO_NS_RITZ_INSIDE; csrc/step.hip:
+ * covo_default_opts); the setters below change them for THAT handle only and make it re-capture its step graphs at the next step.
+ * They exist for A/B measurements and the parity tests: every pair of settings gives the same bits unless stated otherwise.
+ * A handle is single-threaded (as every entry point that takes one). */
 
-/* 1: the fused single-instance steps merge their softmax records inside the rollout launch, by the workgroup that takes the last
- * ticket, instead of with a launch of their own (merge_kernel; the default: the in-launch merge measured slower at every size,
- * csrc/step.hip).  Also COVO_MERGE_IN_ROLLOUT=1 in the environment.  Same arithmetic, same bits (csrc/softmax_merge.hpp).  Drops
- * captured step graphs. */
-int covo_debug_set_merge_in_rollout(int on);
+/* 0: covo-offline / MPPI steps of <= 256 sample groups run their staged launches (begin | noise | rollout + records | merge)
+ * instead of the ONE fused launch of csrc/step_small.hip (the default where eligible). */
+int covo_debug_set_fuse_small(covo_handle_t h, int on);
 
 /* 0: covo-online's noise GEMM runs as a launch of its own behind the Sigma chain (rounds 1-4) instead of streamed under the
- * factorisation inside the chain's finalize launch (the default for one matrix on a GPU of one's own; COVO_STREAM_GEMM=0 in the
- * environment).  Same actions, a_cov and means bit for bit.  Drops captured step graphs. */
-int covo_debug_set_stream_gemm(int on);
+ * factorisation inside the chain's finalize launch (the default for one matrix on a GPU of one's own).  Same actions, a_cov and
+ * means bit for bit. */
+int covo_debug_set_stream_gemm(covo_handle_t h, int on);
+
+/* 0: eager covo-online steps keep the begin launch (mean shift, key derivation, sequence bump) instead of folding its work into the
+ * Hessian's first launch (the default; every launch of a folded step reads args->state where it lies instead of the handle's
+ * fixed-address copy).  Same bits (tests/test_gpu_parity.py::test_folded_begin_equals_the_begin_launch). */
+int covo_debug_set_fold_begin(covo_handle_t h, int on);
 
 /* Debug aid: copy `count` doubles from offset `offset_doubles` of the Sigma pipeline's scratch (layout in
  * sigma_ns.hip: 11 matrices [batch][128][128], then 3 712 doubles of slots per matrix -- SC_* in sigma_ns.hip: lambda_min, delta,
  * scale, the iterate the result was taken from, iteration counts, barrier status ... --, then the filter's iterate buffers) to
  * `out` (device or pinned host). */
 int covo_debug_sigma_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
-/* Test hook (process-wide): how many of the eigh-free Sigma chain's last Chebyshev squarings / Newton-Schulz iterations
- * run inside the two persistent launches (phases separated by barriers inside the launch) instead of as one / two launches
- * each.  Defaults: one matrix (15, 11) = all but the first of each; batched launches (15, 4).  The call sets both; (64, 64) = all
- * but the first of each, (0, 0) = every phase its own launch, (-1, -1) = back to the defaults.  The result does not depend on it
- * bit for bit; graphs captured before the call are re-captured at their next step. */
-int covo_debug_set_ns_tail(int n_squarings, int n_iters);
-/* Test hook (process-wide): 0 switches the deflation of the bottom eigenpair in the eigh-free Sigma chain off (sigma_ns.hip: the
- * Newton-Schulz iteration then runs on B itself, ~2 iterations more); default on.  Results agree to fp64 rounding either way
- * (not bit for bit: another iteration sequence); graphs captured before the call keep their behaviour. */
-int covo_debug_set_ns_deflate(int on);
-/* Test hook (process-wide): 1 makes the Sigma chain's persistent launches behave as if their workgroups had NOT all landed on one
- * XCD (sigma_ns.hip: every access stays an agent-scope atomic, COH_AGENT) -- the fallback of the placement check, which no
- * MI355X box takes by itself; 0 (default): as detected.  Same Sigma and L bit for bit. */
-int covo_debug_set_ns_coherence(int force_agent);
-/* Test hook (process-wide): 0 makes the one-matrix Sigma chain evaluate its Rayleigh-Ritz pairs AFTER the squaring launch
- * (ns_ritz_scan_kernel, what batches and shared-device handles do) instead of inside it; default 1.  Same Sigma and L bit for
- * bit: lambda_min is a function of the matrix alone (sigma_ns.hip: ritz_decide).  Also COVO_NS_RITZ_INSIDE=0 in the environment.
- * 2: a timing reference only -- rounds 1-4's rule (the Ritz step reads the filter's last iterate and nothing else; Sigma then
- * differs in the last bits). */
-int covo_debug_set_ns_ritz_inside(int on);
+/* How many of the eigh-free Sigma chain's last Chebyshev squarings / Newton-Schulz iterations run inside the two persistent
+ * launches (phases separated by barriers inside the launch) instead of as one / two launches each.  Defaults: one matrix (15, 11)
+ * = all but the first of each; batched launches (15, 4).  The call sets both; (64, 64) = all but the first of each, (0, 0) = every
+ * phase its own launch, (-1, -1) = back to the defaults.  The result does not depend on it bit for bit. */
+int covo_debug_set_ns_tail(covo_handle_t h, int n_squarings, int n_iters);
+/* 0 switches the deflation of the bottom eigenpair in the eigh-free Sigma chain off (sigma_ns.hip: the Newton-Schulz iteration then
+ * runs on B itself, ~2 iterations more); default on.  Results agree to fp64 rounding either way (not bit for bit: another
+ * iteration sequence). */
+int covo_debug_set_ns_deflate(covo_handle_t h, int on);
+/* 1 makes the Sigma chain's persistent launches behave as if their workgroups had NOT all landed on one XCD (sigma_ns.hip: every
+ * access stays an agent-scope atomic, COH_AGENT) -- the fallback of the placement check, which no MI355X box takes by itself; 0
+ * (default): as detected.  Same Sigma and L bit for bit. */
+int covo_debug_set_ns_coherence(covo_handle_t h, int force_agent);
+/* 0 makes the one-matrix Sigma chain evaluate its Rayleigh-Ritz pairs AFTER the squaring launch (ns_ritz_scan_kernel, what batches
+ * and shared-device handles do) instead of inside it; default 1.  Same Sigma and L bit for bit: lambda_min is a function of the
+ * matrix alone (sigma_ns.hip: ritz_decide).  2: a timing reference only -- rounds 1-4's rule (the Ritz step reads the filter's last
+ * iterate and nothing else; Sigma then differs in the last bits). */
+int covo_debug_set_ns_ritz_inside(covo_handle_t h, int on);
 int covo_debug_hess_workspace(covo_handle_t h, double *out, int64_t offset_doubles, int64_t count, void *stream);
 /* Test hook: `count` doubles at `offset_doubles` of the Hessians of the LAST covo_mpc_step_batched on this handle
  * ([n_envs][128][128], the Sigma chain's input), copied to the HOST buffer `out` (asynchronously on `stream`). */
@@ -440,7 +442,9 @@ typedef struct covo_step_args {
     int32_t n_samples;       /* <= n_local */
     int32_t T;               /* rows of pos_traj / vel_traj */
     int32_t n_table;         /* offline: rows of L_table */
-    const float *state;      /* float[32], the noisy state (controllers/covo.py:198) */
+    const float *state;      /* float[32], the noisy state (controllers/covo.py:198).  Must stay valid and unchanged until the step
+                              * has run: eager covo-online steps read it where it lies from EVERY launch (the begin work rides in the
+                              * Hessian's first launch, covo_debug_set_fold_begin); other steps copy it in their begin launch */
     const float *pos_traj;
     const float *vel_traj;
     float *a_mean;           /* float[128] in/out */
@@ -577,7 +581,11 @@ int covo_run_episode_batched(covo_handle_t h, const covo_batch_args *args, const
 /* Profiling aid: `reps` copies of the selected launches of one control step, captured into one hipGraph and
  * replayed; *us_out = GPU microseconds per copy.  step_mask bits: 1 shift_mean, 2 Hessian, 4 Sigma, 8 noise GEMM,
  * 16 rollout, 32 softmax update; hess_mask bits: the four kernels of the adjoint Hessian; sigma_stages 1..4:
- * prep+squarings, +Ritz, +Newton-Schulz, +finalize.  Uses the buffers in `args` exactly like covo_mpc_step. */
+ * prep+squarings, +Ritz, +Newton-Schulz, +finalize.  Uses the buffers in `args` exactly like covo_mpc_step -- and, like a
+ * real step, MUTATES the controller state they hold: every replayed copy that includes the update writes args->a_mean, MPPI's
+ * begin work / fused small step shifts args->a_cov in place once per copy (plus once for the scratch refresh an eager handle
+ * needs first), and the handle's sequence number advances.  Time on a state you can afford to lose, or snapshot a_mean / a_cov
+ * around the call (bench.py times after its value-bearing steps). */
 int covo_debug_time_step(covo_handle_t h, const covo_env_params *params, const covo_step_args *args, int32_t step_mask,
                          int32_t hess_mask, int32_t sigma_stages, int32_t reps, float *us_out, void *stream);
 

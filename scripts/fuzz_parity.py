@@ -108,11 +108,11 @@ for trial in range(int(sys.argv[4]) if len(sys.argv) > 4 else 24):
             os.makedirs("gpurun_out", exist_ok=True)
             np.save(f"gpurun_out/fail_sigma_{trial}.npy", Rm)
             for on in (1, 0):  # with / without the deflation (sigma_ns.hip)
-                core.lib.covo_debug_set_ns_deflate(on)
+                core.lib.covo_debug_set_ns_deflate(core.h, on)
                 S2, _ = core.sigma(torch.from_numpy(Rm[None].copy()).to(T.DEV), 0.5)
                 e2 = np.linalg.norm(S2[0].cpu().numpy() - ref) / np.linalg.norm(ref)
                 print("    deflate", on, "err", e2, "chain (squarings, iterations, deflated)", T._sigma_chain_iters(core), flush=True)
-            core.lib.covo_debug_set_ns_deflate(1)
+            core.lib.covo_debug_set_ns_deflate(core.h, 1)
         else:
             n3 += 1
 print("sigma:", n3, "passed, worst rel err", worst)

@@ -14,7 +14,7 @@ Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
 w = np.concatenate([[-2.0, -1.1, -0.7], np.geomspace(0.01, 900.0, n - 3)])
 R = torch.from_numpy(np.ascontiguousarray((Q * w) @ Q.T)).cuda()[None]
 for tail in ((0, 0), (0, 2), (0, 64), (64, 0), (64, 64)):
-    _lib.check(lib.covo_debug_set_ns_tail(*tail))
+    _lib.check(lib.covo_debug_set_ns_tail(core.h, *tail))
     for _ in range(5): core.sigma(R, 0.5)
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
@@ -41,4 +41,4 @@ for tail in ((0, 0), (0, 2), (0, 64), (64, 0), (64, 64)):
         v = [x for x in st.tolist() if x >= 0]
         print("   stamps (us):", " ".join(f"{x / 100.0:.2f}" for x in v))
         print("   deltas (us):", " ".join(f"{(b - a) / 100.0:.2f}" for a, b in zip(v, v[1:])))
-_lib.check(lib.covo_debug_set_ns_tail(-1, -1))
+_lib.check(lib.covo_debug_set_ns_tail(core.h, -1, -1))

@@ -14,8 +14,8 @@ params = env.default_params
 lib = _lib.load_library()
 for rnd in range(2):
     for on in (1, 0):
-        _lib.check(lib.covo_debug_set_stream_gemm(on), "stream")
         c, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam0.01", device="cuda:0", compute_info=False)
+        _lib.check(lib.covo_debug_set_stream_gemm(c.core.h, on), "stream")
         obs, info, state = env.reset(cr.PRNGKey(1), params)
         cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(2))
         key = cr.PRNGKey(3)
@@ -33,4 +33,3 @@ for rnd in range(2):
         print(f"stream={on}: sigma {T(4):.1f}  sigma+gemm {T(12):.1f}  +rollout {T(28):.1f}  whole {T(63):.1f} us; 100 real steps on one state: "
               f"{e0.elapsed_time(e1) * 10:.1f} us/step")
         c.core.close()
-_lib.check(lib.covo_debug_set_stream_gemm(1), "stream")

@@ -5,9 +5,9 @@ import sys, os, json, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from covo_mpc_amd import _lib
 sq, it, defl = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-lib = _lib.load_library()
-_lib.check(lib.covo_debug_set_ns_tail(sq, it))
-_lib.check(lib.covo_debug_set_ns_deflate(defl))
+# (per-handle switches since round 6: every handle bench.py creates takes these defaults from the environment, csrc/step.hip)
+os.environ["COVO_NS_TAIL"] = f"{sq},{it}"
+os.environ["COVO_NS_DEFLATE"] = str(defl)
 sys.argv = ["bench.py", "--no-cpu-baseline", "--no-info-leg"] + sys.argv[4:]
 import bench
 buf = io.StringIO()

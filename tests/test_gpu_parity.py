@@ -692,7 +692,7 @@ def test_sigma_tail_launch_is_bit_identical():
             R_d = torch.from_numpy(np.ascontiguousarray(Rm)).to(DEV)
             outs = []
             for tail in ((0, 0), (0, 2), (6, 3), (64, 64), (-1, -1)):
-                _lib.check(lib.covo_debug_set_ns_tail(*tail))
+                _lib.check(lib.covo_debug_set_ns_tail(core.h, *tail))
                 Sig, L = core.sigma(R_d[None], 0.5)
                 outs.append((Sig.clone(), L.clone()))
             assert torch.isfinite(outs[0][0]).all()
@@ -703,7 +703,7 @@ def test_sigma_tail_launch_is_bit_identical():
         R_b = torch.from_numpy(np.ascontiguousarray(np.stack(batch))).to(DEV)
         outs = []
         for tail in ((0, 0), (64, 0), (0, 64), (64, 64), (-1, -1)):
-            _lib.check(lib.covo_debug_set_ns_tail(*tail))
+            _lib.check(lib.covo_debug_set_ns_tail(core.h, *tail))
             Sig, L = core.sigma(R_b, 0.5, batch=11)
             outs.append((Sig.clone(), L.clone()))
         assert torch.isfinite(outs[0][0]).all()
@@ -717,15 +717,15 @@ def test_sigma_tail_launch_is_bit_identical():
         tail_modes = lambda b: core_scalars(core, b)[21:23]
         Sig_x, L_x = core.sigma(R_b[:1].contiguous(), 0.5)
         assert list(tail_modes(1)) == [2.0, 2.0], tail_modes(1)  # both persistent launches found themselves on one XCD
-        _lib.check(lib.covo_debug_set_ns_coherence(1))
+        _lib.check(lib.covo_debug_set_ns_coherence(core.h, 1))
         Sig_a, L_a = core.sigma(R_b[:1].contiguous(), 0.5)
         assert list(tail_modes(1)) == [1.0, 1.0], tail_modes(1)
         assert torch.equal(Sig_a, Sig_x) and torch.equal(L_a, L_x)
         Sig_a, L_a = core.sigma(R_b, 0.5, batch=11)
         assert torch.equal(Sig_a, outs[0][0]) and torch.equal(L_a, outs[0][1])
     finally:
-        _lib.check(lib.covo_debug_set_ns_coherence(0))
-        _lib.check(lib.covo_debug_set_ns_tail(-1, -1))
+        _lib.check(lib.covo_debug_set_ns_coherence(core.h, 0))
+        _lib.check(lib.covo_debug_set_ns_tail(core.h, -1, -1))
 
 
 def test_batched_step_single_instance_and_errors():
@@ -1049,7 +1049,7 @@ def _sigma_chain_iters(core):
 def test_sigma_early_ritz_inside_equals_scan_equals_batch():
     """lambda_min is the Ritz value of X_kwin, kwin = the first filter iterate whose bottom Ritz pair passes its own residual
     test (sigma_ns.hip: ritz_eval / ritz_decide) -- a function of the matrix alone.  The evaluations riding inside the
-    squaring launch (one matrix), the scan launch after the squarings (covo_debug_set_ns_ritz_inside(0)) and the batched chain
+    squaring launch (one matrix), the scan launch after the squarings (covo_debug_set_ns_ritz_inside(handle, 0)) and the batched chain
     give the same Sigma and L bit for bit; on real Hessians kwin comes well before the filter's own stop."""
     g = np.load(os.path.join(HERE, "golden", "hessians_r03.npz"))
     mats = [m for k in g.files for m in g[k]]
@@ -1068,7 +1068,7 @@ def test_sigma_early_ritz_inside_equals_scan_equals_batch():
     res, kwin, ksq = {}, [], []
     try:
         for inside in (1, 0):
-            core.lib.covo_debug_set_ns_ritz_inside(inside)
+            _lib.check(core.lib.covo_debug_set_ns_ritz_inside(core.h, inside))
             for i, Rm in enumerate(mats):
                 Sigma, L = core.sigma(torch.from_numpy(Rm[None].copy()).to(DEV), 0.5)
                 res[inside, i] = (Sigma[0].cpu().numpy(), L[0].cpu().numpy())
@@ -1082,7 +1082,7 @@ def test_sigma_early_ritz_inside_equals_scan_equals_batch():
                 ref = R.optimize_sigma(Rm, 0.5, 32, 4)
                 assert np.linalg.norm(res[inside, i][0] - ref) / np.linalg.norm(ref) < 1e-6, (inside, i)
     finally:
-        core.lib.covo_debug_set_ns_ritz_inside(1)
+        _lib.check(core.lib.covo_debug_set_ns_ritz_inside(core.h, 1))
     for i in range(len(mats)):
         assert np.array_equal(res[1, i][0], res[0, i][0]) and np.array_equal(res[1, i][1], res[0, i][1]), i
     kwin, ksq = np.array(kwin), np.array(ksq)
@@ -1122,7 +1122,7 @@ def test_sigma_deflation_on_real_hessians():
             ref = R.optimize_sigma(Rm, 0.5, 32, 4)
             res = {}
             for on in (1, 0):
-                core.lib.covo_debug_set_ns_deflate(on)
+                _lib.check(core.lib.covo_debug_set_ns_deflate(core.h, on))
                 Sigma, L = core.sigma(torch.from_numpy(Rm[None].copy()).to(DEV), 0.5)
                 Sigma, L = Sigma[0].cpu().numpy(), L[0].cpu().numpy().astype(np.float64)
                 err = np.linalg.norm(Sigma - ref) / np.linalg.norm(ref)
@@ -1136,7 +1136,7 @@ def test_sigma_deflation_on_real_hessians():
                 saved.append(res[0][1] - res[1][1])
             n_defl += res[1][2]
     finally:
-        core.lib.covo_debug_set_ns_deflate(1)
+        _lib.check(core.lib.covo_debug_set_ns_deflate(core.h, 1))
     assert np.mean(saved) >= 1.5, saved
     # batched (covo-offline's table path): same matrices in one call, per-matrix deflation state
     Rb = np.stack(mats)
@@ -1267,8 +1267,8 @@ def test_small_fused_step_equals_staged(name, N, lam, graph, monkeypatch):
     res = []
     try:
         for fuse in (1, 0):
-            _lib.check(lib.covo_debug_set_fuse_small(fuse), "fuse_small")
             c, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=False)
+            _lib.check(lib.covo_debug_set_fuse_small(c.core.h, fuse), "fuse_small")  # (a switch of THIS handle)
             obs, info, state = env.reset(cr.PRNGKey(14), params)
             cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
             if N == 1000:
@@ -1288,7 +1288,7 @@ def test_small_fused_step_equals_staged(name, N, lam, graph, monkeypatch):
             res.append(out)
             c.core.close()
     finally:
-        _lib.check(lib.covo_debug_set_fuse_small(1), "fuse_small")
+        pass
     for step, (f, s) in enumerate(zip(*res)):
         for what, x, y in zip(("a_mean", "a", "cost", "a_cov"), f, s):
             assert torch.equal(x, y), (name, N, graph, step, what, (x - y).abs().max().item())
@@ -1317,7 +1317,7 @@ def test_small_fused_step_on_a_sharded_rank_leaves_the_merged_record():
     recs = []
     try:
         for fuse in (1, 0):
-            _lib.check(lib.covo_debug_set_fuse_small(fuse), "fuse_small")
+            _lib.check(lib.covo_debug_set_fuse_small(core.h, fuse), "fuse_small")
             args, am, am_shift, _ = core._prepare_step(_lib.MODE_COVO_OFFLINE, dstate, a_mean, L_table=L, derive_keys=True)
             rec = torch.zeros(_lib.COVO_PARTIAL_FLOATS, device=DEV)
             args.partial_out = rec.data_ptr()
@@ -1328,49 +1328,9 @@ def test_small_fused_step_on_a_sharded_rank_leaves_the_merged_record():
             recs.append((rec.clone(), am_shift.clone(), core.cost.clone()))
             core._args_cache = None
     finally:
-        _lib.check(lib.covo_debug_set_fuse_small(1), "fuse_small")
+        _lib.check(lib.covo_debug_set_fuse_small(core.h, 1), "fuse_small")
     assert all(torch.equal(x, y) for x, y in zip(*recs)) and recs[0][0][1] > 0 and torch.isfinite(recs[0][0]).all()
     core.close()
-
-
-@pytest.mark.parametrize("name,N,lam", [("covo-online", 65536, "0.01"), ("covo-online", 4096, "1.0"), ("mppi", 65536, "0.01"),
-                                        ("covo-offline", 32768, "0.01"), ("covo-online", 1000, "0.01")])
-@pytest.mark.parametrize("graph", ["graph", "eager"])
-def test_merge_inside_the_rollout_launch_equals_the_merge_launch(name, N, lam, graph, monkeypatch):
-    """VERDICT r04 item 4 (built, bit-identical, measured slower, opt-in): the fused steps' softmax update finishing INSIDE the
-    rollout launch -- the workgroup that takes the last ticket merges the records (rollout_merge_last: merge_kernel's arithmetic
-    over virtual lanes, csrc/softmax_merge.hpp; covo_debug_set_merge_in_rollout(1)) -- against the merge as a launch of its own
-    (the default): the same means bit for bit, with 256 records from
-    768-thread workgroups, 64 from 192-thread ones, a ragged count, with and without position statistics."""
-    import covo_mpc_amd as cm
-    from covo_mpc_amd import random as cr
-    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type="gaussian", disable_rollover_terminate=True,
-                         generate_noisy_state=True, device=DEV)
-    monkeypatch.setenv("COVO_GRAPH" if graph == "graph" else "COVO_NO_GRAPH", "1")
-    lib = _lib.load_library()
-    params = env.default_params
-    res = []
-    try:
-        for on in (1, 0):
-            _lib.check(lib.covo_debug_set_merge_in_rollout(on), "merge_in_rollout")
-            c, _ = cm.envs.get_controller(env, name, f"N{N}_H32_lam{lam}", device=DEV, compute_info=(N == 4096))
-            obs, info, state = env.reset(cr.PRNGKey(24), params)
-            cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
-            key = cr.PRNGKey(26)
-            out = []
-            for step in range(4):
-                key, k_act, k_step = cr.split(key, 3)
-                u, cp, _ = c(obs, state, params, k_act, cp, info)
-                out.append((cp.a_mean.clone(), c.core.cost.clone()))
-                obs, state, reward, done, info = env.step(k_step, state, u.cpu().numpy(), params)
-            assert c.core.device_status() == 0
-            res.append(out)
-            c.core.close()
-    finally:
-        _lib.check(lib.covo_debug_set_merge_in_rollout(0), "merge_in_rollout")
-    for step, (f, s) in enumerate(zip(*res)):
-        assert torch.equal(f[0], s[0]) and torch.equal(f[1], s[1]), (name, N, graph, step, (f[0] - s[0]).abs().max().item())
-    assert torch.isfinite(res[0][-1][0]).all()
 
 
 @pytest.mark.parametrize("N,lam", [(65536, "0.01"), (4096, "0.01"), (1000, "1.0"), (70000, "0.01")])
@@ -1378,7 +1338,7 @@ def test_merge_inside_the_rollout_launch_equals_the_merge_launch(name, N, lam, g
 def test_streamed_gemm_equals_the_gemm_launch(N, lam, graph, monkeypatch):
     """covo-online's noise GEMM streamed under the factorisation inside the Sigma chain's finalize launch (the default for one
     matrix; sigma_ns.hip: ns_finalize_stream_kernel -- one workgroup factors and sends panel after panel, the others multiply)
-    against the GEMM as a launch of its own behind the chain (covo_debug_set_stream_gemm(0)): actions, costs, a_cov and the new
+    against the GEMM as a launch of its own behind the chain (covo_debug_set_stream_gemm(handle, 0)): actions, costs, a_cov and the new
     mean bit for bit -- at the headline size (8 worker waves own two tiles), a small one (most workers idle), a ragged count, one
     beyond 65 536, eager and as a captured graph, with and without the position statistics.
     Round 6: the streamed launch's last step is also checked against oracle/ directly -- costs of a 2 048-sample subsample at
@@ -1393,8 +1353,8 @@ def test_streamed_gemm_equals_the_gemm_launch(N, lam, graph, monkeypatch):
     res = []
     try:
         for on in (1, 0):
-            _lib.check(lib.covo_debug_set_stream_gemm(on), "stream_gemm")
             c, _ = cm.envs.get_controller(env, "covo-online", f"N{N}_H32_lam{lam}", device=DEV, compute_info=(N == 4096))
+            _lib.check(lib.covo_debug_set_stream_gemm(c.core.h, on), "stream_gemm")  # (a switch of THIS handle)
             obs, info, state = env.reset(cr.PRNGKey(34), params)
             cp = c.reset(state, params, c.init_control_params, cr.PRNGKey(5))
             key = cr.PRNGKey(36)
@@ -1411,11 +1371,46 @@ def test_streamed_gemm_equals_the_gemm_launch(N, lam, graph, monkeypatch):
             res.append(out)
             c.core.close()
     finally:
-        _lib.check(lib.covo_debug_set_stream_gemm(1), "stream_gemm")
+        pass
     for step, (f, s) in enumerate(zip(*res)):
         for what, x, y in zip(("a_mean", "a", "cost", "a_cov"), f, s):
             assert torch.equal(x, y), (N, graph, step, what, (x - y).abs().max().item())
     assert torch.isfinite(res[0][-1][0]).all() and torch.isfinite(res[0][-1][3]).all()
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "none"])
+def test_folded_begin_equals_the_begin_launch(kind, monkeypatch):
+    """eager covo-online steps fold the begin work (mean shift, key derivation, sequence bump) into the Hessian's first
+    launch and read args->state where it lies (covo_debug_set_fold_begin(handle, 1), the default) -- against the begin launch of
+    its own with the fixed-address state copy (0): actions, costs, a_cov and the new mean bit for bit over a few closed-loop
+    steps, and the two settings live side by side on two handles of one process (the switches are per handle since round 6)."""
+    import covo_mpc_amd as cm
+    from covo_mpc_amd import random as cr
+    env = cm.envs.Quad3D(task="tracking_zigzag", enable_randomizer=False, disturb_type=kind, disable_rollover_terminate=True,
+                         generate_noisy_state=True, device=DEV)
+    monkeypatch.setenv("COVO_NO_GRAPH", "1")
+    lib = _lib.load_library()
+    params = env.default_params
+    ctrls = []
+    for on in (1, 0):
+        c, _ = cm.envs.get_controller(env, "covo-online", "N4096_H32_lam0.01", device=DEV, compute_info=False)
+        _lib.check(lib.covo_debug_set_fold_begin(c.core.h, on), "fold_begin")
+        ctrls.append(c)
+    obs, info, state = env.reset(cr.PRNGKey(44), params)
+    cps = [c.reset(state, params, c.init_control_params, cr.PRNGKey(5)) for c in ctrls]
+    key = cr.PRNGKey(46)
+    for step in range(4):
+        key, k_act, k_step = cr.split(key, 3)
+        outs = []
+        for i, c in enumerate(ctrls):  # interleaved: two handles with different settings alive at once
+            u, cps[i], _ = c(obs, state, params, k_act, cps[i], info)
+            outs.append((cps[i].a_mean.clone(), c.core.a.clone(), c.core.cost.clone(), cps[i].a_cov.clone(), u.clone()))
+        for what, x, y in zip(("a_mean", "a", "cost", "a_cov", "u"), *outs):
+            assert torch.equal(x, y), (kind, step, what, (x - y).abs().max().item())
+        obs, state, reward, done, info = env.step(k_step, state, outs[0][4].cpu().numpy(), params)
+    assert all(c.core.device_status() == 0 for c in ctrls) and torch.isfinite(outs[0][0]).all()
+    for c in ctrls:
+        c.core.close()
 
 
 def test_sigma_batch_beyond_residency_persistent_equals_shared_device():
