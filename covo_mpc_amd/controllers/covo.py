@@ -1,10 +1,14 @@
 """CoVO-MPC controller behind quadjax's call signature: quadjax/controllers/covo.py:13-283.
 
 Differs from MPPI only in how the sampling covariance is chosen (covo.py:205-208): `online`
-takes the exact Hessian of the rollout cost at the shifted mean (hyper-dual HIP kernel),
-maps its spectrum to the optimal Sigma (Jacobi eigendecomposition kernel) and factors it;
+takes the exact Hessian of the rollout cost at the shifted mean (second-order adjoint on fp64
+MFMAs, csrc/hessian_adj.hip; the per-pair hyper-dual kernel of csrc/hessian.hip is the
+independent cross-check), forms the optimal Sigma = c (R + delta I)^(-1/2) WITHOUT an
+eigendecomposition (Chebyshev-filter lambda_min + Rayleigh-Ritz, coupled Newton-Schulz, one
+Cholesky: csrc/sigma_ns.hip; the Jacobi eigensolver of csrc/sigma.hip is the cross-check) and
+samples from its factor -- one C call per control step (covo_mpc_step, csrc/step.hip);
 `offline` looks Sigma up in a per-episode table built at reset() along a PID-tracked nominal
-trajectory (covo.py:44-112).
+trajectory (covo.py:44-112; csrc/pid_nominal.hip + the batched Hessian / Sigma launches).
 """
 from __future__ import annotations
 

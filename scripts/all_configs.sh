@@ -15,6 +15,6 @@ import json, sys
 f = sys.argv[1]
 d = json.loads(open(f"gpurun_out/{f}.json").read().strip().splitlines()[-1])
 cl = d.get("closed_loop", {})
-print(f, d["config"]["controller"], d["config"].get("task"), d["config"]["N_global"], f'{d["value"]:.0f} steps/s', f'{d["ms_per_step"] * 1e3:.1f} us/step', "closed loop:", {k: (round(v) if isinstance(v, float) else v) for k, v in cl.items()} if isinstance(cl, dict) else cl)
+print(f, d["config"]["controller"], d["config"].get("task"), d["config"]["N_global"], f'{d["value"]:.0f} steps/s', f'{d["ms_per_step"] * 1e3:.1f} us/step', "closed loop:", {k: ((round(v) if abs(v) >= 100 else round(v, 4)) if isinstance(v, float) else v) for k, v in cl.items()} if isinstance(cl, dict) else cl)
 PY
 done
