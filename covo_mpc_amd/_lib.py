@@ -142,6 +142,7 @@ _SIGS = {
     "covo_debug_set_fold_begin": (C.c_int, [_P, C.c_int]),
     "covo_debug_set_stream_gemm": (C.c_int, [_P, C.c_int]),
     "covo_debug_set_ns_coherence": (C.c_int, [_P, C.c_int]),
+    "covo_debug_set_ns_merged": (C.c_int, [_P, C.c_int]),
     "covo_debug_time_step": (C.c_int, [_P, C.POINTER(EnvParamsC), C.POINTER(StepArgsC), C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.POINTER(C.c_float), _P]),
     "covo_debug_time_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),

@@ -562,6 +562,14 @@ int covo_debug_set_ns_deflate(covo_handle_t h, int on)
     return 0;
 }
 
+int covo_debug_set_ns_merged(covo_handle_t h, int on)
+{
+    REQUIRE(h, "covo_debug_set_ns_merged: null handle");
+    h->opt.ns_merged = on ? 1 : 0;
+    ++h->opt.epoch;
+    return 0;
+}
+
 int covo_debug_set_ns_coherence(covo_handle_t h, int force_agent)
 {
     REQUIRE(h, "covo_debug_set_ns_coherence: null handle");

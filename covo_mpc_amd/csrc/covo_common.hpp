@@ -21,6 +21,7 @@ struct CovoOpts {
     int ns_tail_iters, ns_tail_squarings, ns_tail_iters_batched, ns_tail_squarings_batched;  // phases folded into the persistent launches
     int ns_deflate;      // the Newton-Schulz iteration deflates the bottom eigenpair
     int ns_force_agent;  // take the agent-scope coherence fallback although the placement check passed
+    int ns_merged;       // one matrix: squaring chain + evaluations + Newton-Schulz iterations as ONE launch (ns_chain_kernel)
     int ns_ritz_inside;  // 1: the Rayleigh-Ritz evaluations ride in the squaring launch; 0: one scan launch; 2: the last iterate only
     int epoch;
 };

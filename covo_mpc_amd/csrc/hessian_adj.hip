@@ -153,6 +153,7 @@ int launch_hessian(const float *state, const float *pos_traj, const float *vel_t
     A.stats.diag = nullptr;
     A.stats.stride = 0;
     A.stats.flags = nullptr;
+    A.stats.ready = nullptr;
     if (stats != nullptr) A.stats = *stats;
     // launch shapes: KB 32 waves; KC 9 chains + KM's 32 hyper-dual workgroups (which also contract with the costate); KD 36 tiles
     // batched: chains and hyper-dual workgroups as two launches (hessian_adj_body.hpp: adj_hd_kernel) -- 66.5 -> 62.5 us at 32 instances;

@@ -763,6 +763,7 @@ __global__ __launch_bounds__(512) void adj_gemm_kernel(const AdjArgs A)
         sym_tile_stats(wv < 4, rv, I, J, (int)blockIdx.x, lane, wv & 3, so, st_tmp, st_part);
         // the chain's first launch may be the persistent one: its barrier flags are cleared here, a launch ahead
         if (so.flags != nullptr && blockIdx.x == 0 && tid < 64) so.flags[(size_t)b * so.stride + tid] = 0.0;
+        if (so.ready != nullptr && blockIdx.x == 0 && tid == 64) so.ready[(size_t)b * so.stride] = 0.0;
     }
 }
 #undef ADJ_FOR_STATE

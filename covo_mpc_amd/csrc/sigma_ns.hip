@@ -122,6 +122,8 @@ enum { SC_SHIFT = 0, SC_LMIN, SC_DELTA, SC_SCALE, SC_SUMLOGB, SC_ZBUF, SC_ITERS,
        SC_PREP = 320,          // prep partials: 8 x {max rowabs, sum v^2, trace, min diag}
        // the Rayleigh-Ritz evaluations of X_2 .. X_16 (slot + k - 2; all zeroed by the first squaring):
        SC_VERD = 320,          // verdicts: 0 not yet, 1 not taken, 2 taken (ritz_decide)
+       SC_READY = 335,         // != 0: the chain's result (ritz_publish: U, delta, scale, lo, ...) is complete in memory -- what the
+                               // Newton-Schulz workgroups of the MERGED launch wait for (round 6; cleared a launch ahead: KD / ns_prep_kernel)
        SC_HAVE_DIAG = 336,     // != 0: X_k's evaluation has read the diagonal of X_(k-1) (its column picks) ...
        SC_HAVE_COLS = 352,     // ... and its columns of X_k: the chain may come round to those buffers again (ns_square_evaluator)
        SC_SQ_FINAL = 368,      // != 0: the filter stopped by itself (stationary / cap) and X_(SC_SQ_FINAL) is its last iterate
@@ -272,6 +274,7 @@ __device__ __forceinline__ SymStatsOut ns_stats_out(double *s)
     o.diag = s + SC_DIAG;
     o.stride = 0;
     o.flags = nullptr;
+    o.ready = nullptr;
     return o;
 }
 __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__ Rin, double *__restrict__ Aall,
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(256) void ns_prep_kernel(const double *__restrict__
     double *s = scall + (size_t)b * SC_COUNT;
     if (w == 0 && tid < SC_COEF) s[tid] = 0.0;  // scalars and the two "done" flags
     if (w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
+    if (w == 0 && tid == 64) s[SC_READY] = 0.0;  // (a launch ahead of the merged launch whose Newton-Schulz workgroups poll it)
     int I, J;
     tri_tile(w, I, J);
     const int i = 16 * I + (lane >> 4) + 4 * wv, j = 16 * J + (lane & 15);
@@ -306,7 +310,7 @@ __device__ __forceinline__ void ns_square_first_stats(double *s, int w, int tid,
                                                       double &beta, double &nrm)
 {
     if (w == 0 && tid < SC_COEF) gst<COH>(s + tid, 0.0);
-    if (w == 0 && tid < 49) gst<COH>(s + SC_VERD + tid, 0.0);  // the evaluations' slots and SC_SQ_FINAL
+    if (w == 0 && tid < 49 && SC_VERD + tid != SC_READY) gst<COH>(s + SC_VERD + tid, 0.0);  // the evaluations' slots and SC_SQ_FINAL
     if (COH == COH_NONE && w == 0 && tid < 64) s[SC_FLAGS + tid] = 0.0;
     double ra = 0.0, dgv = 0.0;
     if (tid < SN) {
@@ -901,6 +905,10 @@ __device__ __forceinline__ void ritz_publish(const RitzLds &L, double u, double 
         gst<COH_AGENT>(s + SC_RESID, L.o_resid2);
         gst<COH_AGENT>(s + SC_KWIN, (double)k);
     }
+    // every store above acknowledged (write-through), then the flag the merged launch's Newton-Schulz workgroups poll (ns_wait_result)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) gst<COH_AGENT>(s + SC_READY, 1.0);
 }
 // The verdict on X_k, in k order (kwin = the FIRST k that passes, whatever order the evaluations finish in): waits for the verdict
 // on X_(k-1); `final` = X_k is the filter's last iterate (taken if nothing passed before).  Returns true when the chain's result
@@ -1373,9 +1381,11 @@ __device__ __forceinline__ int ns_flag_barrier(unsigned *flags, unsigned phase, 
 // matrix runs its WHOLE tail at its own pace next to the others (4 per XCD at 32 matrices) instead of paying, launch by launch,
 // for the slowest matrix of the batch; when the grid exceeds what is resident, workgroups are dispatched in id order, so the
 // matrices ahead of a partially resident one are complete or running and always finish: no deadlock.
-__device__ __forceinline__ bool ns_tail_block(int nw, int batch, int &b, int &w)
+__device__ __forceinline__ bool ns_tail_block(int nw, int batch, int &b, int &w, unsigned xcd0 = 0u)
 {
-    const unsigned slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    // xcd0 (batch 1 only): the workgroups that stay are the linear ids = xcd0 (mod 8) -- the Newton-Schulz workgroups of the merged
+    // launch sit on XCD 1, its squaring chain on XCD 0
+    const unsigned slot = blockIdx.x >> 3, xcd = (blockIdx.x - xcd0) & 7u;
     b = (int)(slot / (unsigned)nw) * 8 + (int)xcd;
     w = (int)(slot % (unsigned)nw);
     return b < batch;
@@ -1630,12 +1640,24 @@ __device__ __forceinline__ void ns_square_evaluator(const double *__restrict__ A
     }
 }
 // NEVAL: evaluating workgroups per matrix (0: none -- the evaluations are a launch of their own, ns_ritz_scan_kernel)
-template <int NEVAL, bool LEAN>
+// DYN (the merged launch): the reduction buffer and the evaluations' RitzLds live in the launch's dynamic LDS (`dyn`) -- the merged
+// kernel's static LDS + the 129 KiB its log-det workgroup needs must stay under 160 KiB
+constexpr size_t NS_SQ_DYN_DOUBLES = 2 * 4 * 4 * 64 + 8 + (sizeof(RitzLds) + 7) / 8;
+template <int NEVAL, bool LEAN, bool DYN = false>
 __device__ __forceinline__ void ns_square_tail_pair_impl(const double *A, const XBufs xb_all, double *scall, int step_first, int step_last,
-                                                         int batch, int force_agent, int deflate)
+                                                         int batch, int force_agent, int deflate, double *dyn = nullptr)
 {
-    __shared__ double redp[2][4][4][64];
-    __shared__ double partp[2][4];
+    double (*redp)[4][4][64];
+    double (*partp)[4];
+    if constexpr (DYN) {
+        redp = reinterpret_cast<double (*)[4][4][64]>(dyn);
+        partp = reinterpret_cast<double (*)[4]>(dyn + 2 * 4 * 4 * 64);
+    } else {
+        __shared__ double redp_s[2][4][4][64];
+        __shared__ double partp_s[2][4];
+        redp = redp_s;
+        partp = partp_s;
+    }
     constexpr bool EVAL = NEVAL > 0;
     constexpr int NW = NS_SQ_PAIR_WG + NEVAL;
     int b, w;
@@ -1646,8 +1668,13 @@ __device__ __forceinline__ void ns_square_tail_pair_impl(const double *A, const 
     scall += (size_t)b * SC_COUNT;
     const unsigned xcc = ns_xcc_id();
     if (EVAL && w >= NS_SQ_PAIR_WG) {
-        __shared__ RitzLds L;
-        ns_square_evaluator<NEVAL, LEAN>(A + (size_t)b * SN * SN, xb, scall, w - NS_SQ_PAIR_WG, xcc, deflate, L);
+        if constexpr (DYN) {
+            RitzLds &L = *reinterpret_cast<RitzLds *>(dyn + 2 * 4 * 4 * 64 + 8);
+            ns_square_evaluator<NEVAL, LEAN>(A + (size_t)b * SN * SN, xb, scall, w - NS_SQ_PAIR_WG, xcc, deflate, L);
+        } else {
+            __shared__ RitzLds L;
+            ns_square_evaluator<NEVAL, LEAN>(A + (size_t)b * SN * SN, xb, scall, w - NS_SQ_PAIR_WG, xcc, deflate, L);
+        }
         return;
     }
     if (EVAL && w == 0) EV_STAMP(scall, 0);
@@ -1769,20 +1796,46 @@ __device__ void ns_logdetB_workgroup(const double *__restrict__ A, double *__res
 // early_logdet (one matrix): linear id 2 factors B = A + delta I for its log det (ns_logdetB_workgroup; the launch then carries
 // 129 KiB of dynamic LDS: one workgroup per CU, which is how the XCD's 32 CUs host the 32 workgroups of the iterations anyway)
 // (a template argument: the factorisation's registers -- 184 against 122 -- must not cost the batched launches their third wave per SIMD)
+// MERGED launch (round 6, one matrix): the squaring chain with its evaluations (XCD 0) and the Newton-Schulz workgroups (XCD 1; log det
+// on XCD 2, the coefficient table on XCD 3) are ONE launch -- ns_chain_kernel below.  The Newton-Schulz side is resident, placed and
+// waiting (ns_wait_result: SC_READY, raised by ritz_publish behind its acknowledged write-through stores) when the evaluation that
+// decides arrives: the launch boundary, the dispatch and the launch's ramp are off the chain.  Same arithmetic, same bits.  (The
+// same overlap with TWO launches on two streams cost 16 us per step in cross-stream fork + join: scripts/probe/ns_concurrent_spike.patch.)
+// Bounded like every wait of the chain (0.2 s -> SC_BARFAIL -> NaN outputs + sticky status).
+__device__ __forceinline__ bool ns_wait_result(double *s)
+{
+    __shared__ int ready_ok;
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        int good = 1;
+        while (gld<COH_AGENT>(s + SC_READY) == 0.0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 20000000LL) {
+                good = 0;
+                gst<COH_AGENT>(s + SC_BARFAIL, 1.0);
+                break;
+            }
+        }
+        ready_ok = good;
+    }
+    __syncthreads();
+    return ready_ok != 0;
+}
 template <bool EARLY_LOGDET>
-__global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
-                                                                int batch, int force_agent, int with_table)
+__device__ __forceinline__ void ns_iter_tail_pair_impl(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
+                                                       int batch, int force_agent, int with_table, int merged, double *ld_sm)
 {
     // dynamic LDS: the factorisation's matrix (129 KiB, EARLY_LOGDET) / the iterations' reduction buffer (32 KiB: four tiles x four
     // K-quarters, ns_YZ_quad_body; the pairs of part 1 use half of it) -- static and dynamic together must stay under 160 KiB
-    extern __shared__ __attribute__((aligned(16))) double ld_sm[];
     double (*redp)[4][4][64] = reinterpret_cast<double (*)[4][4][64]>(ld_sm);
     __shared__ double partp[2][4];
     if (EARLY_LOGDET && blockIdx.x == 2) {  // (another of the linear ids the launch sends away: XCD 2)
+        if (merged && !ns_wait_result(scall)) return;
         ns_logdetB_workgroup<4>(A, scall, ld_sm, &partp[0][0]);
         return;
     }
-    if (with_table && blockIdx.x == 1) {
+    if (with_table && blockIdx.x == (merged ? 3u : 1u)) {  // (merged: XCD 1 hosts the iterations)
+        if (merged && !ns_wait_result(scall)) return;
         if (threadIdx.x == 0) {
             ns_coef_table<COH_AGENT>(scall);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1791,11 +1844,12 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
         return;
     }
     int b, w;
-    if (!ns_tail_block(NS_PAIR_WG, batch, b, w)) return;
+    if (!ns_tail_block(NS_PAIR_WG, batch, b, w, merged ? 1u : 0u)) return;
     const size_t off = (size_t)b * SN * SN;
     scall += (size_t)b * SC_COUNT;
     const unsigned xcc = ns_xcc_id();
     const bool odd = (iter_first & 1) != 0;
+    if (merged && !ns_wait_result(scall)) return;
 #ifdef NS_STAMPS
     if (threadIdx.x == 0) g_nstamp = 0;
     __syncthreads();
@@ -1852,6 +1906,29 @@ __global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A,
     if (b == 0 && w == 0 && threadIdx.x == 0)
         for (int i = 0; i < 192; ++i) scall[SC_STAMPS + i] = (i < g_nstamp) ? (double)(g_stamp[i] - g_stamp[0]) : -1.0;
 #endif
+}
+template <bool EARLY_LOGDET>
+__global__ __launch_bounds__(256) void ns_iter_tail_pair_kernel(const double *A, const NsBufs B, double *scall, int iter_first, int iter_last,
+                                                                int batch, int force_agent, int with_table)
+{
+    extern __shared__ __attribute__((aligned(16))) double ld_sm[];
+    ns_iter_tail_pair_impl<EARLY_LOGDET>(A, B, scall, iter_first, iter_last, batch, force_agent, with_table, 0, ld_sm);
+}
+// one matrix, every squaring and every iteration folded: linear ids = 0 (mod 8) are the squaring launch's workgroups (chain +
+// evaluations), = 1 (mod 8) the iterations', 2 the log-det workgroup, 3 the coefficient table -- 8 x 32 ids, 129 KiB of dynamic LDS
+// (one workgroup per CU: the launch wants the GPU to itself like the two it replaces)
+template <int NEVAL>
+__global__ __launch_bounds__(256) void ns_chain_kernel(const double *A, const XBufs xb_all, const NsBufs B, double *scall, int force_agent,
+                                                       int deflate)
+{
+    extern __shared__ __attribute__((aligned(16))) double ld_sm[];
+    static_assert(NS_SQ_DYN_DOUBLES * sizeof(double) <= (size_t)SN * (SN + 1) * sizeof(double), "the squaring side's LDS fits the launch's");
+    static_assert(NS_SQ_PAIR_WG + NEVAL <= NS_PAIR_WG, "grid = 8 x NS_PAIR_WG covers the squaring side");
+    if ((blockIdx.x & 7u) == 0u) {
+        ns_square_tail_pair_impl<NEVAL, false, true>(A, xb_all, scall, 0, NS_SQUARINGS - 1, 1, force_agent, deflate, ld_sm);
+        return;
+    }
+    ns_iter_tail_pair_impl<true>(A, B, scall, 1, NS_ITERS - 1, 1, force_agent, 1, 1, ld_sm);
 }
 
 // ---- log det B on its own (round 5).  Sigma = c B^(-1/2) needs log c = 2 log(sigma) + log det B / (2 n) (covo.py:124-128).  Rounds
@@ -2443,6 +2520,7 @@ SymStatsOut sigma_ns_stats_out(void *workspace, int batch)
     o.diag = sc + SC_DIAG;
     o.stride = SC_COUNT;
     o.flags = sc + SC_FLAGS;
+    o.ready = sc + SC_READY;
     return o;
 }
 // 11 matrices, the slots, then the filter's history X_3 .. X_16 and X_1 (XBufs)
@@ -2469,6 +2547,8 @@ int launch_sigma_ns(const CovoOpts &opt, const double *R, int batch, float sampl
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_iter_tail_pair_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_chain_kernel<NS_SQ_EVAL_WG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         COVO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ns_finalize_stream_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -2486,6 +2566,25 @@ int launch_sigma_ns(const CovoOpts &opt, const double *R, int batch, float sampl
         hipLaunchKernelGGL(ns_square_kernel<false>, ns_grid(NS_TILES, batch), dim3(256), 0, s, ns_xk(xb, i), ns_xk(xb, i + 1), sc, i, batch);
     // every squaring folded: the Rayleigh-Ritz evaluations ride in the squaring launch and stop it (ns_square_evaluator)
     const bool eval_inside = fold_first && opt.ns_ritz_inside == 1;
+    // round 6: one matrix with both persistent launches whole -> ONE launch (ns_chain_kernel): the iterations' workgroups wait inside
+    // for the chain's result.  r_has_stats: SC_READY and the barrier flag words were cleared a launch ahead (KD).
+    const bool merged = opt.ns_merged && batch == 1 && persistent_ok && eval_inside && r_has_stats && sq_tail >= NS_SQUARINGS - 1 &&
+                        opt.ns_tail_iters >= NS_ITERS - 1 && g_dbg_sigma_stages >= 3;
+    if (merged) {
+        NsBufs B;
+        for (int k = 0; k < 2; ++k) {
+            B.Y[k] = Y[k];
+            B.Yt[k] = Yt[k];
+            B.Z[k] = Z[k];
+            B.Zt[k] = Zt[k];
+        }
+        B.T = T;
+        B.Tt = Tt;
+        B.A = A;
+        B.X1 = ns_xk(xb, 1);
+        hipLaunchKernelGGL((ns_chain_kernel<NS_SQ_EVAL_WG>), ns_tail_grid(NS_PAIR_WG, 1), dim3(256), lds, s, A, xb, B, sc, opt.ns_force_agent,
+                           opt.ns_deflate);
+    } else
     if (sq_tail > 0) {
         if (eval_inside && batch == 1)
             hipLaunchKernelGGL((ns_square_tail_pair_kernel<NS_SQ_EVAL_WG>), ns_tail_grid(NS_SQ_PAIR_WG + NS_SQ_EVAL_WG, batch), dim3(256), 0,
@@ -2498,13 +2597,13 @@ int launch_sigma_ns(const CovoOpts &opt, const double *R, int batch, float sampl
                                fold_first ? 0 : sq_sep, NS_SQUARINGS - 1, batch, opt.ns_force_agent, opt.ns_deflate);
     }
     if (g_dbg_sigma_stages < 2) return 0;
-    if (!eval_inside) hipLaunchKernelGGL(ns_ritz_scan_kernel, dim3(batch * RITZ_NK), dim3(256), 0, s, A, xb, sc, opt.ns_deflate, opt.ns_ritz_inside == 2 ? 1 : 0);
+    if (!eval_inside && !merged) hipLaunchKernelGGL(ns_ritz_scan_kernel, dim3(batch * RITZ_NK), dim3(256), 0, s, A, xb, sc, opt.ns_deflate, opt.ns_ritz_inside == 2 ? 1 : 0);
     if (g_dbg_sigma_stages < 3) return 0;
     // Iteration 0 is no product (NsFirst): Y1 and Z1 are written out element-wise from A and X_1 -- by the first phase of the persistent
     // launch when one matrix folds every iteration into it, else by a launch of their own (which also makes the coefficient table).
     const double *Xq = ns_xk(xb, 1);  // X_1
     const bool fold_all = batch == 1 && persistent_ok && opt.ns_tail_iters >= NS_ITERS - 1;
-    if (!fold_all) hipLaunchKernelGGL(ns_first_elem_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Xq, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
+    if (!fold_all && !merged) hipLaunchKernelGGL(ns_first_elem_kernel, ns_grid(65, batch), dim3(256), 0, s, A, Xq, Y[1], Yt[1], Z[1], Zt[1], sc, 1, batch);
     bool early_logdet = false;
     int n_tail = persistent_ok ? (batch == 1 ? opt.ns_tail_iters : opt.ns_tail_iters_batched) : 0;
     if (n_tail > NS_ITERS - 1) n_tail = NS_ITERS - 1;
@@ -2535,7 +2634,8 @@ int launch_sigma_ns(const CovoOpts &opt, const double *R, int batch, float sampl
         B.X1 = Xq;
         // one matrix: log det B rides in this launch (ns_logdetB_workgroup), ~50 us before the finalize launch wants it
         early_logdet = batch == 1;
-        if (early_logdet)
+        if (merged) {
+        } else if (early_logdet)
             hipLaunchKernelGGL(ns_iter_tail_pair_kernel<true>, ns_tail_grid(NS_PAIR_WG, batch), dim3(256), lds, s, A, B, sc,
                                fold_all ? 1 : n_sep, NS_ITERS - 1, batch, opt.ns_force_agent, fold_all ? 1 : 0);
         else

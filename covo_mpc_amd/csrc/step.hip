@@ -138,6 +138,7 @@ static const int g_dbg_eps_ahead = [] {  // COVO_EPS_AHEAD=0: the GEMM draws eps
 //                         instead of streamed under the factorisation inside it (sigma_ns.hip: ns_finalize_stream_kernel)
 //   COVO_FOLD_BEGIN=0     eager covo-online steps keep the begin launch (default: its work rides in the Hessian's first launch)
 //   COVO_NS_TAIL=sq,it    phases folded into the Sigma chain's persistent launches, as covo_debug_set_ns_tail
+//   COVO_NS_MERGED=0      the Sigma chain's two persistent launches (squarings | iterations) as two launches (rounds 4-5) instead of one
 //   COVO_NS_DEFLATE=0     the undeflated Newton-Schulz iteration;  COVO_NS_RITZ_INSIDE=0 / 2: the Ritz evaluations as one scan
 //                         launch after the squarings / the filter's last iterate only (rounds 1-4's rule, timing reference)
 // covo_debug_set_*(handle, ...) change them per handle afterwards (A/B measurements, parity tests).
@@ -161,6 +162,7 @@ CovoOpts covo_default_opts()
     }
     o.ns_deflate = env_int("COVO_NS_DEFLATE", 1) ? 1 : 0;
     o.ns_force_agent = 0;
+    o.ns_merged = env_int("COVO_NS_MERGED", 1) ? 1 : 0;
     const int ri = env_int("COVO_NS_RITZ_INSIDE", 1);
     o.ns_ritz_inside = ri == 2 ? 2 : (ri ? 1 : 0);
     o.epoch = 0;

@@ -11,6 +11,7 @@ struct SymStatsOut {
     double *diag;   // [128]
     size_t stride;  // doubles between the blocks of consecutive matrices of a batch (all pointers)
     double *flags;  // != null: 64 doubles the producer clears (the barrier flag words of the Sigma chain's persistent launches)
+    double *ready;  // != null: one double the producer clears (the chain's "result is there" flag, polled by the concurrent NS launch)
 };
 
 // 256 threads (4 waves) hold the lower tile (I >= J) of the symmetric matrix: thread (lane = 16 hi + lo, wave wv) holds

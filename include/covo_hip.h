@@ -409,6 +409,11 @@ int covo_debug_set_ns_tail(covo_handle_t h, int n_squarings, int n_iters);
  * runs on B itself, ~2 iterations more); default on.  Results agree to fp64 rounding either way (not bit for bit: another
  * iteration sequence). */
 int covo_debug_set_ns_deflate(covo_handle_t h, int on);
+/* 0: the one-matrix Sigma chain runs its two persistent launches (squarings with the evaluations inside | Newton-Schulz iterations)
+ * as TWO launches (rounds 4-5) instead of one whose iteration workgroups wait inside for the chain's result (csrc/sigma_ns.hip:
+ * ns_chain_kernel; the default for covo-online steps on a GPU of one's own; COVO_NS_MERGED=0 in the environment).  Same Sigma and L
+ * bit for bit. */
+int covo_debug_set_ns_merged(covo_handle_t h, int on);
 /* 1 makes the Sigma chain's persistent launches behave as if their workgroups had NOT all landed on one XCD (sigma_ns.hip: every
  * access stays an agent-scope atomic, COH_AGENT) -- the fallback of the placement check, which no MI355X box takes by itself; 0
  * (default): as detected.  Same Sigma and L bit for bit. */
