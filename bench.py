@@ -200,7 +200,7 @@ def closed_loop(env, controller, params, T, rec=None):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r05_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r06_bench_pmc_summary.json")
 # every file the rollout kernel and the noise GEMM are built from: the hash that decides whether committed PMC counters still
 # describe the kernels of this tree (scripts/pmc_summary.py imports this list)
 KERNEL_SRCS = ["covo_mpc_amd/csrc/" + f for f in (
@@ -373,9 +373,9 @@ def bench_envs(args, world, rank, device, backend):
         }
         traffic = traffic_src = None
         try:  # the committed counter passes of THIS command (scripts/profile_bench.sh), dropped when the kernel sources changed
-            with open(os.path.join(ROOT, "profiles", "r05_bench_envs_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r06_bench_envs_pmc_summary.json")) as f:
                 pm = json.load(f)
-            traffic_src = {"kind": "committed_profile", "file": "profiles/r05_bench_envs_pmc_summary.json", "commit": pm.get("commit"),
+            traffic_src = {"kind": "committed_profile", "file": "profiles/r06_bench_envs_pmc_summary.json", "commit": pm.get("commit"),
                            "kernel_src_sha": pm.get("kernel_src_sha")}
             if pm.get("kernel_src_sha") == kernel_src_sha() and E == 32 and N == 4096:
                 traffic = pm.get("traffic_bytes_per_launch")

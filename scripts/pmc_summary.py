@@ -20,7 +20,7 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
-RND = sys.argv[2] if len(sys.argv) > 2 else "r05"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r06"
 N_LOCAL, H = 65536, 32
 CU, SIMD = 256, 1024
 sys.path.insert(0, root)

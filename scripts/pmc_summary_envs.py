@@ -9,7 +9,7 @@ import collections, csv, glob, json, os, subprocess, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
-RND = sys.argv[2] if len(sys.argv) > 2 else "r05"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r06"
 sys.path.insert(0, root)
 from bench import kernel_src_sha  # noqa: E402
 

@@ -4,7 +4,7 @@
 # traces, every pass has the program itself right after `--`), the phase times and the stand-alone kernel table.
 # Run on the GPU box from the repo root; outputs land in gpurun_out/.   usage: scripts/profile_bench.sh [round tag, default r05]
 R="$(cd "$(dirname "$0")/.." && pwd)"
-RND="${1:-r05}"
+RND="${1:-r06}"
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" > "$R/gpurun_out/bench_line.json" 2> "$R/gpurun_out/bench_line.err"
