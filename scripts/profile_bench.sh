@@ -11,7 +11,7 @@ python3 "$R/bench.py" > "$R/gpurun_out/bench_line.json" 2> "$R/gpurun_out/bench_
 rm -rf "$R/gpurun_out/prof_stats" "$R/gpurun_out/pmc_fetch" "$R/gpurun_out/pmc_write" "$R/gpurun_out/pmc_sq_a" "$R/gpurun_out/pmc_sq_b"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -o bench -- python3 "$R/bench.py" \
     > "$R/gpurun_out/bench_line_under_rocprof.json" 2> "$R/gpurun_out/prof_stats.err"
-PMC_ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-closed-loop --no-info-leg"
+PMC_ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-closed-loop --no-info-leg --no-sweep"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -o bench -- python3 "$R/bench.py" $PMC_ARGS \
     > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -o bench -- python3 "$R/bench.py" $PMC_ARGS \
